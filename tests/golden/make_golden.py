@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""Generate the golden vectors in this directory from the REAL reference (JGCRI/xanthos v2.4.1).
+
+Run in the build container only (needs /root/reference, which does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference is imported unmodified: penman_monteith.py / abcd.py / mrtm.py by file path, and the package
+(for Components.calculate_routing and calibrate_abcd.objective_kge) behind a dummy ``configobj`` module, the one
+third-party import that is not installed here.  Each fixture stores the crafted inputs AND the reference's
+outputs, so tests on the GPU box need no reference code.  Fixtures are data only.
+
+Fixtures written:
+  pm.npz      run_pmpet: 256 cells x 3 years (1994-1996: land-cover switch 1990->2000, leap 1996), nlcs=8
+  abcd.npz    abcd_execute: 300 cells, 6 basins (one single-cell), 60 months, spin-up 36, with / without tmin
+  topo.npz    downstream / upstream / upstream_genmatrix on 24x48 grids (random D8 with edge cases; tree world)
+  mrtm.npz    streamrouting for 28/29/30/31-day months + Components.calculate_routing (3 spin-up + 5 months)
+  kge.npz     objective_kge(basin_runoff) for 16 parameter vectors x 2 basins, both units, with / without tmin
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, '..', '..')))
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+ref_pm = _load('ref_pm', 'xanthos/pet/penman_monteith.py')
+ref_abcd = _load('ref_abcd', 'xanthos/runoff/abcd.py')
+ref_mrtm = _load('ref_mrtm', 'xanthos/routing/mrtm.py')
+
+# package import for Components / calibrate (configobj is the only missing dependency)
+stub = types.ModuleType('configobj')
+stub.ConfigObj = dict
+sys.modules['configobj'] = stub
+sys.path.insert(0, REF)
+import matplotlib  # noqa: E402
+matplotlib.use('Agg')
+from xanthos.components import Components  # noqa: E402
+from xanthos.calibrate import calibrate_abcd as ref_cal  # noqa: E402
+from xanthos.utils.general import set_month_arrays as ref_month_arrays  # noqa: E402
+
+from xanthos_amd import synth  # noqa: E402
+
+
+def bag(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+# ----------------------------------------------------------------------------------------------------- PM
+def golden_pm():
+    rng = np.random.default_rng(101)
+    ncell, nlcs, y0, y1 = 256, 8, 1994, 1996
+    nm = 12 * (y1 - y0 + 1)
+    lc_years = [1990, 2000, 2005]
+    tas = rng.uniform(-25, 38, (ncell, nm))
+    tmin = tas - rng.uniform(1, 12, (ncell, nm))
+    rhs = np.clip(rng.normal(65, 22, (ncell, nm)), 0, 100)
+    wind = rng.uniform(0.3, 9, (ncell, nm))
+    rsds = rng.uniform(20, 340, (ncell, nm))
+    rlds = rng.uniform(140, 440, (ncell, nm))
+    # crafted humidity tiers incl. exact thresholds, the 99.9999 clip and an unclipped > 100 value
+    tiers = [0.0, 69.9, 70.0, 75.0, 80.0, 85.0, 90.0, 92.0, 95.0, 97.0, 99.9999, 99.99995, 100.0, 103.0]
+    for k, v in enumerate(tiers):
+        rhs[k, :] = v
+        rhs[40 + k, 5] = v
+    tas[20, :] = -1.0          # exactly at the water-ET temperature switch
+    tas[21, :] = -1.5
+    tas[22, :] = -0.5
+    elev = rng.uniform(0, 4500, (ncell, 1))
+    elev[3, 0] = 0.0
+    e = rng.exponential(1.0, (ncell, nlcs, len(lc_years)))
+    lct = 100 * e / e.sum(axis=1, keepdims=True)
+    lct[7] = 0.0               # a cell with no land cover: totpct 0 -> 0.01
+    lct[8, 1:, :] = 0.0        # a single-class cell
+    w = synth.make_world(nrow=24, ncol=48, ncell=300, n_basins=4, nlcs=nlcs, seed=5)   # parameter tables only
+    d = bag(cL=w.cL, beta=w.beta, rslimit=w.rslimit, ae=w.ae, be=w.be, Tminopen=w.Tminopen, Tminclose=w.Tminclose,
+            VPDclose=w.VPDclose, VPDopen=w.VPDopen, RBLmin=w.RBLmin, RBLmax=w.RBLmax, rc=w.rc, emiss=w.emiss,
+            alpha=w.alpha, lai=w.lai, laimax=w.laimax, laimin=w.laimin, elev=elev)
+    # TMIN exactly at the open / close thresholds of class 2; vpd near open/close happens through the rhs tiers
+    tmin[30, :] = w.Tminopen[2]
+    tmin[31, :] = w.Tminclose[2]
+    d.tair_load, d.TMIN_load, d.rhs_load, d.wind_load, d.rsds_load, d.rlds_load = tas, tmin, rhs, wind, rsds, rlds
+    d.tairprev_load = np.zeros_like(tas)
+    d.tairprev_load[1:, :] = tas[:-1, :]
+    d.lct_load = lct
+    inputs = {k: np.array(getattr(d, k)) for k in vars(d)}
+    pet = ref_pm.run_pmpet(d, ncell, nlcs, y0, y1, 0, 6, lc_years)
+    pet_alt = ref_pm.run_pmpet(d, ncell, nlcs, y0, y1, 2, 7, lc_years)     # other water / snow slots
+    np.savez_compressed(os.path.join(HERE, 'pm.npz'), pet=pet, pet_alt=pet_alt, start_year=y0, end_year=y1,
+                        nlcs=nlcs, lc_years=np.array(lc_years), **inputs)
+    print('pm.npz', pet.shape, float(np.nanmin(pet)), float(np.nanmax(pet)))
+
+
+# ----------------------------------------------------------------------------------------------------- ABCD
+def golden_abcd():
+    rng = np.random.default_rng(202)
+    ncell, nb, nm, spin = 300, 6, 60, 36
+    basin_ids = rng.integers(1, nb, ncell)      # basins 1..5
+    basin_ids[123] = 6                          # basin 6: a single cell
+    pet = rng.uniform(0, 220, (ncell, nm))
+    precip = rng.gamma(2.0, 40.0, (ncell, nm))
+    tmin = rng.uniform(-12, 14, (ncell, nm))
+    tmin[5, :] = 0.6
+    tmin[6, :] = 2.5
+    tmin[7, ::2] = 0.6
+    tmin[7, 1::2] = 2.5
+    precip[9, :] = np.nan                       # a missing-data cell
+    precip[10, 41] = np.nan                     # NaN after spin-up
+    precip[11, 7] = np.nan                      # NaN inside spin-up
+    precip[12, :] = 0.0
+    pet[13, :] = 0.0
+    pars = np.stack([rng.uniform(0.9, 0.999, nb), rng.uniform(0.1, 2, nb), rng.uniform(0.01, 0.9, nb),
+                     rng.uniform(0.01, 0.9, nb), rng.uniform(0.1, 0.9, nb)], axis=1)
+    calib = '/tmp/_golden_abcd_pars.npy'
+    np.save(calib, pars)
+    out = {}
+    for tag, t in (('snow', tmin), ('nosnow', None)):
+        _pet, aet, q, sav = ref_abcd.abcd_execute(nb, basin_ids, pet, precip, t, calib, nm, spin, jobs=-1)
+        assert np.array_equal(_pet, pet)
+        out['aet_' + tag], out['q_' + tag], out['sav_' + tag] = aet, q, sav
+    # end-of-spin-up basin means, via the class itself on all cells
+    he = ref_abcd.ABCD(pars[basin_ids - 1], pet, precip, tmin, basin_ids, nm, spin)
+    he.spinup()
+    out['sm0'], out['gw0'] = np.array(he.soil_water_storage0), np.array(he.groundwater_storage0)
+    np.savez_compressed(os.path.join(HERE, 'abcd.npz'), basin_ids=basin_ids, pet=pet, precip=precip, tmin=tmin,
+                        pars=pars, n_basins=nb, n_months=nm, spinup=spin, **out)
+    print('abcd.npz', out['q_snow'].shape, int(np.isnan(out['q_snow']).sum()))
+
+
+# ----------------------------------------------------------------------------------------------------- topology
+def _random_world(nrow, ncol, seed):
+    """Land mask incl. date-line / pole edge cells; random D8 codes incl. -9999, 0 and composite junk codes."""
+    rng = np.random.default_rng(seed)
+    land = rng.random((nrow, ncol)) < 0.55
+    land[0, :6] = True
+    land[-1, -6:] = True
+    land[:, 0] |= rng.random(nrow) < 0.7
+    land[:, -1] |= rng.random(nrow) < 0.7
+    cols, rows = np.nonzero(land.T)             # ids increase down a column, then by column
+    n = len(rows)
+    coords = np.stack([np.arange(1, n + 1), -180 + (cols + .5) * 360 / ncol, -90 + (rows + .5) * 180 / nrow,
+                       cols + 1, rows + 1], axis=1).astype(float)
+    codes = rng.choice([1, 2, 4, 8, 16, 32, 64, 128], n).astype(float)
+    codes[rng.random(n) < 0.05] = -9999.
+    codes[rng.random(n) < 0.05] = 0.
+    return coords, codes
+
+
+def golden_topo():
+    out = {}
+    st = bag(ngridrow=24, ngridcol=48)
+    coords, codes = _random_world(24, 48, 303)
+    w = synth.make_world(nrow=24, ncol=48, ncell=500, n_basins=9, seed=11, row_margin=0, outlet_frac=0.02)
+    for tag, (co, fd) in {'rand': (coords, codes), 'tree': (w.coords, w.flow_dir)}.items():
+        ds = ref_mrtm.downstream(co, fd, st)
+        up = ref_mrtm.upstream(co, ds, st)
+        um = ref_mrtm.upstream_genmatrix(up).tocsr()
+        assert um.has_sorted_indices
+        out.update({tag + '_coords': co, tag + '_flowdir': fd, tag + '_dsid': ds, tag + '_upid': up,
+                    tag + '_um_indptr': um.indptr, tag + '_um_indices': um.indices, tag + '_um_data': um.data})
+        print('topo', tag, len(ds), 'edges', int((um.data > 0).sum()), 'dsid edges', int((ds > 0).sum()))
+    np.savez_compressed(os.path.join(HERE, 'topo.npz'), nrow=24, ncol=48, **out)
+    return out, w
+
+
+# ----------------------------------------------------------------------------------------------------- MRTM
+def golden_mrtm(topo, w):
+    rng = np.random.default_rng(404)
+    st = bag(ngridrow=24, ngridcol=48)
+    out = {}
+    for tag in ('rand', 'tree'):
+        co, fd = topo[tag + '_coords'], topo[tag + '_flowdir']
+        n = len(fd)
+        ds = ref_mrtm.downstream(co, fd, st)
+        um = ref_mrtm.upstream_genmatrix(ref_mrtm.upstream(co, ds, st))
+        L = rng.uniform(25e3, 75e3, n)
+        L[rng.random(n) < 0.1] = 1000.0                  # tauinv*dt > 1: the excess-flow branch fires
+        chv = rng.uniform(0.1, 2.5, n)
+        chv[rng.random(n) < 0.05] = 0.0
+        area = rng.uniform(800, 3100, n)
+        S = rng.uniform(0, 5e7, n)
+        S[rng.random(n) < 0.2] = 0.0
+        out.update({tag + '_L': L, tag + '_chv': chv, tag + '_area': area, tag + '_S0': S})
+        for nday in (28, 29, 30, 31):
+            q = rng.gamma(2.0, 30.0, n)
+            q[rng.random(n) < 0.1] = 0.0
+            S1, favg, F = ref_mrtm.streamrouting(L, S, np.zeros(n), chv, q, area, nday, 10800, um)
+            out.update({'%s_q_%d' % (tag, nday): q, '%s_S_%d' % (tag, nday): S1,
+                        '%s_Favg_%d' % (tag, nday): favg, '%s_F_%d' % (tag, nday): F})
+            S = S1
+        # the Components.calculate_routing month loops on a bare object (components.py:249-296)
+        nm, spin, y0 = 5, 3, 1972                                      # 1972: Feb has 29 days under the %4 rule
+        runoff = rng.gamma(2.0, 30.0, (n, 12))[:, :nm].copy()
+        c = object.__new__(Components)
+        c.s = bag(routing_module='mrtm', routing_spinup=spin, nmonths=nm, ngridrow=24, ngridcol=48)
+        c.data = bag(flow_dist=L, flow_dir=fd, instream_flow=np.zeros(n), str_velocity=chv,
+                     chs_prev=np.zeros(n), coords=co, area=area)
+        c.yr_imth_dys = ref_month_arrays(12, y0, y0)
+        c.routing_timestep_hours = 3 * 3600
+        c.ChStorage = np.zeros((n, nm))
+        c.Avg_ChFlow = np.zeros((n, nm))
+        import xanthos.components as comp_mod
+        comp_mod.routing_mod = ref_mrtm
+        avg = c.calculate_routing(runoff)
+        out.update({tag + '_series_runoff': runoff, tag + '_series_ndays': c.yr_imth_dys[:nm, 2],
+                    tag + '_series_avgchflow': np.array(avg), tag + '_series_chstorage': np.array(c.ChStorage),
+                    tag + '_series_Fend': np.array(c.instream_flow)})
+        print('mrtm', tag, float(avg.max()))
+    np.savez_compressed(os.path.join(HERE, 'mrtm.npz'), series_spinup=3, series_year=1972, **out)
+
+
+# ----------------------------------------------------------------------------------------------------- KGE
+def golden_kge():
+    rng = np.random.default_rng(505)
+    nm, spin = 48, 36
+    out = {'n_months': nm, 'spinup': spin}
+    for b, ncell in enumerate((40, 7)):
+        pet = rng.uniform(0, 200, (ncell, nm))
+        precip = rng.gamma(2.0, 40.0, (ncell, nm))
+        tmin = rng.uniform(-10, 12, (ncell, nm))
+        if b == 0:
+            precip[3, :] = np.nan             # nansum path
+        areas = rng.uniform(900, 3100, ncell)
+        robs = rng.uniform(5, 60, nm)
+        pars = np.stack([rng.uniform(1e-4, 1 - 1e-4, 16), rng.uniform(1e-4, 8 - 1e-4, 16),
+                         rng.uniform(1e-4, 1 - 1e-4, 16), rng.uniform(1e-4, 1 - 1e-4, 16),
+                         rng.uniform(1e-4, 1 - 1e-4, 16)], axis=1)
+        pars[0] = [0.98, 0.4, 0.3, 0.2, 0.5]
+        out.update({'pet_%d' % b: pet, 'precip_%d' % b: precip, 'tmin_%d' % b: tmin, 'areas_%d' % b: areas,
+                    'robs_%d' % b: robs, 'pars_%d' % b: pars})
+        idx = (np.arange(ncell),)
+        for unit in ('km3_per_mth', 'mm_per_mth'):
+            for tag, t, npar in (('snow', tmin, 5), ('nosnow', None, 4)):
+                ed = np.array([ref_cal.objective_kge(p[:npar], ref_cal.basin_runoff, 0, pet, precip, t, nm, spin,
+                                                     unit, areas, robs, idx, pet.shape, None) for p in pars])
+                series = np.array([ref_cal.basin_runoff(p[:npar], 0, pet, precip, t, nm, spin, unit, areas, idx,
+                                                        pet.shape, None) for p in pars])
+                out['ed_%d_%s_%s' % (b, unit, tag)] = ed
+                out['series_%d_%s_%s' % (b, unit, tag)] = series
+        print('kge basin', b, out['ed_%d_km3_per_mth_snow' % b][:3])
+    np.savez_compressed(os.path.join(HERE, 'kge.npz'), **out)
+
+
+if __name__ == '__main__':
+    import warnings
+    warnings.simplefilter('ignore')
+    golden_pm()
+    golden_abcd()
+    topo, w = golden_topo()
+    golden_mrtm(topo, w)
+    golden_kge()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')
