@@ -1,0 +1,176 @@
+/*
+ * xanthos_hip.h -- C-ABI of libxanthos_hip.so: the MI355X (gfx950) implementation of the Xanthos monthly
+ * PET -> runoff -> routing hot path.
+ *
+ * The reference (JGCRI/xanthos v2.4.1) is pure Python/numpy and has no FFI of its own; its "plugin API" for this
+ * path is a set of module-level Python functions that xanthos/components.py calls.  Each entry point below states
+ * the reference function (file:line under /root/reference) whose work it replaces.  The Python stubs that bind
+ * these symbols with ctypes are in xanthos_amd/_hip.py; INTEGRATION.md shows the lines a Xanthos maintainer would
+ * add to pet/penman_monteith.py, runoff/abcd.py and routing/mrtm.py.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, fp64 only.  All 2-D arrays are [ncell, nmonths], C order (month
+ *     fastest) -- exactly the reference's in-memory layout, so uploads/downloads are plain copies.
+ *   - Pointers named d_* are DEVICE pointers (from xh_malloc, or any HIP allocation on the context's device);
+ *     pointers named h_* are HOST pointers (small index/table arrays read during the call).
+ *   - Every function returns XH_OK (0) or an error code; xh_last_error(ctx) gives the message.
+ *   - Kernels are enqueued on the context's own HIP stream and the call returns without waiting; xh_sync,
+ *     xh_memcpy_d2h and xh_timing_get wait for the stream.  Calls on one context must not be concurrent
+ *     (one context per host thread); different contexts are independent.
+ *   - A call never falls back to the CPU: if the device or the code object is unusable it fails.
+ */
+#ifndef XANTHOS_HIP_H
+#define XANTHOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XH_OK 0
+#define XH_ERR_ARG 1     /* bad argument (NULL, size, unsupported value)          */
+#define XH_ERR_HIP 2     /* a HIP runtime call or kernel failed                   */
+#define XH_ERR_LIMIT 3   /* problem exceeds a compiled-in limit (e.g. land classes) */
+#define XH_ERR_DEVICE 4  /* routing kernel reported a device-side fault (spin timeout) */
+
+#define XH_MAX_LCS 32    /* max land-cover classes in xh_pm_pet */
+
+typedef struct xh_ctx xh_ctx;
+typedef struct xh_route_plan xh_route_plan;
+
+/* ------------------------------------------------------------------ context, memory, timing */
+int xh_abi_version(void);                                  /* bumps when a signature changes */
+int xh_device_count(int *n);
+int xh_ctx_create(int device, xh_ctx **out);
+void xh_ctx_destroy(xh_ctx *ctx);
+const char *xh_last_error(const xh_ctx *ctx);              /* ctx may be NULL: last error of a failed xh_ctx_create */
+int xh_device_name(xh_ctx *ctx, char *buf, size_t len);
+
+int xh_malloc(xh_ctx *ctx, size_t bytes, void **d_ptr);
+int xh_free(xh_ctx *ctx, void *d_ptr);
+int xh_memcpy_h2d(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int xh_memcpy_d2h(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* waits for the stream */
+int xh_memcpy_d2d(xh_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+int xh_memset(xh_ctx *ctx, void *d_ptr, int value, size_t bytes);
+int xh_sync(xh_ctx *ctx);
+/* Gather / scatter whole rows of a [nrows_total, ncols] device array by row index (shard packing, samples). */
+int xh_gather_rows(xh_ctx *ctx, const double *d_src, const int64_t *d_rows, int64_t nrows, int64_t ncols,
+                   double *d_dst);
+int xh_scatter_rows(xh_ctx *ctx, const double *d_src, const int64_t *d_rows, int64_t nrows, int64_t ncols,
+                    double *d_dst);
+/* [rows, cols] -> [cols, rows] */
+int xh_transpose(xh_ctx *ctx, const double *d_src, int64_t rows, int64_t cols, double *d_dst);
+
+/* HIP-event timing of the kernels each entry point launches, accumulated per kernel name on the context's stream.
+ * Names: "pm_pet", "abcd_spinup", "abcd_basin_mean", "abcd_sim", "mrtm_route", "mrtm_fallback", "calib_abcd",
+ * "calib_kge".  xh_timing_get waits for the stream, then returns total milliseconds and launch count. */
+int xh_timing_reset(xh_ctx *ctx);
+int xh_timing_enable(xh_ctx *ctx, int on);
+int xh_timing_get(xh_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
+
+/* ------------------------------------------------------------------ Penman-Monteith PET
+ * Replaces pet/penman_monteith.py:run_pmpet (:394-477) with SetData (:17-99), et_veg (:223-334),
+ * et_water (:337-361) and et_snow (:364-377) fused into one kernel over (cell, month).
+ * Host tables are the DataLoader fields of data_load.py:94-117.                                         */
+typedef struct xh_pm_tables {
+    int32_t nlcs;                       /* number of land-cover classes (>= 7: rows 0 and 6 are hard-wired, :361,:377) */
+    const double *cL, *beta, *rslimit, *Tminopen, *Tminclose, *VPDclose, *VPDopen, *RBLmin, *RBLmax, *rc,
+        *emiss;                         /* host, [nlcs] each (gcam_ET_para.csv columns 0-2, 5-12)      */
+    const double *alpha, *lai, *laimin, *laimax; /* host, [nlcs*12] each, row = class, col = month of year */
+} xh_pm_tables;
+
+int xh_pm_pet(xh_ctx *ctx, const xh_pm_tables *h_tab,
+              int64_t ncell, int32_t nmonths,       /* nmonths = 12 * number of years                    */
+              int32_t start_year,
+              int32_t n_lc_years, const int32_t *h_lc_years, /* years of the land-cover slices (pm_lc_years) */
+              int32_t water_idx, int32_t snow_idx,
+              const double *d_tas, const double *d_tmin, const double *d_rhs, const double *d_wind,
+              const double *d_rsds, const double *d_rlds,
+              const double *d_tairprev,             /* [ncell,nmonths] or NULL: NULL = tas of the previous CELL,
+                                                       zeros for cell 0 (data_load.py:128-129)            */
+              const double *d_lct,                  /* [ncell, nlcs, n_lc_years]                          */
+              const double *d_elev,                 /* [ncell]                                            */
+              double *d_pet);                       /* out [ncell, nmonths]                               */
+
+/* ------------------------------------------------------------------ ABCD runoff
+ * Replaces runoff/abcd.py:abcd_execute / abcd_parallel / _run_basins (:314-422) and the ABCD class
+ * (:41-311): spin-up, per-basin December means (set_vals :246-282), simulation.
+ *   h_basin_index[ncell] : dense 0-based group id used for the spin-up means (cells of one basin share it)
+ *   h_par_index[ncell]   : row of d_pars used by each cell (basin row for abcd_execute; cell row for ABCD(pars))
+ *   d_pars[npar_rows,5]  : a, b (x1000 applied inside, abcd.py:48), c, d, m
+ *   d_tmin may be NULL   : no snow component (abcd.py:44,51,144-146)
+ * Outputs may individually be NULL.  spinup < 25 is rejected like the reference's IndexError (:258-266).  */
+int xh_abcd(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spinup, int32_t n_groups,
+            const int32_t *h_basin_index, const int32_t *h_par_index, int64_t npar_rows, const double *d_pars,
+            const double *d_pet, const double *d_precip, const double *d_tmin,
+            double *d_aet, double *d_q, double *d_sav,
+            double *d_sm0, double *d_gw0);          /* optional out [n_groups]: post-spin-up initial state */
+
+/* ------------------------------------------------------------------ MRTM routing
+ * xh_route_plan_create replaces the per-call topology work of routing/mrtm.py:upstream_genmatrix (:194-230):
+ * it takes UM = UP - I as CSR (row i = sorted columns j with +1 for "j flows into i" and -1 on the diagonal),
+ * finds the independent river networks and lays them out for the LDS-resident kernel.  Row order of the
+ * entries is preserved so sums are accumulated exactly as scipy's csr mat-vec does.                       */
+int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h_indptr, const int32_t *h_indices,
+                         const int8_t *h_sign, xh_route_plan **out);
+void xh_route_plan_destroy(xh_route_plan *plan);
+/* info[0]=networks, [1]=largest network (cells), [2]=LDS units, [3]=cells routed by the global fallback,
+ * [4]=largest unit (cells), [5]=padded slots */
+int xh_route_plan_info(const xh_route_plan *plan, int64_t info[8]);
+
+/* Host-side topology (integer work, no device needed).
+ * xh_mrtm_downstream replaces routing/mrtm.py:downstream + make_flowdirgrid (:85-120, :233-258): D8 decode, the
+ * longitude wrap quirk ((col+1) mod ncol for off-grid columns), off-grid rows -> self, ocean/self targets -> -1.
+ *   h_ilon / h_ilat [ncell]: 1-based column / row of each cell (coords[:,3], coords[:,4]); h_id [ncell]: 1-based
+ *   cell ids (coords[:,0]); h_flowdir [ncell]: D8 codes (-9999 = none).  h_dsid out [ncell], 1-based or -1.
+ * xh_mrtm_upstream replaces routing/mrtm.py:upstream (:123-191): for each cell its 8 in-grid neighbours (no
+ * date-line wrap), those draining into it first, then the count.  h_upid out [ncell, 9].
+ * xh_mrtm_um_csr replaces upstream_genmatrix (:194-230): UM = UP - I as CSR with ascending columns;
+ *   h_indptr [ncell+1], h_indices / h_sign sized ncell + sum(upid[:,8]).                                      */
+int xh_mrtm_downstream(int64_t ncell, int32_t nrow, int32_t ncol, const int64_t *h_id, const int32_t *h_ilon,
+                       const int32_t *h_ilat, const double *h_flowdir, int64_t *h_dsid);
+int xh_mrtm_upstream(int64_t ncell, int32_t nrow, int32_t ncol, const int64_t *h_id, const int32_t *h_ilon,
+                     const int32_t *h_ilat, const int64_t *h_dsid, int64_t *h_upid);
+int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int32_t *h_indices, int8_t *h_sign);
+
+/* xh_route_series replaces routing/mrtm.py:streamrouting (:16-82) and the month loops of
+ * components.py:calculate_routing (:273-294): spin-up over months [0, spinup_months) then all nmonths,
+ * nt = int(nday*86400/dt) explicit-Euler sub-steps per month, all inside one persistent kernel.
+ *   h_ndays[nmonths]; d_runoff [ncell, nmonths] (mm/month); d_flow_dist, d_velocity, d_area [ncell]
+ *   d_S0 [ncell] or NULL (zeros); outputs d_chstorage / d_avgchflow [ncell, nmonths] (either may be NULL),
+ *   d_S_end / d_F_end [ncell] optional.  streamrouting() itself is the nmonths = 1, spinup = 0 case.
+ * flags: XH_ROUTE_ATOMIC routes with global fp64 atomic scatter-adds (non bit-reproducible variant).       */
+#define XH_ROUTE_DEFAULT 0
+#define XH_ROUTE_FORCE_FALLBACK 1   /* route every network with the global-memory kernels (testing)        */
+#define XH_ROUTE_ATOMIC 2           /* with the fallback: scatter-add outflow with global_atomic_add_f64   */
+int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
+                    const int32_t *h_ndays, double dt,
+                    const double *d_flow_dist, const double *d_velocity, const double *d_area,
+                    const double *d_runoff, const double *d_S0,
+                    double *d_chstorage, double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags);
+
+/* ------------------------------------------------------------------ calibration objective
+ * Replaces calibrate/calibrate_abcd.py:basin_runoff + objective_kge (:134-213) for set_calibrate = 0, batched
+ * over a population: every member runs ABCD on the basin's cells, the simulated runoff is summed over cells per
+ * month (nansum; x area x 1e-6 if d_area != NULL) and scored against h_obs with ED = 1 - KGE.
+ *   d_pet_t / d_precip_t / d_tmin_t : [nmonths, ncell_b] (cell fastest; use xh_transpose), d_tmin_t may be NULL
+ *   h_pars [nmembers, npar] with npar = 5 (a,b,c,d,m) or 4 (no snow)
+ *   h_ed [nmembers] out; h_series [nmembers, nmonths] optional out                                          */
+int xh_calib_objective(xh_ctx *ctx, int64_t ncell_b, int32_t nmonths, int32_t spinup, int32_t nmembers,
+                       int32_t npar, const double *h_pars, const double *d_pet_t, const double *d_precip_t,
+                       const double *d_tmin_t, const double *d_area, const double *h_obs, double *h_ed,
+                       double *h_series);
+
+/* ------------------------------------------------------------------ bench support (not on the hot path)
+ * Fills the eight forcing arrays of the synthetic benchmark world on the device (same distributions as
+ * xanthos_amd/synth.py:make_forcing); d_lat [ncell] degrees.                                              */
+int xh_synth_forcing(xh_ctx *ctx, uint64_t seed, int64_t ncell, int32_t nmonths, const double *d_lat,
+                     double *d_tas, double *d_tmin, double *d_rhs, double *d_wind, double *d_rsds,
+                     double *d_rlds, double *d_precip, double *d_abcd_tmin);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XANTHOS_HIP_H */

@@ -1,0 +1,186 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against (1) the golden vectors generated from
+the real reference and (2) the numpy oracle on seeded synthetic inputs.
+
+Tolerances: routing is bit-exact (same operation order as numpy/scipy, -ffp-contract=off) for identical runoff;
+PM and ABCD are fp64 within 1e-9 relative (only exp/log/sqrt/pow implementations differ, a few ulp) -- far
+inside the 1e-6 the north star states.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def close(x, ref, rtol=RTOL, atol=1e-9):
+    x, ref = np.asarray(x), np.asarray(ref)
+    assert x.shape == ref.shape
+    assert np.array_equal(np.isnan(x), np.isnan(ref)), 'NaN pattern differs'
+    m = ~np.isnan(ref)
+    err = np.abs(x[m] - ref[m]) - (atol + rtol * np.abs(ref[m]))
+    assert (err <= 0).all(), 'max excess {:.3e}'.format(err.max())
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from xanthos_amd import _hip
+    assert _hip.device_count() > 0, 'no GPU visible'
+    return _hip
+
+
+PM_FIELDS = ('cL', 'beta', 'rslimit', 'ae', 'be', 'Tminopen', 'Tminclose', 'VPDclose', 'VPDopen', 'RBLmin', 'RBLmax',
+             'rc', 'emiss', 'alpha', 'lai', 'laimax', 'laimin', 'elev', 'tair_load', 'TMIN_load', 'rhs_load',
+             'wind_load', 'rsds_load', 'rlds_load', 'tairprev_load', 'lct_load')
+
+
+def test_pm_golden(hip, golden):
+    from xanthos_amd.pet import penman_monteith as pm
+    g = golden('pm')
+    d = SimpleNamespace(**{k: g[k] for k in PM_FIELDS})
+    lcy = [int(v) for v in g['lc_years']]
+    n = d.tair_load.shape[0]
+    pet = pm.run_pmpet(d, n, int(g['nlcs']), int(g['start_year']), int(g['end_year']), 0, 6, lcy)
+    close(pet, g['pet'])
+    pet = pm.run_pmpet(d, n, int(g['nlcs']), int(g['start_year']), int(g['end_year']), 2, 7, lcy)
+    close(pet, g['pet_alt'])
+    with pytest.raises(IndexError):
+        pm.run_pmpet(d, n, 6, int(g['start_year']), int(g['end_year']), 0, 5, lcy)
+
+
+def test_pm_synthetic_vs_oracle(hip):
+    from oracle import pm as o_pm
+    from xanthos_amd import synth
+    from xanthos_amd.pet import penman_monteith as pm
+    w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=12, seed=77)
+    f = synth.make_forcing(w, 120)                       # 1961-1970: leap years + land-cover switch
+    d = synth.data_bag(w, f)
+    ref = o_pm.run_pmpet(d, w.ncell, w.nlcs, 1961, 1970, 0, 6, w.lc_years)
+    got = pm.run_pmpet(d, w.ncell, w.nlcs, 1961, 1970, 0, 6, w.lc_years)
+    close(got, ref)
+    # tairprev = NULL path: the library derives it from the previous cell itself
+    ctx = hip.get_context()
+    up = ctx.upload
+    bufs = [up(f['tas']), up(f['tmin']), up(f['rhs']), up(f['wind']), up(f['rsds']), up(f['rlds'])]
+    d_pet = pm.run_pmpet_device(ctx, pm.tables_from(d, w.nlcs), w.ncell, 1961, 1970, 0, 6, w.lc_years, *bufs, None,
+                                up(w.lct), up(w.elev.reshape(-1)))
+    assert np.array_equal(d_pet.download(), got)
+
+
+@pytest.mark.parametrize('tag', ['snow', 'nosnow'])
+def test_abcd_golden(hip, golden, tag):
+    from xanthos_amd.runoff import abcd
+    g = golden('abcd')
+    tmin = g['tmin'] if tag == 'snow' else None
+    pet, aet, q, sav = abcd.abcd_execute(int(g['n_basins']), g['basin_ids'], g['pet'], g['precip'], tmin, g['pars'],
+                                         int(g['n_months']), int(g['spinup']), jobs=-1)
+    assert np.array_equal(pet, g['pet'])
+    close(aet, g['aet_' + tag])
+    close(q, g['q_' + tag])
+    close(sav, g['sav_' + tag])
+
+
+def test_abcd_class_and_errors(hip, golden):
+    from xanthos_amd.runoff import abcd
+    g = golden('abcd')
+    bid = g['basin_ids']
+    he = abcd.ABCD(g['pars'][bid - 1], g['pet'], g['precip'], g['tmin'], bid, int(g['n_months']), int(g['spinup']))
+    he.emulate()
+    close(he.rsim.T, g['q_snow'])
+    close(he.soil_water_storage.T, g['sav_snow'])
+    with pytest.raises(IndexError):
+        abcd.ABCD(g['pars'][bid - 1], g['pet'], g['precip'], g['tmin'], bid, 60, 24).emulate()
+    # odd spin-up length (register-tile tail path)
+    from oracle import abcd as o_abcd
+    ref = o_abcd.ABCD(g['pars'][bid - 1], g['pet'], g['precip'], g['tmin'], bid, 60, 39)
+    ref.emulate()
+    he = abcd.ABCD(g['pars'][bid - 1], g['pet'], g['precip'], g['tmin'], bid, 60, 39)
+    he.emulate()
+    close(he.rsim, ref.rsim)
+
+
+def _um(t, tag):
+    from xanthos_amd.routing import mrtm
+    return mrtm.UpstreamMatrix(t[tag + '_um_indptr'], t[tag + '_um_indices'], t[tag + '_um_data'])
+
+
+@pytest.mark.parametrize('flags', [0, 1])
+@pytest.mark.parametrize('tag', ['rand', 'tree'])
+def test_streamrouting_golden_bit_exact(hip, golden, tag, flags):
+    from xanthos_amd.routing import mrtm
+    g, t = golden('mrtm'), golden('topo')
+    um = _um(t, tag)
+    S = g[tag + '_S0']
+    n = len(S)
+    for nday in (28, 29, 30, 31):
+        S, favg, F = mrtm.streamrouting(g[tag + '_L'], S, np.zeros(n), g[tag + '_chv'], g['%s_q_%d' % (tag, nday)],
+                                        g[tag + '_area'], nday, 10800, um, flags=flags)
+        assert np.array_equal(S, g['%s_S_%d' % (tag, nday)])
+        assert np.array_equal(favg, g['%s_Favg_%d' % (tag, nday)])
+        assert np.array_equal(F, g['%s_F_%d' % (tag, nday)])
+
+
+@pytest.mark.parametrize('tag', ['rand', 'tree'])
+def test_route_series_golden_bit_exact(hip, golden, tag):
+    from xanthos_amd.routing import mrtm
+    g, t = golden('mrtm'), golden('topo')
+    chs, avg, fend = mrtm.route_series(_um(t, tag), g[tag + '_L'], g[tag + '_chv'], g[tag + '_area'],
+                                       g[tag + '_series_runoff'], g[tag + '_series_ndays'], int(g['series_spinup']))
+    assert np.array_equal(chs, g[tag + '_series_chstorage'])
+    assert np.array_equal(avg, g[tag + '_series_avgchflow'])
+    assert np.array_equal(fend, g[tag + '_series_Fend'])
+
+
+def test_route_series_atomic_variant_close(hip, golden):
+    """global_atomic_add_f64 scatter variant: same physics, summation order not reproducible -> tolerance."""
+    from xanthos_amd.routing import mrtm
+    g, t = golden('mrtm'), golden('topo')
+    tag = 'tree'
+    chs, avg, _ = mrtm.route_series(_um(t, tag), g[tag + '_L'], g[tag + '_chv'], g[tag + '_area'],
+                                    g[tag + '_series_runoff'], g[tag + '_series_ndays'], int(g['series_spinup']),
+                                    flags=3)
+    close(avg, g[tag + '_series_avgchflow'], rtol=1e-9, atol=1e-6)
+    close(chs, g[tag + '_series_chstorage'], rtol=1e-9, atol=1e-3)
+
+
+def test_route_synthetic_world_vs_oracle(hip):
+    """A 3000-cell world with multi-wave networks and bins of small ones, 14 months incl. spin-up: bit-exact."""
+    from types import SimpleNamespace as NS
+    from oracle import months as o_months
+    from oracle import mrtm as o_mrtm
+    from xanthos_amd import synth
+    from xanthos_amd.routing import mrtm
+    w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=5, seed=3, outlet_frac=0.02)
+    st = NS(ngridrow=w.nrow, ngridcol=w.ncol)
+    ds = mrtm.downstream(w.coords, w.flow_dir, st)
+    um = mrtm.upstream_genmatrix(mrtm.upstream(w.coords, ds, st))
+    info = um.plan(hip.get_context()).info()
+    assert info['largest_network'] > 256 and info['fallback_cells'] == 0 and info['units'] < info['networks']
+    rng = np.random.default_rng(9)
+    runoff = rng.gamma(2.0, 30.0, (w.ncell, 12))
+    runoff[rng.random(w.ncell) < 0.01] = np.nan          # NaN runoff (NaN precip cells) must propagate identically
+    ndays = o_months.set_month_arrays(12, 1972, 1972)[:, 2]
+    ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize('basin', [0, 1])
+@pytest.mark.parametrize('unit', ['km3_per_mth', 'mm_per_mth'])
+@pytest.mark.parametrize('tag', ['snow', 'nosnow'])
+def test_calibration_objective_golden(hip, golden, basin, unit, tag):
+    g = golden('kge')
+    b = str(basin)
+    ctx = hip.get_context()
+    nm, spin = int(g['n_months']), int(g['spinup'])
+    npar = 5 if tag == 'snow' else 4
+    tr = lambda a: ctx.upload(np.ascontiguousarray(a.T))
+    d_tmin = tr(g['tmin_' + b]) if tag == 'snow' else None
+    d_area = ctx.upload(g['areas_' + b]) if unit == 'km3_per_mth' else None
+    ed, series = ctx.calib_objective(g['pet_' + b].shape[0], nm, spin, g['pars_' + b][:, :npar], tr(g['pet_' + b]),
+                                     tr(g['precip_' + b]), d_tmin, d_area, g['robs_' + b], want_series=True)
+    close(series, g['series_%s_%s_%s' % (b, unit, tag)], rtol=1e-9, atol=1e-12)
+    close(ed, g['ed_%s_%s_%s' % (b, unit, tag)], rtol=1e-9, atol=1e-12)

@@ -1,0 +1,379 @@
+"""ctypes binding of libxanthos_hip.so (include/xanthos_hip.h).
+
+This is the only place the shared library is loaded.  There is NO CPU fallback: if the library is missing, or no
+MI355X is visible, the calls raise :class:`HipUnavailable` -- the product path never routes through numpy.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_int, c_int8, c_int32, c_int64, c_size_t, \
+    c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libxanthos_hip.so')
+
+XH_ROUTE_DEFAULT, XH_ROUTE_FORCE_FALLBACK, XH_ROUTE_ATOMIC = 0, 1, 2
+
+
+class HipUnavailable(RuntimeError):
+    """The HIP library or device is not usable; nothing falls back to the CPU."""
+
+
+class HipError(RuntimeError):
+    """A libxanthos_hip call returned an error code."""
+
+
+class PmTables(Structure):
+    _fields_ = [('nlcs', c_int32)] + [(n, POINTER(c_double)) for n in (
+        'cL', 'beta', 'rslimit', 'Tminopen', 'Tminclose', 'VPDclose', 'VPDopen', 'RBLmin', 'RBLmax', 'rc', 'emiss',
+        'alpha', 'lai', 'laimin', 'laimax')]
+
+
+_P = c_void_p
+# name -> (restype, argtypes); mirrors include/xanthos_hip.h one to one
+SIGNATURES = {
+    'xh_abi_version': (c_int, []),
+    'xh_device_count': (c_int, [POINTER(c_int)]),
+    'xh_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
+    'xh_ctx_destroy': (None, [_P]),
+    'xh_last_error': (c_char_p, [_P]),
+    'xh_device_name': (c_int, [_P, ctypes.c_char_p, c_size_t]),
+    'xh_malloc': (c_int, [_P, c_size_t, POINTER(c_void_p)]),
+    'xh_free': (c_int, [_P, _P]),
+    'xh_memcpy_h2d': (c_int, [_P, _P, _P, c_size_t]),
+    'xh_memcpy_d2h': (c_int, [_P, _P, _P, c_size_t]),
+    'xh_memcpy_d2d': (c_int, [_P, _P, _P, c_size_t]),
+    'xh_memset': (c_int, [_P, _P, c_int, c_size_t]),
+    'xh_sync': (c_int, [_P]),
+    'xh_gather_rows': (c_int, [_P, _P, _P, c_int64, c_int64, _P]),
+    'xh_scatter_rows': (c_int, [_P, _P, _P, c_int64, c_int64, _P]),
+    'xh_transpose': (c_int, [_P, _P, c_int64, c_int64, _P]),
+    'xh_timing_reset': (c_int, [_P]),
+    'xh_timing_enable': (c_int, [_P, c_int]),
+    'xh_timing_get': (c_int, [_P, c_char_p, POINTER(c_double), POINTER(c_int64)]),
+    'xh_pm_pet': (c_int, [_P, POINTER(PmTables), c_int64, c_int32, c_int32, c_int32, _P, c_int32, c_int32,
+                          _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'xh_abcd': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'xh_route_plan_create': (c_int, [_P, c_int64, _P, _P, _P, POINTER(c_void_p)]),
+    'xh_route_plan_destroy': (None, [_P]),
+    'xh_route_plan_info': (c_int, [_P, POINTER(c_int64)]),
+    'xh_mrtm_downstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    'xh_mrtm_upstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    'xh_mrtm_um_csr': (c_int, [c_int64, _P, _P, _P, _P]),
+    'xh_route_series': (c_int, [_P, _P, c_int32, c_int32, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32]),
+    'xh_calib_objective': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'xh_synth_forcing': (c_int, [_P, c_uint64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libxanthos_hip.so (once) and declare every signature. Raises HipUnavailable if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise HipUnavailable(
+                '{} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` or '
+                '`make -C xanthos_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.'.format(LIB_PATH))
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as exc:
+            raise HipUnavailable('cannot load {}: {}'.format(LIB_PATH, exc))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _host_ptr(arr):
+    return arr.ctypes.data_as(c_void_p)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class DeviceArray:
+    """A float64 (or raw) buffer in HBM owned by a Context."""
+
+    def __init__(self, ctx, shape, dtype=np.float64):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = c_void_p()
+        ctx._check(lib().xh_malloc(ctx.handle, self.nbytes, byref(p)))
+        self.ptr = p.value
+        ctx._live.add(self)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.nbytes != self.nbytes:
+            raise ValueError('size mismatch: host {} vs device {}'.format(host.shape, self.shape))
+        self.ctx._check(lib().xh_memcpy_h2d(self.ctx.handle, self.ptr, _host_ptr(host), self.nbytes))
+        return self
+
+    def download(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes != self.nbytes or not out.flags.c_contiguous:
+            raise ValueError('bad output buffer')
+        self.ctx._check(lib().xh_memcpy_d2h(self.ctx.handle, _host_ptr(out), self.ptr, self.nbytes))
+        return out
+
+    def zero(self):
+        self.ctx._check(lib().xh_memset(self.ctx.handle, self.ptr, 0, self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr is not None and self.ctx.handle is not None:
+            lib().xh_free(self.ctx.handle, self.ptr)
+            self.ctx._live.discard(self)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _dptr(x):
+    """Device pointer of a DeviceArray / raw int / None."""
+    if x is None:
+        return None
+    if isinstance(x, DeviceArray):
+        return x.ptr
+    return int(x)
+
+
+class Context:
+    """One HIP device + stream (xh_ctx). Not thread-safe; use one per host thread."""
+
+    def __init__(self, device=0):
+        L = lib()
+        h = c_void_p()
+        rc = L.xh_ctx_create(int(device), byref(h))
+        if rc != 0:
+            msg = L.xh_last_error(None)
+            raise HipUnavailable('xh_ctx_create(device={}) failed: {}. There is no CPU fallback.'.format(
+                device, msg.decode() if msg else rc))
+        self.handle = h.value
+        self.device = int(device)
+        self._live = set()
+
+    # ---- plumbing
+    def _check(self, rc):
+        if rc != 0:
+            msg = lib().xh_last_error(self.handle)
+            raise HipError('libxanthos_hip error {}: {}'.format(rc, msg.decode() if msg else ''))
+
+    def name(self):
+        buf = ctypes.create_string_buffer(256)
+        self._check(lib().xh_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def close(self):
+        if self.handle is not None:
+            for a in list(self._live):
+                a.free()
+            lib().xh_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(lib().xh_sync(self.handle))
+
+    def empty(self, shape, dtype=np.float64):
+        return DeviceArray(self, shape, dtype)
+
+    def upload(self, host, dtype=np.float64):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        return DeviceArray(self, host.shape, dtype).upload(host)
+
+    def timing_reset(self):
+        self._check(lib().xh_timing_reset(self.handle))
+
+    def timing(self, name):
+        ms, n = c_double(), c_int64()
+        self._check(lib().xh_timing_get(self.handle, name.encode(), byref(ms), byref(n)))
+        return ms.value, n.value
+
+    def gather_rows(self, src, rows_dev, nrows, ncols, dst):
+        self._check(lib().xh_gather_rows(self.handle, _dptr(src), _dptr(rows_dev), nrows, ncols, _dptr(dst)))
+
+    def scatter_rows(self, src, rows_dev, nrows, ncols, dst):
+        self._check(lib().xh_scatter_rows(self.handle, _dptr(src), _dptr(rows_dev), nrows, ncols, _dptr(dst)))
+
+    def transpose(self, src, rows, cols, dst):
+        self._check(lib().xh_transpose(self.handle, _dptr(src), rows, cols, _dptr(dst)))
+
+    # ---- Penman-Monteith
+    def pm_pet(self, tables, ncell, nmonths, start_year, lc_years, water_idx, snow_idx, tas, tmin, rhs, wind, rsds,
+               rlds, tairprev, lct, elev, pet):
+        """tables: dict of host arrays (cL ... laimax); the rest device arrays / pointers."""
+        keep = []
+        t = PmTables()
+        t.nlcs = int(np.asarray(tables['cL']).shape[0])
+        for name, _ in PmTables._fields_[1:]:
+            a = as_f64(tables[name]).ravel()
+            want = t.nlcs * (12 if name in ('alpha', 'lai', 'laimin', 'laimax') else 1)
+            if a.size != want:
+                raise ValueError('PM table {} has {} values, expected {}'.format(name, a.size, want))
+            keep.append(a)
+            setattr(t, name, a.ctypes.data_as(POINTER(c_double)))
+        lcy = np.ascontiguousarray(lc_years, dtype=np.int32)
+        self._check(lib().xh_pm_pet(self.handle, byref(t), ncell, nmonths, start_year, len(lcy), _host_ptr(lcy),
+                                    water_idx, snow_idx, _dptr(tas), _dptr(tmin), _dptr(rhs), _dptr(wind),
+                                    _dptr(rsds), _dptr(rlds), _dptr(tairprev), _dptr(lct), _dptr(elev), _dptr(pet)))
+
+    # ---- ABCD
+    def abcd(self, ncell, nmonths, spinup, n_groups, basin_index, par_index, npar_rows, pars, pet, precip, tmin,
+             aet, q, sav, sm0=None, gw0=None):
+        bi = np.ascontiguousarray(basin_index, dtype=np.int32)
+        pi = np.ascontiguousarray(par_index, dtype=np.int32)
+        self._check(lib().xh_abcd(self.handle, ncell, nmonths, spinup, n_groups, _host_ptr(bi), _host_ptr(pi),
+                                  npar_rows, _dptr(pars), _dptr(pet), _dptr(precip), _dptr(tmin), _dptr(aet),
+                                  _dptr(q), _dptr(sav), _dptr(sm0), _dptr(gw0)))
+
+    # ---- MRTM
+    def route_plan(self, indptr, indices, sign):
+        return RoutePlan(self, indptr, indices, sign)
+
+    def route_series(self, plan, nmonths, spinup_months, ndays, dt, flow_dist, velocity, area, runoff, S0, chs, avg,
+                     S_end=None, F_end=None, flags=XH_ROUTE_DEFAULT):
+        nd = np.ascontiguousarray(ndays, dtype=np.int32)
+        if nd.size != nmonths:
+            raise ValueError('ndays must have nmonths entries')
+        self._check(lib().xh_route_series(self.handle, plan.handle, nmonths, spinup_months, _host_ptr(nd), float(dt),
+                                          _dptr(flow_dist), _dptr(velocity), _dptr(area), _dptr(runoff), _dptr(S0),
+                                          _dptr(chs), _dptr(avg), _dptr(S_end), _dptr(F_end), int(flags)))
+
+    # ---- calibration objective
+    def calib_objective(self, ncell_b, nmonths, spinup, pars, pet_t, precip_t, tmin_t, area, obs, want_series=False):
+        pars = as_f64(pars)
+        nmem, npar = pars.shape
+        obs = as_f64(obs)
+        if obs.size != nmonths:
+            raise ValueError('obs must have nmonths entries')
+        ed = np.empty(nmem)
+        series = np.empty((nmem, nmonths)) if want_series else None
+        self._check(lib().xh_calib_objective(self.handle, ncell_b, nmonths, spinup, nmem, npar, _host_ptr(pars),
+                                             _dptr(pet_t), _dptr(precip_t), _dptr(tmin_t), _dptr(area),
+                                             _host_ptr(obs), _host_ptr(ed),
+                                             _host_ptr(series) if want_series else None))
+        return (ed, series) if want_series else ed
+
+    # ---- bench support
+    def synth_forcing(self, seed, ncell, nmonths, lat, out):
+        """out: dict name -> DeviceArray for synth.FORCING_NAMES."""
+        self._check(lib().xh_synth_forcing(self.handle, int(seed), ncell, nmonths, _dptr(lat), _dptr(out['tas']),
+                                           _dptr(out['tmin']), _dptr(out['rhs']), _dptr(out['wind']),
+                                           _dptr(out['rsds']), _dptr(out['rlds']), _dptr(out['precip']),
+                                           _dptr(out['abcd_tmin'])))
+
+
+class RoutePlan:
+    """Device-side routing layout for one UM matrix (xh_route_plan)."""
+
+    def __init__(self, ctx, indptr, indices, sign):
+        self.ctx = ctx
+        ip = np.ascontiguousarray(indptr, dtype=np.int64)
+        ix = np.ascontiguousarray(indices, dtype=np.int32)
+        sg = np.ascontiguousarray(sign, dtype=np.int8)
+        self.ncell = ip.size - 1
+        h = c_void_p()
+        ctx._check(lib().xh_route_plan_create(ctx.handle, self.ncell, _host_ptr(ip), _host_ptr(ix), _host_ptr(sg),
+                                              byref(h)))
+        self.handle = h.value
+
+    def info(self):
+        arr = (c_int64 * 8)()
+        self.ctx._check(lib().xh_route_plan_info(self.handle, arr))
+        keys = ('networks', 'largest_network', 'units', 'fallback_cells', 'largest_unit', 'slots', 'single_downstream')
+        return dict(zip(keys, list(arr)[:7]))
+
+    def close(self):
+        if self.handle is not None and self.ctx.handle is not None:
+            lib().xh_route_plan_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- host-only topology helpers (no device needed)
+def _topo_args(coords):
+    coords = np.asarray(coords)
+    ids = np.ascontiguousarray(coords[:, 0], dtype=np.int64)
+    ilon = np.ascontiguousarray(coords[:, 3], dtype=np.int32)
+    ilat = np.ascontiguousarray(coords[:, 4], dtype=np.int32)
+    return ids, ilon, ilat
+
+
+def _check_host(rc):
+    if rc != 0:
+        msg = lib().xh_last_error(None)
+        raise HipError('libxanthos_hip error {}: {}'.format(rc, msg.decode() if msg else ''))
+
+
+def mrtm_downstream(coords, flowdir, nrow, ncol):
+    ids, ilon, ilat = _topo_args(coords)
+    fd = as_f64(flowdir)
+    out = np.empty(ids.size, dtype=np.int64)
+    _check_host(lib().xh_mrtm_downstream(ids.size, nrow, ncol, _host_ptr(ids), _host_ptr(ilon), _host_ptr(ilat),
+                                         _host_ptr(fd), _host_ptr(out)))
+    return out
+
+
+def mrtm_upstream(coords, dsid, nrow, ncol):
+    ids, ilon, ilat = _topo_args(coords)
+    ds = np.ascontiguousarray(dsid, dtype=np.int64)
+    out = np.empty((ids.size, 9), dtype=np.int64)
+    _check_host(lib().xh_mrtm_upstream(ids.size, nrow, ncol, _host_ptr(ids), _host_ptr(ilon), _host_ptr(ilat),
+                                       _host_ptr(ds), _host_ptr(out)))
+    return out
+
+
+def mrtm_um_csr(upid):
+    up = np.ascontiguousarray(upid, dtype=np.int64)
+    n = up.shape[0]
+    nnz = n + int(up[:, 8].sum())
+    indptr = np.empty(n + 1, dtype=np.int64)
+    indices = np.empty(nnz, dtype=np.int32)
+    sign = np.empty(nnz, dtype=np.int8)
+    _check_host(lib().xh_mrtm_um_csr(n, _host_ptr(up), _host_ptr(indptr), _host_ptr(indices), _host_ptr(sign)))
+    return indptr, indices, sign
+
+
+_contexts = {}
+
+
+def get_context(device=0):
+    """Process-wide context per device."""
+    ctx = _contexts.get(device)
+    if ctx is None or ctx.handle is None:
+        ctx = _contexts[device] = Context(device)
+    return ctx
+
+
+def device_count():
+    n = c_int(0)
+    lib().xh_device_count(byref(n))
+    return n.value

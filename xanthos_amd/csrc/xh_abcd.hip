@@ -1,0 +1,244 @@
+// ABCD(+snow) monthly water balance on gfx950.
+//
+// Replaces xanthos/runoff/abcd.py: ABCD.spinup / set_vals / simulate (:246-311), abcd_dist (:171-228),
+// set_rain_and_snow (:141-169) and the basin-chunk driver _run_basins / abcd_parallel / abcd_execute (:314-422).
+//
+// Three launches:
+//   k_abcd<SPINUP>      one thread per cell marches the first `spinup` months from (SM, GW) = (100, 500) and keeps
+//                       soil moisture / groundwater of the last three Decembers (rows -1, -13, -25; :255-259)
+//   k_abcd_basin_mean   one workgroup per basin: nan-mean over the basin's cells per December, mean of the three
+//                       (fixed-order tree reduction in LDS => bitwise reproducible)
+//   k_abcd<SIM>         one thread per cell marches all months from the basin means and writes AET, Q, Sav
+//
+// Memory: arrays stay in the reference layout [ncell, nmonths] (month fastest).  A thread walks its own row in
+// tiles of TM months: 16-byte loads of the next tile are issued before the current tile is computed (software
+// prefetch in registers), results leave as 16-byte stores.  State (snowpack, soil moisture, groundwater) lives in
+// registers for the whole march.  Algorithmic HBM bytes per simulated cell-month: 24 read + 24 written
+// (+ 24 x spinup/nmonths for the spin-up pass) = 52.8 B at spinup 120 / 600 months.
+#include <algorithm>
+#include <cmath>
+
+#include "xh_abcd_dev.h"
+#include "xh_common.h"
+
+namespace {
+
+constexpr int TM = 4;           // months per register tile (rows are 16-B aligned because nmonths is even)
+
+using namespace xh_abcd_dev;
+
+struct Tile {
+    double pet[TM], pr[TM], tn[TM];
+};
+
+__device__ __forceinline__ void load_tile(Tile &t, const double *__restrict__ pet, const double *__restrict__ pr,
+                                          const double *__restrict__ tn, int64_t off) {
+#pragma unroll
+    for (int j = 0; j < TM; j += 2) {
+        const double2 a = *reinterpret_cast<const double2 *>(pet + off + j);
+        const double2 b = *reinterpret_cast<const double2 *>(pr + off + j);
+        t.pet[j] = a.x, t.pet[j + 1] = a.y;
+        t.pr[j] = b.x, t.pr[j + 1] = b.y;
+        if (tn) {
+            const double2 c = *reinterpret_cast<const double2 *>(tn + off + j);
+            t.tn[j] = c.x, t.tn[j + 1] = c.y;
+        } else {
+            t.tn[j] = 0.0, t.tn[j + 1] = 0.0;
+        }
+    }
+}
+
+// SPINUP = true : march months [0, nsteps) without output, record the Decembers in dec[6][ncell]
+// SPINUP = false: march months [0, nsteps) from sm0/gw0 of the cell's basin, write aet / q / sav
+template <bool SPINUP>
+__global__ void __launch_bounds__(64) k_abcd(int64_t ncell, int nmonths, int nsteps, const int *__restrict__ par_index,
+                                             const int *__restrict__ basin_index, const double *__restrict__ pars,
+                                             const double *__restrict__ pet, const double *__restrict__ precip,
+                                             const double *__restrict__ tmin, const double *__restrict__ sm0,
+                                             const double *__restrict__ gw0, double *__restrict__ dec,
+                                             double *__restrict__ aet, double *__restrict__ q,
+                                             double *__restrict__ sav) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const bool snow_on = tmin != nullptr;
+    const AbcdPar P = load_par(pars, par_index[c], snow_on);
+    AbcdState s;
+    s.snowpack = 0.0;                                                 // SN0 (:98); also reset before simulate()
+    if (SPINUP) {
+        s.sm = 100.0;                                                 // inv[1] (:82-83)
+        s.gw = 500.0;                                                 // inv[2] (:84)
+    } else {
+        const int b = basin_index[c];
+        s.sm = sm0[b];
+        s.gw = gw0[b];
+    }
+    const int64_t row = c * (int64_t)nmonths;
+    const int ntiles = nsteps / TM;
+    Tile cur, nxt;
+    if (ntiles > 0) load_tile(cur, pet, precip, tmin, row);
+    for (int t = 0; t < ntiles; ++t) {
+        const int m0 = t * TM;
+        if (t + 1 < ntiles) load_tile(nxt, pet, precip, tmin, row + m0 + TM);
+        double oa[TM], oq[TM], os[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            abcd_month(P, s, snow_on, (m0 + j) == 0, cur.pet[j], cur.pr[j], cur.tn[j], oa[j], oq[j]);
+            os[j] = s.sm;
+            if (SPINUP) {
+                const int m = m0 + j;
+                const int k = (m == nsteps - 1) ? 0 : ((m == nsteps - 13) ? 1 : ((m == nsteps - 25) ? 2 : -1));
+                if (k >= 0) {
+                    dec[(int64_t)k * ncell + c] = s.sm;
+                    dec[(int64_t)(3 + k) * ncell + c] = s.gw;
+                }
+            }
+        }
+        if (!SPINUP) {
+#pragma unroll
+            for (int j = 0; j < TM; j += 2) {
+                if (aet) *reinterpret_cast<double2 *>(aet + row + m0 + j) = make_double2(oa[j], oa[j + 1]);
+                if (q) *reinterpret_cast<double2 *>(q + row + m0 + j) = make_double2(oq[j], oq[j + 1]);
+                if (sav) *reinterpret_cast<double2 *>(sav + row + m0 + j) = make_double2(os[j], os[j + 1]);
+            }
+        }
+        cur = nxt;
+    }
+    for (int m = ntiles * TM; m < nsteps; ++m) {                      // tail months (spin-up length is arbitrary)
+        double oa, oq;
+        abcd_month(P, s, snow_on, m == 0, pet[row + m], precip[row + m], tmin ? tmin[row + m] : 0.0, oa, oq);
+        if (SPINUP) {
+            const int k = (m == nsteps - 1) ? 0 : ((m == nsteps - 13) ? 1 : ((m == nsteps - 25) ? 2 : -1));
+            if (k >= 0) {
+                dec[(int64_t)k * ncell + c] = s.sm;
+                dec[(int64_t)(3 + k) * ncell + c] = s.gw;
+            }
+        } else {
+            if (aet) aet[row + m] = oa;
+            if (q) q[row + m] = oq;
+            if (sav) sav[row + m] = s.sm;
+        }
+    }
+}
+
+// set_vals (:246-282): per basin, mean over the Decembers {-1,-13,-25} of nanmean over the basin's cells.
+// One workgroup per basin; cells of basin b are cells[ptr[b] .. ptr[b+1]).
+__global__ void __launch_bounds__(256) k_abcd_basin_mean(const int *__restrict__ ptr, const int *__restrict__ cells,
+                                                         int64_t ncell, const double *__restrict__ dec,
+                                                         double *__restrict__ sm0, double *__restrict__ gw0) {
+    __shared__ double ssum[6][256];
+    __shared__ int scnt[6][256];
+    const int b = blockIdx.x;
+    const int lo = ptr[b], hi = ptr[b + 1];
+    double sum[6] = {0, 0, 0, 0, 0, 0};
+    int cnt[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int c = cells[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double v = dec[(int64_t)k * ncell + c];
+            if (v == v) {
+                sum[k] += v;
+                cnt[k] += 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        ssum[k][threadIdx.x] = sum[k];
+        scnt[k][threadIdx.x] = cnt[k];
+    }
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                ssum[k][threadIdx.x] += ssum[k][threadIdx.x + stride];
+                scnt[k][threadIdx.x] += scnt[k][threadIdx.x + stride];
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double mean[6];
+        for (int k = 0; k < 6; ++k) mean[k] = ssum[k][0] / (double)scnt[k][0];   // 0/0 = NaN like nanmean of all-NaN
+        sm0[b] = ((mean[0] + mean[1]) + mean[2]) / 3.0;
+        gw0[b] = ((mean[3] + mean[4]) + mean[5]) / 3.0;
+    }
+}
+
+}  // namespace
+
+extern "C" int xh_abcd(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spinup, int32_t n_groups,
+                       const int32_t *h_basin_index, const int32_t *h_par_index, int64_t npar_rows,
+                       const double *d_pars, const double *d_pet, const double *d_precip, const double *d_tmin,
+                       double *d_aet, double *d_q, double *d_sav, double *d_sm0_out, double *d_gw0_out) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, h_basin_index && h_par_index && d_pars && d_pet && d_precip, "xh_abcd: NULL argument");
+    XH_REQUIRE(ctx, ncell >= 0 && nmonths > 0 && nmonths % 2 == 0, "xh_abcd: nmonths must be positive and even");
+    XH_REQUIRE(ctx, ncell < (int64_t)1 << 31, "xh_abcd: too many cells");
+    // the reference indexes rows -1, -13, -25 of the spin-up series and raises IndexError below 25 (:258-266)
+    XH_REQUIRE(ctx, spinup >= 25, "xh_abcd: spin-up of %d months is too short (needs >= 25; abcd.py:258-266)", spinup);
+    XH_REQUIRE(ctx, spinup <= nmonths, "xh_abcd: spin-up (%d) exceeds the number of months (%d)", spinup, nmonths);
+    XH_REQUIRE(ctx, n_groups >= 1, "xh_abcd: n_groups must be >= 1");
+    if (ncell == 0) return XH_OK;
+
+    // CSR of cells per basin (host, tiny) + index arrays -> scratch
+    std::vector<int> ptr(n_groups + 1, 0), cells(ncell), bidx(ncell), pidx(ncell);
+    for (int64_t c = 0; c < ncell; ++c) {
+        const int b = h_basin_index[c], p = h_par_index[c];
+        XH_REQUIRE(ctx, b >= 0 && b < n_groups, "xh_abcd: basin index %d of cell %lld out of range", b, (long long)c);
+        XH_REQUIRE(ctx, p >= 0 && p < npar_rows, "xh_abcd: parameter row %d of cell %lld out of range", p, (long long)c);
+        ptr[b + 1]++;
+        bidx[c] = b;
+        pidx[c] = p;
+    }
+    for (int b = 0; b < n_groups; ++b) ptr[b + 1] += ptr[b];
+    {
+        std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+        for (int64_t c = 0; c < ncell; ++c) cells[fill[bidx[c]]++] = (int)c;
+    }
+    const size_t n_int = (size_t)(n_groups + 1) + 3 * (size_t)ncell;
+    const size_t int_bytes = (n_int * sizeof(int) + 255) & ~size_t(255);
+    const size_t dbl = (6 * (size_t)ncell + 2 * (size_t)n_groups) * sizeof(double);
+    void *buf = nullptr;
+    int rc = xh_scratch(ctx, 1, int_bytes + dbl, &buf);
+    if (rc) return rc;
+    int *d_ptr = static_cast<int *>(buf);
+    int *d_cells = d_ptr + (n_groups + 1);
+    int *d_bidx = d_cells + ncell;
+    int *d_pidx = d_bidx + ncell;
+    double *d_dec = reinterpret_cast<double *>(static_cast<char *>(buf) + int_bytes);
+    double *d_sm0 = d_dec + 6 * ncell;
+    double *d_gw0 = d_sm0 + n_groups;
+    XH_HIP(ctx, hipMemcpyAsync(d_ptr, ptr.data(), sizeof(int) * (n_groups + 1), hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_cells, cells.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_bidx, bidx.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_pidx, pidx.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host vectors die at return
+
+    const unsigned blocks = (unsigned)((ncell + 63) / 64);
+    {
+        xh_span sp = xh_span_begin(ctx, "abcd_spinup");
+        hipLaunchKernelGGL(k_abcd<true>, dim3(blocks), dim3(64), 0, ctx->stream, ncell, (int)nmonths, (int)spinup,
+                           d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, (const double *)nullptr,
+                           (const double *)nullptr, d_dec, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+        xh_span_end(sp);
+    }
+    {
+        xh_span sp = xh_span_begin(ctx, "abcd_basin_mean");
+        hipLaunchKernelGGL(k_abcd_basin_mean, dim3((unsigned)n_groups), dim3(256), 0, ctx->stream, d_ptr, d_cells, ncell,
+                           d_dec, d_sm0, d_gw0);
+        xh_span_end(sp);
+    }
+    {
+        xh_span sp = xh_span_begin(ctx, "abcd_sim");
+        hipLaunchKernelGGL(k_abcd<false>, dim3(blocks), dim3(64), 0, ctx->stream, ncell, (int)nmonths, (int)nmonths,
+                           d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, d_sm0, d_gw0, (double *)nullptr, d_aet, d_q,
+                           d_sav);
+        xh_span_end(sp);
+    }
+    XH_HIP(ctx, hipGetLastError());
+    if (d_sm0_out) XH_HIP(ctx, hipMemcpyAsync(d_sm0_out, d_sm0, sizeof(double) * n_groups, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_gw0_out) XH_HIP(ctx, hipMemcpyAsync(d_gw0_out, d_gw0, sizeof(double) * n_groups, hipMemcpyDeviceToDevice, ctx->stream));
+    return XH_OK;
+}

@@ -1,0 +1,257 @@
+// Batched ABCD calibration objective on gfx950.
+//
+// Replaces xanthos/calibrate/calibrate_abcd.py:basin_runoff + objective_kge (:134-213) for set_calibrate = 0.
+// The reference evaluates ONE parameter vector per call (python + numpy over the basin's cells) and scipy's
+// differential evolution calls it 10^3..10^5 times per basin.  Here a whole population is evaluated at once:
+//
+//   k_calib_march<SPINUP>  lanes <-> cells of the basin (forcing is stored [month, cell], so a wave reads 512
+//                          contiguous bytes per month), every thread carries MB members' ABCD state in registers
+//                          (forcing is loaded once per MB members).  Spin-up pass: per-wave sums/counts of the
+//                          three December soil-moisture / groundwater rows.  Simulation pass: per-wave monthly
+//                          sums of runoff (x area x 1e-6 for km3), nansum semantics.
+//   k_calib_init           per member: basin mean of the Decembers (one basin id for all cells, :143) in fixed
+//                          chunk order
+//   k_calib_series / kge   per (member, month): sum the per-wave partials in fixed order; per member: KGE distance
+//
+// All cross-lane / cross-wave sums run in a fixed order, so results are reproducible run to run.
+#include <cmath>
+
+#include "xh_abcd_dev.h"
+#include "xh_common.h"
+
+namespace {
+
+using namespace xh_abcd_dev;
+
+constexpr int MB = 4;   // members per thread
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ AbcdPar member_par(const double *__restrict__ pars, int npar, int member) {
+    const double *p = pars + (int64_t)member * npar;
+    AbcdPar P;
+    const double a = p[0];
+    P.b = p[1] * 1000.0;
+    P.c = p[2];
+    P.d = p[3];
+    P.m = npar > 4 ? p[4] : 0.0;
+    P.a2 = a * 2.0;
+    P.b_over_a = P.b / a;
+    P.d1 = P.d + 1.0;
+    return P;
+}
+
+// grid.x = cell chunks of 64, grid.y = member blocks of MB; block = 64 threads (one wave)
+template <bool SPINUP>
+__global__ void __launch_bounds__(64) k_calib_march(int ncell, int nsteps, int nmembers, int npar,
+                                                    const double *__restrict__ pars,
+                                                    const double *__restrict__ pet_t, const double *__restrict__ pr_t,
+                                                    const double *__restrict__ tn_t, const double *__restrict__ area,
+                                                    const double *__restrict__ sm0, const double *__restrict__ gw0,
+                                                    double *__restrict__ dec_sum,    // [chunk][member][6]
+                                                    int *__restrict__ dec_cnt,       // [chunk][member][6]
+                                                    double *__restrict__ part) {     // [chunk][member][nsteps]
+    const int chunk = blockIdx.x, lane = threadIdx.x;
+    const int c = chunk * 64 + lane;
+    const bool valid = c < ncell;
+    const int cc = valid ? c : ncell - 1;
+    const int mb0 = blockIdx.y * MB;
+    const bool snow_on = tn_t != nullptr;
+    const double scale = (valid && area) ? area[cc] : 1.0;
+
+    AbcdPar P[MB];
+    AbcdState s[MB];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+        const int mem = min(mb0 + j, nmembers - 1);
+        P[j] = member_par(pars, npar, mem);
+        s[j].snowpack = 0.0;
+        s[j].sm = SPINUP ? 100.0 : sm0[mem];
+        s[j].gw = SPINUP ? 500.0 : gw0[mem];
+    }
+    double pet = pet_t[cc], pr = pr_t[cc], tn = snow_on ? tn_t[cc] : 0.0;
+    for (int m = 0; m < nsteps; ++m) {
+        const double pet_c = pet, pr_c = pr, tn_c = tn;
+        if (m + 1 < nsteps) {                                    // prefetch next month (coalesced across lanes)
+            const int64_t o = (int64_t)(m + 1) * ncell + cc;
+            pet = pet_t[o];
+            pr = pr_t[o];
+            tn = snow_on ? tn_t[o] : 0.0;
+        }
+        const int k = SPINUP ? ((m == nsteps - 1) ? 0 : ((m == nsteps - 13) ? 1 : ((m == nsteps - 25) ? 2 : -1))) : -1;
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            double aet, q;
+            abcd_month(P[j], s[j], snow_on, m == 0, pet_c, pr_c, tn_c, aet, q);
+            if (SPINUP) {
+                if (k >= 0) {                                    // wave-uniform
+                    const bool sm_ok = valid && (s[j].sm == s[j].sm), gw_ok = valid && (s[j].gw == s[j].gw);
+                    const double ssm = wave_sum(sm_ok ? s[j].sm : 0.0), sgw = wave_sum(gw_ok ? s[j].gw : 0.0);
+                    const int nsm = __popcll(__ballot(sm_ok)), ngw = __popcll(__ballot(gw_ok));
+                    if (lane == 0 && mb0 + j < nmembers) {
+                        const int64_t o = ((int64_t)chunk * nmembers + (mb0 + j)) * 6;
+                        dec_sum[o + k] = ssm;
+                        dec_sum[o + 3 + k] = sgw;
+                        dec_cnt[o + k] = nsm;
+                        dec_cnt[o + 3 + k] = ngw;
+                    }
+                }
+            } else {
+                double v = area ? q * scale * 1e-6 : q;          // rsim * bsn_areas * 1e-6 (:159) or rsim (:162)
+                v = (valid && v == v) ? v : 0.0;                 // nansum
+                const double tot = wave_sum(v);
+                if (lane == 0 && mb0 + j < nmembers)
+                    part[((int64_t)chunk * nmembers + (mb0 + j)) * nsteps + m] = tot;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_calib_init(int nchunks, int nmembers, const double *__restrict__ dec_sum,
+                                                   const int *__restrict__ dec_cnt, double *__restrict__ sm0,
+                                                   double *__restrict__ gw0) {
+    const int mem = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mem >= nmembers) return;
+    double sum[6] = {0, 0, 0, 0, 0, 0};
+    long long cnt[6] = {0, 0, 0, 0, 0, 0};
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int64_t o = ((int64_t)ch * nmembers + mem) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            sum[k] += dec_sum[o + k];
+            cnt[k] += dec_cnt[o + k];
+        }
+    }
+    double mean[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) mean[k] = sum[k] / (double)cnt[k];
+    sm0[mem] = ((mean[0] + mean[1]) + mean[2]) / 3.0;            // abcd.py:274-278
+    gw0[mem] = ((mean[3] + mean[4]) + mean[5]) / 3.0;
+}
+
+// series[member][month] = sum over chunks of part[chunk][member][month]
+__global__ void __launch_bounds__(256) k_calib_series(int nchunks, int nmembers, int nmonths,
+                                                      const double *__restrict__ part, double *__restrict__ series) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)nmembers * nmonths;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int ch = 0; ch < nchunks; ++ch) acc += part[(int64_t)ch * n + i];
+    series[i] = acc;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) sh[threadIdx.x] += sh[threadIdx.x + stride];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// one workgroup per member: ED = sqrt((r-1)^2 + (sd_m/sd_o - 1)^2 + (mean_m/mean_o - 1)^2) (:196-213)
+__global__ void __launch_bounds__(256) k_calib_kge(int nmonths, const double *__restrict__ series,
+                                                   const double *__restrict__ obs, double *__restrict__ ed) {
+    __shared__ double sh[256];
+    const int mem = blockIdx.x;
+    const double *x = series + (int64_t)mem * nmonths;
+    double sx = 0.0, so = 0.0;
+    for (int m = threadIdx.x; m < nmonths; m += blockDim.x) {
+        sx += x[m];
+        so += obs[m];
+    }
+    const double n = (double)nmonths;
+    const double mx = block_sum(sx, sh) / n, mo = block_sum(so, sh) / n;
+    double vxx = 0.0, voo = 0.0, vxo = 0.0;
+    for (int m = threadIdx.x; m < nmonths; m += blockDim.x) {
+        const double dx = x[m] - mx, d_o = obs[m] - mo;
+        vxx += dx * dx;
+        voo += d_o * d_o;
+        vxo += dx * d_o;
+    }
+    vxx = block_sum(vxx, sh);
+    voo = block_sum(voo, sh);
+    vxo = block_sum(vxo, sh);
+    if (threadIdx.x == 0) {
+        const double relvar = sqrt(vxx / n) / sqrt(voo / n);     // np.std, population
+        const double bias = mx / mo;
+        const double c00 = voo / (n - 1.0), c11 = vxx / (n - 1.0), c01 = vxo / (n - 1.0);   // np.corrcoef via np.cov
+        double r = c01 / sqrt(c11) / sqrt(c00);
+        r = r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);               // corrcoef clips to [-1, 1]
+        ed[mem] = sqrt((r - 1.0) * (r - 1.0) + (relvar - 1.0) * (relvar - 1.0) + (bias - 1.0) * (bias - 1.0));
+    }
+}
+
+}  // namespace
+
+extern "C" int xh_calib_objective(xh_ctx *ctx, int64_t ncell_b, int32_t nmonths, int32_t spinup, int32_t nmembers,
+                                  int32_t npar, const double *h_pars, const double *d_pet_t, const double *d_precip_t,
+                                  const double *d_tmin_t, const double *d_area, const double *h_obs, double *h_ed,
+                                  double *h_series) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, h_pars && d_pet_t && d_precip_t && h_obs && h_ed, "xh_calib_objective: NULL argument");
+    XH_REQUIRE(ctx, ncell_b > 0 && ncell_b < ((int64_t)1 << 24) && nmonths > 1 && nmembers > 0,
+               "xh_calib_objective: bad size");
+    XH_REQUIRE(ctx, npar == 4 || npar == 5, "xh_calib_objective: npar must be 4 (no snow) or 5");
+    XH_REQUIRE(ctx, (npar == 5) == (d_tmin_t != nullptr), "xh_calib_objective: npar = 5 requires tmin and vice versa");
+    XH_REQUIRE(ctx, spinup >= 25 && spinup <= nmonths, "xh_calib_objective: spin-up must be in [25, nmonths]");
+
+    const int ncell = (int)ncell_b;
+    const int nchunks = (ncell + 63) / 64;
+    const int nmblocks = (nmembers + MB - 1) / MB;
+    const size_t n_part = (size_t)nchunks * nmembers * nmonths;
+    const size_t n_dec = (size_t)nchunks * nmembers * 6;
+    const size_t dbl = (size_t)nmembers * npar + (size_t)nmonths + 2 * (size_t)nmembers + n_dec + n_part +
+                       (size_t)nmembers * nmonths + (size_t)nmembers;
+    void *buf = nullptr;
+    int rc = xh_scratch(ctx, 1, dbl * sizeof(double) + n_dec * sizeof(int) + 256, &buf);
+    if (rc) return rc;
+    double *d_pars = static_cast<double *>(buf);
+    double *d_obs = d_pars + (size_t)nmembers * npar;
+    double *d_sm0 = d_obs + nmonths;
+    double *d_gw0 = d_sm0 + nmembers;
+    double *d_dec = d_gw0 + nmembers;
+    double *d_part = d_dec + n_dec;
+    double *d_series = d_part + n_part;
+    double *d_ed = d_series + (size_t)nmembers * nmonths;
+    int *d_cnt = reinterpret_cast<int *>(d_ed + nmembers);
+    XH_HIP(ctx, hipMemcpyAsync(d_pars, h_pars, sizeof(double) * nmembers * npar, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_obs, h_obs, sizeof(double) * nmonths, hipMemcpyHostToDevice, ctx->stream));
+
+    const dim3 grid((unsigned)nchunks, (unsigned)nmblocks), block(64);
+    {
+        xh_span sp = xh_span_begin(ctx, "calib_abcd");
+        hipLaunchKernelGGL(k_calib_march<true>, grid, block, 0, ctx->stream, ncell, (int)spinup, (int)nmembers, (int)npar,
+                           d_pars, d_pet_t, d_precip_t, d_tmin_t, d_area, (const double *)nullptr,
+                           (const double *)nullptr, d_dec, d_cnt, (double *)nullptr);
+        hipLaunchKernelGGL(k_calib_init, dim3((unsigned)((nmembers + 63) / 64)), dim3(64), 0, ctx->stream, nchunks,
+                           (int)nmembers, d_dec, d_cnt, d_sm0, d_gw0);
+        hipLaunchKernelGGL(k_calib_march<false>, grid, block, 0, ctx->stream, ncell, (int)nmonths, (int)nmembers,
+                           (int)npar, d_pars, d_pet_t, d_precip_t, d_tmin_t, d_area, d_sm0, d_gw0, (double *)nullptr,
+                           (int *)nullptr, d_part);
+        xh_span_end(sp);
+    }
+    {
+        xh_span sp = xh_span_begin(ctx, "calib_kge");
+        const int64_t n = (int64_t)nmembers * nmonths;
+        hipLaunchKernelGGL(k_calib_series, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, nchunks,
+                           (int)nmembers, (int)nmonths, d_part, d_series);
+        hipLaunchKernelGGL(k_calib_kge, dim3((unsigned)nmembers), dim3(256), 0, ctx->stream, (int)nmonths, d_series,
+                           d_obs, d_ed);
+        xh_span_end(sp);
+    }
+    XH_HIP(ctx, hipGetLastError());
+    XH_HIP(ctx, hipMemcpyAsync(h_ed, d_ed, sizeof(double) * nmembers, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_series)
+        XH_HIP(ctx, hipMemcpyAsync(h_series, d_series, sizeof(double) * nmembers * nmonths, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return XH_OK;
+}

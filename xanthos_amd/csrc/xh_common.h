@@ -1,0 +1,62 @@
+// Internal declarations shared by the libxanthos_hip.so translation units (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "xanthos_hip.h"
+
+struct xh_timer_slot {
+    double done_ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct xh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool timing = true;
+    std::map<std::string, xh_timer_slot> timers;
+    std::vector<hipEvent_t> event_pool;
+    // grow-only scratch buffers (device)
+    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    hipDeviceProp_t prop;
+};
+
+int xh_fail(xh_ctx *ctx, int code, const char *fmt, ...);
+extern std::string g_xh_create_error;
+
+#define XH_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return xh_fail((ctx), XH_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define XH_REQUIRE(ctx, cond, ...)                                   \
+    do {                                                             \
+        if (!(cond)) return xh_fail((ctx), XH_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+// scratch slot `which` with at least `bytes` bytes (device memory owned by the context)
+int xh_scratch(xh_ctx *ctx, int which, size_t bytes, void **out);
+
+// RAII-free timing helpers: record a start/stop event pair around kernels of one entry point
+struct xh_span {
+    xh_ctx *ctx;
+    const char *name;
+    hipEvent_t a = nullptr, b = nullptr;
+};
+xh_span xh_span_begin(xh_ctx *ctx, const char *name);
+void xh_span_end(xh_span &s);
+
+static inline int xh_is_leap_gregorian(int y) { return (y % 4 == 0 && y % 100 != 0) || (y % 400 == 0); }

@@ -1,0 +1,285 @@
+// Context, device memory, row gather/scatter, transpose and HIP-event timing for libxanthos_hip.so.
+#include "xh_common.h"
+
+std::string g_xh_create_error;
+
+int xh_fail(xh_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_xh_create_error = buf;
+    return code;
+}
+
+int xh_scratch(xh_ctx *ctx, int which, size_t bytes, void **out) {
+    if (bytes > ctx->scratch_bytes[which]) {
+        if (ctx->scratch[which]) {
+            XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            XH_HIP(ctx, hipFree(ctx->scratch[which]));
+            ctx->scratch[which] = nullptr;
+            ctx->scratch_bytes[which] = 0;
+        }
+        size_t want = bytes + (bytes >> 2) + 4096;
+        XH_HIP(ctx, hipMalloc(&ctx->scratch[which], want));
+        ctx->scratch_bytes[which] = want;
+    }
+    *out = ctx->scratch[which];
+    return XH_OK;
+}
+
+xh_span xh_span_begin(xh_ctx *ctx, const char *name) {
+    xh_span s{ctx, name};
+    if (!ctx->timing) return s;
+    auto take = [&](hipEvent_t &e) {
+        if (!ctx->event_pool.empty()) {
+            e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else if (hipEventCreate(&e) != hipSuccess) {
+            e = nullptr;
+        }
+    };
+    take(s.a);
+    take(s.b);
+    if (s.a && s.b) (void)hipEventRecord(s.a, ctx->stream);
+    return s;
+}
+
+void xh_span_end(xh_span &s) {
+    if (!s.ctx->timing || !s.a || !s.b) return;
+    (void)hipEventRecord(s.b, s.ctx->stream);
+    s.ctx->timers[s.name].pending.emplace_back(s.a, s.b);
+}
+
+extern "C" {
+
+int xh_abi_version(void) { return 1; }
+
+int xh_device_count(int *n) {
+    if (!n) return XH_ERR_ARG;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return xh_fail(nullptr, XH_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *n = c;
+    return XH_OK;
+}
+
+int xh_ctx_create(int device, xh_ctx **out) {
+    if (!out) return xh_fail(nullptr, XH_ERR_ARG, "xh_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return xh_fail(nullptr, XH_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return xh_fail(nullptr, XH_ERR_ARG, "device %d out of range [0,%d)", device, n);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return xh_fail(nullptr, XH_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    xh_ctx *ctx = new xh_ctx();
+    ctx->device = device;
+    e = hipGetDeviceProperties(&ctx->prop, device);
+    if (e != hipSuccess) {
+        delete ctx;
+        return xh_fail(nullptr, XH_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    }
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return xh_fail(nullptr, XH_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return XH_OK;
+}
+
+void xh_ctx_destroy(xh_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->timers)
+        for (auto &p : kv.second.pending) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 4; ++i)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *xh_last_error(const xh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_xh_create_error.c_str(); }
+
+int xh_device_name(xh_ctx *ctx, char *buf, size_t len) {
+    if (!ctx || !buf || !len) return XH_ERR_ARG;
+    snprintf(buf, len, "%s (%s, %d CUs)", ctx->prop.name, ctx->prop.gcnArchName, ctx->prop.multiProcessorCount);
+    return XH_OK;
+}
+
+int xh_malloc(xh_ctx *ctx, size_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr) return XH_ERR_ARG;
+    XH_HIP(ctx, hipSetDevice(ctx->device));
+    XH_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 16));
+    return XH_OK;
+}
+
+int xh_free(xh_ctx *ctx, void *d_ptr) {
+    if (!ctx) return XH_ERR_ARG;
+    if (!d_ptr) return XH_OK;
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    XH_HIP(ctx, hipFree(d_ptr));
+    return XH_OK;
+}
+
+int xh_memcpy_h2d(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !h_src))) return XH_ERR_ARG;
+    XH_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host buffer may be reused on return
+    return XH_OK;
+}
+
+int xh_memcpy_d2h(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    if (!ctx || (bytes && (!h_dst || !d_src))) return XH_ERR_ARG;
+    XH_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return XH_OK;
+}
+
+int xh_memcpy_d2d(xh_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !d_src))) return XH_ERR_ARG;
+    XH_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return XH_OK;
+}
+
+int xh_memset(xh_ctx *ctx, void *d_ptr, int value, size_t bytes) {
+    if (!ctx || (bytes && !d_ptr)) return XH_ERR_ARG;
+    XH_HIP(ctx, hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
+    return XH_OK;
+}
+
+int xh_sync(xh_ctx *ctx) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return XH_OK;
+}
+
+int xh_timing_reset(xh_ctx *ctx) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &kv : ctx->timers) {
+        for (auto &p : kv.second.pending) {
+            ctx->event_pool.push_back(p.first);
+            ctx->event_pool.push_back(p.second);
+        }
+        kv.second.pending.clear();
+        kv.second.done_ms = 0.0;
+        kv.second.launches = 0;
+    }
+    return XH_OK;
+}
+
+int xh_timing_enable(xh_ctx *ctx, int on) {
+    if (!ctx) return XH_ERR_ARG;
+    ctx->timing = on != 0;
+    return XH_OK;
+}
+
+int xh_timing_get(xh_ctx *ctx, const char *name, double *total_ms, int64_t *launches) {
+    if (!ctx || !name) return XH_ERR_ARG;
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto it = ctx->timers.find(name);
+    double ms = 0.0;
+    int64_t n = 0;
+    if (it != ctx->timers.end()) {
+        xh_timer_slot &s = it->second;
+        for (auto &p : s.pending) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) {
+                s.done_ms += t;
+                s.launches += 1;
+            }
+            ctx->event_pool.push_back(p.first);
+            ctx->event_pool.push_back(p.second);
+        }
+        s.pending.clear();
+        ms = s.done_ms;
+        n = s.launches;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    return XH_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ row movers
+// One workgroup per row chunk; lanes run along the row so both sides are coalesced 16-B accesses.
+__global__ void __launch_bounds__(256) k_gather_rows(const double *__restrict__ src, const int64_t *__restrict__ rows,
+                                                     int64_t nrows, int64_t ncols, double *__restrict__ dst,
+                                                     int scatter) {
+    for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const int64_t g = rows[r];
+        const double *s = scatter ? src + r * ncols : src + g * ncols;
+        double *d = scatter ? dst + g * ncols : dst + r * ncols;
+        for (int64_t c = threadIdx.x; c < ncols; c += blockDim.x) d[c] = s[c];
+    }
+}
+
+// 32x32 LDS tile transpose (+1 padding column: conflict-free column reads of 8-byte elements)
+__global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ src, int64_t rows, int64_t cols,
+                                                   double *__restrict__ dst) {
+    __shared__ double tile[32][33];
+    const int64_t tr = (int64_t)blockIdx.y * 32, tc = (int64_t)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t r = tr + j, c = tc + tx;
+        if (r < rows && c < cols) tile[j][tx] = src[r * cols + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t c = tc + j, r = tr + tx;
+        if (r < rows && c < cols) dst[c * rows + r] = tile[tx][j];
+    }
+}
+
+extern "C" {
+
+static int move_rows(xh_ctx *ctx, const double *d_src, const int64_t *d_rows, int64_t nrows, int64_t ncols,
+                     double *d_dst, int scatter) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, d_src && d_rows && d_dst && nrows >= 0 && ncols >= 0, "xh_gather/scatter_rows: bad argument");
+    if (nrows == 0 || ncols == 0) return XH_OK;
+    int grid = (int)(nrows < 65536 ? nrows : 65536);
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, ctx->stream, d_src, d_rows, nrows, ncols, d_dst,
+                       scatter);
+    XH_HIP(ctx, hipGetLastError());
+    return XH_OK;
+}
+
+int xh_gather_rows(xh_ctx *ctx, const double *d_src, const int64_t *d_rows, int64_t nrows, int64_t ncols,
+                   double *d_dst) {
+    return move_rows(ctx, d_src, d_rows, nrows, ncols, d_dst, 0);
+}
+
+int xh_scatter_rows(xh_ctx *ctx, const double *d_src, const int64_t *d_rows, int64_t nrows, int64_t ncols,
+                    double *d_dst) {
+    return move_rows(ctx, d_src, d_rows, nrows, ncols, d_dst, 1);
+}
+
+int xh_transpose(xh_ctx *ctx, const double *d_src, int64_t rows, int64_t cols, double *d_dst) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, d_src && d_dst && rows >= 0 && cols >= 0, "xh_transpose: bad argument");
+    if (rows == 0 || cols == 0) return XH_OK;
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    XH_REQUIRE(ctx, grid.y <= 65535u, "xh_transpose: too many rows");
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, ctx->stream, d_src, rows, cols, d_dst);
+    XH_HIP(ctx, hipGetLastError());
+    return XH_OK;
+}
+
+}  // extern "C"

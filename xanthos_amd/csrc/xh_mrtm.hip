@@ -1,0 +1,741 @@
+// Modified River Transport Model (MRTM) channel routing on gfx950.
+//
+// Replaces xanthos/routing/mrtm.py:streamrouting (:16-82) and the spin-up / simulation month loops of
+// xanthos/components.py:calculate_routing (:273-294).  The reference does, per 3-hour sub-step, one or two
+// scipy CSR mat-vecs with UM = UP - I plus ~8 numpy vector ops, 8*nday sub-steps per month, one Python call per
+// month.  600 months are ~146,000 strictly sequential sub-steps, so launch-per-sub-step is hopeless.
+//
+// Design: the flow graph splits into independent river networks (weakly-connected components of UM).  A
+// network (or a bin of small networks) is a "unit" that one workgroup owns for the WHOLE series: per-cell state
+// (storage S, running mean flow, 1/tau, lateral inflow) lives in registers, the flows F exchanged between
+// neighbours live in LDS, and the month and sub-step loops run inside one persistent kernel with two workgroup
+// barriers per sub-step.  HBM is touched once per cell-month (read runoff, write ChStorage / Avg_ChFlow).
+//
+// Exactness: row i of UM.dot(F) is accumulated as 0 + sum_j sign_j * F[col_j] in stored (ascending column)
+// order, exactly like scipy's csr_matvec, and the reference's "any excess flow" branch is evaluated in the
+// equivalent two-phase per-cell form (identical when no cell fires), with -ffp-contract=off.
+// Results are bit-identical to the numpy/scipy path for identical runoff.
+//
+// Networks that do not fit a workgroup (more than 4096 cells, or a row with more than 9 entries) are routed by
+// the global-memory kernels at the bottom (two launches per sub-step; optional fp64 atomic scatter-add variant).
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "xh_common.h"
+
+namespace {
+
+constexpr int W_MAX = 9;             // 8 D8 neighbours + the diagonal
+constexpr int UNIT_MAX_CELLS = 4096;
+constexpr int BIN_CELLS = 256;       // small networks share a single-wave workgroup of up to this many cells
+constexpr int N_CLASS = 8;
+
+struct UnitClass {
+    int nt, kc;
+};
+// shapes tried in order: first one with nt*kc >= cells
+constexpr UnitClass CLASSES[N_CLASS] = {{64, 1}, {64, 2}, {64, 4}, {256, 2}, {256, 4}, {1024, 2}, {1024, 4}, {512, 8}};
+
+struct RouteArgs {
+    const int *unit_slot0;           // [units of this launch] first slot of each unit
+    const int *cell_of_slot;         // [total_slots] global cell id, -1 = padding
+    const unsigned *ent;             // [W_MAX][total_slots] byte offset of each gathered term in the pair buffer
+    const unsigned char *cnt;        // [total_slots] number of terms
+    int64_t total_slots;
+    int nmonths, nit;
+    const int *sched_m;              // [nit] month index routed at iteration it (spin-up months first)
+    const int *sched_nt;             // [nit] sub-steps
+    const double *sched_secs;        // [nit] nday*24*3600
+    const unsigned char *sched_write;  // [nit] 1 = store outputs (simulation pass)
+    double dt, dtinv;
+    const double *flow_dist, *velocity, *area, *runoff, *S0;
+    double *chs, *avg, *S_end, *F_end;
+};
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
+// One workgroup = one routing unit for the whole series.  blockDim.x = NT, each thread owns KC cells
+// (slot l = k*NT + tid, so consecutive lanes touch consecutive LDS pairs).
+template <int KC, int NTMAX>
+__global__ void __launch_bounds__(NTMAX) k_mrtm_units(RouteArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double2 lds[];
+    const int NT = blockDim.x, tid = threadIdx.x;
+    const int NP = NT * KC;
+    double2 *bufA = lds;                // trial flows  {F, -F}
+    double2 *bufB = lds + (NP + 1);     // final flows  {F2, -F2}; slot NP of each buffer is the constant {0,0}
+    const char *baseA = reinterpret_cast<const char *>(bufA);
+    const char *baseB = reinterpret_cast<const char *>(bufB);
+    const int slot0 = a.unit_slot0[blockIdx.x];
+
+    int gc[KC], W[KC];
+    bool act[KC];
+    double S[KC], tauinv[KC], area[KC], erl[KC], favg[KC], F[KC], qn[KC];
+    unsigned e[KC][W_MAX];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const int64_t slot = (int64_t)slot0 + k * NT + tid;
+        gc[k] = a.cell_of_slot[slot];
+        const bool valid = gc[k] >= 0;
+        tauinv[k] = valid ? a.velocity[gc[k]] / a.flow_dist[gc[k]] : 0.0;     // mrtm.py:40
+        area[k] = valid ? a.area[gc[k]] : 0.0;
+        S[k] = (valid && a.S0) ? a.S0[gc[k]] : 0.0;
+        F[k] = 0.0;
+        W[k] = __builtin_amdgcn_readfirstlane(wave_max_i32((int)a.cnt[slot]));
+        act[k] = __builtin_amdgcn_readfirstlane(wave_max_i32(valid ? 1 : 0)) != 0;
+#pragma unroll
+        for (int w = 0; w < W_MAX; ++w) e[k][w] = a.ent[(int64_t)w * a.total_slots + slot];
+        qn[k] = valid ? a.runoff[(int64_t)gc[k] * a.nmonths + a.sched_m[0]] : 0.0;
+    }
+    if (tid == 0) {
+        bufA[NP] = make_double2(0.0, 0.0);
+        bufB[NP] = make_double2(0.0, 0.0);
+    }
+    const double dt = a.dt, dtinv = a.dtinv;
+
+    for (int it = 0; it < a.nit; ++it) {
+        const int m = a.sched_m[it], nt = a.sched_nt[it];
+        const double secs = a.sched_secs[it];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            erl[k] = (qn[k] * area[k]) * 1000.0 / secs;                       // mrtm.py:45
+            favg[k] = 0.0;
+        }
+        if (it + 1 < a.nit) {                                                  // prefetch next month's runoff
+            const int m2 = a.sched_m[it + 1];
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                qn[k] = gc[k] >= 0 ? a.runoff[(int64_t)gc[k] * a.nmonths + m2] : 0.0;
+        }
+        for (int t = 0; t < nt; ++t) {
+            bool sx[KC];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                if (act[k]) {
+                    F[k] = S[k] * tauinv[k];                                   // mrtm.py:50
+                    bufA[k * NT + tid] = make_double2(F[k], -F[k]);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                if (act[k]) {
+                    double acc = 0.0;                                          // UM.dot(F), row order (mrtm.py:51)
+#pragma unroll
+                    for (int w = 0; w < W_MAX; ++w)
+                        if (w < W[k]) acc += *reinterpret_cast<const double *>(baseA + e[k][w]);
+                    const double dsdt = acc + erl[k];
+                    sx[k] = (dsdt * dt) < (-S[k]);                             // mrtm.py:54
+                    const double f2 = sx[k] ? (dsdt + F[k]) + S[k] * dtinv : F[k];   // mrtm.py:60
+                    S[k] = sx[k] ? 0.0 : S[k];                                 // mrtm.py:63
+                    F[k] = f2;
+                    bufB[k * NT + tid] = make_double2(f2, -f2);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                if (act[k]) {
+                    double acc = 0.0;                                          // UM.dot(F) again with the adjusted flows
+#pragma unroll
+                    for (int w = 0; w < W_MAX; ++w)
+                        if (w < W[k]) acc += *reinterpret_cast<const double *>(baseB + e[k][w]);
+                    const double dsdt = acc + erl[k];                          // mrtm.py:68
+                    S[k] = sx[k] ? S[k] : S[k] + dsdt * dt;                    // mrtm.py:69 / :76
+                    favg[k] += F[k];                                           // mrtm.py:78
+                }
+            }
+        }
+        if (a.sched_write[it]) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                if (gc[k] >= 0) {
+                    const int64_t o = (int64_t)gc[k] * a.nmonths + m;
+                    if (a.chs) a.chs[o] = S[k];
+                    if (a.avg) a.avg[o] = favg[k] / (double)nt;                // mrtm.py:80
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        if (gc[k] >= 0) {
+            if (a.S_end) a.S_end[gc[k]] = S[k];
+            if (a.F_end) a.F_end[gc[k]] = F[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- global fallback
+struct FbArgs {
+    int n;                           // cells routed by the fallback
+    const int *cells;                // [n] global cell ids
+    const int *ptr;                  // [n+1] CSR over `cells` order
+    const int *col;                  // global cell id of each term
+    const signed char *sgn;
+    const int *ds;                   // [n] single downstream cell (atomic variant), -1 = none
+    int nmonths;
+    double dt, dtinv;
+    const double *flow_dist, *velocity, *area, *runoff, *S0;
+    double *S, *F, *F2, *favg, *erl, *inflow;   // [ncell] work arrays in cell order
+    unsigned char *sx;
+    double *chs, *avg, *S_end, *F_end;
+};
+
+__global__ void __launch_bounds__(256) k_fb_init(FbArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int c = a.cells[i];
+    a.S[c] = a.S0 ? a.S0[c] : 0.0;
+    a.F2[c] = 0.0;
+}
+
+__global__ void __launch_bounds__(256) k_fb_month_begin(FbArgs a, int m, double secs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int c = a.cells[i];
+    a.erl[c] = (a.runoff[(int64_t)c * a.nmonths + m] * a.area[c]) * 1000.0 / secs;
+    a.favg[c] = 0.0;
+    a.F[c] = a.S[c] * (a.velocity[c] / a.flow_dist[c]);
+    if (a.inflow) a.inflow[c] = 0.0;
+}
+
+// phase A: trial step, excess-flow test, adjusted flow F2
+template <bool ATOMIC>
+__global__ void __launch_bounds__(256) k_fb_phase_a(FbArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int c = a.cells[i];
+    double acc = 0.0;
+    if (ATOMIC) {
+        acc = a.inflow[c] - a.F[c];
+        a.inflow[c] = 0.0;
+    } else {
+        for (int j = a.ptr[i]; j < a.ptr[i + 1]; ++j) acc += a.sgn[j] > 0 ? a.F[a.col[j]] : -a.F[a.col[j]];
+    }
+    const double dsdt = acc + a.erl[c];
+    const double S = a.S[c], F = a.F[c];
+    const bool sx = (dsdt * a.dt) < (-S);
+    a.F2[c] = sx ? (dsdt + F) + S * a.dtinv : F;
+    if (sx) a.S[c] = 0.0;
+    a.sx[c] = sx ? 1 : 0;
+}
+
+// phase B: final storage update, running mean, next trial flow
+template <bool ATOMIC>
+__global__ void __launch_bounds__(256) k_fb_phase_b(FbArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int c = a.cells[i];
+    double acc = 0.0;
+    if (ATOMIC) {
+        acc = a.inflow[c] - a.F2[c];
+        a.inflow[c] = 0.0;
+    } else {
+        for (int j = a.ptr[i]; j < a.ptr[i + 1]; ++j) acc += a.sgn[j] > 0 ? a.F2[a.col[j]] : -a.F2[a.col[j]];
+    }
+    const double dsdt = acc + a.erl[c];
+    double S = a.S[c];
+    if (!a.sx[c]) S = S + dsdt * a.dt;
+    a.S[c] = S;
+    a.favg[c] += a.F2[c];
+    a.F[c] = S * (a.velocity[c] / a.flow_dist[c]);
+}
+
+// scatter-add of each cell's outflow to its downstream cell: global_atomic_add_f64 (-munsafe-fp-atomics)
+__global__ void __launch_bounds__(256) k_fb_scatter(FbArgs a, int which) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int c = a.cells[i];
+    const int d = a.ds[i];
+    if (d >= 0) unsafeAtomicAdd(&a.inflow[d], which ? a.F2[c] : a.F[c]);
+}
+
+__global__ void __launch_bounds__(256) k_fb_month_end(FbArgs a, int m, int nt, int write) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int c = a.cells[i];
+    if (write) {
+        const int64_t o = (int64_t)c * a.nmonths + m;
+        if (a.chs) a.chs[o] = a.S[c];
+        if (a.avg) a.avg[o] = a.favg[c] / (double)nt;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fb_finish(FbArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int c = a.cells[i];
+    if (a.S_end) a.S_end[c] = a.S[c];
+    if (a.F_end) a.F_end[c] = a.F2[c];
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+template <typename T>
+int upload(xh_ctx *ctx, DevBuf &b, const std::vector<T> &v) {
+    b.bytes = v.size() * sizeof(T);
+    XH_HIP(ctx, hipMalloc(&b.p, b.bytes ? b.bytes : 16));
+    if (b.bytes) XH_HIP(ctx, hipMemcpy(b.p, v.data(), b.bytes, hipMemcpyHostToDevice));
+    return XH_OK;
+}
+
+}  // namespace
+
+struct xh_route_plan {
+    xh_ctx *ctx = nullptr;
+    int64_t ncell = 0, n_networks = 0, largest_network = 0, n_units = 0, largest_unit = 0, total_slots = 0;
+    // LDS units, grouped by class
+    std::vector<int> class_units[N_CLASS];       // slot0 of the units of each class
+    DevBuf d_class_units[N_CLASS];
+    DevBuf d_cell_of_slot, d_ent, d_cnt;
+    // fallback
+    int64_t n_fb = 0;
+    bool fb_single_ds = true;
+    DevBuf d_fb_cells, d_fb_ptr, d_fb_col, d_fb_sgn, d_fb_ds;
+    // whole-graph copies so XH_ROUTE_FORCE_FALLBACK can route everything
+    DevBuf d_all_cells, d_all_ptr, d_all_col, d_all_sgn, d_all_ds;
+    bool all_single_ds = true;
+    int64_t all_nnz = 0;
+    hipStream_t streams[N_CLASS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[N_CLASS + 1] = {};
+    hipStream_t fb_stream = nullptr;
+};
+
+namespace {
+
+int find_root(std::vector<int> &parent, int x) {
+    while (parent[x] != x) {
+        parent[x] = parent[parent[x]];
+        x = parent[x];
+    }
+    return x;
+}
+
+void free_buf(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+}
+
+template <int KC, int NTMAX>
+void launch_units(const xh_route_plan *plan, int cls, RouteArgs args, hipStream_t st) {
+    const int nt = CLASSES[cls].nt;
+    const size_t lds = 2 * (size_t)(nt * KC + 1) * sizeof(double2);
+    args.unit_slot0 = static_cast<const int *>(plan->d_class_units[cls].p);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mrtm_units<KC, NTMAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_mrtm_units<KC, NTMAX>), dim3((unsigned)plan->class_units[cls].size()), dim3(nt), lds, st, args);
+}
+
+}  // namespace
+
+extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h_indptr, const int32_t *h_indices,
+                                    const int8_t *h_sign, xh_route_plan **out) {
+    if (!ctx || !out) return XH_ERR_ARG;
+    *out = nullptr;
+    XH_REQUIRE(ctx, h_indptr && ncell >= 0 && ncell < ((int64_t)1 << 31), "xh_route_plan_create: bad argument");
+    const int64_t nnz = h_indptr[ncell];
+    XH_REQUIRE(ctx, nnz == 0 || (h_indices && h_sign), "xh_route_plan_create: NULL indices");
+    XH_REQUIRE(ctx, nnz < ((int64_t)1 << 31), "xh_route_plan_create: too many entries");
+    const int n = (int)ncell;
+
+    // ---- networks = weakly connected components of the entries
+    std::vector<int> parent(n);
+    std::iota(parent.begin(), parent.end(), 0);
+    std::vector<int> deg(n, 0);
+    for (int i = 0; i < n; ++i) {
+        XH_REQUIRE(ctx, h_indptr[i + 1] >= h_indptr[i], "xh_route_plan_create: indptr not monotone");
+        deg[i] = (int)(h_indptr[i + 1] - h_indptr[i]);
+        for (int64_t j = h_indptr[i]; j < h_indptr[i + 1]; ++j) {
+            const int c = h_indices[j];
+            XH_REQUIRE(ctx, c >= 0 && c < n, "xh_route_plan_create: column %d out of range", c);
+            XH_REQUIRE(ctx, h_sign[j] == 1 || h_sign[j] == -1, "xh_route_plan_create: UM entries must be +1 / -1");
+            const int ra = find_root(parent, i), rb = find_root(parent, c);
+            if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+        }
+    }
+    std::vector<int> comp(n), comp_size;
+    {
+        std::vector<int> id(n, -1);
+        for (int i = 0; i < n; ++i) {
+            const int r = find_root(parent, i);
+            if (id[r] < 0) {
+                id[r] = (int)comp_size.size();
+                comp_size.push_back(0);
+            }
+            comp[i] = id[r];
+            comp_size[comp[i]]++;
+        }
+    }
+    const int ncomp = (int)comp_size.size();
+    std::vector<int> comp_maxdeg(ncomp, 0);
+    for (int i = 0; i < n; ++i) comp_maxdeg[comp[i]] = std::max(comp_maxdeg[comp[i]], deg[i]);
+    std::vector<std::vector<int>> comp_cells(ncomp);
+    for (int c = 0; c < ncomp; ++c) comp_cells[c].reserve(comp_size[c]);
+    for (int i = 0; i < n; ++i) comp_cells[comp[i]].push_back(i);
+
+    xh_route_plan *plan = new xh_route_plan();
+    plan->ctx = ctx;
+    plan->ncell = ncell;
+    plan->n_networks = ncomp;
+    plan->largest_network = ncomp ? *std::max_element(comp_size.begin(), comp_size.end()) : 0;
+
+    // ---- units: big networks alone, small ones first-fit-decreasing into bins of BIN_CELLS
+    std::vector<int> order(ncomp);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return comp_size[x] > comp_size[y]; });
+    std::vector<std::vector<int>> units;          // cells of each unit
+    std::vector<int> fb_cells;
+    {
+        std::vector<int> bin_free;                // remaining capacity of open bins
+        std::vector<int> bin_unit;
+        size_t first_open = 0;
+        for (int ci : order) {
+            const int sz = comp_size[ci];
+            if (sz > UNIT_MAX_CELLS || comp_maxdeg[ci] > W_MAX) {
+                fb_cells.insert(fb_cells.end(), comp_cells[ci].begin(), comp_cells[ci].end());
+                continue;
+            }
+            if (sz > BIN_CELLS / 2) {
+                units.push_back(comp_cells[ci]);
+                continue;
+            }
+            bool placed = false;
+            for (size_t b = first_open; b < bin_free.size(); ++b) {
+                if (bin_free[b] >= sz) {
+                    std::vector<int> &u = units[bin_unit[b]];
+                    u.insert(u.end(), comp_cells[ci].begin(), comp_cells[ci].end());
+                    bin_free[b] -= sz;
+                    placed = true;
+                    break;
+                }
+            }
+            if (!placed) {
+                bin_unit.push_back((int)units.size());
+                bin_free.push_back(BIN_CELLS - sz);
+                units.push_back(comp_cells[ci]);
+            }
+            while (first_open < bin_free.size() && bin_free[first_open] == 0) ++first_open;
+        }
+    }
+    std::sort(fb_cells.begin(), fb_cells.end());
+
+    // ---- slot layout
+    std::vector<int> cell_of_slot;
+    std::vector<int> slot_of_cell(n, -1), unit_slot0, unit_np;
+    for (auto &u : units) {
+        // cells with many terms first, so that only the first wave stripes run long gather loops
+        std::stable_sort(u.begin(), u.end(), [&](int x, int y) { return deg[x] > deg[y]; });
+        int cls = -1;
+        for (int k = 0; k < N_CLASS; ++k)
+            if (CLASSES[k].nt * CLASSES[k].kc >= (int)u.size()) {
+                cls = k;
+                break;
+            }
+        const int np = CLASSES[cls].nt * CLASSES[cls].kc;
+        const int s0 = (int)cell_of_slot.size();
+        plan->class_units[cls].push_back(s0);
+        unit_slot0.push_back(s0);
+        unit_np.push_back(np);
+        for (int l = 0; l < np; ++l) {
+            const int c = l < (int)u.size() ? u[l] : -1;
+            cell_of_slot.push_back(c);
+            if (c >= 0) slot_of_cell[c] = s0 + l;
+        }
+        plan->largest_unit = std::max<int64_t>(plan->largest_unit, (int64_t)u.size());
+    }
+    plan->n_units = (int64_t)units.size();
+    plan->total_slots = (int64_t)cell_of_slot.size();
+    const int64_t ts = plan->total_slots;
+    std::vector<unsigned> ent((size_t)W_MAX * ts);
+    std::vector<unsigned char> cnt(ts, 0);
+    for (size_t ui = 0; ui < units.size(); ++ui) {
+        const int s0 = unit_slot0[ui], np = unit_np[ui];
+        const unsigned zero_off = (unsigned)np * 16u;
+        for (int l = 0; l < np; ++l) {
+            const int slot = s0 + l, c = cell_of_slot[slot];
+            for (int w = 0; w < W_MAX; ++w) ent[(size_t)w * ts + slot] = zero_off;
+            if (c < 0) continue;
+            int w = 0;
+            for (int64_t j = h_indptr[c]; j < h_indptr[c + 1]; ++j, ++w) {
+                const int src = slot_of_cell[h_indices[j]] - s0;      // same unit by construction
+                ent[(size_t)w * ts + slot] = (unsigned)src * 16u + (h_sign[j] < 0 ? 8u : 0u);
+            }
+            cnt[slot] = (unsigned char)w;
+        }
+    }
+
+    // ---- fallback CSR (subset) and whole-graph CSR
+    auto build_csr = [&](const std::vector<int> &cells, std::vector<int> &ptr, std::vector<int> &col,
+                         std::vector<signed char> &sgn, std::vector<int> &ds, bool &single) {
+        ptr.assign(cells.size() + 1, 0);
+        col.clear();
+        sgn.clear();
+        for (size_t i = 0; i < cells.size(); ++i) {
+            const int c = cells[i];
+            for (int64_t j = h_indptr[c]; j < h_indptr[c + 1]; ++j) {
+                col.push_back(h_indices[j]);
+                sgn.push_back((signed char)h_sign[j]);
+            }
+            ptr[i + 1] = (int)col.size();
+        }
+        // downstream cell of each cell = the row in which it appears with +1 (atomic variant needs exactly <= 1,
+        // and every row's only negative term on its diagonal)
+        std::vector<int> ds_cell(n, -1);
+        single = true;
+        for (int r = 0; r < n; ++r)
+            for (int64_t j = h_indptr[r]; j < h_indptr[r + 1]; ++j) {
+                const int c = h_indices[j];
+                if (h_sign[j] > 0) {
+                    if (ds_cell[c] >= 0) single = false;
+                    ds_cell[c] = r;
+                } else if (c != r) {
+                    single = false;
+                }
+            }
+        for (int r = 0; r < n; ++r) {
+            int ndiag = 0;
+            for (int64_t j = h_indptr[r]; j < h_indptr[r + 1]; ++j)
+                if (h_indices[j] == r && h_sign[j] < 0) ++ndiag;
+            if (ndiag != 1) single = false;
+        }
+        ds.resize(cells.size());
+        for (size_t i = 0; i < cells.size(); ++i) ds[i] = ds_cell[cells[i]];
+    };
+    int rc = XH_OK;
+    {
+        std::vector<int> ptr, col, ds;
+        std::vector<signed char> sgn;
+        build_csr(fb_cells, ptr, col, sgn, ds, plan->fb_single_ds);
+        plan->n_fb = (int64_t)fb_cells.size();
+        rc |= upload(ctx, plan->d_fb_cells, fb_cells);
+        rc |= upload(ctx, plan->d_fb_ptr, ptr);
+        rc |= upload(ctx, plan->d_fb_col, col);
+        rc |= upload(ctx, plan->d_fb_sgn, sgn);
+        rc |= upload(ctx, plan->d_fb_ds, ds);
+        std::vector<int> all(n);
+        std::iota(all.begin(), all.end(), 0);
+        build_csr(all, ptr, col, sgn, ds, plan->all_single_ds);
+        plan->all_nnz = (int64_t)col.size();
+        rc |= upload(ctx, plan->d_all_cells, all);
+        rc |= upload(ctx, plan->d_all_ptr, ptr);
+        rc |= upload(ctx, plan->d_all_col, col);
+        rc |= upload(ctx, plan->d_all_sgn, sgn);
+        rc |= upload(ctx, plan->d_all_ds, ds);
+    }
+    rc |= upload(ctx, plan->d_cell_of_slot, cell_of_slot);
+    rc |= upload(ctx, plan->d_ent, ent);
+    rc |= upload(ctx, plan->d_cnt, cnt);
+    for (int k = 0; k < N_CLASS; ++k) {
+        rc |= upload(ctx, plan->d_class_units[k], plan->class_units[k]);
+        if (!plan->class_units[k].empty() && hipStreamCreateWithFlags(&plan->streams[k], hipStreamNonBlocking) != hipSuccess)
+            rc |= XH_ERR_HIP;
+    }
+    if (hipStreamCreateWithFlags(&plan->fb_stream, hipStreamNonBlocking) != hipSuccess) rc |= XH_ERR_HIP;
+    if (hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess) rc |= XH_ERR_HIP;
+    for (int k = 0; k <= N_CLASS; ++k)
+        if (hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming) != hipSuccess) rc |= XH_ERR_HIP;
+    if (rc) {
+        xh_route_plan_destroy(plan);
+        return xh_fail(ctx, XH_ERR_HIP, "xh_route_plan_create: device allocation failed");
+    }
+    *out = plan;
+    return XH_OK;
+}
+
+extern "C" void xh_route_plan_destroy(xh_route_plan *plan) {
+    if (!plan) return;
+    (void)hipStreamSynchronize(plan->ctx->stream);
+    for (int k = 0; k < N_CLASS; ++k) {
+        free_buf(plan->d_class_units[k]);
+        if (plan->streams[k]) (void)hipStreamDestroy(plan->streams[k]);
+    }
+    if (plan->fb_stream) (void)hipStreamDestroy(plan->fb_stream);
+    if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+    for (int k = 0; k <= N_CLASS; ++k)
+        if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
+    DevBuf *bufs[] = {&plan->d_cell_of_slot, &plan->d_ent, &plan->d_cnt, &plan->d_fb_cells, &plan->d_fb_ptr,
+                      &plan->d_fb_col, &plan->d_fb_sgn, &plan->d_fb_ds, &plan->d_all_cells, &plan->d_all_ptr,
+                      &plan->d_all_col, &plan->d_all_sgn, &plan->d_all_ds};
+    for (DevBuf *b : bufs) free_buf(*b);
+    delete plan;
+}
+
+extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[8]) {
+    if (!plan || !info) return XH_ERR_ARG;
+    info[0] = plan->n_networks;
+    info[1] = plan->largest_network;
+    info[2] = plan->n_units;
+    info[3] = plan->n_fb;
+    info[4] = plan->largest_unit;
+    info[5] = plan->total_slots;
+    info[6] = plan->all_single_ds ? 1 : 0;
+    info[7] = 0;
+    return XH_OK;
+}
+
+extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
+                               const int32_t *h_ndays, double dt, const double *d_flow_dist,
+                               const double *d_velocity, const double *d_area, const double *d_runoff,
+                               const double *d_S0, double *d_chstorage, double *d_avgchflow, double *d_S_end,
+                               double *d_F_end, int32_t flags) {
+    if (!ctx || !plan) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, plan->ctx == ctx, "xh_route_series: plan belongs to another context");
+    XH_REQUIRE(ctx, h_ndays && d_flow_dist && d_velocity && d_area && d_runoff, "xh_route_series: NULL argument");
+    XH_REQUIRE(ctx, nmonths > 0 && spinup_months >= 0 && spinup_months <= nmonths,
+               "xh_route_series: need 0 <= spinup_months (%d) <= nmonths (%d)", spinup_months, nmonths);
+    XH_REQUIRE(ctx, dt > 0.0, "xh_route_series: dt must be positive");
+    if (plan->ncell == 0) return XH_OK;
+
+    // month schedule: spin-up months 0..spinup-1 (outputs discarded: the simulation pass overwrites them,
+    // components.py:273-294), then every month
+    const int nit = spinup_months + nmonths;
+    std::vector<int> sm(nit), snt(nit);
+    std::vector<double> ssecs(nit);
+    std::vector<unsigned char> swr(nit);
+    for (int it = 0; it < nit; ++it) {
+        const int m = it < spinup_months ? it : it - spinup_months;
+        XH_REQUIRE(ctx, h_ndays[m] > 0, "xh_route_series: ndays[%d] = %d", m, h_ndays[m]);
+        sm[it] = m;
+        ssecs[it] = (double)((int64_t)h_ndays[m] * 24 * 3600);
+        snt[it] = (int)(ssecs[it] / dt);                                        // int(nday*24*3600/dt), mrtm.py:35
+        XH_REQUIRE(ctx, snt[it] >= 1, "xh_route_series: dt longer than a month");
+        swr[it] = it >= spinup_months ? 1 : 0;
+    }
+    const size_t sched_bytes = (size_t)nit * (2 * sizeof(int) + sizeof(double) + 1) + 64;
+    void *sbuf = nullptr;
+    int rc = xh_scratch(ctx, 2, sched_bytes, &sbuf);
+    if (rc) return rc;
+    double *d_secs = static_cast<double *>(sbuf);
+    int *d_m = reinterpret_cast<int *>(d_secs + nit);
+    int *d_nt = d_m + nit;
+    unsigned char *d_wr = reinterpret_cast<unsigned char *>(d_nt + nit);
+    XH_HIP(ctx, hipMemcpyAsync(d_secs, ssecs.data(), sizeof(double) * nit, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_m, sm.data(), sizeof(int) * nit, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_nt, snt.data(), sizeof(int) * nit, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_wr, swr.data(), (size_t)nit, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    const bool force_fb = (flags & XH_ROUTE_FORCE_FALLBACK) != 0;
+    const bool atomic = (flags & XH_ROUTE_ATOMIC) != 0;
+    const int64_t n_fb = force_fb ? plan->ncell : plan->n_fb;
+
+    xh_span sp = xh_span_begin(ctx, "mrtm_route");
+    XH_HIP(ctx, hipEventRecord(plan->ev_fork, ctx->stream));
+    int njoin = 0;
+    if (!force_fb && plan->n_units > 0) {
+        RouteArgs a;
+        a.unit_slot0 = nullptr;
+        a.cell_of_slot = static_cast<const int *>(plan->d_cell_of_slot.p);
+        a.ent = static_cast<const unsigned *>(plan->d_ent.p);
+        a.cnt = static_cast<const unsigned char *>(plan->d_cnt.p);
+        a.total_slots = plan->total_slots;
+        a.nmonths = nmonths;
+        a.nit = nit;
+        a.sched_m = d_m;
+        a.sched_nt = d_nt;
+        a.sched_secs = d_secs;
+        a.sched_write = d_wr;
+        a.dt = dt;
+        a.dtinv = 1.0 / dt;
+        a.flow_dist = d_flow_dist;
+        a.velocity = d_velocity;
+        a.area = d_area;
+        a.runoff = d_runoff;
+        a.S0 = d_S0;
+        a.chs = d_chstorage;
+        a.avg = d_avgchflow;
+        a.S_end = d_S_end;
+        a.F_end = d_F_end;
+        // largest classes first so the long-running workgroups start first
+        for (int cls = N_CLASS - 1; cls >= 0; --cls) {
+            if (plan->class_units[cls].empty()) continue;
+            hipStream_t st = plan->streams[cls];
+            XH_HIP(ctx, hipStreamWaitEvent(st, plan->ev_fork, 0));
+            switch (cls) {
+                case 0: launch_units<1, 64>(plan, cls, a, st); break;
+                case 1: launch_units<2, 64>(plan, cls, a, st); break;
+                case 2: launch_units<4, 64>(plan, cls, a, st); break;
+                case 3: launch_units<2, 256>(plan, cls, a, st); break;
+                case 4: launch_units<4, 256>(plan, cls, a, st); break;
+                case 5: launch_units<2, 1024>(plan, cls, a, st); break;
+                case 6: launch_units<4, 1024>(plan, cls, a, st); break;
+                case 7: launch_units<8, 512>(plan, cls, a, st); break;
+            }
+            XH_HIP(ctx, hipGetLastError());
+            XH_HIP(ctx, hipEventRecord(plan->ev_join[njoin], st));
+            XH_HIP(ctx, hipStreamWaitEvent(ctx->stream, plan->ev_join[njoin], 0));
+            ++njoin;
+        }
+    }
+    if (n_fb > 0) {
+        const bool single = force_fb ? plan->all_single_ds : plan->fb_single_ds;
+        if (atomic && !single) {
+            xh_span_end(sp);
+            return xh_fail(ctx, XH_ERR_ARG, "xh_route_series: XH_ROUTE_ATOMIC needs one downstream cell per cell");
+        }
+        // work arrays in cell order: S, F, F2, favg, erl, inflow (6 doubles) + sx flag
+        void *wbuf = nullptr;
+        const size_t nc = (size_t)plan->ncell;
+        rc = xh_scratch(ctx, 3, nc * (6 * sizeof(double) + 1) + 64, &wbuf);
+        if (rc) return rc;
+        FbArgs f;
+        f.n = (int)n_fb;
+        f.cells = static_cast<const int *>((force_fb ? plan->d_all_cells : plan->d_fb_cells).p);
+        f.ptr = static_cast<const int *>((force_fb ? plan->d_all_ptr : plan->d_fb_ptr).p);
+        f.col = static_cast<const int *>((force_fb ? plan->d_all_col : plan->d_fb_col).p);
+        f.sgn = static_cast<const signed char *>((force_fb ? plan->d_all_sgn : plan->d_fb_sgn).p);
+        f.ds = static_cast<const int *>((force_fb ? plan->d_all_ds : plan->d_fb_ds).p);
+        f.nmonths = nmonths;
+        f.dt = dt;
+        f.dtinv = 1.0 / dt;
+        f.flow_dist = d_flow_dist;
+        f.velocity = d_velocity;
+        f.area = d_area;
+        f.runoff = d_runoff;
+        f.S0 = d_S0;
+        f.S = static_cast<double *>(wbuf);
+        f.F = f.S + nc;
+        f.F2 = f.F + nc;
+        f.favg = f.F2 + nc;
+        f.erl = f.favg + nc;
+        f.inflow = atomic ? f.erl + nc : nullptr;
+        f.sx = reinterpret_cast<unsigned char *>(f.erl + 2 * nc);
+        f.chs = d_chstorage;
+        f.avg = d_avgchflow;
+        f.S_end = d_S_end;
+        f.F_end = d_F_end;
+        hipStream_t st = plan->fb_stream;
+        XH_HIP(ctx, hipStreamWaitEvent(st, plan->ev_fork, 0));
+        const dim3 grid((unsigned)((n_fb + 255) / 256)), block(256);
+        hipLaunchKernelGGL(k_fb_init, grid, block, 0, st, f);
+        for (int it = 0; it < nit; ++it) {
+            hipLaunchKernelGGL(k_fb_month_begin, grid, block, 0, st, f, sm[it], ssecs[it]);
+            for (int t = 0; t < snt[it]; ++t) {
+                if (atomic) {
+                    hipLaunchKernelGGL(k_fb_scatter, grid, block, 0, st, f, 0);
+                    hipLaunchKernelGGL(k_fb_phase_a<true>, grid, block, 0, st, f);
+                    hipLaunchKernelGGL(k_fb_scatter, grid, block, 0, st, f, 1);
+                    hipLaunchKernelGGL(k_fb_phase_b<true>, grid, block, 0, st, f);
+                } else {
+                    hipLaunchKernelGGL(k_fb_phase_a<false>, grid, block, 0, st, f);
+                    hipLaunchKernelGGL(k_fb_phase_b<false>, grid, block, 0, st, f);
+                }
+            }
+            hipLaunchKernelGGL(k_fb_month_end, grid, block, 0, st, f, sm[it], snt[it], (int)swr[it]);
+        }
+        hipLaunchKernelGGL(k_fb_finish, grid, block, 0, st, f);
+        XH_HIP(ctx, hipGetLastError());
+        XH_HIP(ctx, hipEventRecord(plan->ev_join[N_CLASS], st));
+        XH_HIP(ctx, hipStreamWaitEvent(ctx->stream, plan->ev_join[N_CLASS], 0));
+    }
+    xh_span_end(sp);
+    return XH_OK;
+}

@@ -1,0 +1,339 @@
+// Penman-Monteith monthly PET on gfx950: one fused kernel over (cell, month).
+//
+// Replaces xanthos/pet/penman_monteith.py: run_pmpet (:394-477), SetData (:17-99), et_veg (:223-334),
+// et_water (:337-361), et_snow (:364-377).  The reference evaluates ~250 whole-array numpy expressions on
+// [nlcs, ncell, 12] tensors per simulated year; here each thread owns two consecutive months of one cell, reads
+// the six forcings as 16-byte coalesced loads (arrays are [ncell, nmonths], month fastest), evaluates every
+// land class in registers against per-class tables staged in LDS, and writes PET once.
+// Algorithmic HBM traffic: 6 x 8 B forcing + 8 B PET per cell-month (+ land cover, amortised) = 61.3 B.
+//
+// Arithmetic follows the reference expression by expression (same association order; compiled with
+// -ffp-contract=off), so differences come only from exp/log/sqrt implementations (a few ulp).
+#include <algorithm>
+
+#include "xh_common.h"
+
+namespace {
+
+constexpr double LAMBDA1 = 2.46e6;   // penman_monteith.py:76
+constexpr double CP = 1006.0;        // :77
+constexpr double SIGMA = 4.9e-3;     // :78
+constexpr double SIGMA2 = 5.67e-8;   // :79
+constexpr double GAMMA = 0.67;       // :80
+
+// rows of the per-class parameter block
+enum { V_CL = 0, V_BETA, V_RSLIMIT, V_TOPEN, V_TCLOSE, V_TSPAN, V_VCLOSE, V_VOPEN, V_VSPAN, V_RBLMIN, V_RBLMAX,
+       V_RBLSPAN, V_RC, V_INVRC, V_EMISS, PM_NVEC };
+
+struct PmTablesDev {
+    int nlcs, n_lc_years, water_idx, snow_idx, start_year, nyears;
+    double wind_pow;                     // (2/10)^0.11 (:99)
+    double vec[PM_NVEC][XH_MAX_LCS];
+    double one_m_alpha[XH_MAX_LCS][12], lai[XH_MAX_LCS][12], fc[XH_MAX_LCS][12];
+};
+
+struct PmLds {
+    double vec[PM_NVEC][XH_MAX_LCS];
+    double one_m_alpha[XH_MAX_LCS][12], lai[XH_MAX_LCS][12], fc[XH_MAX_LCS][12];
+};
+
+__device__ __forceinline__ int days_in_month(int year, int moy) {
+    const int d = (moy == 1) ? 28 : ((moy == 3 || moy == 5 || moy == 8 || moy == 10) ? 30 : 31);
+    const bool leap = (year % 4 == 0 && year % 100 != 0) || (year % 400 == 0);   // calendar.isleap (:57)
+    return d + ((moy == 1 && leap) ? 1 : 0);
+}
+
+struct PmCell {          // per-cell quantities shared by the months a thread handles
+    double p;            // air pressure (calc_p :185-188)
+};
+
+// One (cell, month): returns PET. lctw[l] = land-cover fraction of class l, totpct = their sum (0 -> 0.01).
+__device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_idx, int snow_idx, double wind_pow,
+                                           double p, double T, double TN, double RH, double W, double RS,
+                                           double RL, double TP, int moy, double dz,
+                                           const double *__restrict__ lct_cell, int lct_stride, double totpct) {
+    // ---- terms shared by every land class (SetData :83-99, et_veg :226-282)
+    const double esx = 6.10588 * exp(17.32491 * T / (T + 238.102));
+    const double vap = esx * (RH / 100.0);
+    const double tk1 = T + 238.1;
+    const double sx = 238.1 * 17.325 * esx / (tk1 * tk1);
+    const double vpd = esx - vap;
+    const double xr = (273.15 + T) / 293.15;
+    const double sq = sqrt(xr);
+    const double rcorr = p / (101300.0 * (xr * sq * sqrt(sq)));      // pow(x, 1.75) = x * x^(1/2) * x^(1/4)
+    const double gcu = 0.00001 * rcorr;
+    const double rh = RH > 99.9999 ? 99.9 : RH;                       // calc_rh :205-209
+    const double r100 = rh / 100.0;
+    const double r2 = r100 * r100, r4 = r2 * r2, r8 = r4 * r4;
+    double fwet = rh < 70.0 ? 0.0 : rh;                               // calc_fwet :165-172
+    fwet = rh >= 70.0 ? r8 : fwet;
+    fwet = rh >= 80.0 ? r8 * r2 : fwet;
+    fwet = rh >= 90.0 ? r8 * r4 : fwet;
+    fwet = rh >= 95.0 ? r8 * r8 : fwet;
+    const double g = (moy == 0) ? 0.0 : 1.6198 * (T - TP);            // calc_g :212-216
+    const double t273 = T + 273.0;
+    const double t273_2 = t273 * t273;
+    const double sig_t4 = SIGMA * (t273_2 * t273_2);
+    const double rl_term = RL * 86400.0 * dz;
+    const double secs = 86400.0 * dz;
+    const double tk = T + 273.15;
+    const double rho = p / (tk * 287.058);
+    const double rr = rho * CP / (4.0 * SIGMA2 * (tk * tk * tk));
+    const double rho_cp = rho * CP;
+    const double log_r100 = log(r100);
+    const double one_m_fwet = 1.0 - fwet;
+
+    double acc = 0.0;
+    for (int l = 0; l < nlcs; ++l) {
+        double et;
+        const double oma = (l == water_idx) ? L.one_m_alpha[0][moy]
+                                            : ((l == snow_idx) ? L.one_m_alpha[6][moy] : L.one_m_alpha[l][moy]);
+        if (l == snow_idx) {
+            // et_snow (:364-377): emissivity 0.85, albedo of land class 6
+            const double rnl = sig_t4 * 0.85 * dz - rl_term;
+            double rn = oma * RS * 86400.0 * dz - rnl;
+            rn = rn < 0.0 ? 0.0 : rn;
+            et = rn / secs * dz * 0.6 / 2845.0;
+            et = et < 0.0 ? 0.0 : et;
+        } else if (l == water_idx) {
+            // et_water (:337-361): emissivity 0.98, albedo of land class 0
+            const double rsn = oma * RS * 86400.0 * dz;
+            const double rnl = sig_t4 * 0.98 * dz - rl_term;
+            double rn = rsn - rnl;
+            rn = rn < 0.0 ? 0.0 : rn;
+            const double qt = 0.5 * rsn - (moy <= 5 ? 0.8 : 1.3) * rnl;
+            double ax = (rn - qt) / secs;
+            ax = ax < 0.0 ? 0.0 : ax;
+            const double ewetx = rn / secs * dz * 0.6 / 2845.0;
+            const double wind2 = W * wind_pow;
+            const double ewety = dz * 86400.0 * (sx * ax + GAMMA * 6.43 * (0.5 + 0.54 * wind2) * vpd) /
+                                 ((sx + GAMMA) * LAMBDA1);
+            et = T < -1.0 ? ewetx : ewety;
+            et = et < 0.0 ? 0.0 : et;
+        } else {
+            // et_veg (:223-334)
+            const double topen = L.vec[V_TOPEN][l], tclose = L.vec[V_TCLOSE][l];
+            double mtmin = 0.0;                                       // calc_mtmin :102-114
+            mtmin = TN >= topen ? 1.0 : mtmin;
+            mtmin = TN <= tclose ? 0.1 : mtmin;
+            mtmin = (TN < topen && TN > tclose) ? (TN - tclose) / L.vec[V_TSPAN][l] : mtmin;
+            const double vclose = L.vec[V_VCLOSE][l], vopen = L.vec[V_VOPEN][l], vspan = L.vec[V_VSPAN][l];
+            const bool vmid = (vpd > vopen) && (vpd < vclose);
+            double mvpd = vpd;                                        // calc_vpd :117-129
+            mvpd = vpd <= vopen ? 1.0 : mvpd;
+            mvpd = vpd >= vclose ? 0.1 : mvpd;
+            mvpd = vmid ? (vclose - vpd) / vspan : mvpd;
+            const double gs1 = L.vec[V_CL][l] * mtmin * mvpd * rcorr;    // :242
+            const double rblmin = L.vec[V_RBLMIN][l], rblmax = L.vec[V_RBLMAX][l];
+            double rtotc = 0.0;                                       // calc_rtotc :132-145
+            rtotc = vpd <= vopen ? rblmax : rtotc;
+            rtotc = vpd >= vclose ? rblmin : rtotc;
+            rtotc = vmid ? rblmax - L.vec[V_RBLSPAN][l] * (vclose - vpd) / vspan : rtotc;
+
+            const double rnl = sig_t4 * L.vec[V_EMISS][l] * dz - rl_term;  // calc_a :148-162
+            const double rn = oma * RS * 86400.0 * dz - rnl;
+            const double a = rn / secs;
+
+            const double lai = L.lai[l][moy], fc = L.fc[l][moy];
+            const double ac = fc * a;
+            const double asoil = (1.0 - fc) * a - g;
+            double rtot = rtotc * rcorr;
+            rtot = rtot > 80.0 ? 80.0 : rtot;
+            const double rc = L.vec[V_RC][l], inv_rc = L.vec[V_INVRC][l], rslimit = L.vec[V_RSLIMIT][l];
+            double ra = rc * rr / (rc + rr);
+            ra = ra > rtot ? rtot : ra;
+
+            const double gsum = gs1 + inv_rc + gcu;                   // calc_cc :192-197
+            double cc = gsum < 0.0001 ? 10000.0 : (fwet == 1.0 ? 0.00001 : (lai < 0.0001 ? 0.00001 : 0.0));
+            cc = cc == 0.0 ? inv_rc * (gs1 + gcu) * lai * one_m_fwet / gsum : cc;
+            double rs = cc == 0.0 ? 100000.0 : 1.0 / cc;              // :285-291
+            rs = rs > rslimit ? rslimit : rs;
+
+            const double lf = lai * fwet;                             // :296-301
+            const double lai_fwet = lf == 0.0 ? 1.0 : lf;
+            double rhc = lai > 0.00001 ? rc / lai_fwet : rslimit;
+            rhc = rhc > rslimit ? rslimit : rhc;
+            double rhrc = rhc * rr / (rhc + rr);
+            rhrc = rhrc > rtot ? rtot : rhrc;
+
+            const double apres = dz * 86400.0 * (sx * ac + rho_cp * vpd * fc / rhrc) * fwet /
+                                 ((sx + p * 0.01 * CP * rhc / (LAMBDA1 * 0.622 * rhrc)) * LAMBDA1);   // :306-307
+            const double ewet_c = rh >= 70.0 ? apres : 0.0;
+
+            const double rasoil = rtot * rr / (rtot + rr);
+            const double soil_num = 86400.0 * dz * (sx * asoil + rho_cp * (1.0 - fc) * vpd / rasoil);
+            const double soil_den = (sx + GAMMA * rtot / rasoil) * LAMBDA1;
+            const double ewet_soil = soil_num * fwet / soil_den;      // :314-315
+            const double esoilpot = soil_num * one_m_fwet / soil_den; // :316-317
+            const double esoil = ewet_soil + esoilpot * exp((vpd / L.vec[V_BETA][l]) * log_r100);   // pow(rh/100, vpd/beta) :323
+
+            double trans = dz * 86400.0 * (sx * ac + rho_cp * vpd * fc / ra) * one_m_fwet /
+                           ((sx + GAMMA * (1.0 + rs / ra)) * LAMBDA1);                          // :326-327
+            trans = fc == 0.0 ? 0.0 : trans;
+            et = trans + ewet_c + esoil;
+            et = et < 0.0 ? 0.0 : et;
+        }
+        const double term = et * lct_cell[l * lct_stride];            // arr *= lct (:467)
+        acc = (l == 0) ? term : acc + term;                           // np.sum over classes, in order (:470)
+    }
+    return acc / totpct;
+}
+
+// Thread <-> (cell, pair of consecutive months). nmonths is a multiple of 12, hence even.
+__global__ void __launch_bounds__(256) k_pm_pet(const PmTablesDev *__restrict__ tab,
+                                                const int *__restrict__ lc_of_year, int64_t ncell, int nmonths,
+                                                const double *__restrict__ tas, const double *__restrict__ tmin,
+                                                const double *__restrict__ rhs, const double *__restrict__ wind,
+                                                const double *__restrict__ rsds, const double *__restrict__ rlds,
+                                                const double *__restrict__ tairprev,
+                                                const double *__restrict__ lct, const double *__restrict__ elev,
+                                                double *__restrict__ pet) {
+    __shared__ PmLds L;
+    const int nlcs = tab->nlcs;
+    {
+        for (int i = threadIdx.x; i < PM_NVEC * XH_MAX_LCS; i += blockDim.x) {
+            const int v = i / XH_MAX_LCS, l = i % XH_MAX_LCS;
+            if (l < nlcs) L.vec[v][l] = tab->vec[v][l];
+        }
+        for (int i = threadIdx.x; i < nlcs * 12; i += blockDim.x) {
+            const int l = i / 12, m = i % 12;
+            L.one_m_alpha[l][m] = tab->one_m_alpha[l][m];
+            L.lai[l][m] = tab->lai[l][m];
+            L.fc[l][m] = tab->fc[l][m];
+        }
+    }
+    __syncthreads();
+    const int water_idx = tab->water_idx, snow_idx = tab->snow_idx, start_year = tab->start_year;
+    const int n_lc_years = tab->n_lc_years;
+    const double wind_pow = tab->wind_pow;
+    const int half = nmonths >> 1;
+    const int64_t total = ncell * (int64_t)half;
+    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total;
+         item += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = item / half;
+        const int m0 = (int)(item - c * half) * 2;
+        const int64_t off = c * nmonths + m0;
+        const double2 T = *reinterpret_cast<const double2 *>(tas + off);
+        const double2 TN = *reinterpret_cast<const double2 *>(tmin + off);
+        const double2 RH = *reinterpret_cast<const double2 *>(rhs + off);
+        const double2 W = *reinterpret_cast<const double2 *>(wind + off);
+        const double2 RS = *reinterpret_cast<const double2 *>(rsds + off);
+        const double2 RL = *reinterpret_cast<const double2 *>(rlds + off);
+        double2 TP;
+        if (tairprev) {
+            TP = *reinterpret_cast<const double2 *>(tairprev + off);
+        } else if (c > 0) {
+            TP = *reinterpret_cast<const double2 *>(tas + off - nmonths);   // previous CELL (data_load.py:128-129)
+        } else {
+            TP = make_double2(0.0, 0.0);
+        }
+        const int yr_i = m0 / 12;                   // both months are in the same year (m0 even, 12 even)
+        const int year = start_year + yr_i;
+        const int moy = m0 - yr_i * 12;
+        const double *lct_cell = lct + c * (int64_t)nlcs * n_lc_years + lc_of_year[yr_i];
+        double totpct = 0.0;
+        for (int l = 0; l < nlcs; ++l) {
+            const double v = lct_cell[l * n_lc_years];
+            totpct = (l == 0) ? v : totpct + v;
+        }
+        totpct = totpct == 0.0 ? 0.01 : totpct;     // :47
+        const double p = 101325.0 * pow(1.0 - 0.0065 * elev[c] / 288.15, 5.2558);   // calc_p :185-188
+        double2 out;
+        out.x = pm_month(L, nlcs, water_idx, snow_idx, wind_pow, p, T.x, TN.x, RH.x, W.x, RS.x, RL.x, TP.x, moy,
+                         (double)days_in_month(year, moy), lct_cell, n_lc_years, totpct);
+        out.y = pm_month(L, nlcs, water_idx, snow_idx, wind_pow, p, T.y, TN.y, RH.y, W.y, RS.y, RL.y, TP.y,
+                         moy + 1, (double)days_in_month(year, moy + 1), lct_cell, n_lc_years, totpct);
+        *reinterpret_cast<double2 *>(pet + off) = out;
+    }
+}
+
+int land_cover_index(int year, const std::vector<int> &sorted_years) {   // SetData :33-43
+    if (year >= sorted_years.back()) return (int)sorted_years.size() - 1;
+    for (size_t i = 0; i < sorted_years.size(); ++i)
+        if (sorted_years[i] - year >= -4) return (int)i;
+    return (int)sorted_years.size() - 1;
+}
+
+}  // namespace
+
+extern "C" int xh_pm_pet(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int32_t nmonths, int32_t start_year,
+                         int32_t n_lc_years, const int32_t *h_lc_years, int32_t water_idx, int32_t snow_idx,
+                         const double *d_tas, const double *d_tmin, const double *d_rhs, const double *d_wind,
+                         const double *d_rsds, const double *d_rlds, const double *d_tairprev, const double *d_lct,
+                         const double *d_elev, double *d_pet) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, t && h_lc_years && d_tas && d_tmin && d_rhs && d_wind && d_rsds && d_rlds && d_lct && d_elev &&
+                        d_pet, "xh_pm_pet: NULL argument");
+    XH_REQUIRE(ctx, ncell >= 0 && nmonths > 0 && nmonths % 12 == 0, "xh_pm_pet: nmonths must be a positive multiple of 12");
+    XH_REQUIRE(ctx, n_lc_years >= 1, "xh_pm_pet: need at least one land-cover year");
+    const int nlcs = t->nlcs;
+    if (nlcs > XH_MAX_LCS) return xh_fail(ctx, XH_ERR_LIMIT, "xh_pm_pet: nlcs=%d exceeds XH_MAX_LCS=%d", nlcs, XH_MAX_LCS);
+    // the reference reads albedo rows 0 and 6 for water and snow regardless of the indices (:361, :377)
+    XH_REQUIRE(ctx, nlcs >= 7, "xh_pm_pet: nlcs=%d; the reference indexes land classes 0 and 6, so nlcs >= 7", nlcs);
+    XH_REQUIRE(ctx, water_idx >= 0 && water_idx < nlcs && snow_idx >= 0 && snow_idx < nlcs,
+               "xh_pm_pet: water_idx/snow_idx out of range");
+    if (ncell == 0) return XH_OK;
+
+    const int nyears = nmonths / 12;
+    PmTablesDev h;
+    memset(&h, 0, sizeof(h));
+    h.nlcs = nlcs;
+    h.n_lc_years = n_lc_years;
+    h.water_idx = water_idx;
+    h.snow_idx = snow_idx;
+    h.start_year = start_year;
+    h.nyears = nyears;
+    h.wind_pow = pow(2.0 / 10.0, 0.11);
+    for (int l = 0; l < nlcs; ++l) {
+        h.vec[V_CL][l] = t->cL[l];
+        h.vec[V_BETA][l] = t->beta[l];
+        h.vec[V_RSLIMIT][l] = t->rslimit[l];
+        h.vec[V_TOPEN][l] = t->Tminopen[l];
+        h.vec[V_TCLOSE][l] = t->Tminclose[l];
+        h.vec[V_TSPAN][l] = t->Tminopen[l] - t->Tminclose[l];
+        h.vec[V_VCLOSE][l] = t->VPDclose[l];
+        h.vec[V_VOPEN][l] = t->VPDopen[l];
+        h.vec[V_VSPAN][l] = t->VPDclose[l] - t->VPDopen[l];
+        h.vec[V_RBLMIN][l] = t->RBLmin[l];
+        h.vec[V_RBLMAX][l] = t->RBLmax[l];
+        h.vec[V_RBLSPAN][l] = t->RBLmax[l] - t->RBLmin[l];
+        h.vec[V_RC][l] = t->rc[l];
+        h.vec[V_INVRC][l] = 1.0 / t->rc[l];
+        h.vec[V_EMISS][l] = t->emiss[l];
+        for (int m = 0; m < 12; ++m) {
+            const double lai = t->lai[l * 12 + m], lmin = t->laimin[l * 12 + m], lmax = t->laimax[l * 12 + m];
+            double den = exp(-0.5 * lmin) - exp(-0.5 * lmax);           // :257-261
+            den = den == 0.0 ? 1.0 : den;
+            double fc = (exp(-0.5 * lmin) - exp(-0.5 * lai)) / den;
+            fc = fc > 1.0 ? 1.0 : fc;
+            h.one_m_alpha[l][m] = 1.0 - t->alpha[l * 12 + m];
+            h.lai[l][m] = lai;
+            h.fc[l][m] = fc;
+        }
+    }
+    std::vector<int> sorted(h_lc_years, h_lc_years + n_lc_years);
+    std::sort(sorted.begin(), sorted.end());
+    std::vector<int> lc_of_year(nyears);
+    for (int y = 0; y < nyears; ++y) lc_of_year[y] = land_cover_index(start_year + y, sorted);
+
+    void *d_tab = nullptr;
+    const size_t tab_bytes = (sizeof(PmTablesDev) + 255) & ~size_t(255);
+    int rc = xh_scratch(ctx, 0, tab_bytes + sizeof(int) * nyears, &d_tab);
+    if (rc) return rc;
+    int *d_lcy = reinterpret_cast<int *>(static_cast<char *>(d_tab) + tab_bytes);
+    XH_HIP(ctx, hipMemcpyAsync(d_tab, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_lcy, lc_of_year.data(), sizeof(int) * nyears, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h / lc_of_year are stack/heap locals
+
+    const int64_t items = ncell * (int64_t)(nmonths / 2);
+    int64_t blocks = (items + 255) / 256;
+    const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 32;
+    if (blocks > cap) blocks = cap;
+    xh_span sp = xh_span_begin(ctx, "pm_pet");
+    hipLaunchKernelGGL(k_pm_pet, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       static_cast<const PmTablesDev *>(d_tab), d_lcy, ncell, (int)nmonths, d_tas, d_tmin, d_rhs,
+                       d_wind, d_rsds, d_rlds, d_tairprev, d_lct, d_elev, d_pet);
+    xh_span_end(sp);
+    XH_HIP(ctx, hipGetLastError());
+    return XH_OK;
+}
