@@ -165,8 +165,8 @@ int xh_calib_objective(xh_ctx *ctx, int64_t ncell_b, int32_t nmonths, int32_t sp
 
 /* ------------------------------------------------------------------ bench support (not on the hot path)
  * Fills the eight forcing arrays of the synthetic benchmark world on the device (same distributions as
- * xanthos_amd/synth.py:make_forcing); d_lat [ncell] degrees.                                              */
-int xh_synth_forcing(xh_ctx *ctx, uint64_t seed, int64_t ncell, int32_t nmonths, const double *d_lat,
+ * xanthos_amd/synth.py:make_forcing); d_lat [ncell] degrees; nan_frac = share of cells whose precipitation is NaN.                                             */
+int xh_synth_forcing(xh_ctx *ctx, uint64_t seed, double nan_frac, int64_t ncell, int32_t nmonths, const double *d_lat,
                      double *d_tas, double *d_tmin, double *d_rhs, double *d_wind, double *d_rsds,
                      double *d_rlds, double *d_precip, double *d_abcd_tmin);
 

@@ -63,7 +63,7 @@ SIGNATURES = {
     'xh_mrtm_um_csr': (c_int, [c_int64, _P, _P, _P, _P]),
     'xh_route_series': (c_int, [_P, _P, c_int32, c_int32, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32]),
     'xh_calib_objective': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'xh_synth_forcing': (c_int, [_P, c_uint64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'xh_synth_forcing': (c_int, [_P, c_uint64, c_double, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None
@@ -278,9 +278,9 @@ class Context:
         return (ed, series) if want_series else ed
 
     # ---- bench support
-    def synth_forcing(self, seed, ncell, nmonths, lat, out):
+    def synth_forcing(self, seed, ncell, nmonths, lat, out, nan_frac=0.001):
         """out: dict name -> DeviceArray for synth.FORCING_NAMES."""
-        self._check(lib().xh_synth_forcing(self.handle, int(seed), ncell, nmonths, _dptr(lat), _dptr(out['tas']),
+        self._check(lib().xh_synth_forcing(self.handle, int(seed), float(nan_frac), ncell, nmonths, _dptr(lat), _dptr(out['tas']),
                                            _dptr(out['tmin']), _dptr(out['rhs']), _dptr(out['wind']),
                                            _dptr(out['rsds']), _dptr(out['rlds']), _dptr(out['precip']),
                                            _dptr(out['abcd_tmin'])))

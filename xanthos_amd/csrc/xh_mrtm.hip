@@ -16,7 +16,7 @@
 // equivalent two-phase per-cell form (identical when no cell fires), with -ffp-contract=off.
 // Results are bit-identical to the numpy/scipy path for identical runoff.
 //
-// Networks that do not fit a workgroup (more than 4096 cells, or a row with more than 9 entries) are routed by
+// Networks that do not fit a workgroup (more than 3072 cells, or a row with more than 9 entries) are routed by
 // the global-memory kernels at the bottom (two launches per sub-step; optional fp64 atomic scatter-add variant).
 #include <algorithm>
 #include <cmath>
@@ -27,7 +27,8 @@
 namespace {
 
 constexpr int W_MAX = 9;             // 8 D8 neighbours + the diagonal
-constexpr int UNIT_MAX_CELLS = 4096;
+constexpr int W_BASE = 3;            // terms per row gathered branch-free (diagonal + two tributaries)
+constexpr int UNIT_MAX_CELLS = 3072;  // 44 B of LDS per cell: pair buffers + tail-term table
 constexpr int BIN_CELLS = 256;       // small networks share a single-wave workgroup of up to this many cells
 constexpr int N_CLASS = 8;
 
@@ -35,7 +36,7 @@ struct UnitClass {
     int nt, kc;
 };
 // shapes tried in order: first one with nt*kc >= cells
-constexpr UnitClass CLASSES[N_CLASS] = {{64, 1}, {64, 2}, {64, 4}, {256, 2}, {256, 4}, {1024, 2}, {1024, 4}, {512, 8}};
+constexpr UnitClass CLASSES[N_CLASS] = {{64, 1}, {64, 2}, {64, 4}, {256, 2}, {256, 4}, {1024, 2}, {768, 4}, {768, 4}};
 
 struct RouteArgs {
     const int *unit_slot0;           // [units of this launch] first slot of each unit
@@ -59,6 +60,43 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
+// acc[k] = 0 + sum of the row's terms in stored order, read from the pair buffer at `base`.
+// Stripe 0 holds the unit's highest-degree cells (cells are sorted by number of terms), so it carries all W_MAX term
+// offsets in registers and gathers them branch-free; the other stripes carry W_BASE and fall back to the LDS table
+// xe [W_MAX - W_BASE][NP] (offsets in 8-byte units) only in units with more confluence cells than stripe 0 holds.
+template <int KC>
+__device__ __forceinline__ void gather_terms(const char *base, const unsigned (&e0)[W_MAX], const unsigned (&e)[KC][W_BASE],
+                                             double (&acc)[KC], const int (&W)[KC], const unsigned short *xe, int NP,
+                                             int NT, int tid) {
+    double v0[W_MAX], v[KC][W_BASE];
+#pragma unroll
+    for (int w = 0; w < W_MAX; ++w) v0[w] = *reinterpret_cast<const double *>(base + e0[w]);
+#pragma unroll
+    for (int k = 1; k < KC; ++k)
+#pragma unroll
+        for (int w = 0; w < W_BASE; ++w) v[k][w] = *reinterpret_cast<const double *>(base + e[k][w]);
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < W_MAX; ++w) s += v0[w];
+        acc[0] = s;
+    }
+#pragma unroll
+    for (int k = 1; k < KC; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < W_BASE; ++w) s += v[k][w];
+        acc[k] = s;
+    }
+#pragma unroll
+    for (int k = 1; k < KC; ++k) {
+        if (W[k] > W_BASE) {                                 // wave-uniform and rare
+            for (int w = W_BASE; w < W[k]; ++w)
+                acc[k] += *reinterpret_cast<const double *>(base + 8u * xe[(w - W_BASE) * NP + k * NT + tid]);
+        }
+    }
+}
+
 // One workgroup = one routing unit for the whole series.  blockDim.x = NT, each thread owns KC cells
 // (slot l = k*NT + tid, so consecutive lanes touch consecutive LDS pairs).
 template <int KC, int NTMAX>
@@ -68,14 +106,19 @@ __global__ void __launch_bounds__(NTMAX) k_mrtm_units(RouteArgs a) {
     const int NP = NT * KC;
     double2 *bufA = lds;                // trial flows  {F, -F}
     double2 *bufB = lds + (NP + 1);     // final flows  {F2, -F2}; slot NP of each buffer is the constant {0,0}
+    unsigned short *xe = reinterpret_cast<unsigned short *>(lds + 2 * (NP + 1));   // [W_MAX - W_BASE][NP]
     const char *baseA = reinterpret_cast<const char *>(bufA);
     const char *baseB = reinterpret_cast<const char *>(bufB);
     const int slot0 = a.unit_slot0[blockIdx.x];
 
-    int gc[KC], W[KC];
-    bool act[KC];
+    // Gather terms: the first W_BASE terms of every row are read unconditionally (rows with fewer terms point at
+    // the constant-zero slot, adding +0.0 is exact), so the loads of all stripes issue back to back with no branch
+    // in between; rows with more terms (confluences of 3+ tributaries, a few per cent of the cells, sorted to the
+    // front of the unit) finish in a wave-uniform tail loop.
+    int gc[KC];
     double S[KC], tauinv[KC], area[KC], erl[KC], favg[KC], F[KC], qn[KC];
-    unsigned e[KC][W_MAX];
+    unsigned e0[W_MAX], e[KC][W_BASE];
+    int W[KC];
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
         const int64_t slot = (int64_t)slot0 + k * NT + tid;
@@ -85,10 +128,15 @@ __global__ void __launch_bounds__(NTMAX) k_mrtm_units(RouteArgs a) {
         area[k] = valid ? a.area[gc[k]] : 0.0;
         S[k] = (valid && a.S0) ? a.S0[gc[k]] : 0.0;
         F[k] = 0.0;
-        W[k] = __builtin_amdgcn_readfirstlane(wave_max_i32((int)a.cnt[slot]));
-        act[k] = __builtin_amdgcn_readfirstlane(wave_max_i32(valid ? 1 : 0)) != 0;
+        W[k] = __builtin_amdgcn_readfirstlane(wave_max_i32((int)a.cnt[slot]));   // most terms of any row in this stripe
 #pragma unroll
-        for (int w = 0; w < W_MAX; ++w) e[k][w] = a.ent[(int64_t)w * a.total_slots + slot];
+        for (int w = 0; w < W_BASE; ++w) e[k][w] = a.ent[(int64_t)w * a.total_slots + slot];
+        if (k == 0) {
+#pragma unroll
+            for (int w = 0; w < W_MAX; ++w) e0[w] = a.ent[(int64_t)w * a.total_slots + slot];
+        }
+        for (int w = W_BASE; w < W_MAX; ++w)
+            xe[(w - W_BASE) * NP + k * NT + tid] = (unsigned short)(a.ent[(int64_t)w * a.total_slots + slot] >> 3);
         qn[k] = valid ? a.runoff[(int64_t)gc[k] * a.nmonths + a.sched_m[0]] : 0.0;
     }
     if (tid == 0) {
@@ -113,41 +161,30 @@ __global__ void __launch_bounds__(NTMAX) k_mrtm_units(RouteArgs a) {
         }
         for (int t = 0; t < nt; ++t) {
             bool sx[KC];
+            double acc[KC];
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
-                if (act[k]) {
-                    F[k] = S[k] * tauinv[k];                                   // mrtm.py:50
-                    bufA[k * NT + tid] = make_double2(F[k], -F[k]);
-                }
+                F[k] = S[k] * tauinv[k];                                       // mrtm.py:50
+                bufA[k * NT + tid] = make_double2(F[k], -F[k]);
             }
             __syncthreads();
+            gather_terms<KC>(baseA, e0, e, acc, W, xe, NP, NT, tid);        // UM.dot(F), row order (mrtm.py:51)
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
-                if (act[k]) {
-                    double acc = 0.0;                                          // UM.dot(F), row order (mrtm.py:51)
-#pragma unroll
-                    for (int w = 0; w < W_MAX; ++w)
-                        if (w < W[k]) acc += *reinterpret_cast<const double *>(baseA + e[k][w]);
-                    const double dsdt = acc + erl[k];
-                    sx[k] = (dsdt * dt) < (-S[k]);                             // mrtm.py:54
-                    const double f2 = sx[k] ? (dsdt + F[k]) + S[k] * dtinv : F[k];   // mrtm.py:60
-                    S[k] = sx[k] ? 0.0 : S[k];                                 // mrtm.py:63
-                    F[k] = f2;
-                    bufB[k * NT + tid] = make_double2(f2, -f2);
-                }
+                const double dsdt = acc[k] + erl[k];
+                sx[k] = (dsdt * dt) < (-S[k]);                                 // mrtm.py:54
+                const double f2 = sx[k] ? (dsdt + F[k]) + S[k] * dtinv : F[k]; // mrtm.py:60
+                S[k] = sx[k] ? 0.0 : S[k];                                     // mrtm.py:63
+                F[k] = f2;
+                bufB[k * NT + tid] = make_double2(f2, -f2);
             }
             __syncthreads();
+            gather_terms<KC>(baseB, e0, e, acc, W, xe, NP, NT, tid);        // UM.dot(F) again, adjusted flows
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
-                if (act[k]) {
-                    double acc = 0.0;                                          // UM.dot(F) again with the adjusted flows
-#pragma unroll
-                    for (int w = 0; w < W_MAX; ++w)
-                        if (w < W[k]) acc += *reinterpret_cast<const double *>(baseB + e[k][w]);
-                    const double dsdt = acc + erl[k];                          // mrtm.py:68
-                    S[k] = sx[k] ? S[k] : S[k] + dsdt * dt;                    // mrtm.py:69 / :76
-                    favg[k] += F[k];                                           // mrtm.py:78
-                }
+                const double dsdt = acc[k] + erl[k];                           // mrtm.py:68
+                S[k] = sx[k] ? S[k] : S[k] + dsdt * dt;                        // mrtm.py:69 / :76
+                favg[k] += F[k];                                               // mrtm.py:78
             }
         }
         if (a.sched_write[it]) {
@@ -327,7 +364,16 @@ void free_buf(DevBuf &b) {
 template <int KC, int NTMAX>
 void launch_units(const xh_route_plan *plan, int cls, RouteArgs args, hipStream_t st) {
     const int nt = CLASSES[cls].nt;
-    const size_t lds = 2 * (size_t)(nt * KC + 1) * sizeof(double2);
+    size_t lds = 2 * (size_t)(nt * KC + 1) * sizeof(double2) + (size_t)(W_MAX - W_BASE) * nt * KC * sizeof(unsigned short);
+    // Placement control: the dispatcher stacks small workgroups on one CU until a resource runs out, and a stack of
+    // routing waves saturates that CU's LDS pipe while other CUs idle.  Asking for an even share of the 160 KiB
+    // makes at most ceil(units / CUs) workgroups fit per CU, so the units spread over the whole chip.
+    {
+        const int cus = plan->ctx->prop.multiProcessorCount > 0 ? plan->ctx->prop.multiProcessorCount : 256;
+        const int64_t per_cu = (plan->n_units + cus - 1) / cus;
+        const size_t share = ((size_t)(160 * 1024) / (size_t)(per_cu > 0 ? per_cu : 1)) & ~size_t(1023);
+        if (share > lds) lds = share;
+    }
     args.unit_slot0 = static_cast<const int *>(plan->d_class_units[cls].p);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mrtm_units<KC, NTMAX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -666,8 +712,8 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
                 case 3: launch_units<2, 256>(plan, cls, a, st); break;
                 case 4: launch_units<4, 256>(plan, cls, a, st); break;
                 case 5: launch_units<2, 1024>(plan, cls, a, st); break;
-                case 6: launch_units<4, 1024>(plan, cls, a, st); break;
-                case 7: launch_units<8, 512>(plan, cls, a, st); break;
+                case 6: launch_units<4, 768>(plan, cls, a, st); break;
+                case 7: break;
             }
             XH_HIP(ctx, hipGetLastError());
             XH_HIP(ctx, hipEventRecord(plan->ev_join[njoin], st));

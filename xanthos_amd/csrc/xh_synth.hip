@@ -27,7 +27,7 @@ __device__ __forceinline__ double nrm(uint64_t seed, uint64_t stream, uint64_t i
     return sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * M_PI * u2);
 }
 
-__global__ void __launch_bounds__(256) k_synth(uint64_t seed, int64_t ncell, int nmonths, const double *__restrict__ lat,
+__global__ void __launch_bounds__(256) k_synth(uint64_t seed, double nan_frac, int64_t ncell, int nmonths, const double *__restrict__ lat,
                                                double *tas, double *tmin, double *rhs, double *wind, double *rsds,
                                                double *rlds, double *precip, double *abcd_tmin) {
     const int64_t total = ncell * (int64_t)nmonths;
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_synth(uint64_t seed, int64_t ncell, int
         rsds[i] = 30.0 + 300.0 * uni(seed, 11, idx);
         rlds[i] = 150.0 + 280.0 * uni(seed, 12, idx);
         double pr = -40.0 * (log(1.0 - uni(seed, 13, idx)) + log(1.0 - uni(seed, 14, idx)));
-        if (uni(seed, 15, (uint64_t)c) < 0.001) pr = NAN;        // missing-data cells (precip keeps NaN, data_load.py:186)
+        if (uni(seed, 15, (uint64_t)c) < nan_frac) pr = NAN;        // missing-data cells (precip keeps NaN, data_load.py:186)
         precip[i] = pr;
         abcd_tmin[i] = tn;
     }
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_synth(uint64_t seed, int64_t ncell, int
 
 }  // namespace
 
-extern "C" int xh_synth_forcing(xh_ctx *ctx, uint64_t seed, int64_t ncell, int32_t nmonths, const double *d_lat,
+extern "C" int xh_synth_forcing(xh_ctx *ctx, uint64_t seed, double nan_frac, int64_t ncell, int32_t nmonths, const double *d_lat,
                                 double *d_tas, double *d_tmin, double *d_rhs, double *d_wind, double *d_rsds,
                                 double *d_rlds, double *d_precip, double *d_abcd_tmin) {
     if (!ctx) return XH_ERR_ARG;
@@ -70,7 +70,7 @@ extern "C" int xh_synth_forcing(xh_ctx *ctx, uint64_t seed, int64_t ncell, int32
     int64_t blocks = (total + 255) / 256;
     const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 16;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, seed, ncell, (int)nmonths, d_lat,
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, seed, nan_frac, ncell, (int)nmonths, d_lat,
                        d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds, d_precip, d_abcd_tmin);
     XH_HIP(ctx, hipGetLastError());
     return XH_OK;

@@ -1,0 +1,129 @@
+"""Device-resident PET -> runoff -> routing pipeline.
+
+One object owns the static grid data and the six output arrays in HBM and enqueues the three stages back to back
+on the context's stream; nothing crosses PCIe between stages.  ``components.Components`` (the reference-shaped
+harness), ``bench.py`` and the multi-GPU sharding all drive this class; the per-stage plugin functions in
+``pet/``, ``runoff/`` and ``routing/`` are the host-array entry points around the same C-ABI calls.
+"""
+import numpy as np
+
+from . import _hip
+from .pet import penman_monteith as pm_mod
+from .routing import mrtm as mrtm_mod
+from .utils import set_month_arrays
+
+FORCING = ('tas', 'tmin', 'rhs', 'wind', 'rsds', 'rlds', 'precip', 'abcd_tmin')
+OUTPUTS = ('pet', 'aet', 'q', 'sav', 'chs', 'avg')
+
+
+class DevicePipeline:
+    """PM -> ABCD -> MRTM for one set of cells (the whole grid, or one rank's shard) on one GPU."""
+
+    def __init__(self, ctx, *, ncell, nmonths, start_year, basin_ids, abcd_pars, pm_tables, lct, elev, lc_years,
+                 um, flow_dist, velocity, area, abcd_spinup, routing_spinup, water_idx=0, snow_idx=6, use_snow=True,
+                 route_flags=0):
+        self.ctx = ctx
+        self.ncell, self.nmonths, self.start_year = int(ncell), int(nmonths), int(start_year)
+        self.end_year = self.start_year + self.nmonths // 12 - 1
+        self.abcd_spinup, self.routing_spinup = int(abcd_spinup), int(routing_spinup)
+        self.water_idx, self.snow_idx, self.use_snow = water_idx, snow_idx, use_snow
+        self.lc_years = sorted(lc_years)
+        self.pm_tables = pm_tables
+        self.route_flags = route_flags
+        basin_ids = np.asarray(basin_ids)
+        uniq, inv = np.unique(basin_ids, return_inverse=True)
+        self.basin_index = inv.astype(np.int32)
+        self.n_groups = len(uniq)
+        self.par_index = (basin_ids - 1).astype(np.int32)          # row of abcd_pars = basin id - 1 (abcd.py:332)
+        self.npar_rows = int(np.asarray(abcd_pars).shape[0])
+        up = ctx.upload
+        self.d_pars = up(np.asarray(abcd_pars, dtype=np.float64))
+        self.d_lct = up(lct)
+        self.d_elev = up(np.asarray(elev, dtype=np.float64).reshape(-1))
+        self.um = um
+        self.d_flow_dist, self.d_velocity, self.d_area = up(flow_dist), up(velocity), up(area)
+        self.ndays = set_month_arrays(self.nmonths, self.start_year, self.end_year)[:, 2]
+        self.forcing = {}
+        self.d_tairprev = None
+        self.out = {k: ctx.empty((self.ncell, self.nmonths)) for k in OUTPUTS}
+        self.plan = um.plan(ctx) if um is not None else None
+
+    # ---- forcing
+    def alloc_forcing(self):
+        for k in FORCING:
+            if k not in self.forcing:
+                self.forcing[k] = self.ctx.empty((self.ncell, self.nmonths))
+        return self.forcing
+
+    def set_forcing(self, host, tairprev=None):
+        """host: dict of [ncell, nmonths] arrays keyed by FORCING (abcd_tmin optional when use_snow is False)."""
+        for k in FORCING:
+            if k in host and host[k] is not None:
+                arr = np.asarray(host[k], dtype=np.float64)
+                if arr.shape != (self.ncell, self.nmonths):
+                    raise ValueError('forcing {} has shape {}, expected {}'.format(k, arr.shape,
+                                                                                   (self.ncell, self.nmonths)))
+                if k in self.forcing:
+                    self.forcing[k].upload(arr)
+                else:
+                    self.forcing[k] = self.ctx.upload(arr)
+        if tairprev is not None:
+            self.d_tairprev = self.ctx.upload(tairprev)
+
+    # ---- stages (asynchronous; call ctx.sync() or download to wait)
+    def run_pm(self):
+        f = self.forcing
+        pm_mod.run_pmpet_device(self.ctx, self.pm_tables, self.ncell, self.start_year, self.end_year, self.water_idx,
+                                self.snow_idx, self.lc_years, f['tas'], f['tmin'], f['rhs'], f['wind'], f['rsds'],
+                                f['rlds'], self.d_tairprev, self.d_lct, self.d_elev, self.out['pet'])
+
+    def run_abcd(self):
+        f = self.forcing
+        self.ctx.abcd(self.ncell, self.nmonths, self.abcd_spinup, self.n_groups, self.basin_index, self.par_index,
+                      self.npar_rows, self.d_pars, self.out['pet'], f['precip'],
+                      f['abcd_tmin'] if self.use_snow else None, self.out['aet'], self.out['q'], self.out['sav'])
+
+    def run_mrtm(self, runoff=None):
+        self.ctx.route_series(self.plan, self.nmonths, self.routing_spinup, self.ndays, 10800.0, self.d_flow_dist,
+                              self.d_velocity, self.d_area, self.out['q'] if runoff is None else runoff, None,
+                              self.out['chs'], self.out['avg'], flags=self.route_flags)
+
+    def run(self, stages=('pm', 'abcd', 'mrtm')):
+        if 'pm' in stages:
+            self.run_pm()
+        if 'abcd' in stages:
+            self.run_abcd()
+        if 'mrtm' in stages:
+            self.run_mrtm()
+
+    def download(self, names=OUTPUTS):
+        return {k: self.out[k].download() for k in names}
+
+    def rows(self, darr, cells):
+        """Download selected rows of a [ncell, nmonths] device array."""
+        cells = np.ascontiguousarray(cells, dtype=np.int64)
+        d_idx = self.ctx.upload(cells, dtype=np.int64)
+        d_tmp = self.ctx.empty((len(cells), self.nmonths))
+        self.ctx.gather_rows(darr, d_idx, len(cells), self.nmonths, d_tmp)
+        host = d_tmp.download()
+        d_idx.free()
+        d_tmp.free()
+        return host
+
+
+def topology_from_world(world):
+    """dsid -> upid -> UM for a synth world / DataLoader-like object (coords, flow_dir, nrow, ncol)."""
+    from types import SimpleNamespace
+    st = SimpleNamespace(ngridrow=world.nrow, ngridcol=world.ncol)
+    ds = mrtm_mod.downstream(world.coords, world.flow_dir, st)
+    return mrtm_mod.upstream_genmatrix(mrtm_mod.upstream(world.coords, ds, st))
+
+
+def pipeline_from_world(ctx, world, nmonths, start_year, abcd_spinup, routing_spinup, um=None, **kw):
+    tables = pm_mod.tables_from(world, world.nlcs)
+    if um is None:
+        um = topology_from_world(world)
+    return DevicePipeline(ctx, ncell=world.ncell, nmonths=nmonths, start_year=start_year, basin_ids=world.basin_ids,
+                          abcd_pars=world.abcd_pars, pm_tables=tables, lct=world.lct, elev=world.elev,
+                          lc_years=world.lc_years, um=um, flow_dist=world.flow_dist, velocity=world.velocity,
+                          area=world.area, abcd_spinup=abcd_spinup, routing_spinup=routing_spinup, **kw)

@@ -46,9 +46,9 @@ class UpstreamMatrix:
         return sparse.csr_matrix((self.sign.astype(int), self.indices, self.indptr), shape=self.shape)
 
     def plan(self, ctx):
-        p = self._plans.get(ctx.device)
+        p = self._plans.get(ctx.handle)
         if p is None or p.handle is None or p.ctx.handle is None:
-            p = self._plans[ctx.device] = ctx.route_plan(self.indptr, self.indices, self.sign)
+            p = self._plans[ctx.handle] = ctx.route_plan(self.indptr, self.indices, self.sign)
         return p
 
 
