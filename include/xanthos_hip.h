@@ -116,9 +116,16 @@ int xh_abcd(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spinup, int32_t
 int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h_indptr, const int32_t *h_indices,
                          const int8_t *h_sign, xh_route_plan **out);
 void xh_route_plan_destroy(xh_route_plan *plan);
-/* info[0]=networks, [1]=largest network (cells), [2]=LDS units, [3]=cells routed by the global fallback,
- * [4]=largest unit (cells), [5]=padded slots */
-int xh_route_plan_info(const xh_route_plan *plan, int64_t info[8]);
+/* info[0]=networks, [1]=largest network (cells), [2]=workgroup-per-network units, [3]=cells routed by the global
+ * fallback, [4]=largest such unit (cells), [5]=padded slots, [6]=1 if every cell has one downstream cell,
+ * [7]=dataflow units, [8]=stream edges between them, [9]=pipeline depth, [10]=cells routed by the dataflow kernel,
+ * [11]=most imported streams of one unit */
+int xh_route_plan_info(const xh_route_plan *plan, int64_t info[12]);
+
+/* Diagnostics: with XH_FLOW_STATS=1 in the environment the dataflow kernel records, per unit, {shader cycles inside the
+ * sub-step loops, shader cycles total, 100 MHz ticks total, shape bits}; this call waits for the stream and copies
+ * up to max_words 64-bit words (4 per unit) of the last xh_route_series launch. */
+int xh_route_plan_stats(xh_route_plan *plan, int64_t max_words, uint64_t *h_words, int64_t *n_words);
 
 /* Host-side topology (integer work, no device needed).
  * xh_mrtm_downstream replaces routing/mrtm.py:downstream + make_flowdirgrid (:85-120, :233-258): D8 decode, the
@@ -145,6 +152,7 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
 #define XH_ROUTE_DEFAULT 0
 #define XH_ROUTE_FORCE_FALLBACK 1   /* route every network with the global-memory kernels (testing)        */
 #define XH_ROUTE_ATOMIC 2           /* with the fallback: scatter-add outflow with global_atomic_add_f64   */
+#define XH_ROUTE_NO_DATAFLOW 4      /* one workgroup per network even for tree-shaped networks (testing)   */
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,
                     const double *d_flow_dist, const double *d_velocity, const double *d_area,

@@ -122,12 +122,14 @@ def test_streamrouting_golden_bit_exact(hip, golden, tag, flags):
         assert np.array_equal(F, g['%s_F_%d' % (tag, nday)])
 
 
+@pytest.mark.parametrize('flags', [0, 4])       # dataflow units (default) / one workgroup per network
 @pytest.mark.parametrize('tag', ['rand', 'tree'])
-def test_route_series_golden_bit_exact(hip, golden, tag):
+def test_route_series_golden_bit_exact(hip, golden, tag, flags):
     from xanthos_amd.routing import mrtm
     g, t = golden('mrtm'), golden('topo')
     chs, avg, fend = mrtm.route_series(_um(t, tag), g[tag + '_L'], g[tag + '_chv'], g[tag + '_area'],
-                                       g[tag + '_series_runoff'], g[tag + '_series_ndays'], int(g['series_spinup']))
+                                       g[tag + '_series_runoff'], g[tag + '_series_ndays'], int(g['series_spinup']),
+                                       flags=flags)
     assert np.array_equal(chs, g[tag + '_series_chstorage'])
     assert np.array_equal(avg, g[tag + '_series_avgchflow'])
     assert np.array_equal(fend, g[tag + '_series_Fend'])
@@ -145,8 +147,10 @@ def test_route_series_atomic_variant_close(hip, golden):
     close(chs, g[tag + '_series_chstorage'], rtol=1e-9, atol=1e-3)
 
 
-def test_route_synthetic_world_vs_oracle(hip):
-    """A 3000-cell world with multi-wave networks and bins of small ones, 14 months incl. spin-up: bit-exact."""
+@pytest.mark.parametrize('flags', [0, 4])
+def test_route_synthetic_world_vs_oracle(hip, flags):
+    """A 3000-cell world with networks far larger than one unit, 14 months incl. spin-up: bit-exact both as
+    dataflow units linked by streams (flags=0) and as one workgroup per network (flags=4)."""
     from types import SimpleNamespace as NS
     from oracle import months as o_months
     from oracle import mrtm as o_mrtm
@@ -158,12 +162,13 @@ def test_route_synthetic_world_vs_oracle(hip):
     um = mrtm.upstream_genmatrix(mrtm.upstream(w.coords, ds, st))
     info = um.plan(hip.get_context()).info()
     assert info['largest_network'] > 256 and info['fallback_cells'] == 0 and info['units'] < info['networks']
+    assert info['flow_cells'] == w.ncell and info['flow_edges'] > 10 and info['flow_depth'] > 2
     rng = np.random.default_rng(9)
     runoff = rng.gamma(2.0, 30.0, (w.ncell, 12))
     runoff[rng.random(w.ncell) < 0.01] = np.nan          # NaN runoff (NaN precip cells) must propagate identically
     ndays = o_months.set_month_arrays(12, 1972, 1972)[:, 2]
     ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
-    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=flags)
     for a, b in zip(got, ref):
         assert np.array_equal(a, b, equal_nan=True)
 

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxanthos_hip.so')
 
-XH_ROUTE_DEFAULT, XH_ROUTE_FORCE_FALLBACK, XH_ROUTE_ATOMIC = 0, 1, 2
+XH_ROUTE_DEFAULT, XH_ROUTE_FORCE_FALLBACK, XH_ROUTE_ATOMIC, XH_ROUTE_NO_DATAFLOW = 0, 1, 2, 4
 
 
 class HipUnavailable(RuntimeError):
@@ -58,6 +58,7 @@ SIGNATURES = {
     'xh_route_plan_create': (c_int, [_P, c_int64, _P, _P, _P, POINTER(c_void_p)]),
     'xh_route_plan_destroy': (None, [_P]),
     'xh_route_plan_info': (c_int, [_P, POINTER(c_int64)]),
+    'xh_route_plan_stats': (c_int, [_P, c_int64, _P, POINTER(c_int64)]),
     'xh_mrtm_downstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     'xh_mrtm_upstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     'xh_mrtm_um_csr': (c_int, [c_int64, _P, _P, _P, _P]),
@@ -301,10 +302,21 @@ class RoutePlan:
         self.handle = h.value
 
     def info(self):
-        arr = (c_int64 * 8)()
+        arr = (c_int64 * 12)()
         self.ctx._check(lib().xh_route_plan_info(self.handle, arr))
-        keys = ('networks', 'largest_network', 'units', 'fallback_cells', 'largest_unit', 'slots', 'single_downstream')
-        return dict(zip(keys, list(arr)[:7]))
+        keys = ('networks', 'largest_network', 'units', 'fallback_cells', 'largest_unit', 'slots', 'single_downstream',
+                'flow_units', 'flow_edges', 'flow_depth', 'flow_cells', 'flow_max_imports')
+        return dict(zip(keys, list(arr)))
+
+    def stats(self):
+        """[units, 4] uint64 cycle accounting of the last launch (needs XH_FLOW_STATS=1), or None."""
+        n = c_int64(0)
+        self.ctx._check(lib().xh_route_plan_stats(self.handle, 0, None, byref(n)))
+        if n.value == 0:
+            return None
+        out = np.empty(n.value, dtype=np.uint64)
+        self.ctx._check(lib().xh_route_plan_stats(self.handle, n.value, _host_ptr(out), byref(n)))
+        return out.reshape(-1, 6)
 
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:

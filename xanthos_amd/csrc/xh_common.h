@@ -29,7 +29,16 @@ struct xh_ctx {
     void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
     hipDeviceProp_t prop;
+    // device-side fault word (bounded spins of the dataflow routing kernel) + pinned host mirror
+    unsigned *d_fault = nullptr;
+    unsigned *h_fault = nullptr;
+    bool fault_pending = false;
 };
+
+// Device fault word: kernels set it non-zero instead of hanging; the next synchronising call reports XH_ERR_DEVICE.
+int xh_fault_word(xh_ctx *ctx, unsigned **d_word);   // lazily allocated, zeroed on the stream
+int xh_fault_collect(xh_ctx *ctx);                   // enqueue device -> pinned host copy after the kernel
+int xh_fault_check(xh_ctx *ctx);                     // after a stream sync: XH_ERR_DEVICE if the word was set
 
 int xh_fail(xh_ctx *ctx, int code, const char *fmt, ...);
 extern std::string g_xh_create_error;

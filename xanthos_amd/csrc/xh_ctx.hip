@@ -32,6 +32,35 @@ int xh_scratch(xh_ctx *ctx, int which, size_t bytes, void **out) {
     return XH_OK;
 }
 
+int xh_fault_word(xh_ctx *ctx, unsigned **d_word) {
+    if (!ctx->d_fault) {
+        XH_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_fault), 64));
+        XH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_fault), 64, hipHostMallocDefault));
+        *ctx->h_fault = 0;
+    }
+    XH_HIP(ctx, hipMemsetAsync(ctx->d_fault, 0, 64, ctx->stream));
+    *d_word = ctx->d_fault;
+    return XH_OK;
+}
+
+int xh_fault_collect(xh_ctx *ctx) {
+    if (!ctx->d_fault) return XH_OK;
+    XH_HIP(ctx, hipMemcpyAsync(ctx->h_fault, ctx->d_fault, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->fault_pending = true;
+    return XH_OK;
+}
+
+int xh_fault_check(xh_ctx *ctx) {
+    if (!ctx->fault_pending) return XH_OK;
+    ctx->fault_pending = false;
+    const unsigned code = *ctx->h_fault;
+    *ctx->h_fault = 0;
+    if (code)
+        return xh_fail(ctx, XH_ERR_DEVICE, "routing kernel fault %u: a bounded wait between routing units timed out "
+                       "(units not co-resident or a producer stalled); outputs of that call are invalid", code);
+    return XH_OK;
+}
+
 xh_span xh_span_begin(xh_ctx *ctx, const char *name) {
     xh_span s{ctx, name};
     if (!ctx->timing) return s;
@@ -109,6 +138,8 @@ void xh_ctx_destroy(xh_ctx *ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 4; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->d_fault) (void)hipFree(ctx->d_fault);
+    if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -147,7 +178,7 @@ int xh_memcpy_d2h(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (!ctx || (bytes && (!h_dst || !d_src))) return XH_ERR_ARG;
     XH_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return XH_OK;
+    return xh_fault_check(ctx);
 }
 
 int xh_memcpy_d2d(xh_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
@@ -165,7 +196,7 @@ int xh_memset(xh_ctx *ctx, void *d_ptr, int value, size_t bytes) {
 int xh_sync(xh_ctx *ctx) {
     if (!ctx) return XH_ERR_ARG;
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return XH_OK;
+    return xh_fault_check(ctx);
 }
 
 int xh_timing_reset(xh_ctx *ctx) {

@@ -23,6 +23,7 @@
 #include <numeric>
 
 #include "xh_common.h"
+#include "xh_mrtm_flow.h"
 
 namespace {
 
@@ -330,8 +331,14 @@ struct xh_route_plan {
     xh_ctx *ctx = nullptr;
     int64_t ncell = 0, n_networks = 0, largest_network = 0, n_units = 0, largest_unit = 0, total_slots = 0;
     // LDS units, grouped by class
-    std::vector<int> class_units[N_CLASS];       // slot0 of the units of each class
+    std::vector<int> class_units[N_CLASS];       // slot0 of the units of each class (every network)
     DevBuf d_class_units[N_CLASS];
+    std::vector<int> rest_units[N_CLASS];        // only the units of networks the dataflow kernel does not route
+    DevBuf d_rest_units[N_CLASS];
+    FlowPlan *flow = nullptr;                    // tree-shaped networks as single-wave dataflow units
+    int64_t n_rest_units = 0, n_fb_rest = 0;
+    bool fb_rest_single_ds = true;
+    DevBuf d_fbr_cells, d_fbr_ptr, d_fbr_col, d_fbr_sgn, d_fbr_ds;
     DevBuf d_cell_of_slot, d_ent, d_cnt;
     // fallback
     int64_t n_fb = 0;
@@ -362,7 +369,7 @@ void free_buf(DevBuf &b) {
 }
 
 template <int KC, int NTMAX>
-void launch_units(const xh_route_plan *plan, int cls, RouteArgs args, hipStream_t st) {
+void launch_units(const xh_route_plan *plan, int cls, RouteArgs args, hipStream_t st, bool rest_only) {
     const int nt = CLASSES[cls].nt;
     size_t lds = 2 * (size_t)(nt * KC + 1) * sizeof(double2) + (size_t)(W_MAX - W_BASE) * nt * KC * sizeof(unsigned short);
     // Placement control: the dispatcher stacks small workgroups on one CU until a resource runs out, and a stack of
@@ -370,14 +377,15 @@ void launch_units(const xh_route_plan *plan, int cls, RouteArgs args, hipStream_
     // makes at most ceil(units / CUs) workgroups fit per CU, so the units spread over the whole chip.
     {
         const int cus = plan->ctx->prop.multiProcessorCount > 0 ? plan->ctx->prop.multiProcessorCount : 256;
-        const int64_t per_cu = (plan->n_units + cus - 1) / cus;
+        const int64_t per_cu = ((rest_only ? plan->n_rest_units : plan->n_units) + cus - 1) / cus;
         const size_t share = ((size_t)(160 * 1024) / (size_t)(per_cu > 0 ? per_cu : 1)) & ~size_t(1023);
         if (share > lds) lds = share;
     }
-    args.unit_slot0 = static_cast<const int *>(plan->d_class_units[cls].p);
+    const std::vector<int> &list = rest_only ? plan->rest_units[cls] : plan->class_units[cls];
+    args.unit_slot0 = static_cast<const int *>((rest_only ? plan->d_rest_units[cls] : plan->d_class_units[cls]).p);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mrtm_units<KC, NTMAX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_mrtm_units<KC, NTMAX>), dim3((unsigned)plan->class_units[cls].size()), dim3(nt), lds, st, args);
+    hipLaunchKernelGGL((k_mrtm_units<KC, NTMAX>), dim3((unsigned)list.size()), dim3(nt), lds, st, args);
 }
 
 }  // namespace
@@ -433,24 +441,46 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
     plan->n_networks = ncomp;
     plan->largest_network = ncomp ? *std::max_element(comp_size.begin(), comp_size.end()) : 0;
 
-    // ---- units: big networks alone, small ones first-fit-decreasing into bins of BIN_CELLS
+    // ---- tree-shaped networks also get a dataflow layout (xh_mrtm_flow.hip); XH_MRTM_FLOW=0 disables it
+    std::vector<char> flow_cell;
+    {
+        const char *env = getenv("XH_MRTM_FLOW");
+        if (!(env && env[0] == '0')) {
+            const int frc = flow_plan_build(ctx, n, h_indptr, h_indices, h_sign, comp, ncomp, flow_cell, &plan->flow);
+            if (frc) {
+                xh_route_plan_destroy(plan);
+                return frc;
+            }
+        }
+        if (flow_cell.empty()) flow_cell.assign(n, 0);
+    }
+    std::vector<char> comp_flow(ncomp, 0);
+    for (int i = 0; i < n; ++i)
+        if (flow_cell[i]) comp_flow[comp[i]] = 1;
+
+    // ---- units: big networks alone, small ones first-fit-decreasing into bins of BIN_CELLS.  Two passes keep
+    //      every unit either wholly routed by the dataflow kernel or wholly not.
     std::vector<int> order(ncomp);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return comp_size[x] > comp_size[y]; });
     std::vector<std::vector<int>> units;          // cells of each unit
-    std::vector<int> fb_cells;
-    {
+    std::vector<char> unit_is_flow;
+    std::vector<int> fb_cells, fb_rest_cells;
+    for (int pass = 0; pass < 2; ++pass) {
         std::vector<int> bin_free;                // remaining capacity of open bins
         std::vector<int> bin_unit;
         size_t first_open = 0;
         for (int ci : order) {
+            if ((comp_flow[ci] != 0) != (pass == 0)) continue;
             const int sz = comp_size[ci];
             if (sz > UNIT_MAX_CELLS || comp_maxdeg[ci] > W_MAX) {
                 fb_cells.insert(fb_cells.end(), comp_cells[ci].begin(), comp_cells[ci].end());
+                if (pass == 1) fb_rest_cells.insert(fb_rest_cells.end(), comp_cells[ci].begin(), comp_cells[ci].end());
                 continue;
             }
             if (sz > BIN_CELLS / 2) {
                 units.push_back(comp_cells[ci]);
+                unit_is_flow.push_back(pass == 0);
                 continue;
             }
             bool placed = false;
@@ -467,16 +497,19 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
                 bin_unit.push_back((int)units.size());
                 bin_free.push_back(BIN_CELLS - sz);
                 units.push_back(comp_cells[ci]);
+                unit_is_flow.push_back(pass == 0);
             }
             while (first_open < bin_free.size() && bin_free[first_open] == 0) ++first_open;
         }
     }
     std::sort(fb_cells.begin(), fb_cells.end());
+    std::sort(fb_rest_cells.begin(), fb_rest_cells.end());
 
     // ---- slot layout
     std::vector<int> cell_of_slot;
     std::vector<int> slot_of_cell(n, -1), unit_slot0, unit_np;
-    for (auto &u : units) {
+    for (size_t ui = 0; ui < units.size(); ++ui) {
+        auto &u = units[ui];
         // cells with many terms first, so that only the first wave stripes run long gather loops
         std::stable_sort(u.begin(), u.end(), [&](int x, int y) { return deg[x] > deg[y]; });
         int cls = -1;
@@ -488,6 +521,10 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
         const int np = CLASSES[cls].nt * CLASSES[cls].kc;
         const int s0 = (int)cell_of_slot.size();
         plan->class_units[cls].push_back(s0);
+        if (!unit_is_flow[ui]) {
+            plan->rest_units[cls].push_back(s0);
+            plan->n_rest_units++;
+        }
         unit_slot0.push_back(s0);
         unit_np.push_back(np);
         for (int l = 0; l < np; ++l) {
@@ -566,6 +603,13 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
         rc |= upload(ctx, plan->d_fb_col, col);
         rc |= upload(ctx, plan->d_fb_sgn, sgn);
         rc |= upload(ctx, plan->d_fb_ds, ds);
+        build_csr(fb_rest_cells, ptr, col, sgn, ds, plan->fb_rest_single_ds);
+        plan->n_fb_rest = (int64_t)fb_rest_cells.size();
+        rc |= upload(ctx, plan->d_fbr_cells, fb_rest_cells);
+        rc |= upload(ctx, plan->d_fbr_ptr, ptr);
+        rc |= upload(ctx, plan->d_fbr_col, col);
+        rc |= upload(ctx, plan->d_fbr_sgn, sgn);
+        rc |= upload(ctx, plan->d_fbr_ds, ds);
         std::vector<int> all(n);
         std::iota(all.begin(), all.end(), 0);
         build_csr(all, ptr, col, sgn, ds, plan->all_single_ds);
@@ -581,6 +625,7 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
     rc |= upload(ctx, plan->d_cnt, cnt);
     for (int k = 0; k < N_CLASS; ++k) {
         rc |= upload(ctx, plan->d_class_units[k], plan->class_units[k]);
+        rc |= upload(ctx, plan->d_rest_units[k], plan->rest_units[k]);
         if (!plan->class_units[k].empty() && hipStreamCreateWithFlags(&plan->streams[k], hipStreamNonBlocking) != hipSuccess)
             rc |= XH_ERR_HIP;
     }
@@ -601,6 +646,7 @@ extern "C" void xh_route_plan_destroy(xh_route_plan *plan) {
     (void)hipStreamSynchronize(plan->ctx->stream);
     for (int k = 0; k < N_CLASS; ++k) {
         free_buf(plan->d_class_units[k]);
+        free_buf(plan->d_rest_units[k]);
         if (plan->streams[k]) (void)hipStreamDestroy(plan->streams[k]);
     }
     if (plan->fb_stream) (void)hipStreamDestroy(plan->fb_stream);
@@ -609,12 +655,14 @@ extern "C" void xh_route_plan_destroy(xh_route_plan *plan) {
         if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
     DevBuf *bufs[] = {&plan->d_cell_of_slot, &plan->d_ent, &plan->d_cnt, &plan->d_fb_cells, &plan->d_fb_ptr,
                       &plan->d_fb_col, &plan->d_fb_sgn, &plan->d_fb_ds, &plan->d_all_cells, &plan->d_all_ptr,
-                      &plan->d_all_col, &plan->d_all_sgn, &plan->d_all_ds};
+                      &plan->d_all_col, &plan->d_all_sgn, &plan->d_all_ds, &plan->d_fbr_cells, &plan->d_fbr_ptr,
+                      &plan->d_fbr_col, &plan->d_fbr_sgn, &plan->d_fbr_ds};
     for (DevBuf *b : bufs) free_buf(*b);
+    flow_plan_destroy(plan->flow);
     delete plan;
 }
 
-extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[8]) {
+extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[12]) {
     if (!plan || !info) return XH_ERR_ARG;
     info[0] = plan->n_networks;
     info[1] = plan->largest_network;
@@ -623,7 +671,24 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[8]) {
     info[4] = plan->largest_unit;
     info[5] = plan->total_slots;
     info[6] = plan->all_single_ds ? 1 : 0;
-    info[7] = 0;
+    int64_t fi[5];
+    flow_plan_info(plan->flow, fi);
+    info[7] = fi[0];                  // dataflow units
+    info[8] = fi[1];                  // stream edges
+    info[9] = fi[2];                  // pipeline depth
+    info[10] = fi[3];                 // cells routed by the dataflow kernel
+    info[11] = fi[4];                 // most imported streams of a unit
+    return XH_OK;
+}
+
+extern "C" int xh_route_plan_stats(xh_route_plan *plan, int64_t max_words, uint64_t *h_words, int64_t *n_words) {
+    if (!plan || !n_words) return XH_ERR_ARG;
+    std::vector<unsigned long long> st;
+    int rc = flow_stats_fetch(plan->ctx, plan->flow, st);
+    if (rc) return rc;
+    *n_words = (int64_t)st.size();
+    if (h_words)
+        for (int64_t i = 0; i < (int64_t)st.size() && i < max_words; ++i) h_words[i] = st[i];
     return XH_OK;
 }
 
@@ -671,12 +736,26 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
 
     const bool force_fb = (flags & XH_ROUTE_FORCE_FALLBACK) != 0;
     const bool atomic = (flags & XH_ROUTE_ATOMIC) != 0;
-    const int64_t n_fb = force_fb ? plan->ncell : plan->n_fb;
+    bool use_flow = !force_fb && plan->flow != nullptr && (flags & XH_ROUTE_NO_DATAFLOW) == 0;
 
     xh_span sp = xh_span_begin(ctx, "mrtm_route");
     XH_HIP(ctx, hipEventRecord(plan->ev_fork, ctx->stream));
     int njoin = 0;
-    if (!force_fb && plan->n_units > 0) {
+    if (use_flow) {     // tree-shaped networks: single-wave dataflow units on the context's own stream
+        int ntmax = 0;
+        for (int v : snt) ntmax = std::max(ntmax, v);
+        const FlowSched fs{nmonths, nit, ntmax, d_m, d_nt, d_secs, d_wr, dt};
+        const FlowIO fio{d_flow_dist, d_velocity, d_area, d_runoff, d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end};
+        rc = flow_launch(ctx, plan->flow, fs, fio, ctx->stream);
+        if (rc == XH_ERR_LIMIT) {
+            use_flow = false;   // units cannot all be resident on this device: one workgroup per network instead
+        } else if (rc) {
+            return rc;
+        }
+    }
+    const int64_t n_fb = force_fb ? plan->ncell : (use_flow ? plan->n_fb_rest : plan->n_fb);
+    const int64_t n_lds_units = use_flow ? plan->n_rest_units : plan->n_units;
+    if (!force_fb && n_lds_units > 0) {
         RouteArgs a;
         a.unit_slot0 = nullptr;
         a.cell_of_slot = static_cast<const int *>(plan->d_cell_of_slot.p);
@@ -702,17 +781,17 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
         a.F_end = d_F_end;
         // largest classes first so the long-running workgroups start first
         for (int cls = N_CLASS - 1; cls >= 0; --cls) {
-            if (plan->class_units[cls].empty()) continue;
+            if ((use_flow ? plan->rest_units[cls] : plan->class_units[cls]).empty()) continue;
             hipStream_t st = plan->streams[cls];
             XH_HIP(ctx, hipStreamWaitEvent(st, plan->ev_fork, 0));
             switch (cls) {
-                case 0: launch_units<1, 64>(plan, cls, a, st); break;
-                case 1: launch_units<2, 64>(plan, cls, a, st); break;
-                case 2: launch_units<4, 64>(plan, cls, a, st); break;
-                case 3: launch_units<2, 256>(plan, cls, a, st); break;
-                case 4: launch_units<4, 256>(plan, cls, a, st); break;
-                case 5: launch_units<2, 1024>(plan, cls, a, st); break;
-                case 6: launch_units<4, 768>(plan, cls, a, st); break;
+                case 0: launch_units<1, 64>(plan, cls, a, st, use_flow); break;
+                case 1: launch_units<2, 64>(plan, cls, a, st, use_flow); break;
+                case 2: launch_units<4, 64>(plan, cls, a, st, use_flow); break;
+                case 3: launch_units<2, 256>(plan, cls, a, st, use_flow); break;
+                case 4: launch_units<4, 256>(plan, cls, a, st, use_flow); break;
+                case 5: launch_units<2, 1024>(plan, cls, a, st, use_flow); break;
+                case 6: launch_units<4, 768>(plan, cls, a, st, use_flow); break;
                 case 7: break;
             }
             XH_HIP(ctx, hipGetLastError());
@@ -722,7 +801,12 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
         }
     }
     if (n_fb > 0) {
-        const bool single = force_fb ? plan->all_single_ds : plan->fb_single_ds;
+        const bool single = force_fb ? plan->all_single_ds : (use_flow ? plan->fb_rest_single_ds : plan->fb_single_ds);
+        const DevBuf &b_cells = force_fb ? plan->d_all_cells : (use_flow ? plan->d_fbr_cells : plan->d_fb_cells);
+        const DevBuf &b_ptr = force_fb ? plan->d_all_ptr : (use_flow ? plan->d_fbr_ptr : plan->d_fb_ptr);
+        const DevBuf &b_col = force_fb ? plan->d_all_col : (use_flow ? plan->d_fbr_col : plan->d_fb_col);
+        const DevBuf &b_sgn = force_fb ? plan->d_all_sgn : (use_flow ? plan->d_fbr_sgn : plan->d_fb_sgn);
+        const DevBuf &b_ds = force_fb ? plan->d_all_ds : (use_flow ? plan->d_fbr_ds : plan->d_fb_ds);
         if (atomic && !single) {
             xh_span_end(sp);
             return xh_fail(ctx, XH_ERR_ARG, "xh_route_series: XH_ROUTE_ATOMIC needs one downstream cell per cell");
@@ -734,11 +818,11 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
         if (rc) return rc;
         FbArgs f;
         f.n = (int)n_fb;
-        f.cells = static_cast<const int *>((force_fb ? plan->d_all_cells : plan->d_fb_cells).p);
-        f.ptr = static_cast<const int *>((force_fb ? plan->d_all_ptr : plan->d_fb_ptr).p);
-        f.col = static_cast<const int *>((force_fb ? plan->d_all_col : plan->d_fb_col).p);
-        f.sgn = static_cast<const signed char *>((force_fb ? plan->d_all_sgn : plan->d_fb_sgn).p);
-        f.ds = static_cast<const int *>((force_fb ? plan->d_all_ds : plan->d_fb_ds).p);
+        f.cells = static_cast<const int *>(b_cells.p);
+        f.ptr = static_cast<const int *>(b_ptr.p);
+        f.col = static_cast<const int *>(b_col.p);
+        f.sgn = static_cast<const signed char *>(b_sgn.p);
+        f.ds = static_cast<const int *>(b_ds.p);
         f.nmonths = nmonths;
         f.dt = dt;
         f.dtinv = 1.0 / dt;
@@ -783,5 +867,6 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
         XH_HIP(ctx, hipStreamWaitEvent(ctx->stream, plan->ev_join[N_CLASS], 0));
     }
     xh_span_end(sp);
+    if (use_flow) return xh_fault_collect(ctx);
     return XH_OK;
 }

@@ -1,0 +1,601 @@
+// MRTM routing as a dataflow of single-wave units (gfx950).
+//
+// One workgroup per river network (xh_mrtm.hip) is bounded by the largest network: all of its cells share one CU,
+// which then issues ~70 instructions x (cells / 64) per sub-step while 200 other CUs idle.  But the dependency in
+//     dS_i/dt = sum_{j upstream of i} F_j - F_i + lateral_i          (mrtm.py:50-51)
+// runs one way only: a cell needs the flows of the cells UPSTREAM of it, never those downstream.  A tributary can
+// therefore be integrated months ahead of the river it joins.  This file cuts every tree-shaped network into
+// connected pieces of at most 64 cells, packs pieces of equal pipeline depth into UNITS of 64 lanes (one wave, one
+// cell per lane), and links the units by one-way streams in HBM:
+//
+//   - inside a unit the sub-step loop is what xh_mrtm.hip does, minus the workgroup barriers: the two flow exchanges
+//     per sub-step go through LDS, whose operations complete in issue order for a single wave;
+//   - a piece's outlet lane appends {trial flow F, adjusted flow F2} of every sub-step to its stream with
+//     write-through (sc1, agent-scope) stores; at the end of a month it publishes the month (stores drained with
+//     s_waitcnt vmcnt(0) -> relaxed agent-scope store of the month counter).  No release fence: an agent-scope release
+//     writes back every dirty line of the XCD's L2, which cost ~60 us per unit per month next to the output stores;
+//   - the consuming unit waits for that counter at the start of the same month (relaxed agent-scope polls with
+//     s_sleep, one agent-scope acquire), then its "ghost" lanes read the stream eight sub-steps ahead into
+//     registers and drop each pair into ghost slots of the LDS flow buffers, where the consuming cell's gather
+//     finds them like any other neighbour.  The values and the order of every sum are unchanged, so results stay
+//     bit-identical to numpy/scipy;
+//   - streams are rings of RING months; a producer that would lap its consumer waits on the consumer's progress
+//     counter.  Units only ever wait on units strictly upstream (data) or downstream (ring space) of themselves,
+//     pieces of one unit have the same depth, and the launch keeps every unit resident, so the waits cannot cycle.
+//     Every spin is bounded by the 100 MHz real-time counter and raises the context's fault word instead of hanging.
+//
+// Throughput is then set by the sub-step latency of ONE wave (a few hundred cycles) instead of the instruction
+// issue of the largest network, and the whole chip is busy: ~1,500 units over 256 CUs for the 67,420-cell grid.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <numeric>
+
+#include "xh_mrtm_flow.h"
+
+namespace {
+
+constexpr int W_MAX = 9;          // terms per row: 8 D8 neighbours + the diagonal
+constexpr int LANES = 64;         // cells per unit (one per lane)
+constexpr int G_MAX = 64;         // imported streams per unit (one ghost slot per lane)
+constexpr int NPAIR = LANES + G_MAX + 1;   // LDS pairs per flow buffer: cells, ghosts, constant zero
+constexpr int RING = 4;           // months of stream kept in HBM per edge
+constexpr int PF = 8;             // sub-steps of ghost prefetch held in registers
+constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2;
+constexpr unsigned long long SPIN_LIMIT_TICKS = 2000000000ull;   // 20 s of the 100 MHz real-time counter
+
+struct FlowArgs {
+    const int *cell_of_slot;        // [units*64] global cell id or -1
+    const unsigned *ent;            // [W_MAX][units*64] byte offsets into a flow buffer
+    const int *export_edge;         // [units*64] stream this lane's cell feeds, or -1
+    const int *ghost_edge;          // [units*64] stream that ghost slot `lane` of the unit imports, or -1
+    const int *edge_cons_unit;      // [edges]
+    const int *unit_terms;          // [units] longest row (terms) of each unit
+    int64_t total_slots;
+    int nmonths, nit, ntmax;
+    const int *sched_m, *sched_nt;
+    const double *sched_secs;
+    const unsigned char *sched_write;
+    double dt, dtinv;
+    const double *flow_dist, *velocity, *area, *runoff, *S0;
+    double *chs, *avg, *S_end, *F_end;
+    double2 *xbuf;                  // [edges][RING][ntmax] {F, F2}
+    unsigned *ready;                // [edges] months published
+    unsigned *done;                 // [units] months consumed
+    unsigned *fault;
+    unsigned long long *stats;      // [units][4] optional cycle accounting (XH_FLOW_STATS=1)
+};
+
+__device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// All lanes with `need` wait until *p >= target.  Returns false (and raises the fault word) on timeout / fault.
+__device__ __forceinline__ bool wave_wait_ge(bool need, const unsigned *p, unsigned target, unsigned *fault,
+                                             unsigned code) {
+    bool ok = !need;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        if (!ok) ok = ld_relaxed(p) >= target;
+        if (__all(ok)) return true;
+        if (ld_relaxed(fault) != 0) return false;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
+            __hip_atomic_store(fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+// Whole series for one unit; WU = terms gathered per row (the unit's longest row, rounded up to 3, 5 or 9): LDS
+// instructions from a lone wave are slow, so a unit without big confluences should not issue nine reads per gather.
+template <int WU>
+__device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
+    double2 *bufA = lds;               // trial flows {F, -F}: cells 0..63, ghosts 64..127, zero 128
+    double2 *bufB = lds + NPAIR;       // adjusted flows {F2, -F2}
+    const char *baseA = reinterpret_cast<const char *>(bufA);
+    const char *baseB = reinterpret_cast<const char *>(bufB);
+    const int lane = threadIdx.x, unit = blockIdx.x;
+    const int64_t slot = (int64_t)unit * LANES + lane;
+
+    const int gc = a.cell_of_slot[slot];
+    const bool valid = gc >= 0;
+    const double tauinv = valid ? a.velocity[gc] / a.flow_dist[gc] : 0.0;      // mrtm.py:40
+    const double area = valid ? a.area[gc] : 0.0;
+    double S = (valid && a.S0) ? a.S0[gc] : 0.0;
+    double F = 0.0;
+    unsigned e[WU];
+#pragma unroll
+    for (int w = 0; w < WU; ++w) e[w] = a.ent[(int64_t)w * a.total_slots + slot];
+    const int xedge = a.export_edge[slot];
+    const int gedge = a.ghost_edge[slot];
+    const bool has_x = xedge >= 0, has_g = gedge >= 0;
+    const bool any_x = __any(has_x), any_g = __any(has_g);
+    const unsigned *ready_p = a.ready + (has_g ? gedge : 0);
+    const unsigned *done_p = a.done + (has_x ? a.edge_cons_unit[xedge] : 0);
+
+    bufA[LANES + lane] = make_double2(0.0, 0.0);
+    bufB[LANES + lane] = make_double2(0.0, 0.0);
+    if (lane == 0) {
+        bufA[NPAIR - 1] = make_double2(0.0, 0.0);
+        bufB[NPAIR - 1] = make_double2(0.0, 0.0);
+    }
+    const double dt = a.dt, dtinv = a.dtinv;
+    double qn = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[0]] : 0.0;
+    bool alive = true;
+    unsigned long long cyc_loop = 0, cyc_wait_data = 0, cyc_wait_ring = 0;
+    const unsigned long long cyc_begin = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+
+    for (int it = 0; it < a.nit && alive; ++it) {
+        const int m = a.sched_m[it], nt = a.sched_nt[it];
+        const double secs = a.sched_secs[it];
+        const double erl = (qn * area) * 1000.0 / secs;                        // mrtm.py:45
+        double favg = 0.0;
+        if (it + 1 < a.nit) qn = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[it + 1]] : 0.0;
+
+        const int rs = it % RING;
+        const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+        if (any_g) {      // the streams this unit imports must hold month `it`
+            alive = wave_wait_ge(has_g, ready_p, (unsigned)it + 1u, a.fault, FAULT_DATA_WAIT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        const unsigned long long w1 = __builtin_amdgcn_s_memtime();
+        if (any_x && it >= RING && alive)   // ring slot `rs` must have been consumed (month it - RING)
+            alive = wave_wait_ge(has_x, done_p, (unsigned)(it - RING) + 1u, a.fault, FAULT_RING_WAIT);
+        cyc_wait_data += w1 - w0;
+        cyc_wait_ring += __builtin_amdgcn_s_memtime() - w1;
+        if (!alive) break;
+        const double2 *iptr = a.xbuf + ((int64_t)(has_g ? gedge : 0) * RING + rs) * a.ntmax;
+        double2 *optr = a.xbuf + ((int64_t)(has_x ? xedge : 0) * RING + rs) * a.ntmax;
+
+        double2 q[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) q[j] = (has_g && j < nt) ? iptr[j] : make_double2(0.0, 0.0);
+
+        auto substep = [&](int t, double2 gv) {
+            F = S * tauinv;                                                    // mrtm.py:50
+            bufA[lane] = make_double2(F, -F);
+            if (has_g) {                                                       // ghosts are only ever added (+1 terms)
+                reinterpret_cast<double *>(bufA + LANES + lane)[0] = gv.x;
+                reinterpret_cast<double *>(bufB + LANES + lane)[0] = gv.y;
+            }
+            __builtin_amdgcn_wave_barrier();
+            double v[WU];
+#pragma unroll
+            for (int w = 0; w < WU; ++w) v[w] = *reinterpret_cast<const double *>(baseA + e[w]);
+            double acc = 0.0;                                                  // UM.dot(F), row order (mrtm.py:51)
+#pragma unroll
+            for (int w = 0; w < WU; ++w) acc += v[w];
+            const double dsdt = acc + erl;
+            const bool sx = (dsdt * dt) < (-S);                                // mrtm.py:54
+            const double f2 = sx ? (dsdt + F) + S * dtinv : F;                 // mrtm.py:60
+            S = sx ? 0.0 : S;                                                  // mrtm.py:63
+            bufB[lane] = make_double2(f2, -f2);
+            if (has_x) {      // write-through (sc1) stores: the month can then be published without an L2 write-back
+                unsigned long long *o = reinterpret_cast<unsigned long long *>(optr + t);
+                __hip_atomic_store(o, (unsigned long long)__double_as_longlong(F), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(o + 1, (unsigned long long)__double_as_longlong(f2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int w = 0; w < WU; ++w) v[w] = *reinterpret_cast<const double *>(baseB + e[w]);
+            double acc2 = 0.0;                                                 // UM.dot(F) with the adjusted flows
+#pragma unroll
+            for (int w = 0; w < WU; ++w) acc2 += v[w];
+            const double dsdt2 = acc2 + erl;                                   // mrtm.py:68
+            S = sx ? S : S + dsdt2 * dt;                                       // mrtm.py:69 / :76
+            F = f2;
+            favg += f2;                                                        // mrtm.py:78
+            __builtin_amdgcn_wave_barrier();
+        };
+
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+        int t0 = 0;
+        for (; t0 + PF <= nt; t0 += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const double2 gv = q[j];
+                if (has_g && t0 + j + PF < nt) q[j] = iptr[t0 + j + PF];
+                substep(t0 + j, gv);
+            }
+        }
+        for (int t = t0; t < nt; ++t) substep(t, (has_g) ? iptr[t] : make_double2(0.0, 0.0));
+        cyc_loop += __builtin_amdgcn_s_memtime() - c0;
+
+        if (a.sched_write[it] && valid) {
+            const int64_t o = (int64_t)gc * a.nmonths + m;
+            if (a.chs) a.chs[o] = S;
+            if (a.avg) a.avg[o] = favg / (double)nt;                           // mrtm.py:80
+        }
+        if (any_x) {      // publish month `it`: every stream store above was write-through, so draining them is enough
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (has_x) __hip_atomic_store(a.ready + xedge, (unsigned)it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (any_g && lane == 0)   // this month's imports are consumed: their ring slots may be reused
+            __hip_atomic_store(a.done + unit, (unsigned)it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (valid) {
+        if (a.S_end) a.S_end[gc] = S;
+        if (a.F_end) a.F_end[gc] = F;
+    }
+    if (a.stats && lane == 0) {      // shader cycles inside the sub-step loops / whole unit, real-time ticks, shape
+        unsigned long long *st = a.stats + (int64_t)unit * 6;
+        st[4] = cyc_wait_data;
+        st[5] = cyc_wait_ring;
+        st[0] = cyc_loop;
+        st[1] = __builtin_amdgcn_s_memtime() - cyc_begin;
+        st[2] = __builtin_amdgcn_s_memrealtime() - rt_begin;
+        st[3] = (unsigned long long)WU | (any_g ? 16u : 0u) | (any_x ? 32u : 0u);
+    }
+}
+
+__global__ void __launch_bounds__(LANES) k_mrtm_flow(FlowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double2 lds[];
+    const int wu = a.unit_terms[blockIdx.x];        // uniform per workgroup
+    if (wu <= 3) flow_unit<3>(a, lds);
+    else if (wu <= 5) flow_unit<5>(a, lds);
+    else flow_unit<W_MAX>(a, lds);
+}
+
+struct Buf {
+    void *p = nullptr;
+};
+
+template <typename T>
+int put(xh_ctx *ctx, Buf &b, const std::vector<T> &v) {
+    XH_HIP(ctx, hipMalloc(&b.p, v.empty() ? 16 : v.size() * sizeof(T)));
+    if (!v.empty()) XH_HIP(ctx, hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return XH_OK;
+}
+
+}  // namespace
+
+struct FlowPlan {
+    int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0;
+    Buf d_cell_of_slot, d_ent, d_export_edge, d_ghost_edge, d_edge_cons_unit, d_unit_terms;
+    // per-call exchange buffers (grow-only)
+    void *d_x = nullptr;
+    size_t x_bytes = 0;
+    unsigned long long *d_stats = nullptr;
+};
+
+void flow_plan_destroy(FlowPlan *fp) {
+    if (!fp) return;
+    Buf *bufs[] = {&fp->d_cell_of_slot, &fp->d_ent, &fp->d_export_edge, &fp->d_ghost_edge, &fp->d_edge_cons_unit,
+                   &fp->d_unit_terms};
+    for (Buf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (fp->d_x) (void)hipFree(fp->d_x);
+    if (fp->d_stats) (void)hipFree(fp->d_stats);
+    delete fp;
+}
+
+void flow_plan_info(const FlowPlan *fp, int64_t info[5]) {
+    info[0] = fp ? fp->n_units : 0;
+    info[1] = fp ? fp->n_edges : 0;
+    info[2] = fp ? fp->depth : 0;
+    info[3] = fp ? fp->n_cells : 0;
+    info[4] = fp ? fp->max_imports : 0;
+}
+
+int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
+                    const std::vector<int> &comp, int ncomp, std::vector<char> &handled, FlowPlan **out) {
+    *out = nullptr;
+    handled.assign(n, 0);
+    if (n == 0) return XH_OK;
+
+    // ---- which networks are plain trees: rows are {-1 on the diagonal, +1 elsewhere}, every cell feeds <= 1 row,
+    //      at most W_MAX terms per row, no cycle
+    std::vector<int> ds(n, -1);
+    std::vector<char> comp_ok(ncomp, 1);
+    for (int r = 0; r < n; ++r) {
+        int ndiag = 0;
+        if (indptr[r + 1] - indptr[r] > W_MAX) comp_ok[comp[r]] = 0;
+        for (int64_t j = indptr[r]; j < indptr[r + 1]; ++j) {
+            const int c = indices[j];
+            if (sign[j] < 0) {
+                if (c == r) ++ndiag;
+                else comp_ok[comp[r]] = 0;
+            } else {
+                if (c == r || ds[c] >= 0) comp_ok[comp[r]] = 0;
+                ds[c] = r;
+            }
+        }
+        if (ndiag != 1) comp_ok[comp[r]] = 0;
+    }
+    {   // cycles: follow the downstream pointers with three colours
+        std::vector<char> colour(n, 0);
+        std::vector<int> path;
+        for (int s = 0; s < n; ++s) {
+            if (colour[s]) continue;
+            path.clear();
+            int v = s;
+            while (v >= 0 && colour[v] == 0) {
+                colour[v] = 1;
+                path.push_back(v);
+                v = ds[v];
+            }
+            if (v >= 0 && colour[v] == 1) comp_ok[comp[v]] = 0;       // ran into the current path: a cycle
+            for (int p : path) colour[p] = 2;
+        }
+    }
+
+    // ---- bottom-up cut into connected pieces of <= LANES cells with <= G_MAX imported streams
+    std::vector<int> nchild(n, 0);
+    for (int c = 0; c < n; ++c)
+        if (ds[c] >= 0) nchild[ds[c]]++;
+    std::vector<int> child_ptr(n + 1, 0);
+    for (int c = 0; c < n; ++c) child_ptr[c + 1] = child_ptr[c] + nchild[c];
+    std::vector<int> child(child_ptr[n]);
+    {
+        std::vector<int> fill(child_ptr.begin(), child_ptr.end() - 1);
+        for (int c = 0; c < n; ++c)
+            if (ds[c] >= 0) child[fill[ds[c]]++] = c;
+    }
+    std::vector<int> queue;
+    queue.reserve(n);
+    std::vector<int> left(nchild);
+    for (int c = 0; c < n; ++c)
+        if (comp_ok[comp[c]] && nchild[c] == 0) queue.push_back(c);
+    std::vector<int> dsu(n);
+    std::iota(dsu.begin(), dsu.end(), 0);
+    auto find = [&](int x) {
+        while (dsu[x] != x) {
+            dsu[x] = dsu[dsu[x]];
+            x = dsu[x];
+        }
+        return x;
+    };
+    std::vector<int> open_cnt(n, 0), open_imp(n, 0);
+    std::vector<int> closed_roots;                 // piece roots in closing order (upstream pieces first)
+    std::vector<int> kids;
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+        const int v = queue[qi];
+        kids.assign(child.begin() + child_ptr[v], child.begin() + child_ptr[v + 1]);
+        std::sort(kids.begin(), kids.end(), [&](int x, int y) {
+            return open_cnt[x] != open_cnt[y] ? open_cnt[x] < open_cnt[y] : x < y;
+        });
+        int total = 1, imp = (int)kids.size();
+        for (int c : kids) {
+            if (total + open_cnt[c] <= LANES && imp - 1 + open_imp[c] <= G_MAX) {
+                dsu[find(c)] = v;                   // c's open piece joins v's
+                total += open_cnt[c];
+                imp += open_imp[c] - 1;
+            } else {
+                closed_roots.push_back(c);          // c's piece is final; its outlet streams into v
+            }
+        }
+        open_cnt[v] = total;
+        open_imp[v] = imp;
+        if (ds[v] < 0) {
+            closed_roots.push_back(v);
+        } else if (--left[ds[v]] == 0) {
+            queue.push_back(ds[v]);
+        }
+    }
+    // cells of ok networks that were never reached (cannot happen for trees) stay unhandled
+    std::vector<char> reached(n, 0);
+    for (int v : queue) reached[v] = 1;
+
+    // ---- pieces, their stream edges and pipeline depth
+    const int npiece = (int)closed_roots.size();
+    std::vector<int> piece_of_root(n, -1);
+    for (int p = 0; p < npiece; ++p) piece_of_root[closed_roots[p]] = p;
+    std::vector<int> piece(n, -1);
+    std::vector<int> piece_size(npiece, 0), piece_imp(npiece, 0), piece_depth(npiece, 0);
+    for (int c = 0; c < n; ++c)
+        if (reached[c]) {
+            piece[c] = piece_of_root[find(c)];
+            piece_size[piece[c]]++;
+        }
+    std::vector<int> edge_prod_cell, edge_cons_cell;     // one stream per closed piece that has a downstream cell
+    std::vector<int> edge_of_prod(n, -1);
+    for (int p = 0; p < npiece; ++p) {                   // closing order: upstream pieces come first
+        const int r = closed_roots[p];
+        if (ds[r] >= 0) {
+            const int cp = piece[ds[r]];
+            edge_of_prod[r] = (int)edge_prod_cell.size();
+            edge_prod_cell.push_back(r);
+            edge_cons_cell.push_back(ds[r]);
+            piece_imp[cp]++;
+            piece_depth[cp] = std::max(piece_depth[cp], piece_depth[p] + 1);
+        }
+    }
+    const int nedge = (int)edge_prod_cell.size();
+
+    // ---- pack pieces of equal depth into units (first-fit decreasing on cells, bounded imports)
+    const int maxdepth = npiece ? *std::max_element(piece_depth.begin(), piece_depth.end()) : 0;
+    std::vector<int> order(npiece);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        return piece_depth[x] != piece_depth[y] ? piece_depth[x] < piece_depth[y] : piece_size[x] > piece_size[y];
+    });
+    std::vector<int> unit_of_piece(npiece, -1), unit_cells_n, unit_imp_n, unit_depth;
+    {
+        size_t first_open = 0;
+        int cur_depth = -1;
+        for (int p : order) {
+            if (piece_depth[p] != cur_depth) {
+                cur_depth = piece_depth[p];
+                first_open = unit_cells_n.size();
+            }
+            int u = -1;
+            for (size_t b = first_open; b < unit_cells_n.size(); ++b)
+                if (unit_cells_n[b] + piece_size[p] <= LANES && unit_imp_n[b] + piece_imp[p] <= G_MAX) {
+                    u = (int)b;
+                    break;
+                }
+            if (u < 0) {
+                u = (int)unit_cells_n.size();
+                unit_cells_n.push_back(0);
+                unit_imp_n.push_back(0);
+                unit_depth.push_back(cur_depth);
+            }
+            unit_of_piece[p] = u;
+            unit_cells_n[u] += piece_size[p];
+            unit_imp_n[u] += piece_imp[p];
+            while (first_open < unit_cells_n.size() && unit_cells_n[first_open] >= LANES) ++first_open;
+        }
+    }
+    const int nunit = (int)unit_cells_n.size();
+    if (nunit == 0) return XH_OK;
+
+    // ---- slots, ghosts, gather offsets
+    const int64_t ts = (int64_t)nunit * LANES;
+    std::vector<int> cell_of_slot(ts, -1), export_edge(ts, -1), ghost_edge(ts, -1), slot_of_cell(n, -1);
+    std::vector<int> fill(nunit, 0), gfill(nunit, 0), edge_cons_unit(nedge), edge_ghost(nedge);
+    for (int c = 0; c < n; ++c)
+        if (piece[c] >= 0) {
+            const int u = unit_of_piece[piece[c]];
+            const int s = fill[u]++;
+            cell_of_slot[(int64_t)u * LANES + s] = c;
+            slot_of_cell[c] = s;
+            handled[c] = 1;
+        }
+    for (int ed = 0; ed < nedge; ++ed) {
+        const int u = unit_of_piece[piece[edge_cons_cell[ed]]];
+        const int g = gfill[u]++;
+        edge_cons_unit[ed] = u;
+        edge_ghost[ed] = g;
+        ghost_edge[(int64_t)u * LANES + g] = ed;
+        const int pc = edge_prod_cell[ed];
+        export_edge[(int64_t)unit_of_piece[piece[pc]] * LANES + slot_of_cell[pc]] = ed;
+    }
+    std::vector<unsigned> ent((size_t)W_MAX * ts, (unsigned)(NPAIR - 1) * 16u);
+    std::vector<int> unit_terms(nunit, 1);
+    for (int c = 0; c < n; ++c) {
+        if (piece[c] < 0) continue;
+        const int u = unit_of_piece[piece[c]];
+        unit_terms[u] = std::max(unit_terms[u], (int)(indptr[c + 1] - indptr[c]));
+        const int64_t slot = (int64_t)u * LANES + slot_of_cell[c];
+        int w = 0;
+        for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j, ++w) {
+            const int src = indices[j];
+            unsigned off;
+            if (piece[src] >= 0 && unit_of_piece[piece[src]] == u) {
+                off = (unsigned)slot_of_cell[src] * 16u + (sign[j] < 0 ? 8u : 0u);
+            } else {                                    // the outlet of an upstream piece in another unit
+                const int ed = edge_of_prod[src];
+                if (ed < 0 || edge_cons_unit[ed] != u)
+                    return xh_fail(ctx, XH_ERR_ARG, "flow plan: inconsistent stream edge at cell %d", c);
+                off = (unsigned)(LANES + edge_ghost[ed]) * 16u;
+            }
+            ent[(size_t)w * ts + slot] = off;
+        }
+    }
+
+    FlowPlan *fp = new FlowPlan();
+    fp->n_units = nunit;
+    fp->n_edges = nedge;
+    fp->depth = maxdepth + 1;
+    fp->n_cells = (int)std::count(handled.begin(), handled.end(), (char)1);
+    fp->max_imports = *std::max_element(unit_imp_n.begin(), unit_imp_n.end());
+    int rc = put(ctx, fp->d_cell_of_slot, cell_of_slot);
+    rc |= put(ctx, fp->d_ent, ent);
+    rc |= put(ctx, fp->d_export_edge, export_edge);
+    rc |= put(ctx, fp->d_ghost_edge, ghost_edge);
+    rc |= put(ctx, fp->d_edge_cons_unit, edge_cons_unit);
+    rc |= put(ctx, fp->d_unit_terms, unit_terms);
+    if (rc) {
+        flow_plan_destroy(fp);
+        return XH_ERR_HIP;
+    }
+    *out = fp;
+    return XH_OK;
+}
+
+int flow_stats_fetch(xh_ctx *ctx, FlowPlan *fp, std::vector<unsigned long long> &out) {
+    out.clear();
+    if (!fp || !fp->d_stats) return XH_OK;
+    out.resize((size_t)fp->n_units * 6);
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    XH_HIP(ctx, hipMemcpy(out.data(), fp->d_stats, out.size() * 8, hipMemcpyDeviceToHost));
+    return XH_OK;
+}
+
+int flow_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st) {
+    if (!fp || fp->n_units == 0) return XH_OK;
+    // exchange block: streams, then the counters (zeroed every call)
+    const size_t x_streams = (size_t)std::max(fp->n_edges, 1) * RING * (size_t)s.ntmax * sizeof(double2);
+    const size_t x_cnt = ((size_t)(fp->n_edges + fp->n_units) * sizeof(unsigned) + 255) & ~size_t(255);
+    if (x_streams + x_cnt > fp->x_bytes) {
+        if (fp->d_x) {
+            XH_HIP(ctx, hipStreamSynchronize(st));
+            XH_HIP(ctx, hipFree(fp->d_x));
+            fp->d_x = nullptr;
+        }
+        XH_HIP(ctx, hipMalloc(&fp->d_x, x_streams + x_cnt));
+        fp->x_bytes = x_streams + x_cnt;
+    }
+    unsigned *cnt = reinterpret_cast<unsigned *>(static_cast<char *>(fp->d_x) + x_streams);
+    XH_HIP(ctx, hipMemsetAsync(cnt, 0, x_cnt, st));
+
+    // Every unit should be resident at once (a unit that is not resident stalls the units feeding it through the
+    // ring back-pressure until it is dispatched).  Asking for a share of the CU's LDS bounds the workgroups per CU,
+    // which also spreads the units over the chip; the share leaves room for ONE MORE workgroup per CU than the even
+    // split needs, because the even split itself (5 x 32 KiB on a 160 KiB CU) was measured to admit one fewer than
+    // hipOccupancyMaxActiveBlocksPerMultiprocessor reports (routing 18.0 ms -> 10.7 ms for 120 months).
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    int per_cu = (fp->n_units + cus - 1) / cus + 1;
+    {
+        const char *env = getenv("XH_FLOW_PER_CU_EXTRA");     // experiments only
+        if (env) per_cu += atoi(env);
+    }
+    size_t lds = 2 * (size_t)NPAIR * sizeof(double2);
+    const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
+    if (share > lds) lds = share;
+    XH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mrtm_flow), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    int resident = 0;
+    XH_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k_mrtm_flow, LANES, lds));
+    if ((int64_t)(resident - 1) * cus < fp->n_units)
+        return xh_fail(ctx, XH_ERR_LIMIT, "dataflow routing: %d units but only (%d - 1) x %d can be resident", fp->n_units,
+                       resident, cus);
+
+    FlowArgs a;
+    a.cell_of_slot = static_cast<const int *>(fp->d_cell_of_slot.p);
+    a.ent = static_cast<const unsigned *>(fp->d_ent.p);
+    a.export_edge = static_cast<const int *>(fp->d_export_edge.p);
+    a.ghost_edge = static_cast<const int *>(fp->d_ghost_edge.p);
+    a.edge_cons_unit = static_cast<const int *>(fp->d_edge_cons_unit.p);
+    a.unit_terms = static_cast<const int *>(fp->d_unit_terms.p);
+    a.total_slots = (int64_t)fp->n_units * LANES;
+    a.nmonths = s.nmonths;
+    a.nit = s.nit;
+    a.ntmax = s.ntmax;
+    a.sched_m = s.d_m;
+    a.sched_nt = s.d_nt;
+    a.sched_secs = s.d_secs;
+    a.sched_write = s.d_wr;
+    a.dt = s.dt;
+    a.dtinv = 1.0 / s.dt;
+    a.flow_dist = io.flow_dist;
+    a.velocity = io.velocity;
+    a.area = io.area;
+    a.runoff = io.runoff;
+    a.S0 = io.S0;
+    a.chs = io.chs;
+    a.avg = io.avg;
+    a.S_end = io.S_end;
+    a.F_end = io.F_end;
+    a.xbuf = static_cast<double2 *>(fp->d_x);
+    a.ready = cnt;
+    a.done = cnt + fp->n_edges;
+    unsigned *fault = nullptr;
+    int rc = xh_fault_word(ctx, &fault);
+    if (rc) return rc;
+    a.fault = fault;
+    a.stats = nullptr;
+    {
+        const char *env = getenv("XH_FLOW_STATS");
+        if (env && env[0] == '1') {
+            if (!fp->d_stats) XH_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&fp->d_stats), (size_t)fp->n_units * 48));
+            a.stats = fp->d_stats;
+        }
+    }
+    // the fault word is zeroed on the context stream; `st` may be a different stream ordered after it by the caller
+    hipLaunchKernelGGL(k_mrtm_flow, dim3((unsigned)fp->n_units), dim3(LANES), lds, st, a);
+    XH_HIP(ctx, hipGetLastError());
+    return XH_OK;
+}
