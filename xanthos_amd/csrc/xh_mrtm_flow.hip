@@ -10,10 +10,11 @@
 //
 //   - inside a unit the sub-step loop is what xh_mrtm.hip does, minus the workgroup barriers: the two flow exchanges
 //     per sub-step go through LDS, whose operations complete in issue order for a single wave;
-//   - a piece's outlet lane appends {trial flow F, adjusted flow F2} of every sub-step to its stream with
-//     write-through (sc1, agent-scope) stores; at the end of a month it publishes the month (stores drained with
-//     s_waitcnt vmcnt(0) -> relaxed agent-scope store of the month counter).  No release fence: an agent-scope release
-//     writes back every dirty line of the XCD's L2, which cost ~60 us per unit per month next to the output stores;
+//   - a piece's outlet lane appends {trial flow F, adjusted flow F2} of every sub-step to its stream (one 16-byte
+//     cached store per sub-step, so the L2 merges them into whole lines); at the end of a month it publishes the
+//     month: s_waitcnt vmcnt(0) -> agent-scope release -> s_waitcnt vmcnt(0) -> relaxed agent-scope store of the
+//     month counter.  (XH_FLOW_STREAM_PLAIN=0 selects write-through sc1 stores without the release instead: same
+//     speed, but 9.8 GB instead of 3.6 GB of HBM writes per 720-month run because every 8-byte store goes to fabric.)
 //   - the consuming unit waits for that counter at the start of the same month (relaxed agent-scope polls with
 //     s_sleep, one agent-scope acquire), then its "ghost" lanes read the stream eight sub-steps ahead into
 //     registers and drop each pair into ghost slots of the LDS flow buffers, where the consuming cell's gather
@@ -63,7 +64,8 @@ struct FlowArgs {
     unsigned *ready;                // [edges] months published
     unsigned *done;                 // [units] months consumed
     unsigned *fault;
-    unsigned long long *stats;      // [units][4] optional cycle accounting (XH_FLOW_STATS=1)
+    unsigned long long *stats;      // [units][6] optional cycle accounting (XH_FLOW_STATS=1)
+    int plain_streams;              // 1 (default): cached stream stores + agent release per month; 0: sc1 stores
 };
 
 __device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
@@ -124,6 +126,9 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
     double qn = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[0]] : 0.0;
     bool alive = true;
     unsigned long long cyc_loop = 0, cyc_wait_data = 0, cyc_wait_ring = 0;
+    double ob_s[8], ob_a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ob_s[j] = ob_a[j] = 0.0;
     const unsigned long long cyc_begin = __builtin_amdgcn_s_memtime();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
 
@@ -172,7 +177,9 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
             const double f2 = sx ? (dsdt + F) + S * dtinv : F;                 // mrtm.py:60
             S = sx ? 0.0 : S;                                                  // mrtm.py:63
             bufB[lane] = make_double2(f2, -f2);
-            if (has_x) {      // write-through (sc1) stores: the month can then be published without an L2 write-back
+            if (has_x && a.plain_streams) {
+                optr[t] = make_double2(F, f2);
+            } else if (has_x) {   // write-through (sc1) stores: the month is published without an L2 write-back
                 unsigned long long *o = reinterpret_cast<unsigned long long *>(optr + t);
                 __hip_atomic_store(o, (unsigned long long)__double_as_longlong(F), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(o + 1, (unsigned long long)__double_as_longlong(f2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -203,13 +210,40 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
         for (int t = t0; t < nt; ++t) substep(t, (has_g) ? iptr[t] : make_double2(0.0, 0.0));
         cyc_loop += __builtin_amdgcn_s_memtime() - c0;
 
-        if (a.sched_write[it] && valid) {
-            const int64_t o = (int64_t)gc * a.nmonths + m;
-            if (a.chs) a.chs[o] = S;
-            if (a.avg) a.avg[o] = favg / (double)nt;                           // mrtm.py:80
+        // Outputs leave as whole 64-byte groups of 8 months per cell (a lone 8-byte store per month made the L2 write
+        // the same line back many times: 13 GB of HBM writes for 0.65 GB of output).
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            ob_s[j] = ob_s[j + 1];
+            ob_a[j] = ob_a[j + 1];
         }
-        if (any_x) {      // publish month `it`: every stream store above was write-through, so draining them is enough
+        ob_s[7] = S;
+        ob_a[7] = favg / (double)nt;                                           // mrtm.py:80
+        if (a.sched_write[it] && valid) {
+            if ((m & 7) == 7) {
+                const int64_t o = (int64_t)gc * a.nmonths + (m - 7);
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    if (a.chs) *reinterpret_cast<double2 *>(a.chs + o + j) = make_double2(ob_s[j], ob_s[j + 1]);
+                    if (a.avg) *reinterpret_cast<double2 *>(a.avg + o + j) = make_double2(ob_a[j], ob_a[j + 1]);
+                }
+            } else if (m == a.nmonths - 1) {                                    // last, partial group
+                const int r = (m & 7) + 1;
+                const int64_t o = (int64_t)gc * a.nmonths + (m + 1 - r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j >= 8 - r) {
+                        if (a.chs) a.chs[o + j - (8 - r)] = ob_s[j];
+                        if (a.avg) a.avg[o + j - (8 - r)] = ob_a[j];
+                    }
+            }
+        }
+        if (any_x) {      // publish month `it`
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (a.plain_streams) {   // cached stores: one agent-scope release (L2 write-back) per month makes them visible
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             if (has_x) __hip_atomic_store(a.ready + xedge, (unsigned)it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (any_g && lane == 0)   // this month's imports are consumed: their ring slots may be reused
@@ -587,6 +621,10 @@ int flow_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     if (rc) return rc;
     a.fault = fault;
     a.stats = nullptr;
+    {
+        const char *env = getenv("XH_FLOW_STREAM_PLAIN");     // 0 = write-through (sc1) stream stores, no release fence
+        a.plain_streams = (env && env[0] == '0') ? 0 : 1;
+    }
     {
         const char *env = getenv("XH_FLOW_STATS");
         if (env && env[0] == '1') {
