@@ -1,0 +1,77 @@
+"""CPU tests of the host-side mirror: .ini surface, selector validation, month tables, DE driver, sharding math."""
+import os
+
+import numpy as np
+import pytest
+
+from xanthos_amd import synth
+from xanthos_amd.calibrate.calibrate_abcd import differential_evolution_batched, expand_str_range
+from xanthos_amd.ini_reader import ConfigReader, ValidationException, parse_ini
+
+
+@pytest.fixture(scope='module')
+def example(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp('xanthos_example'))
+    w = synth.make_world(nrow=24, ncol=48, ncell=300, n_basins=5, seed=21)
+    f = synth.make_forcing(w, 36)
+    ini = synth.write_example(root, w, f, 1971, 1973, runoff_spinup=25, routing_spinup=6)
+    return root, w, f, ini
+
+
+def test_ini_surface(example):
+    root, w, f, ini = example
+    raw = parse_ini(ini)
+    assert raw['PET']['penman-monteith']['pm_lc_years'] == ['1970', '1990', '2005']
+    c = ConfigReader(ini)
+    assert (c.pet_module, c.runoff_module, c.routing_module, c.mod_cfg) == ('pm', 'abcd', 'mrtm', 'pm_abcd_mrtm')
+    assert c.nmonths == 36 and c.ncell == 300 and c.n_basins == 5
+    assert c.pm_nlcs == 8 and c.pm_water_idx == 0 and c.pm_snow_idx == 6 and c.pm_lc_years == [1970, 1990, 2005]
+    assert c.runoff_spinup == 25 and c.routing_spinup == 6 and c.ro_jobs == -1
+    assert c.pm_params.endswith(os.path.join('penman_monteith', 'gcam_ET_para.csv'))
+    assert c.calib_file.endswith(os.path.join('abcd', 'pars.npy'))
+    assert c.output_vars == ['q', 'avgchflow'] and c.calibrate == 0
+    c.update({'StartYear': 1972})
+    assert c.StartYear == 1972
+
+
+def test_ini_defaults_and_selector_validation(example, tmp_path):
+    root, w, f, ini = example
+    text = open(ini).read()
+
+    def variant(old, new):
+        p = tmp_path / 'v.ini'
+        p.write_text(text.replace(old, new))
+        return str(p)
+    assert ConfigReader(variant('routing_spinup = 6\n', '')).routing_spinup == 36       # default = nmonths (:412-415)
+    assert ConfigReader(variant('pet_module = pm', 'pet_module = PM')).pet_module == 'pm'   # lower-cased (:214)
+    for bad in ('pet_module = hargreaves', 'pet_module = nosuch'):
+        with pytest.raises(ValidationException):
+            ConfigReader(variant('pet_module = pm', bad))
+    with pytest.raises(ValidationException):
+        ConfigReader(variant('runoff_module = abcd', 'runoff_module = gwam'))
+    with pytest.raises(ValidationException):
+        ConfigReader(variant('routing_module = mrtm', 'routing_module = rtm'))
+
+
+def test_data_loader_transforms(example):
+    from xanthos_amd.data_load import DataLoader
+    root, w, f, ini = example
+    d = DataLoader(ConfigReader(ini))
+    assert np.allclose(d.area, w.area) and np.array_equal(d.basin_ids, w.basin_ids)
+    assert np.array_equal(d.tairprev_load[1:], d.tair_load[:-1]) and not d.tairprev_load[0].any()
+    assert d.flow_dist.min() >= 1000 and d.str_velocity.min() >= 0
+    assert np.isnan(d.precip).sum() == np.isnan(f['precip']).sum()            # precipitation keeps NaN
+    assert d.elev.shape == (300, 1) and d.lct_load.shape == (300, 8, 3)
+
+
+def test_differential_evolution_driver_finds_minimum():
+    target = np.array([0.3, 5.0, 0.7])
+    calls = []
+
+    def f(P):
+        calls.append(P.shape[0])
+        return np.sum((P - target) ** 2, axis=1)
+    x, fun, nfev, nit = differential_evolution_batched(f, [(0, 1), (0, 8), (0, 1)], seed=3)
+    assert np.allclose(x, target, atol=5e-2) and fun < 1e-2
+    assert all(c == 45 for c in calls) and nfev == sum(calls)                # popsize 15 x 3 parameters per generation
+    assert expand_str_range(['0-2', '6', '7-9']) == [0, 1, 2, 6, 7, 8, 9]

@@ -1,0 +1,151 @@
+"""Components: the harness of the PET -> runoff -> routing path (mirror of xanthos/components.py:29-497).
+
+Same selectors (``pet_module = pm``, ``runoff_module = abcd``, ``routing_module = mrtm``), same methods
+(``calculate_pet``, ``calculate_runoff``, ``calculate_routing``, ``simulation``, ``calibrate``) and same result
+attributes (``PET, AET, Q, Sav, ChStorage, Avg_ChFlow`` as host float64 ``[ncell, nmonths]``, components.py:95-100).
+``import_core`` binds the module globals ``pet_mod / runoff_mod / routing_mod`` to this package's plugins, which call
+the HIP kernels through the C-ABI.  ``simulation`` keeps the arrays in HBM between the three stages (one upload of
+the forcing, one download of the six outputs); the per-stage ``calculate_*`` methods remain for callers that drive
+the stages one by one (the calibration routing callback, components.py:486-497).
+"""
+import logging
+import time
+
+import numpy as np
+
+from . import _hip
+from .calibrate import calibrate_abcd as calib_mod
+from .data_load import DataLoader
+from .ini_reader import ValidationException
+from .pipeline import DevicePipeline
+from .utils import set_month_arrays
+
+pet_mod = runoff_mod = routing_mod = None
+
+
+class Components:
+
+    def __init__(self, config):
+        self.s = config
+        self.import_core()
+        self.data = DataLoader(config)
+        self.yr_imth_dys = set_month_arrays(self.s.nmonths, self.s.StartYear, self.s.EndYear)
+        self.routing_timestep_hours = 3 * 3600          # seconds, despite the name (components.py:91)
+        shape = (self.s.ncell, self.s.nmonths)
+        self.PET, self.AET, self.Q = np.zeros(shape), np.zeros(shape), np.zeros(shape)
+        self.Sav, self.ChStorage, self.Avg_ChFlow = np.zeros(shape), np.zeros(shape), np.zeros(shape)
+        self.um = self.dsid = self.upid = None
+        self.instream_flow = None
+        self.q = self.ac = None
+
+    def import_core(self):
+        """Bind the selected plugins (components.py:114-142)."""
+        global pet_mod, runoff_mod, routing_mod
+        if self.s.pet_module == 'pm':
+            from .pet import penman_monteith as pet_mod
+        elif self.s.pet_module != 'none':
+            raise ValidationException("pet_module '{}' is not part of the MI355X hot path".format(self.s.pet_module))
+        if self.s.runoff_module == 'abcd':
+            from .runoff import abcd as runoff_mod
+        elif self.s.runoff_module != 'none':
+            raise ValidationException("runoff_module '{}' is not part of the MI355X hot path".format(self.s.runoff_module))
+        if self.s.routing_module == 'mrtm':
+            from .routing import mrtm as routing_mod
+
+    # ------------------------------------------------------------------ stage by stage (host arrays)
+    def calculate_pet(self):
+        """Monthly PET (components.py:189-210)."""
+        if self.s.pet_module == 'pm':
+            return pet_mod.run_pmpet(self.data, self.s.ncell, self.s.pm_nlcs, self.s.StartYear, self.s.EndYear,
+                                     self.s.pm_water_idx, self.s.pm_snow_idx, self.s.pm_lc_years, device=self.s.device)
+        if self.s.pet_module == 'none':
+            return self.data.pet_out
+
+    def calculate_runoff(self, step_num=None, pet=None):
+        """ABCD over all months (components.py:212-247)."""
+        if self.s.runoff_module == 'abcd':
+            rg = runoff_mod.abcd_execute(n_basins=self.s.n_basins, basin_ids=self.data.basin_ids, pet=pet,
+                                         precip=self.data.precip, tmin=self.data.tmin, calib_file=self.s.calib_file,
+                                         n_months=self.s.nmonths, spinup_steps=self.s.runoff_spinup, jobs=self.s.ro_jobs)
+            self.PET, self.AET, self.Q, self.Sav = rg
+        elif getattr(self.s, 'alt_runoff', None) is not None:
+            self.Q = np.load(self.s.alt_runoff)
+
+    def topology(self):
+        """dsid -> upid -> UM, built once per Components (the reference rebuilds it on every call, :268-270)."""
+        if self.um is None:
+            self.dsid = routing_mod.downstream(self.data.coords, self.data.flow_dir, self.s)
+            self.upid = routing_mod.upstream(self.data.coords, self.dsid, self.s)
+            self.um = routing_mod.upstream_genmatrix(self.upid)
+        return self.um
+
+    def calculate_routing(self, runoff):
+        """Spin-up + simulation of MRTM over all months (components.py:249-296). Returns Avg_ChFlow."""
+        if self.s.routing_module == 'mrtm':
+            um = self.topology()
+            chs, avg, fend = routing_mod.route_series(um, self.data.flow_dist, self.data.str_velocity, self.data.area,
+                                                      runoff, self.yr_imth_dys[:, 2], self.s.routing_spinup,
+                                                      S0=self.data.chs_prev, dt=self.routing_timestep_hours,
+                                                      device=self.s.device)
+            self.ChStorage, self.Avg_ChFlow, self.instream_flow = chs, avg, fend
+            return self.Avg_ChFlow
+
+    # ------------------------------------------------------------------ whole simulation, device resident
+    def simulation(self, run_pet=True, run_runoff=True, run_routing=True, pet_num_steps=0, runoff_num_steps=0,
+                   routing_num_steps=0, notify='simulation'):
+        """Run the configured stages (components.py:298-384)."""
+        if self.s.calibrate:
+            self.calibrate()
+            return
+        logging.info('---{} in progress...'.format(notify))
+        t0 = time.time()
+        s, d = self.s, self.data
+        full = (s.pet_module == 'pm' and s.runoff_module == 'abcd' and run_pet and run_runoff)
+        if not full:
+            pet_out = self.calculate_pet()
+            if run_runoff:
+                self.calculate_runoff(pet=pet_out)
+            if run_routing and s.routing_module == 'mrtm':
+                self.calculate_routing(self.Q)
+            return
+        ctx = _hip.get_context(s.device)
+        um = self.topology() if (run_routing and s.routing_module == 'mrtm') else None
+        pipe = DevicePipeline(ctx, ncell=s.ncell, nmonths=s.nmonths, start_year=s.StartYear, basin_ids=d.basin_ids,
+                              abcd_pars=np.load(s.calib_file) if not isinstance(s.calib_file, np.ndarray) else s.calib_file,
+                              pm_tables=pet_mod.tables_from(d, s.pm_nlcs), lct=d.lct_load, elev=d.elev,
+                              lc_years=s.pm_lc_years, um=um,
+                              flow_dist=d.flow_dist if um is not None else np.zeros(s.ncell),
+                              velocity=d.str_velocity if um is not None else np.zeros(s.ncell), area=d.area,
+                              abcd_spinup=s.runoff_spinup, routing_spinup=getattr(s, 'routing_spinup', 0),
+                              water_idx=s.pm_water_idx, snow_idx=s.pm_snow_idx, use_snow=d.tmin is not None)
+        pipe.set_forcing({'tas': d.tair_load, 'tmin': d.TMIN_load, 'rhs': d.rhs_load, 'wind': d.wind_load,
+                          'rsds': d.rsds_load, 'rlds': d.rlds_load, 'precip': d.precip, 'abcd_tmin': d.tmin},
+                         tairprev=d.tairprev_load)
+        t = time.time()
+        pipe.run_pm()
+        pipe.run_abcd()
+        if um is not None:
+            pipe.run_mrtm()
+        ctx.sync()
+        logging.info('\tPET + runoff + routing kernels: {:.3f} seconds'.format(time.time() - t))
+        out = pipe.download(('pet', 'aet', 'q', 'sav') + (('chs', 'avg') if um is not None else ()))
+        self.PET, self.AET, self.Q, self.Sav = out['pet'], out['aet'], out['q'], out['sav']
+        if um is not None:
+            self.ChStorage, self.Avg_ChFlow = out['chs'], out['avg']
+        logging.info('---{0} has finished successfully: {1} seconds ---'.format(notify, time.time() - t0))
+
+    def calibrate(self):
+        """Calibrate the ABCD parameters per basin (components.py:486-497)."""
+        pet_out = self.calculate_pet()
+        calib_mod.calibrate_all(settings=self.s, data=self.data, pet=pet_out, router_function=self.calculate_routing)
+
+    def output_simulation(self):
+        """Write the selected variables as .npy (the reference's pandas writer, out_writer.py, is outside the hot path)."""
+        import os
+        names = {'pet': self.PET, 'aet': self.AET, 'q': self.Q, 'soilmoisture': self.Sav, 'avgchflow': self.Avg_ChFlow}
+        for var in self.s.output_vars:
+            if var in names:
+                os.makedirs(self.s.OutputFolder, exist_ok=True)
+                np.save(os.path.join(self.s.OutputFolder, '{}_{}_{}_{}.npy'.format(var, self.s.ProjectName,
+                                                                               self.s.StartYear, self.s.EndYear)),
+                        names[var])

@@ -1,0 +1,117 @@
+"""Input loading for the pm / abcd / mrtm path (host side, runs once).
+
+Mirrors the parts of xanthos/data_reader/data_load.py that feed the hot path and keeps every load-time transform that
+changes its inputs:
+
+* area x 0.01 (ha -> km2, :48); coordinates table [id, lon, lat, ilon, ilat] (:51); basin ids (:54)
+* PM forcings pass through nan_to_num (:120-125); ``tairprev`` is tas shifted by one CELL, zeros for cell 0 (:127-129);
+  land cover and elevation nan_to_num (:132,:135); 13 per-class parameters + 4 per-(class, month) tables (:94-117)
+* precipitation keeps NaN (:186); ABCD tmin nan_to_num (:194-195), optional
+* routing: flow distance < 1000 -> 1000 (:204-205), velocity < 0 -> 0 (:207-208), 2-D DRT maps flattened with the
+  reference's ``vectorize`` (:415-425), zero initial channel storage in historic mode (:427-438)
+
+Any setting may be an in-memory ndarray instead of a path (data_load.py:305-307), which is how tests and benchmarks
+inject synthetic forcing.
+"""
+import os
+
+import numpy as np
+
+from .ini_reader import ValidationException
+
+
+def load_file(fn, header_num=0):
+    """.npy / .csv / .txt reader (data_load.py:342-390); NetCDF / MATLAB inputs are outside the hot path."""
+    if isinstance(fn, np.ndarray):
+        return fn
+    if not os.path.isfile(fn):
+        raise IOError('Error: File does not exist:', fn)
+    if fn.endswith('.npy'):
+        return np.load(fn)
+    if fn.endswith('.csv'):
+        return np.genfromtxt(fn, delimiter=',', skip_header=header_num, filling_values='0')
+    if fn.endswith('.txt'):
+        return np.genfromtxt(fn, delimiter=' ', skip_header=header_num, filling_values='0')
+    raise RuntimeError('File {} has unrecognized extension'.format(fn))
+
+
+def vectorize(data, ngridrow, ngridcol, map_index, skip=68):
+    """2-D DRT map (rows north to south) -> per-cell vector (data_load.py:415-425)."""
+    new = np.zeros((ngridrow, ngridcol), dtype=float) - 9999
+    for i in range(data.shape[0]):
+        new[i + skip, :] = data[data.shape[0] - 1 - i, :]
+    return new.reshape((ngridrow * ngridcol,), order='F')[map_index]
+
+
+class DataLoader:
+    """Arrays the three plugins need, as attributes with the reference's names."""
+
+    def __init__(self, s):
+        self.s = s
+        self.area = np.asarray(load_file(s.Area), dtype=float).reshape(-1) * 0.01
+        self.coords = np.asarray(load_file(s.Coord), dtype=float)
+        self.basin_ids = np.asarray(load_file(s.BasinIDs, 1)).reshape(-1).astype(int)
+        self.latitude = np.copy(self.coords[:, 2])
+
+        if s.pet_module == 'pm':
+            et = np.asarray(load_file(s.pm_params), dtype=float)
+            (self.cL, self.beta, self.rslimit, self.ae, self.be, self.Tminopen, self.Tminclose, self.VPDclose,
+             self.VPDopen, self.RBLmin, self.RBLmax, self.rc, self.emiss) = (et[:, k] for k in range(13))
+            self.alpha = np.asarray(load_file(s.pm_alpha), dtype=float)
+            self.lai = np.asarray(load_file(s.pm_lai), dtype=float)
+            self.laimax = np.asarray(load_file(s.pm_laimax), dtype=float)
+            self.laimin = np.asarray(load_file(s.pm_laimin), dtype=float)
+            self.tair_load = self.load_to_array(s.pm_tas, 'pm_tas', nan_to_num=True)
+            self.TMIN_load = self.load_to_array(s.pm_tmin, 'pm_tmin', nan_to_num=True)
+            self.rhs_load = self.load_to_array(s.pm_rhs, 'pm_rhs', nan_to_num=True)
+            self.wind_load = self.load_to_array(s.pm_wind, 'pm_wind', nan_to_num=True)
+            self.rsds_load = self.load_to_array(s.pm_rsds, 'pm_rsds', nan_to_num=True)
+            self.rlds_load = self.load_to_array(s.pm_rlds, 'pm_rlds', nan_to_num=True)
+            self.tairprev_load = np.zeros_like(self.tair_load)
+            self.tairprev_load[1:, :] = self.tair_load[:-1, :]
+            self.lct_load = np.nan_to_num(load_file(s.pm_lct))
+            self.elev = np.nan_to_num(load_file(s.pm_elev))
+        elif s.pet_module == 'none':
+            self.pet_out = self.load_to_array(s.pet_file, 'pet_file')
+
+        if s.runoff_module == 'abcd':
+            self.precip = self.load_to_array(s.PrecipitationFile, 'PrecipitationFile')
+            self.tmin = None if s.TempMinFile is None else self.load_to_array(s.TempMinFile, 'TempMinFile',
+                                                                               nan_to_num=True)
+
+        if s.routing_module == 'mrtm':
+            self.flow_dist = self.load_routing_data(s.flow_distance, rep_val=1000)
+            self.flow_dir = self.load_routing_data(s.flow_direction)
+            self.str_velocity = self.load_routing_data(s.strm_veloc, rep_val=0)
+            self.instream_flow = np.zeros((s.ncell,), dtype=float)
+            self.chs_prev = np.zeros((s.ncell,), dtype=float)      # historic mode (data_load.py:427-438)
+
+        if s.calibrate:
+            self.cal_obs = np.asarray(load_file(s.cal_observed, 0))[:, [0, 3]]
+
+    def load_to_array(self, f, var_name, nan_to_num=False):
+        arr = np.asarray(load_file(f), dtype=float)
+        if nan_to_num:
+            arr = np.nan_to_num(arr)
+        if arr.shape[0] != self.s.ncell or arr.shape[1] != self.s.nmonths:
+            raise ValidationException('Error: Inconsistent {0} data grid size. Expecting size: {1}. Received size: {2}'
+                                      .format(var_name, (self.s.ncell, self.s.nmonths), arr.shape))
+        return arr
+
+    def load_routing_data(self, fn, rep_val=None):
+        """Per-cell vector from a 1-D array or a 2-D DRT map (data_load.py:392-413)."""
+        fd = np.asarray(load_file(fn), dtype=float)
+        if fd.ndim == 2 and fd.shape[1] == self.s.ngridcol:
+            r = self.coords[:, 4].astype(int) - 1
+            c = self.coords[:, 3].astype(int) - 1
+            map_index = np.ravel_multi_index((r, c), (self.s.ngridrow, self.s.ngridcol), order='F')
+            # the DRT maps cover 280 of the 360 rows and sit 68 rows up from the bottom (data_load.py:392, skip=68)
+            skip = 68 if (fd.shape[0] == 280 and self.s.ngridrow == 360) else self.s.ngridrow - fd.shape[0]
+            v = vectorize(fd, self.s.ngridrow, self.s.ngridcol, map_index, skip=skip)
+        else:
+            v = fd.reshape(-1).copy()
+        if v.shape[0] != self.s.ncell:
+            raise ValidationException('routing input {} has {} cells, expected {}'.format(fn, v.shape[0], self.s.ncell))
+        if rep_val is not None:
+            v[v < rep_val] = rep_val
+        return v

@@ -1,0 +1,239 @@
+"""Configuration reader for the pm / abcd / mrtm path -- same .ini surface as xanthos/data_reader/ini_reader.py.
+
+The reference parses the file with ``configobj`` (not installed here) and flattens it into an attribute bag
+(ini_reader.py:24-607).  This module has its own small parser for the same syntax (``[Section]``, nested
+``[[subsection]]``, ``key = value``, ``#`` comments, comma lists, optional quotes) and builds the same attributes for
+the sections the hot path reads: ``[Project]``, ``[PET][[penman-monteith]]``, ``[Runoff][[abcd]]``,
+``[Routing][[mrtm]]`` and ``[Calibrate]``.  Selector strings are lower-cased and validated exactly like the
+reference (:214, :309, :397); selectors that belong to other reference modules are rejected with a clear message
+because only the MI355X hot path is implemented here.  ``update()`` keeps the in-memory override hook (:598-607).
+"""
+import os
+
+
+class ValidationException(Exception):
+    """Invalid Xanthos configuration (ini_reader.py:17)."""
+
+
+def parse_ini(path):
+    """Nested dict of the file's sections; values are str or list of str (comma separated)."""
+    root = {}
+    stack = [root]
+    with open(path, 'r') as fh:
+        for raw in fh:
+            line = _strip_comment(raw).strip()
+            if not line:
+                continue
+            if line.startswith('['):
+                depth = len(line) - len(line.lstrip('['))
+                name = line.strip('[]').strip()
+                if depth < 1 or depth > len(stack):
+                    raise ValidationException('bad section nesting: ' + raw.strip())
+                del stack[depth:]
+                sec = {}
+                stack[-1][name] = sec
+                stack.append(sec)
+            elif '=' in line:
+                key, val = line.split('=', 1)
+                stack[-1][key.strip()] = _value(val.strip())
+            else:
+                raise ValidationException('cannot parse line: ' + raw.strip())
+    return root
+
+
+def _strip_comment(line):
+    out, quote = [], None
+    for ch in line:
+        if quote:
+            if ch == quote:
+                quote = None
+        elif ch in '"\'':
+            quote = ch
+        elif ch == '#':
+            break
+        out.append(ch)
+    return ''.join(out)
+
+
+def _value(text):
+    parts = [p.strip().strip('"\'') for p in text.split(',')]
+    if len(parts) > 1:
+        return [p for p in parts if p != '']
+    return parts[0] if parts else ''
+
+
+class ConfigReader:
+    """Attribute bag of settings for one run (ini_reader.py:24)."""
+
+    PET_OTHER = ('hargreaves', 'hs', 'thornthwaite')
+    RUNOFF_OTHER = ('gwam',)
+
+    def __init__(self, ini):
+        c = parse_ini(ini) if not isinstance(ini, dict) else ini
+        try:
+            p = c['Project']
+        except KeyError:
+            raise ValidationException('no [Project] section in ' + str(ini))
+
+        self.root = p['RootDir']
+        self.ProjectName = p['ProjectName']
+        self.OutputNameStr = p['ProjectName']
+        self.InputFolder = os.path.join(self.root, p['InputFolder'])
+        self.OutDir = os.path.join(self.root, p['OutputFolder'])
+        self.OutputFolder = os.path.join(self.OutDir, self.ProjectName)
+
+        self.Reference = os.path.join(self.InputFolder, p['RefDir']) if 'RefDir' in p else None
+        self.PET = os.path.join(self.InputFolder, p['pet_dir']) if 'pet_dir' in p else self.InputFolder
+        self.RunoffDir = os.path.join(self.InputFolder, p['RunoffDir']) if 'RunoffDir' in p else self.InputFolder
+        self.RoutingDir = os.path.join(self.InputFolder, p['RoutingDir']) if 'RoutingDir' in p else self.InputFolder
+
+        # project-level settings (ini_reader.py:117-142); the grid is hard-wired in the reference (:117-119) --
+        # here ncell / ngridrow / ngridcol may be overridden for reduced test grids
+        self.ncell = int(p.get('ncell', 67420))
+        self.ngridrow = int(p.get('ngridrow', 360))
+        self.ngridcol = int(p.get('ngridcol', 720))
+        self.n_basins = int(p['n_basins'])
+        self.HistFlag = p.get('HistFlag', 'True')
+        self.StartYear = int(p['StartYear'])
+        self.EndYear = int(p['EndYear'])
+        ov = p.get('output_vars', '')
+        self.output_vars = ov if isinstance(ov, list) else [ov]
+        for key in ('OutputFormat', 'OutputUnit', 'OutputInYear', 'AggregateRunoffBasin', 'AggregateRunoffCountry',
+                    'AggregateRunoffGCAMRegion', 'PerformDiagnostics', 'CreateTimeSeriesPlot', 'CalculateDroughtStats',
+                    'CalculateAccessibleWater', 'CalculateHydropowerPotential', 'CalculateHydropowerActual'):
+            setattr(self, key, int(p.get(key, 0)))
+        self.calibrate = int(p.get('Calibrate', 0))
+        self.nmonths = (self.EndYear - self.StartYear + 1) * 12
+        self.device = int(p.get('device', 0))
+
+        self.configure_pet(c.get('PET'))
+        self.configure_runoff(c.get('Runoff'))
+        self.configure_routing(c.get('Routing'))
+        self.mod_cfg = '{0}_{1}_{2}'.format(self.pet_module, self.runoff_module, self.routing_module)
+        if self.mod_cfg == 'none_none_none':
+            raise ValidationException('No PET, Runoff, or Routing model selected.')
+        self.configure_reference_data()
+        if self.calibrate:
+            if 'Calibrate' not in c:
+                raise ValidationException('Calibrate = 1 but no [Calibrate] section.')
+            self.configure_calibration(c['Calibrate'])
+
+    # ------------------------------------------------------------------ modules
+    def configure_pet(self, cfg):
+        """[PET] / [[penman-monteith]] (ini_reader.py:198-300)."""
+        if not cfg:
+            self.pet_module = 'none'
+            return
+        self.pet_module = cfg['pet_module'].lower()
+        if self.pet_module == 'pm':
+            m = cfg['penman-monteith']
+            self.pet_dir = os.path.join(self.PET, m['pet_dir'])
+            for key in ('pm_tas', 'pm_tmin', 'pm_rhs', 'pm_rlds', 'pm_rsds', 'pm_wind', 'pm_lct'):
+                setattr(self, key, os.path.join(self.pet_dir, m[key]))
+            self.pm_nlcs = int(m['pm_nlcs'])
+            self.pm_water_idx = int(m['pm_water_idx'])
+            self.pm_snow_idx = int(m['pm_snow_idx'])
+            years = m['pm_lc_years']
+            self.pm_lc_years = [int(i) for i in (years if isinstance(years, list) else [years])]
+            self.pm_params = os.path.join(self.pet_dir, 'gcam_ET_para.csv')
+            self.pm_alpha = os.path.join(self.pet_dir, 'gcam_albedo.csv')
+            self.pm_lai = os.path.join(self.pet_dir, 'gcam_lai.csv')
+            self.pm_laimin = os.path.join(self.pet_dir, 'gcam_laimin.csv')
+            self.pm_laimax = os.path.join(self.pet_dir, 'gcam_laimax.csv')
+            self.pm_elev = os.path.join(self.pet_dir, 'elev.npy')
+        elif self.pet_module == 'none':
+            try:
+                self.pet_file = cfg['pet_file']
+            except KeyError:
+                raise ValidationException('USAGE: Must provide a pet_file variable in the PET config section that '
+                                          'contains the full path to an input PET file if not using an existing module.')
+        elif self.pet_module in self.PET_OTHER:
+            raise ValidationException("PET module '{0}' belongs to the reference's CPU modules; this package implements "
+                                      "the MI355X hot path only (pet_module = pm).".format(self.pet_module))
+        else:
+            raise ValidationException("ERROR: PET module '{0}' not found. Please check "
+                                      "spelling and try again.".format(self.pet_module))
+
+    def configure_runoff(self, cfg):
+        """[Runoff] / [[abcd]] (ini_reader.py:302-388)."""
+        if not cfg:
+            self.runoff_module = 'none'
+            return
+        self.runoff_module = cfg['runoff_module'].lower()
+        if self.runoff_module == 'abcd':
+            m = cfg['abcd']
+            self.ro_model_dir = os.path.join(self.RunoffDir, m['runoff_dir'])
+            self.calib_file = os.path.join(self.ro_model_dir, m['calib_file'])
+            self.runoff_spinup = int(m['runoff_spinup'])
+            self.ro_jobs = int(m.get('jobs', -1))
+            try:
+                self.PrecipitationFile = m['PrecipitationFile']
+            except KeyError:
+                raise ValidationException('File path not provided for the PrecipitationFile variable in the ABCD '
+                                          'runoff section of the config file.')
+            self.PrecipVarName = m.get('PrecipVarName')
+            self.TempMinFile = m.get('TempMinFile')
+            self.TempMinVarName = m.get('TempMinVarName')
+        elif self.runoff_module == 'none':
+            pass
+        elif self.runoff_module in self.RUNOFF_OTHER:
+            raise ValidationException("Runoff module '{0}' belongs to the reference's CPU modules; this package "
+                                      "implements the MI355X hot path only (runoff_module = abcd).".format(self.runoff_module))
+        else:
+            raise ValidationException("ERROR: Runoff module '{0}' not found. Please check "
+                                      "spelling and try again.".format(self.runoff_module))
+
+    def configure_routing(self, cfg):
+        """[Routing] / [[mrtm]] (ini_reader.py:390-423)."""
+        if not cfg:
+            self.routing_module = 'none'
+            return
+        self.routing_module = cfg['routing_module'].lower()
+        if self.routing_module == 'mrtm':
+            m = cfg['mrtm']
+            self.rt_model_dir = os.path.join(self.RoutingDir, m['routing_dir'])
+            self.strm_veloc = os.path.join(self.rt_model_dir, m['channel_velocity'])
+            self.flow_distance = os.path.join(self.rt_model_dir, m['flow_distance'])
+            self.flow_direction = os.path.join(self.rt_model_dir, m['flow_direction'])
+            self.routing_spinup = int(m['routing_spinup']) if 'routing_spinup' in m else self.nmonths
+            alt = m.get('alt_runoff')
+            self.alt_runoff = None if alt in (None, 'none') else os.path.join(self.rt_model_dir, alt)
+        elif self.routing_module == 'none':
+            pass
+        else:
+            raise ValidationException("ERROR: Routing module '{0}' not found. Please check "
+                                      "spelling and try again.".format(self.routing_module))
+
+    def configure_reference_data(self):
+        """Reference grid files (ini_reader.py:425-437); only the ones the hot path reads."""
+        if self.Reference:
+            self.Area = os.path.join(self.Reference, 'Grid_Areas_ID.csv')
+            self.Coord = os.path.join(self.Reference, 'coordinates.csv')
+            self.BasinIDs = os.path.join(self.Reference, 'basin.csv')
+
+    def configure_calibration(self, cfg):
+        """[Calibrate] (ini_reader.py:506-519)."""
+        self.set_calibrate = int(cfg['set_calibrate'])
+        self.cal_observed = cfg['observed']
+        self.obs_unit = self.ck_obs_unit(self.set_calibrate, cfg['obs_unit'])
+        self.calib_out_dir = cfg['calib_out_dir']
+        basins = cfg.get('calibration_basins')
+        if basins is None:
+            self.cal_basins = ['1-{}'.format(self.n_basins)]
+        else:
+            self.cal_basins = basins if isinstance(basins, list) else [basins]
+
+    @staticmethod
+    def ck_obs_unit(set_calib, unit):
+        """Units accepted for the observations (ini_reader.py:521-545)."""
+        valid = ('km3_per_mth', 'mm_per_mth') if set_calib == 0 else ('m3_per_sec',)
+        if unit not in valid:
+            raise ValidationException("Calibration data input units '{}' not in required units '{}'".format(unit, valid))
+        return unit
+
+    def update(self, args):
+        """Overwrite configuration options in memory (ini_reader.py:598-607)."""
+        for k, v in args.items():
+            if not hasattr(self, k):
+                print('Warning: {} is not a valid parameter'.format(k))
+            setattr(self, k, v)

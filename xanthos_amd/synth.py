@@ -212,3 +212,110 @@ def data_bag(world, forcing):
     d.tairprev_load[1:, :] = d.tair_load[:-1, :]             # the reference's cell-shift (data_load.py:128-129)
     d.lct_load = world.lct
     return d
+
+
+def write_example(root, world, forcing, start_year, end_year, project='pm_abcd_mrtm_synth', runoff_spinup=36,
+                  routing_spinup=None, output_vars=('q', 'avgchflow'), obs=None):
+    """Write ``world`` + ``forcing`` as a Xanthos-style input tree under ``root`` and return the .ini path.
+
+    Layout and file names follow the reference's example (ini_reader.py:254-279, 353-381, 399-416, 425-437):
+    input/reference/{Grid_Areas_ID.csv, coordinates.csv, basin.csv}, input/pet/penman_monteith/*.npy + gcam_*.csv,
+    input/runoff/abcd/{pars.npy, pr.npy, tmin.npy}, input/routing/mrtm/{velocity.npy, flow_dist.npy, flow_dir.npy}.
+    """
+    import os
+    inp = os.path.join(root, 'input')
+    dirs = {k: os.path.join(inp, *v) for k, v in dict(ref=('reference',), pet=('pet', 'penman_monteith'),
+                                                      ro=('runoff', 'abcd'), rt=('routing', 'mrtm')).items()}
+    for d in dirs.values():
+        os.makedirs(d, exist_ok=True)
+    np.savetxt(os.path.join(dirs['ref'], 'Grid_Areas_ID.csv'), world.area * 100.0, delimiter=',', fmt='%.17g')   # ha
+    np.savetxt(os.path.join(dirs['ref'], 'coordinates.csv'), world.coords, delimiter=',', fmt='%.17g')
+    np.savetxt(os.path.join(dirs['ref'], 'basin.csv'), np.concatenate([[0], world.basin_ids]), fmt='%d')   # 1 header row
+    et = np.stack([world.cL, world.beta, world.rslimit, world.ae, world.be, world.Tminopen, world.Tminclose,
+                   world.VPDclose, world.VPDopen, world.RBLmin, world.RBLmax, world.rc, world.emiss], axis=1)
+    np.savetxt(os.path.join(dirs['pet'], 'gcam_ET_para.csv'), et, delimiter=',', fmt='%.17g')
+    for name, arr in (('gcam_albedo', world.alpha), ('gcam_lai', world.lai), ('gcam_laimin', world.laimin),
+                      ('gcam_laimax', world.laimax)):
+        np.savetxt(os.path.join(dirs['pet'], name + '.csv'), arr, delimiter=',', fmt='%.17g')
+    np.save(os.path.join(dirs['pet'], 'elev.npy'), world.elev)
+    np.save(os.path.join(dirs['pet'], 'lct.npy'), world.lct)
+    for key in ('tas', 'tmin', 'rhs', 'wind', 'rsds', 'rlds'):
+        np.save(os.path.join(dirs['pet'], key + '.npy'), forcing[key])
+    np.save(os.path.join(dirs['ro'], 'pars.npy'), world.abcd_pars)
+    np.save(os.path.join(dirs['ro'], 'pr.npy'), forcing['precip'])
+    np.save(os.path.join(dirs['ro'], 'tmin.npy'), forcing['abcd_tmin'])
+    np.save(os.path.join(dirs['rt'], 'velocity.npy'), world.velocity)
+    np.save(os.path.join(dirs['rt'], 'flow_dist.npy'), world.flow_dist)
+    np.save(os.path.join(dirs['rt'], 'flow_dir.npy'), world.flow_dir)
+    nmonths = (end_year - start_year + 1) * 12
+    ini = os.path.join(root, project + '.ini')
+    calib = ''
+    if obs is not None:
+        obs_file = os.path.join(inp, 'obs.csv')
+        np.savetxt(obs_file, obs, delimiter=',', fmt='%.17g')
+        calib = ('\n[Calibrate]\nset_calibrate = 0\nobserved = {}\nobs_unit = km3_per_mth\ncalib_out_dir = {}\n'
+                 'calibration_basins = 1-2\n').format(obs_file, os.path.join(root, 'calib_out'))
+    with open(ini, 'w') as fh:
+        fh.write('''[Project]
+# synthetic pm_abcd_mrtm example written by xanthos_amd.synth.write_example
+ProjectName = {project}
+RootDir = {root}
+InputFolder = input
+OutputFolder = output
+RefDir = reference
+pet_dir = pet
+RunoffDir = runoff
+RoutingDir = routing
+HistFlag = True
+n_basins = {nb}
+ncell = {ncell}
+ngridrow = {nrow}
+ngridcol = {ncol}
+StartYear = {y0}
+EndYear = {y1}
+output_vars = {ov}
+OutputFormat = 1
+OutputUnit = 0
+OutputInYear = 0
+Calibrate = {cal}
+
+[PET]
+pet_module = pm
+[[penman-monteith]]
+pet_dir = penman_monteith
+pm_tas = tas.npy
+pm_tmin = tmin.npy
+pm_rhs = rhs.npy
+pm_rlds = rlds.npy
+pm_rsds = rsds.npy
+pm_wind = wind.npy
+pm_lct = lct.npy
+pm_nlcs = {nlcs}
+pm_water_idx = 0
+pm_snow_idx = 6
+pm_lc_years = {lcy}
+
+[Runoff]
+runoff_module = abcd
+[[abcd]]
+runoff_dir = abcd
+calib_file = pars.npy
+runoff_spinup = {rsp}
+jobs = -1
+PrecipitationFile = {pr}
+TempMinFile = {tn}
+
+[Routing]
+routing_module = mrtm
+[[mrtm]]
+routing_dir = mrtm
+routing_spinup = {rtsp}
+channel_velocity = velocity.npy
+flow_distance = flow_dist.npy
+flow_direction = flow_dir.npy
+{calib}'''.format(project=project, root=root, nb=world.n_basins, ncell=world.ncell, nrow=world.nrow, ncol=world.ncol,
+                  y0=start_year, y1=end_year, ov=', '.join(output_vars), cal=int(obs is not None), nlcs=world.nlcs,
+                  lcy=', '.join(str(y) for y in world.lc_years), rsp=runoff_spinup,
+                  rtsp=nmonths if routing_spinup is None else routing_spinup,
+                  pr=os.path.join(dirs['ro'], 'pr.npy'), tn=os.path.join(dirs['ro'], 'tmin.npy'), calib=calib))
+    return ini
