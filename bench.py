@@ -183,7 +183,8 @@ def main():
     shard = None
     if args.strong and world_size > 1:
         from xanthos_amd import dist as xdist
-        shard = xdist.make_shards(world, um, world_size)[rank]
+        shards = xdist.make_shards(world, um, world_size)
+        shard = shards[rank]
         run_world, run_um = xdist.sub_world(world, um, shard)
     else:
         run_world, run_um = world, um
@@ -218,7 +219,9 @@ def main():
     for _ in range(args.steps):
         pipe.run(args.stages)
         if shard is not None:
-            xdist.gather_outputs(ctx, pipe, shard, world, dist, torch)
+            gathered = xdist.gather_outputs(ctx, pipe, shard, shards, world, dist, torch)
+            torch.cuda.synchronize()
+            del gathered
     ctx.sync()
     barrier()
     elapsed = time.perf_counter() - t0

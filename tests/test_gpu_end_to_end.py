@@ -123,3 +123,33 @@ def test_full_size_grid_each_stage():
     assert np.array_equal(g_chs, chs, equal_nan=True) and np.array_equal(g_avg, avg, equal_nan=True)
     # size-independent property: routing conserves water -- storage change = inflow - outflow at the outlets
     assert np.isnan(g_avg).sum() == np.isnan(avg).sum()
+
+
+def test_basin_sharded_run_equals_whole_world():
+    """Shard one world into 3 basin/network-closed shards, run each shard's pipeline on this GPU, reassemble:
+    every output is bit-identical to the unsharded run (what rank 0 holds after the gather on a multi-GPU node)."""
+    from xanthos_amd import _hip, synth
+    from xanthos_amd.dist import fill_shard_forcing, make_shards, sub_world
+    from xanthos_amd.pipeline import OUTPUTS, pipeline_from_world, topology_from_world
+    ctx = _hip.get_context(0)
+    w = synth.make_world(nrow=60, ncol=120, ncell=4000, n_basins=11, seed=8)
+    um = topology_from_world(w)
+    nm, seed = 36, 99
+    whole = pipeline_from_world(ctx, w, nm, 1971, 25, 6, um=um)
+    ctx.synth_forcing(seed, w.ncell, nm, ctx.upload(w.latitude), whole.alloc_forcing(), nan_frac=0.002)
+    whole.run()
+    ref = whole.download()
+    got = {k: np.full((w.ncell, nm), -1.0) for k in OUTPUTS}
+    shards = make_shards(w, um, 3)
+    assert min(len(s.cells) for s in shards) > 0
+    for s in shards:
+        sw, sum_ = sub_world(w, um, s)
+        pipe = pipeline_from_world(ctx, sw, nm, 1971, 25, 6, um=sum_)
+        pipe.alloc_forcing()
+        fill_shard_forcing(ctx, w, s, pipe, seed, nan_frac=0.002)
+        pipe.run()
+        out = pipe.download()
+        for k in OUTPUTS:
+            got[k][s.cells] = out[k]
+    for k in OUTPUTS:
+        assert np.array_equal(got[k], ref[k], equal_nan=True), k
