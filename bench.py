@@ -246,9 +246,27 @@ def main():
                 k['achieved_GBs'] = algo[name] / (ms / n * 1e-3) / 1e9
                 k['frac_of_hbm_peak'] = k['achieved_GBs'] / HBM_PEAK_GBS
             kernels[name] = k
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/roundN/
+    # pmc_traffic.json, made by tools/pmc_to_json.py): counters cannot be read from inside the run itself
+    traffic, traffic_src = {}, None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', 'pmc_traffic.json'))):
+        try:
+            pm = json.load(open(f))
+            traffic = {'pm_pet': pm.get('k_pm_pet', {}).get('hbm_bytes'), 'abcd_spinup': pm.get('k_abcd<true>', {}).get('hbm_bytes'),
+                       'abcd_sim': pm.get('k_abcd<false>', {}).get('hbm_bytes'),
+                       'mrtm_route': pm.get('k_mrtm_flow', {}).get('hbm_bytes')}
+            traffic_src = os.path.relpath(f, ROOT)
+        except (OSError, ValueError):
+            pass
+    full_config = (args.months == 600 and args.abcd_spinup == 120 and args.routing_spinup == 120 and not args.strong)
+    for k, v in traffic.items():
+        if k in kernels and v and full_config:
+            kernels[k]['traffic_bytes'] = v
     dominant = max((k for k in kernels if k in algo), key=lambda k: kernels[k]['avg_ms'])
     roofline = {'kernel': dominant, 'bound': 'hbm', 'achieved': kernels[dominant]['achieved_GBs'],
-                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dominant]['frac_of_hbm_peak'], 'traffic': None,
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dominant]['frac_of_hbm_peak'],
+                'traffic': kernels[dominant].get('traffic_bytes'), 'traffic_source': traffic_src,
                 'note': 'mrtm_route is bound by sub-step latency (on-chip LDS exchange), not by HBM; see DESIGN.md'
                 if dominant == 'mrtm_route' else ''}
     if dominant == 'mrtm_route':

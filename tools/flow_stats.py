@@ -26,7 +26,7 @@ print('units', len(st), 'clock GHz median', np.median(clock))
 print('loop cycles/substep: median %.0f  p10 %.0f  p90 %.0f  max %.0f' % tuple(np.percentile(loop / nsub, [50, 10, 90, 100])))
 print('loop share of unit time: median %.2f min %.2f' % (np.median(loop / total), (loop / total).min()))
 print('unit wall ms: median %.2f max %.2f' % (np.median(ticks / 1e5), ticks.max() / 1e5))
-for wu in (3, 5, 9):
+for wu in (3, 5, 7, 9):
     for flag, name in ((0, 'isolated'), (16, 'imports'), (32, 'exports'), (48, 'both')):
         sel = ((shape & 15) == wu) & ((shape & 48) == flag)
         if sel.any():

@@ -13,8 +13,8 @@
 //   - a piece's outlet lane appends {trial flow F, adjusted flow F2} of every sub-step to its stream (one 16-byte
 //     cached store per sub-step, so the L2 merges them into whole lines); at the end of a month it publishes the
 //     month: s_waitcnt vmcnt(0) -> agent-scope release -> s_waitcnt vmcnt(0) -> relaxed agent-scope store of the
-//     month counter.  (XH_FLOW_STREAM_PLAIN=0 selects write-through sc1 stores without the release instead: same
-//     speed, but 9.8 GB instead of 3.6 GB of HBM writes per 720-month run because every 8-byte store goes to fabric.)
+//     month counter.  (Write-through sc1 stores without the release were measured at the same speed but 9.8 GB
+//     instead of 3.6 GB of HBM writes per 720-month run, because every 8-byte store goes to the fabric.)
 //   - the consuming unit waits for that counter at the start of the same month (relaxed agent-scope polls with
 //     s_sleep, one agent-scope acquire), then its "ghost" lanes read the stream eight sub-steps ahead into
 //     registers and drop each pair into ghost slots of the LDS flow buffers, where the consuming cell's gather
@@ -65,7 +65,6 @@ struct FlowArgs {
     unsigned *done;                 // [units] months consumed
     unsigned *fault;
     unsigned long long *stats;      // [units][6] optional cycle accounting (XH_FLOW_STATS=1)
-    int plain_streams;              // 1 (default): cached stream stores + agent release per month; 0: sc1 stores
 };
 
 __device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
@@ -89,7 +88,7 @@ __device__ __forceinline__ bool wave_wait_ge(bool need, const unsigned *p, unsig
     }
 }
 
-// Whole series for one unit; WU = terms gathered per row (the unit's longest row, rounded up to 3, 5 or 9): LDS
+// Whole series for one unit; WU = terms gathered per row (the unit's longest row, rounded up to 3, 5, 7 or 9): LDS
 // instructions from a lone wave are slow, so a unit without big confluences should not issue nine reads per gather.
 template <int WU>
 __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
@@ -161,10 +160,7 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
         auto substep = [&](int t, double2 gv) {
             F = S * tauinv;                                                    // mrtm.py:50
             bufA[lane] = make_double2(F, -F);
-            if (has_g) {                                                       // ghosts are only ever added (+1 terms)
-                reinterpret_cast<double *>(bufA + LANES + lane)[0] = gv.x;
-                reinterpret_cast<double *>(bufB + LANES + lane)[0] = gv.y;
-            }
+            if (has_g) reinterpret_cast<double *>(bufA + LANES + lane)[0] = gv.x;   // ghosts are only ever added (+1 terms)
             __builtin_amdgcn_wave_barrier();
             double v[WU];
 #pragma unroll
@@ -175,23 +171,25 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
             const double dsdt = acc + erl;
             const bool sx = (dsdt * dt) < (-S);                                // mrtm.py:54
             const double f2 = sx ? (dsdt + F) + S * dtinv : F;                 // mrtm.py:60
-            S = sx ? 0.0 : S;                                                  // mrtm.py:63
-            bufB[lane] = make_double2(f2, -f2);
-            if (has_x && a.plain_streams) {
-                optr[t] = make_double2(F, f2);
-            } else if (has_x) {   // write-through (sc1) stores: the month is published without an L2 write-back
-                unsigned long long *o = reinterpret_cast<unsigned long long *>(optr + t);
-                __hip_atomic_store(o, (unsigned long long)__double_as_longlong(F), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(o + 1, (unsigned long long)__double_as_longlong(f2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (has_x) optr[t] = make_double2(F, f2);
+            // mrtm.py:56-76: the flows are gathered a second time only "if Sx.any()".  Here "any" is decided per unit:
+            // if no cell of this unit fired and no imported flow was adjusted upstream (F2 == F), every F2 this unit
+            // gathers equals the F it already gathered, so the second sum is bit-identical to the first.
+            if (__any(sx || (has_g && gv.x != gv.y))) {
+                S = sx ? 0.0 : S;                                              // mrtm.py:63
+                bufB[lane] = make_double2(f2, -f2);
+                if (has_g) reinterpret_cast<double *>(bufB + LANES + lane)[0] = gv.y;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int w = 0; w < WU; ++w) v[w] = *reinterpret_cast<const double *>(baseB + e[w]);
+                double acc2 = 0.0;                                             // UM.dot(F) with the adjusted flows
+#pragma unroll
+                for (int w = 0; w < WU; ++w) acc2 += v[w];
+                const double dsdt2 = acc2 + erl;                               // mrtm.py:68
+                S = sx ? S : S + dsdt2 * dt;                                   // mrtm.py:69
+            } else {
+                S = S + dsdt * dt;                                             // mrtm.py:76
             }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int w = 0; w < WU; ++w) v[w] = *reinterpret_cast<const double *>(baseB + e[w]);
-            double acc2 = 0.0;                                                 // UM.dot(F) with the adjusted flows
-#pragma unroll
-            for (int w = 0; w < WU; ++w) acc2 += v[w];
-            const double dsdt2 = acc2 + erl;                                   // mrtm.py:68
-            S = sx ? S : S + dsdt2 * dt;                                       // mrtm.py:69 / :76
             F = f2;
             favg += f2;                                                        // mrtm.py:78
             __builtin_amdgcn_wave_barrier();
@@ -240,10 +238,8 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
         }
         if (any_x) {      // publish month `it`
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (a.plain_streams) {   // cached stores: one agent-scope release (L2 write-back) per month makes them visible
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // cached stream stores: one L2 write-back per month
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (has_x) __hip_atomic_store(a.ready + xedge, (unsigned)it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (any_g && lane == 0)   // this month's imports are consumed: their ring slots may be reused
@@ -269,6 +265,7 @@ __global__ void __launch_bounds__(LANES) k_mrtm_flow(FlowArgs a) {
     const int wu = a.unit_terms[blockIdx.x];        // uniform per workgroup
     if (wu <= 3) flow_unit<3>(a, lds);
     else if (wu <= 5) flow_unit<5>(a, lds);
+    else if (wu <= 7) flow_unit<7>(a, lds);
     else flow_unit<W_MAX>(a, lds);
 }
 
@@ -621,10 +618,6 @@ int flow_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     if (rc) return rc;
     a.fault = fault;
     a.stats = nullptr;
-    {
-        const char *env = getenv("XH_FLOW_STREAM_PLAIN");     // 0 = write-through (sc1) stream stores, no release fence
-        a.plain_streams = (env && env[0] == '0') ? 0 : 1;
-    }
     {
         const char *env = getenv("XH_FLOW_STATS");
         if (env && env[0] == '1') {
