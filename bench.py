@@ -162,13 +162,16 @@ def main():
             print('[bench] ' + msg, file=sys.stderr, flush=True)
 
     dist = torch = None
+    backend = os.environ.get('XH_BENCH_BACKEND', 'nccl')       # "gloo" + XH_BENCH_ONE_DEVICE=1: dry-run of the N > 1
+    if os.environ.get('XH_BENCH_ONE_DEVICE') == '1':           # code path with every rank on GPU 0 (1-GPU test boxes)
+        local_rank = 0
     if world_size > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world_size)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
 
     from xanthos_amd import _hip, synth
     from xanthos_amd.pipeline import FORCING, pipeline_from_world, topology_from_world
@@ -226,7 +229,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int TM = 4;           // months per register tile (rows are 16-B aligned because nmonths is even)
+constexpr int TM = 8;           // months per register tile = one 64-byte sector per row and array (rows are 16-B aligned: nmonths is even)
 
 using namespace xh_abcd_dev;
 
@@ -80,9 +80,12 @@ __global__ void __launch_bounds__(64) k_abcd(int64_t ncell, int nmonths, int nst
         const int m0 = t * TM;
         if (t + 1 < ntiles) load_tile(nxt, pet, precip, tmin, row + m0 + TM);
         double oa[TM], oq[TM], os[TM];
+        AbcdPre pre[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) pre[j] = abcd_pre(P, snow_on, cur.pet[j], cur.pr[j], cur.tn[j]);   // independent: ILP
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-            abcd_month(P, s, snow_on, (m0 + j) == 0, cur.pet[j], cur.pr[j], cur.tn[j], oa[j], oq[j]);
+            abcd_step(P, s, snow_on, (m0 + j) == 0, pre[j], oa[j], oq[j]);
             os[j] = s.sm;
             if (SPINUP) {
                 const int m = m0 + j;

@@ -16,42 +16,71 @@ struct AbcdState {
     double snowpack, sm, gw;
 };
 
-// One month of abcd_dist (:171-228). `first` = month 0 of a march: no snow-melt term in W (:200-201).
-__device__ __forceinline__ void abcd_month(const AbcdPar &P, AbcdState &s, bool snow_on, bool first, double pet,
-                                           double precip, double tmin, double &aet, double &q) {
-    double rain = precip, snm = 0.0;
+// The month update is split in two so that a thread can evaluate the state-INDEPENDENT part (rain / snow split,
+// melt factor, exp(-PET/b)) for a whole tile of months with instruction-level parallelism, and keep only the short
+// state recurrence sequential.  ABCD is a dependent fp64 chain per cell with ~1 wave per SIMD on the chip (67,420
+// cells = 1,054 waves), i.e. latency-bound: hoisting exp and the divisions of the split out of the chain is worth
+// far more than any memory optimisation.  Operations and their order are exactly those of abcd_dist.
+struct AbcdPre {
+    double rain, snow, frac, decay, pet;   // decay = exp(-PET/b) (:211)
+    int kind;                              // 1 = all rain (melt = pack*m), 2 = mixed (melt = pack*m*frac), 0 = no melt
+};
+
+__device__ __forceinline__ AbcdPre abcd_pre(const AbcdPar &P, bool snow_on, double pet, double precip, double tmin) {
+    AbcdPre r;
+    r.pet = pet;
+    r.decay = exp(-pet / P.b);                                        // :211
+    r.rain = precip;
+    r.snow = 0.0;
+    r.frac = 0.0;
+    r.kind = 0;
     if (snow_on) {
         // set_rain_and_snow (:141-169): NaN tmin matches no class => rain = snow = 0
         const bool allrain = tmin > TRAIN;
         const bool mixed = (tmin <= TRAIN) && (tmin >= TSNOW);
         const bool allsnow = tmin < TSNOW;
-        const double frac = (TRAIN - tmin) / (TRAIN - TSNOW);
-        double snow = 0.0;
-        rain = 0.0;
+        r.frac = (TRAIN - tmin) / (TRAIN - TSNOW);
+        r.rain = 0.0;
         if (mixed) {
-            snow = precip * (TRAIN - tmin) / (TRAIN - TSNOW);
-            rain = precip - snow;
+            r.snow = precip * (TRAIN - tmin) / (TRAIN - TSNOW);
+            r.rain = precip - r.snow;
         }
-        if (allrain) rain = precip;
-        if (allsnow) snow = precip;
-        s.snowpack = s.snowpack + snow;                               // :180-183
-        if (allrain) snm = s.snowpack * P.m;                          // :191
-        if (mixed) snm = (s.snowpack * P.m) * frac;                   // :192-193
+        if (allrain) r.rain = precip;
+        if (allsnow) r.snow = precip;
+        r.kind = allrain ? 1 : (mixed ? 2 : 0);
+    }
+    return r;
+}
+
+// State recurrence of abcd_dist (:171-228). `first` = month 0 of a march: no snow-melt term in W (:200-201).
+__device__ __forceinline__ void abcd_step(const AbcdPar &P, AbcdState &s, bool snow_on, bool first, const AbcdPre &r,
+                                          double &aet, double &q) {
+    double snm = 0.0;
+    if (snow_on) {
+        s.snowpack = s.snowpack + r.snow;                             // :180-183
+        const double pm = s.snowpack * P.m;
+        snm = r.kind == 1 ? pm : (r.kind == 2 ? pm * r.frac : 0.0);   // :191-194
         s.snowpack = s.snowpack - snm;                                // :197
     }
-    const double w = first ? rain + s.sm : rain + s.sm + snm;         // :200-203
+    const double w = first ? r.rain + s.sm : r.rain + s.sm + snm;     // :200-203
     const double rpt = (w + P.b) / P.a2;                              // :206-207
     const double y = rpt - sqrt(rpt * rpt - (w * P.b_over_a));        // :208
-    const double sm1 = y * exp(-pet / P.b);                           // :211
+    const double sm1 = y * r.decay;                                   // :211
     const double awet = w - y;
     const double c_awet = P.c * awet;
     s.gw = (s.gw + c_awet) / P.d1;                                    // :219-221
     double e = y - sm1;                                               // :224-226
     e = (0.0 >= e) ? 0.0 : e;                                         // np.maximum(0, e): NaN e stays NaN
-    e = (pet <= e || pet != pet) ? pet : e;                           // np.minimum(pet, e): NaN propagates
+    e = (r.pet <= e || r.pet != r.pet) ? r.pet : e;                   // np.minimum(pet, e): NaN propagates
     s.sm = y - e;                                                     // :227
     aet = e;
     q = (awet - c_awet) + P.d * s.gw;                                 // :228
+}
+
+__device__ __forceinline__ void abcd_month(const AbcdPar &P, AbcdState &s, bool snow_on, bool first, double pet,
+                                           double precip, double tmin, double &aet, double &q) {
+    const AbcdPre r = abcd_pre(P, snow_on, pet, precip, tmin);
+    abcd_step(P, s, snow_on, first, r, aet, q);
 }
 
 __device__ __forceinline__ AbcdPar load_par(const double *__restrict__ pars, int row, bool snow_on) {

@@ -143,4 +143,6 @@ def gather_outputs(ctx, pipe, shard, shards, world, dist, torch, names=('pet', '
     for i, k in enumerate(names):
         ctx._check(_hip.lib().xh_memcpy_d2d(ctx.handle, local[i].data_ptr(), pipe.out[k].ptr, n * nm * 8))
     ctx.sync()                       # our stream -> torch's stream hand-off
+    if dist.get_backend() != 'nccl':
+        local = local.cpu()          # gloo dry runs gather on the host
     return gather_to_root(local, shards, world.ncell, dist)
