@@ -20,7 +20,8 @@ for rep in range(2):
 st = pipe.plan.stats().astype(np.float64)
 nsub = sum(int(d) * 8 for d in pipe.ndays)
 print('route ms', ms / n, 'substeps', nsub, 'us/substep', ms / n * 1e3 / nsub)
-loop, total, ticks, shape = st[:, 0], st[:, 1], st[:, 2], st[:, 3].astype(int)
+raw3 = pipe.plan.stats()[:, 3]
+loop, total, ticks, shape = st[:, 0], st[:, 1], st[:, 2], (raw3 & np.uint64(255)).astype(int)
 clock = total / (ticks / 100e6) / 1e9
 print('units', len(st), 'clock GHz median', np.median(clock))
 print('loop cycles/substep: median %.0f  p10 %.0f  p90 %.0f  max %.0f' % tuple(np.percentile(loop / nsub, [50, 10, 90, 100])))
@@ -46,3 +47,26 @@ for flag, name in ((0, 'isolated'), (16, 'imports'), (32, 'exports'), (48, 'both
         print('%-9s wait-for-data us/month median %.1f p90 %.1f | wait-for-ring median %.1f p90 %.1f | other %.1f' % (
             name, np.median(wd[sel]), np.percentile(wd[sel], 90), np.median(wr[sel]), np.percentile(wr[sel], 90),
             np.median(ovh[sel] - wd[sel] - wr[sel])))
+
+# placement: HW_ID bits (gfx9): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13] ... ; XCC id at bit 40
+hw = (raw3 >> np.uint64(8)) & np.uint64(0xffffffff)
+xcc = ((raw3 >> np.uint64(40)) & np.uint64(15)).astype(int)
+simd = ((hw >> np.uint64(4)) & np.uint64(3)).astype(int)
+cu = ((hw >> np.uint64(8)) & np.uint64(15)).astype(int)
+sh = ((hw >> np.uint64(12)) & np.uint64(1)).astype(int)
+se = ((hw >> np.uint64(13)) & np.uint64(7)).astype(int)
+cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+simd_key = cu_key * 4 + simd
+per_cu = np.bincount(cu_key)
+per_simd = np.bincount(simd_key)
+print('distinct CUs used', (per_cu > 0).sum(), 'units per CU histogram', np.bincount(per_cu[per_cu > 0]))
+print('waves per SIMD histogram', np.bincount(per_simd[per_simd > 0]))
+share = per_simd[simd_key]
+cps = loop / nsub
+for k in sorted(set(share)):
+    sel = share == k
+    print('units on a SIMD holding %d wave(s): n=%d loop cyc/substep median %.0f max %.0f' % (k, sel.sum(), np.median(cps[sel]), cps[sel].max()))
+idx = np.argsort(-cps)[:10]
+print('slowest units: index, cyc/substep, shape(WU|16 imp|32 exp), waves on its SIMD, units on its CU')
+for i in idx:
+    print(' ', i, round(cps[i]), shape[i], share[i], per_cu[cu_key[i]])

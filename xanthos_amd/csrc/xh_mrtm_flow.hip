@@ -94,8 +94,12 @@ template <int WU>
 __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
     double2 *bufA = lds;               // trial flows {F, -F}: cells 0..63, ghosts 64..127, zero 128
     double2 *bufB = lds + NPAIR;       // adjusted flows {F2, -F2}
-    const char *baseA = reinterpret_cast<const char *>(bufA);
-    const char *baseB = reinterpret_cast<const char *>(bufB);
+    // Gather addresses as absolute 32-bit LDS addresses, formed once: the dynamic-LDS base is a link-time constant the
+    // compiler cannot fold, so "base + offset" inside the loop costs one extra VALU instruction per gathered term.
+    typedef __attribute__((address_space(3))) const double lds_cdouble;
+    typedef __attribute__((address_space(3))) const char lds_cchar;
+    lds_cchar *ldsA = (lds_cchar *)bufA;
+    constexpr unsigned B_OFF = NPAIR * sizeof(double2);      // bufB = bufA + B_OFF: an immediate offset in ds_read
     const int lane = threadIdx.x, unit = blockIdx.x;
     const int64_t slot = (int64_t)unit * LANES + lane;
 
@@ -105,9 +109,9 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
     const double area = valid ? a.area[gc] : 0.0;
     double S = (valid && a.S0) ? a.S0[gc] : 0.0;
     double F = 0.0;
-    unsigned e[WU];
+    lds_cchar *e[WU];
 #pragma unroll
-    for (int w = 0; w < WU; ++w) e[w] = a.ent[(int64_t)w * a.total_slots + slot];
+    for (int w = 0; w < WU; ++w) e[w] = ldsA + a.ent[(int64_t)w * a.total_slots + slot];
     const int xedge = a.export_edge[slot];
     const int gedge = a.ghost_edge[slot];
     const bool has_x = xedge >= 0, has_g = gedge >= 0;
@@ -164,7 +168,7 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
             __builtin_amdgcn_wave_barrier();
             double v[WU];
 #pragma unroll
-            for (int w = 0; w < WU; ++w) v[w] = *reinterpret_cast<const double *>(baseA + e[w]);
+            for (int w = 0; w < WU; ++w) v[w] = *(lds_cdouble *)e[w];
             double acc = 0.0;                                                  // UM.dot(F), row order (mrtm.py:51)
 #pragma unroll
             for (int w = 0; w < WU; ++w) acc += v[w];
@@ -181,7 +185,7 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
                 if (has_g) reinterpret_cast<double *>(bufB + LANES + lane)[0] = gv.y;
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int w = 0; w < WU; ++w) v[w] = *reinterpret_cast<const double *>(baseB + e[w]);
+                for (int w = 0; w < WU; ++w) v[w] = *(lds_cdouble *)(e[w] + B_OFF);
                 double acc2 = 0.0;                                             // UM.dot(F) with the adjusted flows
 #pragma unroll
                 for (int w = 0; w < WU; ++w) acc2 += v[w];
@@ -256,12 +260,19 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
         st[0] = cyc_loop;
         st[1] = __builtin_amdgcn_s_memtime() - cyc_begin;
         st[2] = __builtin_amdgcn_s_memrealtime() - rt_begin;
-        st[3] = (unsigned long long)WU | (any_g ? 16u : 0u) | (any_x ? 32u : 0u);
+        // HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20): where this wave ran (placement diagnostics)
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
+        st[3] = (unsigned long long)WU | (any_g ? 16u : 0u) | (any_x ? 32u : 0u) | ((unsigned long long)hw << 8) |
+                ((unsigned long long)(xcc & 15u) << 40);
     }
 }
 
 __global__ void __launch_bounds__(LANES) k_mrtm_flow(FlowArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double2 lds[];
+    // Static LDS: its base is a compile-time constant that folds into the ds_read/ds_write offset field.  (The base of
+    // `extern __shared__` memory is resolved after instruction selection and cost one v_add per gathered term.)  The
+    // launch still requests dynamic LDS, unused, purely to bound the workgroups per CU (see flow_launch).
+    __shared__ __attribute__((aligned(16))) double2 lds[2 * NPAIR];
     const int wu = a.unit_terms[blockIdx.x];        // uniform per workgroup
     if (wu <= 3) flow_unit<3>(a, lds);
     else if (wu <= 5) flow_unit<5>(a, lds);
@@ -573,9 +584,9 @@ int flow_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         const char *env = getenv("XH_FLOW_PER_CU_EXTRA");     // experiments only
         if (env) per_cu += atoi(env);
     }
-    size_t lds = 2 * (size_t)NPAIR * sizeof(double2);
+    const size_t lds_static = 2 * (size_t)NPAIR * sizeof(double2);
     const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
-    if (share > lds) lds = share;
+    size_t lds = share > lds_static + 1024 ? share - lds_static : 0;      // dynamic part on top of the static buffers
     XH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mrtm_flow), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
     int resident = 0;
