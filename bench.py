@@ -66,7 +66,14 @@ def cpu_baseline(pipe, world, args, log):
     t_pm = time.perf_counter() - t
     res['pm'] = n_pm * 12 * pm_years / t_pm
     got = pipe.rows(pipe.out['pet'], cells)[:, :12 * pm_years]
+
+    def gate(x, ref):
+        """Worst |x - ref| as a fraction of the north-star tolerance 1e-6 |ref| + 1e-9 (must stay <= 1)."""
+        m = ~np.isnan(ref)
+        assert np.array_equal(np.isnan(x), np.isnan(ref))
+        return float(np.max(np.abs(x[m] - ref[m]) / (1e-6 * np.abs(ref[m]) + 1e-9)))
     parity['pet'] = float(np.nanmax(np.abs(got - ref_pet) / (np.abs(ref_pet) + 1e-9)))
+    parity['tolerance_used'] = {'pet': gate(got, ref_pet)}
 
     # ---- ABCD: whole basins up to ~cpu_abcd_cells cells, full series, joblib threads like the reference
     order = np.argsort(-np.bincount(world.basin_ids, minlength=world.n_basins + 1))
@@ -96,6 +103,7 @@ def cpu_baseline(pipe, world, args, log):
         m = ~np.isnan(ref)
         assert np.array_equal(np.isnan(got), np.isnan(ref)), name
         parity[name] = float(np.max(np.abs(got[m] - ref[m]) / (np.abs(ref[m]) + 1e-9)))
+        parity['tolerance_used'][name] = gate(got, ref)
 
     # ---- MRTM: the whole grid (networks cannot be sampled), a few months, scipy CSR like the reference
     if 'mrtm' in args.stages:
@@ -140,10 +148,10 @@ def main():
     ap.add_argument('--routing-spinup', type=int, default=120)
     ap.add_argument('--strong', action='store_true', help='shard ONE world by basins over the ranks (configs[3])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-pm-cells', type=int, default=2048)
-    ap.add_argument('--cpu-pm-years', type=int, default=10)
-    ap.add_argument('--cpu-abcd-cells', type=int, default=3000)
-    ap.add_argument('--cpu-mrtm-months', type=int, default=6)
+    ap.add_argument('--cpu-pm-cells', type=int, default=4096)
+    ap.add_argument('--cpu-pm-years', type=int, default=25)
+    ap.add_argument('--cpu-abcd-cells', type=int, default=12000)
+    ap.add_argument('--cpu-mrtm-months', type=int, default=24)
     ap.add_argument('--route-flags', type=int, default=0)
     args = ap.parse_args()
     args.stages = ('pm', 'abcd', 'mrtm') if args.workload == 'pm_abcd_mrtm' else ('pm', 'abcd')

@@ -189,3 +189,55 @@ def test_calibration_objective_golden(hip, golden, basin, unit, tag):
                                      tr(g['precip_' + b]), d_tmin, d_area, g['robs_' + b], want_series=True)
     close(series, g['series_%s_%s_%s' % (b, unit, tag)], rtol=1e-9, atol=1e-12)
     close(ed, g['ed_%s_%s_%s' % (b, unit, tag)], rtol=1e-9, atol=1e-12)
+
+
+def test_edge_sizes(hip):
+    """Smallest legal problems: one cell, one year; a two-cell network; outputs that are not a multiple of 8 months."""
+    from types import SimpleNamespace as NS
+    from oracle import abcd as o_abcd, mrtm as o_mrtm, pm as o_pm
+    from xanthos_amd import synth
+    from xanthos_amd.pet import penman_monteith as pm
+    from xanthos_amd.routing import mrtm
+    from xanthos_amd.runoff import abcd
+    w = synth.make_world(nrow=12, ncol=24, ncell=40, n_basins=2, seed=4)
+    f = synth.make_forcing(w, 36, nan_precip=False)
+    one = NS(**{k: getattr(w, k) for k in ('cL', 'beta', 'rslimit', 'ae', 'be', 'Tminopen', 'Tminclose', 'VPDclose',
+                                           'VPDopen', 'RBLmin', 'RBLmax', 'rc', 'emiss', 'alpha', 'lai', 'laimax',
+                                           'laimin')})
+    one.elev, one.lct = w.elev[:1], w.lct[:1]
+    d = synth.data_bag(one, {k: v[:1, :12] for k, v in f.items()})
+    close(pm.run_pmpet(d, 1, w.nlcs, 1980, 1980, 0, 6, w.lc_years), o_pm.run_pmpet(d, 1, w.nlcs, 1980, 1980, 0, 6, w.lc_years))
+    pars = w.abcd_pars[:1]
+    got = abcd.abcd_execute(1, np.array([1]), f['rsds'][:1, :26] * 0.5, f['precip'][:1, :26], f['abcd_tmin'][:1, :26], pars, 26, 25)
+    ref = o_abcd.abcd_execute(1, np.array([1]), f['rsds'][:1, :26] * 0.5, f['precip'][:1, :26], f['abcd_tmin'][:1, :26], pars, 26, 25, 1)
+    for a, b in zip(got[1:], ref[1:]):
+        close(a, b)
+    # two cells, cell 1 drains into cell 0; 13 months (1 group of 8 + partial group of 5), with and without spin-up
+    um = mrtm.UpstreamMatrix([0, 2, 3], [0, 1, 1], [-1, 1, -1])
+    L, v, area = np.array([30e3, 1000.0]), np.array([1.0, 2.0]), np.array([2500.0, 2400.0])
+    q = np.random.default_rng(2).gamma(2.0, 30.0, (2, 13))
+    ndays = np.array([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31, 31])
+    for spin in (0, 5):
+        ref = o_mrtm.route_series(um.tocsr(), L, v, area, q, ndays, spin)
+        for flags in (0, 4, 1):
+            got = mrtm.route_series(um, L, v, area, q, ndays, spin, flags=flags)
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b), (spin, flags)
+
+
+def test_argument_errors_are_reported(hip):
+    from xanthos_amd.routing import mrtm
+    from xanthos_amd.runoff import abcd
+    ctx = hip.get_context()
+    with pytest.raises(hip.HipError):                                   # nmonths not a multiple of 12
+        ctx.pm_pet({k: np.ones(8 * (12 if k in ('alpha', 'lai', 'laimin', 'laimax') else 1)) for k in
+                    ('cL', 'beta', 'rslimit', 'Tminopen', 'Tminclose', 'VPDclose', 'VPDopen', 'RBLmin', 'RBLmax', 'rc',
+                     'emiss', 'alpha', 'lai', 'laimin', 'laimax')}, 4, 13, 2000, [2000], 0, 6,
+                   *[ctx.empty((4, 13)) for _ in range(6)], None, ctx.empty((4, 8, 1)), ctx.empty(4), ctx.empty((4, 13)))
+    with pytest.raises(IndexError):                                      # spin-up shorter than 25 months
+        abcd.abcd_execute(1, np.ones(3, dtype=int), np.ones((3, 36)), np.ones((3, 36)), None, np.ones((1, 5)) * 0.5, 36, 12)
+    um = mrtm.UpstreamMatrix([0, 1], [0], [-1])
+    with pytest.raises(hip.HipError):                                    # spin-up longer than the series
+        mrtm.route_series(um, [1e4], [1.0], [1e3], np.ones((1, 3)), [30, 30, 30], 5)
+    with pytest.raises(ValueError):
+        mrtm.UpstreamMatrix.from_scipy(__import__('scipy.sparse').sparse.csr_matrix(np.array([[2.0]])))
