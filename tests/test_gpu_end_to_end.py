@@ -153,3 +153,36 @@ def test_basin_sharded_run_equals_whole_world():
             got[k][s.cells] = out[k]
     for k in OUTPUTS:
         assert np.array_equal(got[k], ref[k], equal_nan=True), k
+
+
+def test_dataflow_routing_long_run_under_load():
+    """Full grid, 600 months + 120 spin-up: the dataflow kernel (streams between 1,100+ units, ring slots reused 180
+    times) must reproduce the one-workgroup-per-network kernel bit for bit, also while another context keeps the GPU
+    busy (uneven timing between producers and consumers), and twice in a row (no state leaks between launches)."""
+    from xanthos_amd import _hip, synth
+    from xanthos_amd.pipeline import pipeline_from_world
+    ctx = _hip.get_context(0)
+    w = synth.make_world()
+    nm = 600
+    pipe = pipeline_from_world(ctx, w, nm, 1961, 120, 120)
+    ctx.synth_forcing(3, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.0)
+    pipe.run(('pm', 'abcd'))
+    pipe.route_flags = 4                                   # one workgroup per network: no streams
+    pipe.run_mrtm()
+    ref = pipe.download(('chs', 'avg'))
+    assert np.isfinite(ref['avg']).all() and ref['avg'].max() > 0
+    pipe.route_flags = 0
+    other = _hip.Context(0)                                # second stream on the same device: background load
+    bg = pipeline_from_world(other, w, 120, 1961, 30, 0)
+    other.synth_forcing(4, w.ncell, 120, other.upload(w.latitude), bg.alloc_forcing(), nan_frac=0.0)
+    for rep in range(2):
+        pipe.out['chs'].zero()
+        pipe.out['avg'].zero()
+        if rep == 1:
+            for _ in range(40):
+                bg.run(('pm', 'abcd'))                     # ~50 ms of PM/ABCD kernels racing the routing kernel
+        pipe.run_mrtm()
+        got = pipe.download(('chs', 'avg'))
+        other.sync()
+        assert np.array_equal(got['chs'], ref['chs']) and np.array_equal(got['avg'], ref['avg']), rep
+    other.close()

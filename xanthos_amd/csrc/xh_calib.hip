@@ -25,10 +25,29 @@ using namespace xh_abcd_dev;
 
 constexpr int MB = 4;   // members per thread
 
+// Sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS traffic, fixed order => reproducible); every
+// lane gets the total.  A ds_bpermute butterfly (__shfl_xor) costs 12 LDS-pipe round trips per fp64 sum and was the
+// critical path of the simulation pass, which needs one sum per member and month.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_move(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    double x = v + dpp_move<0x111, 0xf, 0xf>(v);        // row_shr:1
+    x += dpp_move<0x112, 0xf, 0xf>(v);                   // row_shr:2
+    x += dpp_move<0x113, 0xf, 0xf>(v);                   // row_shr:3   -> sums of 4 consecutive lanes
+    x += dpp_move<0x114, 0xf, 0xe>(x);                   // row_shr:4, banks 1-3
+    x += dpp_move<0x118, 0xf, 0xc>(x);                   // row_shr:8, banks 2-3 -> lane 15 of each row = row total
+    x += dpp_move<0x142, 0xa, 0xf>(x);                   // row_bcast:15 into rows 1 and 3
+    x += dpp_move<0x143, 0xc, 0xf>(x);                   // row_bcast:31 into rows 2 and 3 -> lane 63 = wave total
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 __device__ __forceinline__ AbcdPar member_par(const double *__restrict__ pars, int npar, int member) {
@@ -83,10 +102,13 @@ __global__ void __launch_bounds__(64) k_calib_march(int ncell, int nsteps, int n
             tn = snow_on ? tn_t[o] : 0.0;
         }
         const int k = SPINUP ? ((m == nsteps - 1) ? 0 : ((m == nsteps - 13) ? 1 : ((m == nsteps - 25) ? 2 : -1))) : -1;
+        // the rain / snow split does not depend on the member: evaluate it once, then only exp(-PET/b) per member
+        AbcdPre pre = abcd_pre(P[0], snow_on, pet_c, pr_c, tn_c);
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
             double aet, q;
-            abcd_month(P[j], s[j], snow_on, m == 0, pet_c, pr_c, tn_c, aet, q);
+            if (j > 0) pre.decay = exp(-pet_c / P[j].b);
+            abcd_step(P[j], s[j], snow_on, m == 0, pre, aet, q);
             if (SPINUP) {
                 if (k >= 0) {                                    // wave-uniform
                     const bool sm_ok = valid && (s[j].sm == s[j].sm), gw_ok = valid && (s[j].gw == s[j].gw);
