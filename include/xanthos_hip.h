@@ -64,8 +64,8 @@ int xh_scatter_rows(xh_ctx *ctx, const double *d_src, const int64_t *d_rows, int
 int xh_transpose(xh_ctx *ctx, const double *d_src, int64_t rows, int64_t cols, double *d_dst);
 
 /* HIP-event timing of the kernels each entry point launches, accumulated per kernel name on the context's stream.
- * Names: "pm_pet", "abcd_spinup", "abcd_basin_mean", "abcd_sim", "mrtm_route", "mrtm_fallback", "calib_abcd",
- * "calib_kge".  xh_timing_get waits for the stream, then returns total milliseconds and launch count. */
+ * Names: "pm_pet", "abcd_spinup", "abcd_basin_mean", "abcd_sim", "mrtm_route", "calib_abcd", "calib_kge",
+ * "agg_time", "agg_spatial".  xh_timing_get waits for the stream, then returns total milliseconds and launch count. */
 int xh_timing_reset(xh_ctx *ctx);
 int xh_timing_enable(xh_ctx *ctx, int on);
 int xh_timing_get(xh_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
@@ -170,6 +170,18 @@ int xh_calib_objective(xh_ctx *ctx, int64_t ncell_b, int32_t nmonths, int32_t sp
                        int32_t npar, const double *h_pars, const double *d_pet_t, const double *d_precip_t,
                        const double *d_tmin_t, const double *d_area, const double *h_obs, double *h_ed,
                        double *h_series);
+
+/* ------------------------------------------------------------------ output aggregation
+ * xh_agg_time replaces data_writer/out_writer.py:agg_to_year (:237-248) and the mm -> km3 scaling of write()
+ * (:111-112): out[c, g] = f(in[c, g*group .. (g+1)*group)) x (d_scale ? d_scale[c] : 1), with f = NaN-skipping sum
+ * (mode 0; an all-NaN block gives 0, as pandas does) or NaN-skipping mean (mode 1; all-NaN gives NaN).
+ * group = 12 aggregates months to years; group = 1, mode 0 is a plain per-cell scaling (NaN kept).
+ * xh_agg_spatial replaces out_writer.py:agg_spatial (:250-265): out[k, t] = NaN-skipping sum over the cells with
+ * h_group[c] == k (h_group is 0-based, -1 = cell not aggregated); groups without cells give NaN.            */
+int xh_agg_time(xh_ctx *ctx, int64_t ncell, int32_t ncols, int32_t group, int32_t mode, const double *d_scale,
+                const double *d_in, double *d_out);
+int xh_agg_spatial(xh_ctx *ctx, int64_t ncell, int32_t ncols, int32_t n_groups, const int32_t *h_group,
+                   const double *d_in, double *d_out);
 
 /* ------------------------------------------------------------------ bench support (not on the hot path)
  * Fills the eight forcing arrays of the synthetic benchmark world on the device (same distributions as

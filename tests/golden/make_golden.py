@@ -16,6 +16,7 @@ Fixtures written:
   topo.npz    downstream / upstream / upstream_genmatrix on 24x48 grids (random D8 with edge cases; tree world)
   mrtm.npz    streamrouting for 28/29/30/31-day months + Components.calculate_routing (3 spin-up + 5 months)
   kge.npz     objective_kge(basin_runoff) for 16 parameter vectors x 2 basins, both units, with / without tmin
+  writer.npz  OutWriter.agg_to_year (sum / mean), mm -> km3 conversion, agg_spatial with an empty id and NaN cells
 """
 import importlib.util
 import os
@@ -254,6 +255,32 @@ def golden_kge():
     np.savez_compressed(os.path.join(HERE, 'kge.npz'), **out)
 
 
+# ----------------------------------------------------------------------------------------------------- writer
+def golden_writer():
+    """OutWriter.agg_to_year / mm->km3 / agg_spatial on a bare object (out_writer.py:237-265, :111-112)."""
+    import pandas as pd
+    from xanthos.data_writer.out_writer import OutWriter
+    rng = np.random.default_rng(606)
+    ncell, nm = 60, 36
+    q = rng.gamma(2.0, 30.0, (ncell, nm))
+    q[3, :] = np.nan                 # a missing-data cell
+    q[4, 12:24] = np.nan             # one all-NaN year
+    q[5, 7] = np.nan
+    area = rng.uniform(800, 3100, ncell)
+    ids = rng.integers(1, 8, ncell)
+    ids[ids == 5] = 6                # id 5 has no cells -> NaN row
+    ow = object.__new__(OutWriter)
+    ysum = ow.agg_to_year(pd.DataFrame(q), 'sum').values
+    ymean = ow.agg_to_year(pd.DataFrame(q), 'mean').values
+    km3 = pd.DataFrame(q).multiply(area / 1e6, axis=0).values
+    ysum_km3 = pd.DataFrame(ysum).multiply(area / 1e6, axis=0).values
+    names = np.array(['n%d' % i for i in range(1, 9)])
+    spatial = ow.agg_spatial(pd.DataFrame(ysum_km3), ids, names, inc_name_idx=True).drop(columns='name').values
+    np.savez_compressed(os.path.join(HERE, 'writer.npz'), q=q, area=area, ids=ids, ysum=ysum, ymean=ymean, km3=km3,
+                        ysum_km3=ysum_km3, spatial=spatial.astype(float))
+    print('writer.npz', ysum.shape, spatial.shape, int(np.isnan(spatial).sum()))
+
+
 if __name__ == '__main__':
     import warnings
     warnings.simplefilter('ignore')
@@ -262,6 +289,7 @@ if __name__ == '__main__':
     topo, w = golden_topo()
     golden_mrtm(topo, w)
     golden_kge()
+    golden_writer()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')

@@ -49,7 +49,10 @@ def test_run_model_matches_oracle_chain(example):
     assert np.array_equal(pet2, res.PET) and np.array_equal(c.Q, res.Q, equal_nan=True)
     assert np.array_equal(c.calculate_routing(c.Q), res.Avg_ChFlow, equal_nan=True)
     import os
-    assert os.path.isfile(os.path.join(root, 'output', 'pm_abcd_mrtm_synth', 'q_pm_abcd_mrtm_synth_1971_1973.npy'))
+    out_csv = os.path.join(root, 'output', 'pm_abcd_mrtm_synth', 'q_mmpermonth_pm_abcd_mrtm_synth.csv')      # reference naming
+    assert os.path.isfile(out_csv)
+    first = open(out_csv).read().splitlines()[:2]
+    assert first[0].startswith('id,197101,197102') and first[1].startswith('1,')
 
 
 def test_in_memory_forcing_override(example):

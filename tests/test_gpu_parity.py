@@ -241,3 +241,27 @@ def test_argument_errors_are_reported(hip):
         mrtm.route_series(um, [1e4], [1.0], [1e3], np.ones((1, 3)), [30, 30, 30], 5)
     with pytest.raises(ValueError):
         mrtm.UpstreamMatrix.from_scipy(__import__('scipy.sparse').sparse.csr_matrix(np.array([[2.0]])))
+
+
+def test_writer_aggregation_golden(hip, golden, tmp_path):
+    """Device-side month -> year aggregation, mm -> km3 and spatial sums against the reference's OutWriter."""
+    from types import SimpleNamespace as NS
+    from xanthos_amd.data_writer.out_writer import OutWriter
+    g = golden('writer')
+    q = g['q']
+    s = NS(output_vars=['q', 'avgchflow'], ProjectName='p', OutputFolder=str(tmp_path), OutputFormat=4, OutputUnit=1,
+           OutputInYear=1, StartYear=2001, EndYear=2003, device=0)
+    w = OutWriter(s, g['area'], {'q': q, 'avgchflow': q})
+    close(w.agg_to_year(q, 'sum'), g['ysum'], rtol=1e-12, atol=0)
+    close(w.agg_to_year(q, 'mean'), g['ymean'], rtol=1e-12, atol=0)
+    close(w._agg(q, 1, 0, g['area'] / 1e6), g['km3'], rtol=1e-14, atol=0)
+    w.write()
+    close(w.get('q'), g['ysum_km3'], rtol=1e-12, atol=0)              # yearly sum, then x area / 1e6
+    close(w.get('avgchflow'), g['ymean'], rtol=1e-12, atol=0)         # channel flow: yearly mean, no conversion
+    assert np.array_equal(np.load(str(tmp_path / 'q_km3peryear_p.npy')), w.get('q'), equal_nan=True)
+    close(w.agg_spatial(w.get('q'), g['ids'], 8), g['spatial'], rtol=1e-12, atol=0)
+    # a device-resident input gives the same result without the upload
+    d_q = hip.get_context().upload(q)
+    w2 = OutWriter(s, g['area'], {'q': d_q})
+    w2.write()
+    assert np.array_equal(w2.get('q'), w.get('q'), equal_nan=True)

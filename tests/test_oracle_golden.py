@@ -135,3 +135,14 @@ def test_kge_objective_matches_reference(golden, basin, unit, tag):
         assert np.allclose(series, g['series_%s_%s_%s' % (b, unit, tag)][k], rtol=1e-12, atol=0)
         ed = o_calib.kge_distance(series, g['robs_' + b])
         assert abs(ed - g['ed_%s_%s_%s' % (b, unit, tag)][k]) < 1e-12
+
+
+def test_writer_aggregation_matches_reference(golden):
+    from oracle import writer as o_writer
+    g = golden('writer')
+    assert np.allclose(o_writer.agg_to_year(g['q'], 'sum'), g['ysum'], rtol=1e-13, atol=0)
+    assert np.allclose(o_writer.agg_to_year(g['q'], 'mean'), g['ymean'], rtol=1e-13, atol=0, equal_nan=True)
+    assert np.allclose(o_writer.mm_to_km3(g['q'], g['area']), g['km3'], rtol=1e-15, atol=0, equal_nan=True)
+    sp = o_writer.agg_spatial(o_writer.mm_to_km3(o_writer.agg_to_year(g['q'], 'sum'), g['area']), g['ids'], 8)
+    assert np.allclose(sp, g['spatial'], rtol=1e-13, atol=0, equal_nan=True)
+    assert np.isnan(sp[4]).all() and np.isnan(sp[7]).all()          # ids 5 and 8 have no cells

@@ -64,6 +64,8 @@ SIGNATURES = {
     'xh_mrtm_um_csr': (c_int, [c_int64, _P, _P, _P, _P]),
     'xh_route_series': (c_int, [_P, _P, c_int32, c_int32, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32]),
     'xh_calib_objective': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'xh_agg_time': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
+    'xh_agg_spatial': (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
     'xh_synth_forcing': (c_int, [_P, c_uint64, c_double, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
@@ -277,6 +279,14 @@ class Context:
                                              _host_ptr(obs), _host_ptr(ed),
                                              _host_ptr(series) if want_series else None))
         return (ed, series) if want_series else ed
+
+    # ---- output aggregation
+    def agg_time(self, ncell, ncols, group, mode, scale, src, dst):
+        self._check(lib().xh_agg_time(self.handle, ncell, ncols, group, mode, _dptr(scale), _dptr(src), _dptr(dst)))
+
+    def agg_spatial(self, ncell, ncols, n_groups, group_index, src, dst):
+        gi = np.ascontiguousarray(group_index, dtype=np.int32)
+        self._check(lib().xh_agg_spatial(self.handle, ncell, ncols, n_groups, _host_ptr(gi), _dptr(src), _dptr(dst)))
 
     # ---- bench support
     def synth_forcing(self, seed, ncell, nmonths, lat, out, nan_frac=0.001):

@@ -140,12 +140,14 @@ class Components:
         calib_mod.calibrate_all(settings=self.s, data=self.data, pet=pet_out, router_function=self.calculate_routing)
 
     def output_simulation(self):
-        """Write the selected variables as .npy (the reference's pandas writer, out_writer.py, is outside the hot path)."""
-        import os
-        names = {'pet': self.PET, 'aet': self.AET, 'q': self.Q, 'soilmoisture': self.Sav, 'avgchflow': self.Avg_ChFlow}
-        for var in self.s.output_vars:
-            if var in names:
-                os.makedirs(self.s.OutputFolder, exist_ok=True)
-                np.save(os.path.join(self.s.OutputFolder, '{}_{}_{}_{}.npy'.format(var, self.s.ProjectName,
-                                                                               self.s.StartYear, self.s.EndYear)),
-                        names[var])
+        """Aggregate / convert on the device and write the selected variables (components.py:441-474)."""
+        from .data_writer.out_writer import OutWriter
+        all_outputs = {'pet': self.PET, 'aet': self.AET, 'q': self.Q, 'soilmoisture': self.Sav,
+                       'avgchflow': self.Avg_ChFlow}
+        writer = OutWriter(self.s, self.data.area, all_outputs)
+        writer.write()
+        self.q = writer.get('q') if 'q' in writer.output_names else self.Q
+        self.ac = writer.get('avgchflow') if 'avgchflow' in writer.output_names else self.Avg_ChFlow
+        if 'q' in writer.output_names and self.s.AggregateRunoffBasin:
+            ref = type('Ref', (), {'basin_ids': self.data.basin_ids, 'n_basin_names': self.s.n_basins})
+            writer.write_aggregates(ref, self.q, self.s.AggregateRunoffBasin, 0, 0)
