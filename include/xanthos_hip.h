@@ -182,6 +182,9 @@ int xh_agg_time(xh_ctx *ctx, int64_t ncell, int32_t ncols, int32_t group, int32_
                 const double *d_in, double *d_out);
 int xh_agg_spatial(xh_ctx *ctx, int64_t ncell, int32_t ncols, int32_t n_groups, const int32_t *h_group,
                    const double *d_in, double *d_out);
+/* Loader transform on the device: np.nan_to_num in place, as data_load.py applies to the PM forcings
+ * and the ABCD tmin (:120-125, :194-195): NaN -> 0, +inf / -inf -> +/- largest finite double.                */
+int xh_nan_to_num(xh_ctx *ctx, double *d_arr, int64_t n);
 
 /* ------------------------------------------------------------------ bench support (not on the hot path)
  * Fills the eight forcing arrays of the synthetic benchmark world on the device (same distributions as

@@ -63,6 +63,18 @@ def test_in_memory_forcing_override(example):
     wet = Xanthos(ini).execute({'PrecipitationFile': f['precip'] * 2.0})
     m = ~np.isnan(base.Q)
     assert (wet.Q[m] >= base.Q[m] - 1e-9).all() and wet.Q[m].sum() > 1.5 * base.Q[m].sum()
+    # missing values in the forcing: nan_to_num happens on the device and must equal the loader's host transform
+    holes = {k: f[k].copy() for k in ('tas', 'tmin', 'rhs', 'abcd_tmin')}
+    for k, a in holes.items():
+        a[::7, ::5] = np.nan
+    a = Xanthos(ini).execute({'pm_tas': holes['tas'], 'pm_tmin': holes['tmin'], 'pm_rhs': holes['rhs'],
+                              'TempMinFile': holes['abcd_tmin']})
+    b = Xanthos(ini).execute({'pm_tas': np.nan_to_num(holes['tas']), 'pm_tmin': np.nan_to_num(holes['tmin']),
+                              'pm_rhs': np.nan_to_num(holes['rhs']), 'TempMinFile': np.nan_to_num(holes['abcd_tmin']),
+                              'device_transforms': False})
+    for name in ('PET', 'Q', 'Avg_ChFlow'):
+        assert np.array_equal(getattr(a, name), getattr(b, name), equal_nan=True), name
+    assert not np.isnan(a.PET).any()
 
 
 def test_calibration_recovers_kge(example):

@@ -75,3 +75,22 @@ def test_differential_evolution_driver_finds_minimum():
     assert np.allclose(x, target, atol=5e-2) and fun < 1e-2
     assert all(c == 45 for c in calls) and nfev == sum(calls)                # popsize 15 x 3 parameters per generation
     assert expand_str_range(['0-2', '6', '7-9']) == [0, 1, 2, 6, 7, 8, 9]
+
+
+def test_netcdf_and_mat_inputs(tmp_path):
+    """PrecipitationFile / TempMinFile may be NetCDF-classic or MATLAB files with a variable name (data_load.py:366-384)."""
+    import scipy.io as sio
+    from xanthos_amd.data_load import load_file
+    a = np.arange(12.0).reshape(3, 4)
+    nc = str(tmp_path / 'pr.nc')
+    f = sio.netcdf_file(nc, 'w')
+    f.createDimension('c', 3)
+    f.createDimension('m', 4)
+    v = f.createVariable('pr', 'd', ('c', 'm'))
+    v[:] = a
+    f.close()
+    got = load_file(nc, key='pr')
+    assert np.array_equal(got, a) and got.dtype.byteorder in ('=', '<', '|')
+    mat = str(tmp_path / 'tmin.mat')
+    sio.savemat(mat, {'tmin': a})
+    assert np.array_equal(load_file(mat, key='tmin'), a)

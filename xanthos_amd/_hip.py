@@ -66,6 +66,7 @@ SIGNATURES = {
     'xh_calib_objective': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'xh_agg_time': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
     'xh_agg_spatial': (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
+    'xh_nan_to_num': (c_int, [_P, _P, c_int64]),
     'xh_synth_forcing': (c_int, [_P, c_uint64, c_double, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
@@ -287,6 +288,11 @@ class Context:
     def agg_spatial(self, ncell, ncols, n_groups, group_index, src, dst):
         gi = np.ascontiguousarray(group_index, dtype=np.int32)
         self._check(lib().xh_agg_spatial(self.handle, ncell, ncols, n_groups, _host_ptr(gi), _dptr(src), _dptr(dst)))
+
+    def nan_to_num(self, arr):
+        """In-place np.nan_to_num of a DeviceArray."""
+        self._check(lib().xh_nan_to_num(self.handle, _dptr(arr), arr.size))
+        return arr
 
     # ---- bench support
     def synth_forcing(self, seed, ncell, nmonths, lat, out, nan_frac=0.001):

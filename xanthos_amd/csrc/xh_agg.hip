@@ -54,7 +54,29 @@ __global__ void __launch_bounds__(256) k_agg_spatial(int ncols, const int *__res
     out[(int64_t)k * ncols + t] = (hi > lo) ? sum : NAN;
 }
 
+// np.nan_to_num in place (data_load.py:120-125,:194-195: NaN -> 0, +/-inf -> +/-DBL_MAX), loader transform N3
+__global__ void __launch_bounds__(256) k_nan_to_num(double *__restrict__ a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = a[i];
+        if (v != v) a[i] = 0.0;
+        else if (v == INFINITY) a[i] = 1.7976931348623157e308;
+        else if (v == -INFINITY) a[i] = -1.7976931348623157e308;
+    }
+}
+
 }  // namespace
+
+extern "C" int xh_nan_to_num(xh_ctx *ctx, double *d_arr, int64_t n) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, n >= 0 && (d_arr || n == 0), "xh_nan_to_num: bad argument");
+    if (n == 0) return XH_OK;
+    int64_t blocks = (n + 255) / 256;
+    const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_nan_to_num, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_arr, n);
+    XH_HIP(ctx, hipGetLastError());
+    return XH_OK;
+}
 
 extern "C" int xh_agg_time(xh_ctx *ctx, int64_t ncell, int32_t ncols, int32_t group, int32_t mode, const double *d_scale,
                            const double *d_in, double *d_out) {

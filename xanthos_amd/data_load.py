@@ -4,7 +4,8 @@ Mirrors the parts of xanthos/data_reader/data_load.py that feed the hot path and
 changes its inputs:
 
 * area x 0.01 (ha -> km2, :48); coordinates table [id, lon, lat, ilon, ilat] (:51); basin ids (:54)
-* PM forcings pass through nan_to_num (:120-125); ``tairprev`` is tas shifted by one CELL, zeros for cell 0 (:127-129);
+* PM forcings pass through nan_to_num (:120-125) -- on the device after upload (``xh_nan_to_num``), on the host only if
+  ``settings.device_transforms = False``; ``tairprev`` is tas shifted by one CELL, zeros for cell 0 (:127-129);
   land cover and elevation nan_to_num (:132,:135); 13 per-class parameters + 4 per-(class, month) tables (:94-117)
 * precipitation keeps NaN (:186); ABCD tmin nan_to_num (:194-195), optional
 * routing: flow distance < 1000 -> 1000 (:204-205), velocity < 0 -> 0 (:207-208), 2-D DRT maps flattened with the
@@ -20,14 +21,25 @@ import numpy as np
 from .ini_reader import ValidationException
 
 
-def load_file(fn, header_num=0):
-    """.npy / .csv / .txt reader (data_load.py:342-390); NetCDF / MATLAB inputs are outside the hot path."""
+def load_file(fn, header_num=0, key=None):
+    """.npy / .csv / .txt / .nc (NetCDF classic) / .mat reader, same dispatch as data_load.py:342-390."""
     if isinstance(fn, np.ndarray):
         return fn
     if not os.path.isfile(fn):
         raise IOError('Error: File does not exist:', fn)
     if fn.endswith('.npy'):
         return np.load(fn)
+    if fn.endswith('.mat'):
+        import scipy.io as sio
+        return sio.loadmat(fn)[key]
+    if fn.endswith('.nc'):
+        import scipy.io as sio
+        grp = sio.netcdf_file(fn, 'r', mmap=False)
+        data = grp.variables[key][:].copy()
+        grp.close()
+        if data.dtype.byteorder == '>':            # NetCDF classic is big-endian (data_load.py:381-384)
+            data = data.byteswap().view(data.dtype.newbyteorder())
+        return data
     if fn.endswith('.csv'):
         return np.genfromtxt(fn, delimiter=',', skip_header=header_num, filling_values='0')
     if fn.endswith('.txt'):
@@ -75,9 +87,9 @@ class DataLoader:
             self.pet_out = self.load_to_array(s.pet_file, 'pet_file')
 
         if s.runoff_module == 'abcd':
-            self.precip = self.load_to_array(s.PrecipitationFile, 'PrecipitationFile')
-            self.tmin = None if s.TempMinFile is None else self.load_to_array(s.TempMinFile, 'TempMinFile',
-                                                                               nan_to_num=True)
+            self.precip = self.load_to_array(s.PrecipitationFile, 'PrecipitationFile', key=getattr(s, 'PrecipVarName', None))
+            self.tmin = None if s.TempMinFile is None else self.load_to_array(
+                s.TempMinFile, 'TempMinFile', nan_to_num=True, key=getattr(s, 'TempMinVarName', None))
 
         if s.routing_module == 'mrtm':
             self.flow_dist = self.load_routing_data(s.flow_distance, rep_val=1000)
@@ -89,9 +101,11 @@ class DataLoader:
         if s.calibrate:
             self.cal_obs = np.asarray(load_file(s.cal_observed, 0))[:, [0, 3]]
 
-    def load_to_array(self, f, var_name, nan_to_num=False):
-        arr = np.asarray(load_file(f), dtype=float)
-        if nan_to_num:
+    def load_to_array(self, f, var_name, nan_to_num=False, key=None):
+        arr = np.asarray(load_file(f, key=key), dtype=float)
+        # np.nan_to_num of the big forcing arrays (data_load.py:120-125, :194-195) is applied on the device right after
+        # the upload (xh_nan_to_num) unless device_transforms is switched off: a host pass over 2.6 GB costs seconds
+        if nan_to_num and not getattr(self.s, 'device_transforms', True):
             arr = np.nan_to_num(arr)
         if arr.shape[0] != self.s.ncell or arr.shape[1] != self.s.nmonths:
             raise ValidationException('Error: Inconsistent {0} data grid size. Expecting size: {1}. Received size: {2}'

@@ -45,7 +45,7 @@ def run_pmpet(data, ncells, nlcs, start_yr, end_yr, water_idx, snow_idx, land_co
         raise IndexError('index 6 is out of bounds for axis 0 with size {}'.format(nlcs))
     ctx = _hip.get_context(device)
     nmonths = (end_yr - start_yr + 1) * 12
-    up = lambda a: ctx.upload(np.asarray(a)[:, :nmonths])
+    up = lambda a: ctx.nan_to_num(ctx.upload(np.asarray(a)[:, :nmonths]))      # loader transform (data_load.py:120-125)
     lct = np.asarray(data.lct_load, dtype=np.float64)
     if lct.shape[1] != nlcs or lct.shape[2] != len(land_cover_years):
         raise ValueError('lct_load must be [ncell, nlcs, n land-cover years]; got {}'.format(lct.shape))

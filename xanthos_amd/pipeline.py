@@ -67,8 +67,10 @@ class DevicePipeline:
                     self.forcing[k].upload(arr)
                 else:
                     self.forcing[k] = self.ctx.upload(arr)
+                if k != 'precip':                       # loader transform: everything but precipitation loses its NaNs
+                    self.ctx.nan_to_num(self.forcing[k])
         if tairprev is not None:
-            self.d_tairprev = self.ctx.upload(tairprev)
+            self.d_tairprev = self.ctx.nan_to_num(self.ctx.upload(tairprev))
 
     # ---- stages (asynchronous; call ctx.sync() or download to wait)
     def run_pm(self):

@@ -46,7 +46,7 @@ def _run(pars_rows, par_index, basin_ids, pet, precip, tmin, n_months, spinup_st
     bidx, n_groups = _dense_groups(basin_ids)
     d_pet = ctx.upload(np.asarray(pet)[:, :n_months])
     d_pr = ctx.upload(np.asarray(precip)[:, :n_months])
-    d_tn = None if tmin is None else ctx.upload(np.asarray(tmin)[:, :n_months])
+    d_tn = None if tmin is None else ctx.nan_to_num(ctx.upload(np.asarray(tmin)[:, :n_months]))   # data_load.py:194-195
     pars5 = np.zeros((pars_rows.shape[0], 5))
     pars5[:, :pars_rows.shape[1]] = pars_rows
     d_pars = ctx.upload(pars5)
