@@ -265,3 +265,23 @@ def test_writer_aggregation_golden(hip, golden, tmp_path):
     w2 = OutWriter(s, g['area'], {'q': d_q})
     w2.write()
     assert np.array_equal(w2.get('q'), w.get('q'), equal_nan=True)
+
+
+@pytest.mark.parametrize('dt', [7200, 17280])
+def test_route_other_time_steps(hip, dt):
+    """Sub-step counts that are not a multiple of the 8-step stream prefetch (tail path), streams between units."""
+    from types import SimpleNamespace as NS
+    from oracle import mrtm as o_mrtm
+    from xanthos_amd import synth
+    from xanthos_amd.routing import mrtm
+    w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=5, seed=3, outlet_frac=0.02)
+    st = NS(ngridrow=w.nrow, ngridcol=w.ncol)
+    um = mrtm.upstream_genmatrix(mrtm.upstream(w.coords, mrtm.downstream(w.coords, w.flow_dir, st), st))
+    runoff = np.random.default_rng(12).gamma(2.0, 30.0, (w.ncell, 5))
+    ndays = np.array([31, 28, 31, 30, 31])
+    assert any(int(d * 86400 / dt) % 8 for d in ndays)
+    ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2, dt=dt)
+    for flags in (0, 4):
+        got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, dt=dt, flags=flags)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), (dt, flags)
