@@ -186,6 +186,16 @@ int xh_agg_spatial(xh_ctx *ctx, int64_t ncell, int32_t ncols, int32_t n_groups, 
  * and the ABCD tmin (:120-125, :194-195): NaN -> 0, +inf / -inf -> +/- largest finite double.                */
 int xh_nan_to_num(xh_ctx *ctx, double *d_arr, int64_t n);
 
+/* The same objective for SEVERAL basins in one launch, each basin with its own population: one basin alone is only
+ * months x ~1.7 us of dependent chain, far too little to fill the chip.  h_ncell [nbasins]; h_pars [nbasins, nmembers,
+ * npar]; h_pet_t / h_precip_t / h_tmin_t / h_area: host arrays of nbasins DEVICE pointers ([nmonths, ncell_b] each;
+ * h_tmin_t NULL for npar = 4, h_area NULL for mm_per_mth); h_obs [nbasins, nmonths]; h_ed [nbasins, nmembers] out;
+ * h_series [nbasins, nmembers, nmonths] optional out.                                                        */
+int xh_calib_objective_multi(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, int32_t nmonths, int32_t spinup,
+                             int32_t nmembers, int32_t npar, const double *h_pars, const double *const *h_pet_t,
+                             const double *const *h_precip_t, const double *const *h_tmin_t,
+                             const double *const *h_area, const double *h_obs, double *h_ed, double *h_series);
+
 /* ------------------------------------------------------------------ bench support (not on the hot path)
  * Fills the eight forcing arrays of the synthetic benchmark world on the device (same distributions as
  * xanthos_amd/synth.py:make_forcing); d_lat [ncell] degrees; nan_frac = share of cells whose precipitation is NaN.                                             */

@@ -201,3 +201,31 @@ def test_dataflow_routing_long_run_under_load():
         other.sync()
         assert np.array_equal(got['chs'], ref['chs']) and np.array_equal(got['avg'], ref['avg']), rep
     other.close()
+
+
+def test_calibrate_all_lockstep(example, tmp_path):
+    """calibrate_all: every basin of the example searched in lock-step through the multi-basin objective; the files
+    the reference writes per basin (calibrate_abcd.py:130-131) appear and KGE is high where data is clean."""
+    from types import SimpleNamespace as NS
+    from oracle import calib as o_calib
+    from xanthos_amd.calibrate.calibrate_abcd import calibrate_all
+    root, w, f, ini = example
+    nm, spin = 36, 25
+    pet = np.random.default_rng(1).uniform(20, 150, (w.ncell, nm))
+    truth = np.array([0.96, 0.8, 0.5, 0.4, 0.3])
+    rows = []
+    for b in (1, 2, 3):
+        sel = w.basin_ids == b
+        series = o_calib.basin_runoff(truth, 0, pet[sel], f['precip'][sel], f['abcd_tmin'][sel], nm, spin, 'km3_per_mth',
+                                      w.area[sel])
+        rows.append(np.stack([np.full(nm, b), np.zeros(nm), np.zeros(nm), series], axis=1))
+    obs = np.concatenate(rows)
+    settings = NS(set_calibrate=0, obs_unit='km3_per_mth', cal_basins=['1-3'], nmonths=nm, runoff_spinup=spin,
+                  calib_out_dir=str(tmp_path), device=0)
+    data = NS(basin_ids=w.basin_ids, area=w.area, precip=f['precip'], tmin=f['abcd_tmin'], cal_obs=obs[:, [0, 3]])
+    res = calibrate_all(settings, data, pet, seed=11)
+    assert sorted(res) == [1, 2, 3]
+    for b, (x, kge) in res.items():
+        assert kge > 0.98, (b, kge)
+        assert np.load(str(tmp_path / 'kge_result_basin_{}.npy'.format(b)))[0] == kge
+        assert np.load(str(tmp_path / 'abcdm_parameters_basin_{}.npy'.format(b))).shape == (1, 5)

@@ -285,3 +285,27 @@ def test_route_other_time_steps(hip, dt):
         got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, dt=dt, flags=flags)
         for a, b in zip(got, ref):
             assert np.array_equal(a, b), (dt, flags)
+
+
+def test_calibration_objective_multi_basin(hip, golden):
+    """Both golden basins in ONE launch, each with its own population: identical to the per-basin calls."""
+    g = golden('kge')
+    ctx = hip.get_context()
+    nm, spin = int(g['n_months']), int(g['spinup'])
+    tr = lambda a: ctx.upload(np.ascontiguousarray(a.T))
+    for npar, with_tmin in ((5, True), (4, False)):
+        pars = np.stack([g['pars_0'][:, :npar], g['pars_1'][::-1, :npar]])
+        ncells = [g['pet_0'].shape[0], g['pet_1'].shape[0]]
+        pet = [tr(g['pet_0']), tr(g['pet_1'])]
+        pr = [tr(g['precip_0']), tr(g['precip_1'])]
+        tn = [tr(g['tmin_0']), tr(g['tmin_1'])] if with_tmin else None
+        ar = [ctx.upload(g['areas_0']), ctx.upload(g['areas_1'])]
+        obs = np.stack([g['robs_0'], g['robs_1']])
+        ed, series = ctx.calib_objective_multi(ncells, nm, spin, pars, pet, pr, tn, ar, obs, want_series=True)
+        for b in range(2):
+            one, s1 = ctx.calib_objective(ncells[b], nm, spin, pars[b], pet[b], pr[b], tn[b] if tn else None, ar[b],
+                                          obs[b], want_series=True)
+            assert np.array_equal(ed[b], one) and np.array_equal(series[b], s1)
+        tag = 'snow' if with_tmin else 'nosnow'
+        close(ed[0], g['ed_0_km3_per_mth_' + tag], rtol=1e-9, atol=1e-12)
+        close(ed[1], g['ed_1_km3_per_mth_' + tag][::-1], rtol=1e-9, atol=1e-12)

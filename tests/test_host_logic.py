@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from xanthos_amd import synth
-from xanthos_amd.calibrate.calibrate_abcd import differential_evolution_batched, expand_str_range
+from xanthos_amd.calibrate.calibrate_abcd import (differential_evolution_batched, differential_evolution_multi,
+                                                   expand_str_range)
 from xanthos_amd.ini_reader import ConfigReader, ValidationException, parse_ini
 
 
@@ -94,3 +95,17 @@ def test_netcdf_and_mat_inputs(tmp_path):
     mat = str(tmp_path / 'tmin.mat')
     sio.savemat(mat, {'tmin': a})
     assert np.array_equal(load_file(mat, key='tmin'), a)
+
+
+def test_lockstep_multi_basin_de_driver():
+    """Three independent quadratic 'basins' searched in lock-step; converged ones drop out of later calls."""
+    targets = np.array([[0.3, 5.0, 0.7], [0.8, 1.0, 0.2], [0.5, 7.0, 0.5]])
+    seen = []
+
+    def f(active, P):
+        seen.append(tuple(active))
+        return np.sum((P - targets[active][:, None, :]) ** 2, axis=2)
+    x, fun, nfev, nit = differential_evolution_multi(f, [(0, 1), (0, 8), (0, 1)], 3, seed=5)
+    assert np.allclose(x, targets, atol=6e-2) and (fun < 2e-2).all()
+    assert seen[0] == (0, 1, 2) and all(set(a) <= {0, 1, 2} for a in seen)
+    assert (nfev == 45 * (nit + 1)).all()

@@ -40,6 +40,19 @@ for rep in range(2):
         ed = ctx.calib_objective(int(counts[b]), nm, spin, pars, blk['rsds'], blk['precip'], blk['abcd_tmin'], blk['area'], obs)
     dt = time.perf_counter() - t0
 ms_a, n_a = ctx.timing('calib_abcd'); ms_k, n_k = ctx.timing('calib_kge')
+# all basins in ONE launch (xh_calib_objective_multi): each basin with its own population
+pars_nb = np.broadcast_to(pars, (w.n_basins,) + pars.shape).copy()
+obs_nb = np.broadcast_to(obs, (w.n_basins, nm)).copy()
+lst = lambda k: [blk[k] for blk in blocks]
+for rep in range(2):
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    ed_multi = ctx.calib_objective_multi(counts, nm, spin, pars_nb, lst('rsds'), lst('precip'), lst('abcd_tmin'), lst('area'), obs_nb)
+    dt_multi = time.perf_counter() - t0
+ms_m, _ = ctx.timing('calib_abcd')
+assert np.array_equal(ed_multi[-1], ed), 'multi-basin launch differs from the per-basin launch'
+print('same generation as ONE multi-basin launch: %.3f s wall (kernels %.1f ms) = %.3e member-cell-months/s incl. spin-up, %.0f objective evaluations/s' % (
+    dt_multi, ms_m, members * w.ncell * (nm + spin) / dt_multi, members * w.n_basins / dt_multi))
 mcm = members * w.ncell * nm
 print('generation of %d members x %d basins: %.3f s wall, kernels abcd %.1f ms kge %.1f ms' % (members, w.n_basins, dt, ms_a, ms_k))
 print('member-cell-months/s (sim months): %.3e ; incl. spin-up months: %.3e ; objective evaluations/s: %.0f' % (

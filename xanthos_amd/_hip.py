@@ -64,6 +64,7 @@ SIGNATURES = {
     'xh_mrtm_um_csr': (c_int, [c_int64, _P, _P, _P, _P]),
     'xh_route_series': (c_int, [_P, _P, c_int32, c_int32, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32]),
     'xh_calib_objective': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'xh_calib_objective_multi': (c_int, [_P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'xh_agg_time': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
     'xh_agg_spatial': (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
     'xh_nan_to_num': (c_int, [_P, _P, c_int64]),
@@ -279,6 +280,24 @@ class Context:
                                              _dptr(pet_t), _dptr(precip_t), _dptr(tmin_t), _dptr(area),
                                              _host_ptr(obs), _host_ptr(ed),
                                              _host_ptr(series) if want_series else None))
+        return (ed, series) if want_series else ed
+
+    def calib_objective_multi(self, ncells, nmonths, spinup, pars, pet_t, precip_t, tmin_t, area, obs, want_series=False):
+        """Several basins at once. pars [nb, nmem, npar]; pet_t / precip_t / tmin_t / area: lists of DeviceArrays
+        (tmin_t / area may be None); obs [nb, nmonths]. Returns ed [nb, nmem] (and series [nb, nmem, nmonths])."""
+        pars = as_f64(pars)
+        nb, nmem, npar = pars.shape
+        obs = as_f64(obs)
+        if obs.shape != (nb, nmonths):
+            raise ValueError('obs must be [nbasins, nmonths]')
+        nc = np.ascontiguousarray(ncells, dtype=np.int64)
+        ptrs = lambda lst: None if lst is None else (c_void_p * nb)(*[_dptr(x) for x in lst])
+        p_pet, p_pr, p_tn, p_ar = ptrs(pet_t), ptrs(precip_t), ptrs(tmin_t), ptrs(area)
+        ed = np.empty((nb, nmem))
+        series = np.empty((nb, nmem, nmonths)) if want_series else None
+        self._check(lib().xh_calib_objective_multi(self.handle, nb, _host_ptr(nc), nmonths, spinup, nmem, npar,
+                                                   _host_ptr(pars), p_pet, p_pr, p_tn, p_ar, _host_ptr(obs), _host_ptr(ed),
+                                                   _host_ptr(series) if want_series else None))
         return (ed, series) if want_series else ed
 
     # ---- output aggregation

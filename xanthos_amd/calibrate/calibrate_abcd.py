@@ -178,8 +178,104 @@ def process_basin(basin_num, settings, data, pet, router_function=None):
     return cal
 
 
-def calibrate_all(settings, data, pet, router_function=None):
-    """Calibrate every requested basin (:256-262)."""
-    for basin_num in expand_str_range(settings.cal_basins):
-        logging.info('\tCalibrating Basin:  {}'.format(basin_num))
-        process_basin(basin_num, settings, data, pet, router_function)
+def differential_evolution_multi(func, bounds, nbasins, popsize=15, maxiter=1000, tol=0.01, atol=0.0,
+                                 mutation=(0.5, 1.0), recombination=0.7, seed=None):
+    """Lock-step DE/best/1/bin for ``nbasins`` independent problems with a shared generation clock.
+
+    ``func(active, P)``: ``active`` = indices of the basins still searching, ``P`` [len(active), n, d] their trial
+    populations; returns energies [len(active), n].  One call = one generation of every active basin, which is what
+    the multi-basin GPU objective evaluates in a single launch.  Returns (x [nb, d], fun [nb], nfev [nb], nit [nb]).
+    """
+    rng = np.random.default_rng(seed)
+    lo = np.array([b[0] for b in bounds], dtype=float)
+    hi = np.array([b[1] for b in bounds], dtype=float)
+    d = len(bounds)
+    n = max(5, popsize * d)
+    pop = np.empty((nbasins, n, d))
+    for b in range(nbasins):                                             # Latin hypercube per basin
+        seg = (np.arange(n)[:, None] + rng.random((n, d))) / n
+        for j in range(d):
+            pop[b, :, j] = seg[rng.permutation(n), j]
+    clean = lambda e: np.where(np.isfinite(e), e, np.inf)
+    active = np.arange(nbasins)
+    energies = clean(np.asarray(func(active, lo + pop * (hi - lo)), dtype=float))
+    nfev = np.full(nbasins, n)
+    nit = np.zeros(nbasins, dtype=int)
+    for it in range(1, maxiter + 1):
+        fin = np.isfinite(energies).all(axis=1)
+        spread = np.std(np.where(np.isfinite(energies), energies, 0.0), axis=1)
+        conv = fin & (spread <= atol + tol * np.abs(np.mean(np.where(np.isfinite(energies), energies, 0.0), axis=1)))
+        active = np.nonzero(~conv)[0]
+        if len(active) == 0:
+            break
+        k = len(active)
+        best = pop[active, np.argmin(energies[active], axis=1)]           # [k, d]
+        scale = rng.uniform(mutation[0], mutation[1], size=(k, 1, 1))
+        r = np.stack([np.stack([rng.choice(n, 2, replace=False) for _ in range(n)]) for _ in range(k)])   # [k, n, 2]
+        pa = np.take_along_axis(pop[active], r[:, :, :1].repeat(d, axis=2), axis=1)
+        pb = np.take_along_axis(pop[active], r[:, :, 1:].repeat(d, axis=2), axis=1)
+        mutant = best[:, None, :] + scale * (pa - pb)
+        cross = rng.random((k, n, d)) < recombination
+        jj = rng.integers(0, d, (k, n))
+        cross[np.arange(k)[:, None], np.arange(n)[None, :], jj] = True
+        trial = np.where(cross, mutant, pop[active])
+        out = (trial < 0) | (trial > 1)
+        trial[out] = rng.random(int(out.sum()))
+        e_trial = clean(np.asarray(func(active, lo + trial * (hi - lo)), dtype=float))
+        nfev[active] += n
+        nit[active] = it
+        better = e_trial <= energies[active]
+        pa2, ea2 = pop[active], energies[active]
+        pa2[better], ea2[better] = trial[better], e_trial[better]
+        pop[active], energies[active] = pa2, ea2
+    kbest = np.argmin(energies, axis=1)
+    x = lo + pop[np.arange(nbasins), kbest] * (hi - lo)
+    return x, energies[np.arange(nbasins), kbest], nfev, nit
+
+
+def calibrate_all(settings, data, pet, router_function=None, seed=None, popsize=15):
+    """Calibrate every requested basin (:256-262).
+
+    All basins search in lock-step: each generation is ONE multi-basin launch of the objective
+    (xh_calib_objective_multi), ~3x faster than one launch per basin because a single basin cannot fill the chip.
+    Writes the reference's two files per basin (:130-131) and returns {basin: (parameters, kge)}.
+    """
+    if settings.set_calibrate != 0:
+        raise NotImplementedError('set_calibrate = 1 (stream flow) is not supported; see the module docstring')
+    basins = expand_str_range(settings.cal_basins)
+    cals = [Calibrate(basin_num=b, set_calibrate=0, obs_unit=settings.obs_unit, basin_ids=data.basin_ids,
+                      basin_areas=data.area, precip=data.precip, pet=pet, obs=data.cal_obs, tmin=data.tmin,
+                      n_months=settings.nmonths, runoff_spinup=settings.runoff_spinup, out_dir=settings.calib_out_dir,
+                      device=getattr(settings, 'device', 0)) for b in basins]
+    cals = [c for c in cals if c.basin_idx[0].size > 0]
+    if not cals:
+        return {}
+    objs = [c.objective() for c in cals]
+    ctx, nosnow = objs[0].ctx, objs[0].nosnow
+    npar = objs[0].npar
+    obs = np.stack([o.obs for o in objs])
+
+    def func(active, P):
+        sel = [objs[i] for i in active]
+        return ctx.calib_objective_multi([o.ncell for o in sel], settings.nmonths, settings.runoff_spinup,
+                                         P[:, :, :npar], [o.d_pet for o in sel], [o.d_precip for o in sel],
+                                         None if nosnow else [o.d_tmin for o in sel],
+                                         None if objs[0].d_area is None else [o.d_area for o in sel], obs[active])
+    st = time.time()
+    try:
+        x, ed, nfev, nit = differential_evolution_multi(func, cals[0].bounds, len(cals), popsize=popsize, seed=seed)
+    finally:
+        for o in objs:
+            o.close()
+    logging.info('\tCalibrated {} basins in {:.1f} s ({} objective evaluations)'.format(len(cals), time.time() - st,
+                                                                                     int(nfev.sum())))
+    par_names = 'abcd' + 'm' * (not nosnow)
+    results = {}
+    for i, c in enumerate(cals):
+        c.all_pars[0, :], c.kge_vals[0], c.nfev = x[i], 1 - ed[i], int(nfev[i])
+        results[c.basin_num] = (x[i], 1 - ed[i])
+        if c.out_dir is not None:
+            os.makedirs(c.out_dir, exist_ok=True)
+            np.save('{}/kge_result_basin_{}.npy'.format(c.out_dir, c.basin_num), c.kge_vals)
+            np.save('{}/{}_parameters_basin_{}.npy'.format(c.out_dir, par_names, c.basin_num), c.all_pars)
+    return results

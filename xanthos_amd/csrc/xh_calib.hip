@@ -15,6 +15,7 @@
 //
 // All cross-lane / cross-wave sums run in a fixed order, so results are reproducible run to run.
 #include <cmath>
+#include <vector>
 
 #include "xh_abcd_dev.h"
 #include "xh_common.h"
@@ -64,22 +65,33 @@ __device__ __forceinline__ AbcdPar member_par(const double *__restrict__ pars, i
     return P;
 }
 
-// grid.x = cell chunks of 64, grid.y = member blocks of MB; block = 64 threads (one wave)
+struct CalibBasin {
+    int ncell, chunk0, nchunks, pad;
+    const double *pet, *pr, *tn, *area;      // [month, cell] forcing of this basin; area may be NULL (mm_per_mth)
+};
+
+// grid.x = 64-cell chunks of ALL basins of the call, grid.y = member blocks of MB; block = 64 threads (one wave).
+// Every basin carries its own population (pars[basin][member][npar]), so one launch evaluates a whole generation of
+// every basin: a single basin is only months x 1.7 us of dependent chain, far too little to fill the chip.
 template <bool SPINUP>
-__global__ void __launch_bounds__(64) k_calib_march(int ncell, int nsteps, int nmembers, int npar,
-                                                    const double *__restrict__ pars,
-                                                    const double *__restrict__ pet_t, const double *__restrict__ pr_t,
-                                                    const double *__restrict__ tn_t, const double *__restrict__ area,
+__global__ void __launch_bounds__(64) k_calib_march(const CalibBasin *__restrict__ basins,
+                                                    const int *__restrict__ chunk_basin, int nsteps, int nmembers,
+                                                    int npar, const double *__restrict__ pars,
                                                     const double *__restrict__ sm0, const double *__restrict__ gw0,
                                                     double *__restrict__ dec_sum,    // [chunk][member][6]
                                                     int *__restrict__ dec_cnt,       // [chunk][member][6]
                                                     double *__restrict__ part) {     // [chunk][member][nsteps]
     const int chunk = blockIdx.x, lane = threadIdx.x;
-    const int c = chunk * 64 + lane;
+    const int b = chunk_basin[chunk];
+    const CalibBasin B = basins[b];
+    const int ncell = B.ncell;
+    const int c = (chunk - B.chunk0) * 64 + lane;
     const bool valid = c < ncell;
     const int cc = valid ? c : ncell - 1;
     const int mb0 = blockIdx.y * MB;
+    const double *__restrict__ pet_t = B.pet, *__restrict__ pr_t = B.pr, *__restrict__ tn_t = B.tn;
     const bool snow_on = tn_t != nullptr;
+    const double *area = B.area;
     const double scale = (valid && area) ? area[cc] : 1.0;
 
     AbcdPar P[MB];
@@ -87,10 +99,10 @@ __global__ void __launch_bounds__(64) k_calib_march(int ncell, int nsteps, int n
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
         const int mem = min(mb0 + j, nmembers - 1);
-        P[j] = member_par(pars, npar, mem);
+        P[j] = member_par(pars, npar, b * nmembers + mem);
         s[j].snowpack = 0.0;
-        s[j].sm = SPINUP ? 100.0 : sm0[mem];
-        s[j].gw = SPINUP ? 500.0 : gw0[mem];
+        s[j].sm = SPINUP ? 100.0 : sm0[b * nmembers + mem];
+        s[j].gw = SPINUP ? 500.0 : gw0[b * nmembers + mem];
     }
     double pet = pet_t[cc], pr = pr_t[cc], tn = snow_on ? tn_t[cc] : 0.0;
     for (int m = 0; m < nsteps; ++m) {
@@ -133,14 +145,17 @@ __global__ void __launch_bounds__(64) k_calib_march(int ncell, int nsteps, int n
     }
 }
 
-__global__ void __launch_bounds__(64) k_calib_init(int nchunks, int nmembers, const double *__restrict__ dec_sum,
-                                                   const int *__restrict__ dec_cnt, double *__restrict__ sm0,
-                                                   double *__restrict__ gw0) {
-    const int mem = blockIdx.x * blockDim.x + threadIdx.x;
-    if (mem >= nmembers) return;
+// one thread per (basin, member): basin mean of the three Decembers over the basin's chunks, in chunk order
+__global__ void __launch_bounds__(64) k_calib_init(const CalibBasin *__restrict__ basins, int nbasins, int nmembers,
+                                                   const double *__restrict__ dec_sum, const int *__restrict__ dec_cnt,
+                                                   double *__restrict__ sm0, double *__restrict__ gw0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbasins * nmembers) return;
+    const int b = i / nmembers, mem = i - b * nmembers;
+    const CalibBasin B = basins[b];
     double sum[6] = {0, 0, 0, 0, 0, 0};
     long long cnt[6] = {0, 0, 0, 0, 0, 0};
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = B.chunk0; ch < B.chunk0 + B.nchunks; ++ch) {
         const int64_t o = ((int64_t)ch * nmembers + mem) * 6;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -151,18 +166,22 @@ __global__ void __launch_bounds__(64) k_calib_init(int nchunks, int nmembers, co
     double mean[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) mean[k] = sum[k] / (double)cnt[k];
-    sm0[mem] = ((mean[0] + mean[1]) + mean[2]) / 3.0;            // abcd.py:274-278
-    gw0[mem] = ((mean[3] + mean[4]) + mean[5]) / 3.0;
+    sm0[i] = ((mean[0] + mean[1]) + mean[2]) / 3.0;              // abcd.py:274-278
+    gw0[i] = ((mean[3] + mean[4]) + mean[5]) / 3.0;
 }
 
-// series[member][month] = sum over chunks of part[chunk][member][month]
-__global__ void __launch_bounds__(256) k_calib_series(int nchunks, int nmembers, int nmonths,
-                                                      const double *__restrict__ part, double *__restrict__ series) {
+// series[basin][member][month] = sum over the basin's chunks of part[chunk][member][month]
+__global__ void __launch_bounds__(256) k_calib_series(const CalibBasin *__restrict__ basins, int nbasins, int nmembers,
+                                                      int nmonths, const double *__restrict__ part,
+                                                      double *__restrict__ series) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = (int64_t)nmembers * nmonths;
-    if (i >= n) return;
+    const int64_t per_basin = (int64_t)nmembers * nmonths;
+    if (i >= per_basin * nbasins) return;
+    const int b = (int)(i / per_basin);
+    const int64_t r = i - (int64_t)b * per_basin;                // member * nmonths + month
+    const CalibBasin B = basins[b];
     double acc = 0.0;
-    for (int ch = 0; ch < nchunks; ++ch) acc += part[(int64_t)ch * n + i];
+    for (int ch = B.chunk0; ch < B.chunk0 + B.nchunks; ++ch) acc += part[(int64_t)ch * per_basin + r];
     series[i] = acc;
 }
 
@@ -179,11 +198,12 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 }
 
 // one workgroup per member: ED = sqrt((r-1)^2 + (sd_m/sd_o - 1)^2 + (mean_m/mean_o - 1)^2) (:196-213)
-__global__ void __launch_bounds__(256) k_calib_kge(int nmonths, const double *__restrict__ series,
-                                                   const double *__restrict__ obs, double *__restrict__ ed) {
+__global__ void __launch_bounds__(256) k_calib_kge(int nmonths, int nmembers, const double *__restrict__ series,
+                                                   const double *__restrict__ obs_all, double *__restrict__ ed) {
     __shared__ double sh[256];
-    const int mem = blockIdx.x;
+    const int mem = blockIdx.x;                          // basin * nmembers + member
     const double *x = series + (int64_t)mem * nmonths;
+    const double *obs = obs_all + (int64_t)(mem / nmembers) * nmonths;
     double sx = 0.0, so = 0.0;
     for (int m = threadIdx.x; m < nmonths; m += blockDim.x) {
         sx += x[m];
@@ -213,67 +233,99 @@ __global__ void __launch_bounds__(256) k_calib_kge(int nmonths, const double *__
 
 }  // namespace
 
+extern "C" int xh_calib_objective_multi(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, int32_t nmonths,
+                                        int32_t spinup, int32_t nmembers, int32_t npar, const double *h_pars,
+                                        const double *const *h_pet_t, const double *const *h_precip_t,
+                                        const double *const *h_tmin_t, const double *const *h_area,
+                                        const double *h_obs, double *h_ed, double *h_series) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, nbasins > 0 && h_ncell && h_pars && h_pet_t && h_precip_t && h_obs && h_ed,
+               "xh_calib_objective: NULL argument");
+    XH_REQUIRE(ctx, nmonths > 1 && nmembers > 0, "xh_calib_objective: bad size");
+    XH_REQUIRE(ctx, npar == 4 || npar == 5, "xh_calib_objective: npar must be 4 (no snow) or 5");
+    XH_REQUIRE(ctx, (npar == 5) == (h_tmin_t != nullptr), "xh_calib_objective: npar = 5 requires tmin and vice versa");
+    XH_REQUIRE(ctx, spinup >= 25 && spinup <= nmonths, "xh_calib_objective: spin-up must be in [25, nmonths]");
+
+    std::vector<CalibBasin> basins(nbasins);
+    std::vector<int> chunk_basin;
+    for (int b = 0; b < nbasins; ++b) {
+        XH_REQUIRE(ctx, h_ncell[b] > 0 && h_ncell[b] < ((int64_t)1 << 24), "xh_calib_objective: basin %d has %lld cells",
+                   b, (long long)h_ncell[b]);
+        XH_REQUIRE(ctx, h_pet_t[b] && h_precip_t[b] && (npar == 4 || h_tmin_t[b]), "xh_calib_objective: NULL forcing");
+        CalibBasin &B = basins[b];
+        B.ncell = (int)h_ncell[b];
+        B.chunk0 = (int)chunk_basin.size();
+        B.nchunks = (B.ncell + 63) / 64;
+        B.pad = 0;
+        B.pet = h_pet_t[b];
+        B.pr = h_precip_t[b];
+        B.tn = npar == 5 ? h_tmin_t[b] : nullptr;
+        B.area = h_area ? h_area[b] : nullptr;
+        chunk_basin.insert(chunk_basin.end(), B.nchunks, b);
+    }
+    const size_t nchunks = chunk_basin.size();
+    const int nmblocks = (nmembers + MB - 1) / MB;
+    XH_REQUIRE(ctx, nmblocks <= 65535, "xh_calib_objective: too many members");
+    const size_t nbm = (size_t)nbasins * nmembers;
+    const size_t n_part = nchunks * nmembers * (size_t)nmonths;
+    const size_t n_dec = nchunks * nmembers * 6;
+    const size_t dbl = nbm * npar + (size_t)nbasins * nmonths + 2 * nbm + n_dec + n_part + nbm * nmonths + nbm;
+    const size_t tab_bytes = ((sizeof(CalibBasin) * nbasins + sizeof(int) * nchunks) + 255) & ~size_t(255);
+    void *buf = nullptr;
+    int rc = xh_scratch(ctx, 1, dbl * sizeof(double) + n_dec * sizeof(int) + tab_bytes + 256, &buf);
+    if (rc) return rc;
+    double *d_pars = static_cast<double *>(buf);
+    double *d_obs = d_pars + nbm * npar;
+    double *d_sm0 = d_obs + (size_t)nbasins * nmonths;
+    double *d_gw0 = d_sm0 + nbm;
+    double *d_dec = d_gw0 + nbm;
+    double *d_part = d_dec + n_dec;
+    double *d_series = d_part + n_part;
+    double *d_ed = d_series + nbm * nmonths;
+    CalibBasin *d_basins = reinterpret_cast<CalibBasin *>(d_ed + nbm);
+    int *d_chunk_basin = reinterpret_cast<int *>(d_basins + nbasins);
+    int *d_cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(d_basins) + tab_bytes);
+    XH_HIP(ctx, hipMemcpyAsync(d_pars, h_pars, sizeof(double) * nbm * npar, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_obs, h_obs, sizeof(double) * nbasins * nmonths, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_basins, basins.data(), sizeof(CalibBasin) * nbasins, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_chunk_basin, chunk_basin.data(), sizeof(int) * nchunks, hipMemcpyHostToDevice, ctx->stream));
+
+    const dim3 grid((unsigned)nchunks, (unsigned)nmblocks), block(64);
+    {
+        xh_span sp = xh_span_begin(ctx, "calib_abcd");
+        hipLaunchKernelGGL(k_calib_march<true>, grid, block, 0, ctx->stream, d_basins, d_chunk_basin, (int)spinup,
+                           (int)nmembers, (int)npar, d_pars, (const double *)nullptr, (const double *)nullptr, d_dec,
+                           d_cnt, (double *)nullptr);
+        hipLaunchKernelGGL(k_calib_init, dim3((unsigned)((nbm + 63) / 64)), dim3(64), 0, ctx->stream, d_basins,
+                           (int)nbasins, (int)nmembers, d_dec, d_cnt, d_sm0, d_gw0);
+        hipLaunchKernelGGL(k_calib_march<false>, grid, block, 0, ctx->stream, d_basins, d_chunk_basin, (int)nmonths,
+                           (int)nmembers, (int)npar, d_pars, d_sm0, d_gw0, (double *)nullptr, (int *)nullptr, d_part);
+        xh_span_end(sp);
+    }
+    {
+        xh_span sp = xh_span_begin(ctx, "calib_kge");
+        const int64_t n = (int64_t)nbm * nmonths;
+        hipLaunchKernelGGL(k_calib_series, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_basins,
+                           (int)nbasins, (int)nmembers, (int)nmonths, d_part, d_series);
+        hipLaunchKernelGGL(k_calib_kge, dim3((unsigned)nbm), dim3(256), 0, ctx->stream, (int)nmonths, (int)nmembers,
+                           d_series, d_obs, d_ed);
+        xh_span_end(sp);
+    }
+    XH_HIP(ctx, hipGetLastError());
+    XH_HIP(ctx, hipMemcpyAsync(h_ed, d_ed, sizeof(double) * nbm, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_series)
+        XH_HIP(ctx, hipMemcpyAsync(h_series, d_series, sizeof(double) * nbm * nmonths, hipMemcpyDeviceToHost, ctx->stream));
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host tables and result buffers are the caller's / locals
+    return XH_OK;
+}
+
 extern "C" int xh_calib_objective(xh_ctx *ctx, int64_t ncell_b, int32_t nmonths, int32_t spinup, int32_t nmembers,
                                   int32_t npar, const double *h_pars, const double *d_pet_t, const double *d_precip_t,
                                   const double *d_tmin_t, const double *d_area, const double *h_obs, double *h_ed,
                                   double *h_series) {
     if (!ctx) return XH_ERR_ARG;
-    XH_REQUIRE(ctx, h_pars && d_pet_t && d_precip_t && h_obs && h_ed, "xh_calib_objective: NULL argument");
-    XH_REQUIRE(ctx, ncell_b > 0 && ncell_b < ((int64_t)1 << 24) && nmonths > 1 && nmembers > 0,
-               "xh_calib_objective: bad size");
-    XH_REQUIRE(ctx, npar == 4 || npar == 5, "xh_calib_objective: npar must be 4 (no snow) or 5");
     XH_REQUIRE(ctx, (npar == 5) == (d_tmin_t != nullptr), "xh_calib_objective: npar = 5 requires tmin and vice versa");
-    XH_REQUIRE(ctx, spinup >= 25 && spinup <= nmonths, "xh_calib_objective: spin-up must be in [25, nmonths]");
-
-    const int ncell = (int)ncell_b;
-    const int nchunks = (ncell + 63) / 64;
-    const int nmblocks = (nmembers + MB - 1) / MB;
-    const size_t n_part = (size_t)nchunks * nmembers * nmonths;
-    const size_t n_dec = (size_t)nchunks * nmembers * 6;
-    const size_t dbl = (size_t)nmembers * npar + (size_t)nmonths + 2 * (size_t)nmembers + n_dec + n_part +
-                       (size_t)nmembers * nmonths + (size_t)nmembers;
-    void *buf = nullptr;
-    int rc = xh_scratch(ctx, 1, dbl * sizeof(double) + n_dec * sizeof(int) + 256, &buf);
-    if (rc) return rc;
-    double *d_pars = static_cast<double *>(buf);
-    double *d_obs = d_pars + (size_t)nmembers * npar;
-    double *d_sm0 = d_obs + nmonths;
-    double *d_gw0 = d_sm0 + nmembers;
-    double *d_dec = d_gw0 + nmembers;
-    double *d_part = d_dec + n_dec;
-    double *d_series = d_part + n_part;
-    double *d_ed = d_series + (size_t)nmembers * nmonths;
-    int *d_cnt = reinterpret_cast<int *>(d_ed + nmembers);
-    XH_HIP(ctx, hipMemcpyAsync(d_pars, h_pars, sizeof(double) * nmembers * npar, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_obs, h_obs, sizeof(double) * nmonths, hipMemcpyHostToDevice, ctx->stream));
-
-    const dim3 grid((unsigned)nchunks, (unsigned)nmblocks), block(64);
-    {
-        xh_span sp = xh_span_begin(ctx, "calib_abcd");
-        hipLaunchKernelGGL(k_calib_march<true>, grid, block, 0, ctx->stream, ncell, (int)spinup, (int)nmembers, (int)npar,
-                           d_pars, d_pet_t, d_precip_t, d_tmin_t, d_area, (const double *)nullptr,
-                           (const double *)nullptr, d_dec, d_cnt, (double *)nullptr);
-        hipLaunchKernelGGL(k_calib_init, dim3((unsigned)((nmembers + 63) / 64)), dim3(64), 0, ctx->stream, nchunks,
-                           (int)nmembers, d_dec, d_cnt, d_sm0, d_gw0);
-        hipLaunchKernelGGL(k_calib_march<false>, grid, block, 0, ctx->stream, ncell, (int)nmonths, (int)nmembers,
-                           (int)npar, d_pars, d_pet_t, d_precip_t, d_tmin_t, d_area, d_sm0, d_gw0, (double *)nullptr,
-                           (int *)nullptr, d_part);
-        xh_span_end(sp);
-    }
-    {
-        xh_span sp = xh_span_begin(ctx, "calib_kge");
-        const int64_t n = (int64_t)nmembers * nmonths;
-        hipLaunchKernelGGL(k_calib_series, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, nchunks,
-                           (int)nmembers, (int)nmonths, d_part, d_series);
-        hipLaunchKernelGGL(k_calib_kge, dim3((unsigned)nmembers), dim3(256), 0, ctx->stream, (int)nmonths, d_series,
-                           d_obs, d_ed);
-        xh_span_end(sp);
-    }
-    XH_HIP(ctx, hipGetLastError());
-    XH_HIP(ctx, hipMemcpyAsync(h_ed, d_ed, sizeof(double) * nmembers, hipMemcpyDeviceToHost, ctx->stream));
-    if (h_series)
-        XH_HIP(ctx, hipMemcpyAsync(h_series, d_series, sizeof(double) * nmembers * nmonths, hipMemcpyDeviceToHost,
-                                   ctx->stream));
-    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return XH_OK;
+    const double *pet[1] = {d_pet_t}, *pr[1] = {d_precip_t}, *tn[1] = {d_tmin_t}, *ar[1] = {d_area};
+    return xh_calib_objective_multi(ctx, 1, &ncell_b, nmonths, spinup, nmembers, npar, h_pars, pet, pr,
+                                    d_tmin_t ? tn : nullptr, d_area ? ar : nullptr, h_obs, h_ed, h_series);
 }
