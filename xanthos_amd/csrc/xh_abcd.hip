@@ -39,12 +39,8 @@ __device__ __forceinline__ void load_tile(Tile &t, const double *__restrict__ pe
         const double2 b = *reinterpret_cast<const double2 *>(pr + off + j);
         t.pet[j] = a.x, t.pet[j + 1] = a.y;
         t.pr[j] = b.x, t.pr[j + 1] = b.y;
-        if (tn) {
-            const double2 c = *reinterpret_cast<const double2 *>(tn + off + j);
-            t.tn[j] = c.x, t.tn[j + 1] = c.y;
-        } else {
-            t.tn[j] = 0.0, t.tn[j + 1] = 0.0;
-        }
+        const double2 c = *reinterpret_cast<const double2 *>(tn + off + j);   // tn is never NULL here (see caller):
+        t.tn[j] = c.x, t.tn[j + 1] = c.y;                                      // branch-free loads keep vmcnt waits exact
     }
 }
 
@@ -74,15 +70,14 @@ __global__ void __launch_bounds__(64) k_abcd(int64_t ncell, int nmonths, int nst
     }
     const int64_t row = c * (int64_t)nmonths;
     const int ntiles = nsteps / TM;
-    Tile cur, nxt;
-    if (ntiles > 0) load_tile(cur, pet, precip, tmin, row);
-    for (int t = 0; t < ntiles; ++t) {
-        const int m0 = t * TM;
-        if (t + 1 < ntiles) load_tile(nxt, pet, precip, tmin, row + m0 + TM);
+    // Ping-pong register tiles A / B, loop unrolled by two: the loads of the tile after next are in flight while a tile
+    // is computed, and no tile is ever copied (a `cur = nxt` copy made the compiler wait for the loads it had just
+    // issued: s_waitcnt vmcnt(0) at the bottom of every iteration).
+    auto compute_tile = [&](const Tile &tl, int m0) {
         double oa[TM], oq[TM], os[TM];
         AbcdPre pre[TM];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) pre[j] = abcd_pre(P, snow_on, cur.pet[j], cur.pr[j], cur.tn[j]);   // independent: ILP
+        for (int j = 0; j < TM; ++j) pre[j] = abcd_pre(P, snow_on, tl.pet[j], tl.pr[j], tl.tn[j]);   // independent: ILP
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             abcd_step(P, s, snow_on, (m0 + j) == 0, pre[j], oa[j], oq[j]);
@@ -104,7 +99,15 @@ __global__ void __launch_bounds__(64) k_abcd(int64_t ncell, int nmonths, int nst
                 if (sav) *reinterpret_cast<double2 *>(sav + row + m0 + j) = make_double2(os[j], os[j + 1]);
             }
         }
-        cur = nxt;
+    };
+    const double *tn_rows = tmin ? tmin : precip;   // without snow the values are loaded but never used (snow_on false)
+    Tile A, B;
+    if (ntiles > 0) load_tile(A, pet, precip, tn_rows, row);
+    for (int t = 0; t < ntiles; t += 2) {
+        if (t + 1 < ntiles) load_tile(B, pet, precip, tn_rows, row + (int64_t)(t + 1) * TM);
+        compute_tile(A, t * TM);
+        if (t + 2 < ntiles) load_tile(A, pet, precip, tn_rows, row + (int64_t)(t + 2) * TM);
+        if (t + 1 < ntiles) compute_tile(B, (t + 1) * TM);
     }
     for (int m = ntiles * TM; m < nsteps; ++m) {                      // tail months (spin-up length is arbitrary)
         double oa, oq;
