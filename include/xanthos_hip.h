@@ -153,6 +153,7 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
 #define XH_ROUTE_FORCE_FALLBACK 1   /* route every network with the global-memory kernels (testing)        */
 #define XH_ROUTE_ATOMIC 2           /* with the fallback: scatter-add outflow with global_atomic_add_f64   */
 #define XH_ROUTE_NO_DATAFLOW 4      /* one workgroup per network even for tree-shaped networks (testing)   */
+#define XH_ROUTE_NO_SKEW 8          /* dataflow units in lock-step with monthly streams, not time-skewed   */
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,
                     const double *d_flow_dist, const double *d_velocity, const double *d_area,

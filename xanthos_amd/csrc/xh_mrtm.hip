@@ -19,6 +19,7 @@
 // Networks that do not fit a workgroup (more than 3072 cells, or a row with more than 9 entries) are routed by
 // the global-memory kernels at the bottom (two launches per sub-step; optional fp64 atomic scatter-add variant).
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <numeric>
 
@@ -720,17 +721,24 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
         XH_REQUIRE(ctx, snt[it] >= 1, "xh_route_series: dt longer than a month");
         swr[it] = it >= spinup_months ? 1 : 0;
     }
-    const size_t sched_bytes = (size_t)nit * (2 * sizeof(int) + sizeof(double) + 1) + 64;
+    std::vector<int> sg(nit + 1, 0);                     // first global sub-step of each iteration
+    for (int it = 0; it < nit; ++it) {
+        XH_REQUIRE(ctx, (int64_t)sg[it] + snt[it] < (int64_t)1 << 30, "xh_route_series: more than 2^30 sub-steps");
+        sg[it + 1] = sg[it] + snt[it];
+    }
+    const size_t sched_bytes = (size_t)nit * (3 * sizeof(int) + sizeof(double) + 1) + 64;
     void *sbuf = nullptr;
     int rc = xh_scratch(ctx, 2, sched_bytes, &sbuf);
     if (rc) return rc;
     double *d_secs = static_cast<double *>(sbuf);
     int *d_m = reinterpret_cast<int *>(d_secs + nit);
     int *d_nt = d_m + nit;
-    unsigned char *d_wr = reinterpret_cast<unsigned char *>(d_nt + nit);
+    int *d_g = d_nt + nit;
+    unsigned char *d_wr = reinterpret_cast<unsigned char *>(d_g + nit + 1);
     XH_HIP(ctx, hipMemcpyAsync(d_secs, ssecs.data(), sizeof(double) * nit, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipMemcpyAsync(d_m, sm.data(), sizeof(int) * nit, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipMemcpyAsync(d_nt, snt.data(), sizeof(int) * nit, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_g, sg.data(), sizeof(int) * (nit + 1), hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipMemcpyAsync(d_wr, swr.data(), (size_t)nit, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
@@ -742,11 +750,18 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
     XH_HIP(ctx, hipEventRecord(plan->ev_fork, ctx->stream));
     int njoin = 0;
     if (use_flow) {     // tree-shaped networks: single-wave dataflow units on the context's own stream
-        int ntmax = 0;
-        for (int v : snt) ntmax = std::max(ntmax, v);
-        const FlowSched fs{nmonths, nit, ntmax, d_m, d_nt, d_secs, d_wr, dt};
+        int ntmax = 0, ntmin = INT_MAX;
+        for (int v : snt) {
+            ntmax = std::max(ntmax, v);
+            ntmin = std::min(ntmin, v);
+        }
+        const FlowSched fs{nmonths, nit, ntmax, ntmin, sg[nit], d_m, d_nt, d_g, d_secs, d_wr, dt};
         const FlowIO fio{d_flow_dist, d_velocity, d_area, d_runoff, d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end};
-        rc = flow_launch(ctx, plan->flow, fs, fio, ctx->stream);
+        // time-skewed units first; months shorter than the deepest lane lag (long dt) use the monthly-stream kernel
+        static const bool skew_env = !(getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] == '0');
+        rc = XH_ERR_LIMIT;
+        if (skew_env && (flags & XH_ROUTE_NO_SKEW) == 0) rc = skew_launch(ctx, plan->flow, fs, fio, ctx->stream);
+        if (rc == XH_ERR_LIMIT) rc = flow_launch(ctx, plan->flow, fs, fio, ctx->stream);
         if (rc == XH_ERR_LIMIT) {
             use_flow = false;   // units cannot all be resident on this device: one workgroup per network instead
         } else if (rc) {

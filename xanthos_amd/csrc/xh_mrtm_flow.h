@@ -1,14 +1,32 @@
-// Internal interface between xh_mrtm.hip (plan + API) and xh_mrtm_flow.hip (tree-partitioned dataflow routing).
+// Internal interface between xh_mrtm.hip (plan + API), xh_mrtm_flow.hip (tree partition + monthly-stream dataflow
+// kernel) and xh_mrtm_skew.hip (time-skewed dataflow kernel on the same partition).
 #pragma once
 #include <vector>
 
 #include "xh_common.h"
 
-struct FlowPlan;   // opaque: defined in xh_mrtm_flow.hip
+struct FlowBuf {
+    void *p = nullptr;
+};
+
+// Partition of the tree-shaped river networks into single-wave units (64 lanes = 64 cells) linked by one-way streams.
+struct FlowPlan {
+    int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0, max_exports = 0;
+    FlowBuf d_cell_of_slot, d_ent, d_export_edge, d_ghost_edge, d_edge_cons_unit, d_unit_terms;
+    // time-skewed layout (xh_mrtm_skew.hip); skew_ok = every row has <= 4 terms either side of its diagonal
+    bool skew_ok = false;
+    int skew_lmax = 0;                   // largest lane lag of any unit (sub-steps)
+    FlowBuf d_lag, d_ghost_lag, d_ent2, d_unit_p, d_unit_lmax, d_unit_glmax;
+    // per-call exchange buffers (grow-only)
+    void *d_x = nullptr;
+    size_t x_bytes = 0;
+    unsigned long long *d_stats = nullptr;
+};
 
 struct FlowSched {
-    int nmonths, nit, ntmax;
+    int nmonths, nit, ntmax, ntmin, total;
     const int *d_m, *d_nt;            // [nit] month index / sub-steps of each iteration
+    const int *d_g;                   // [nit + 1] first global sub-step of each iteration; d_g[nit] = total
     const double *d_secs;             // [nit]
     const unsigned char *d_wr;        // [nit] 1 = simulation pass (store outputs)
     double dt;
@@ -20,7 +38,7 @@ struct FlowIO {
 };
 
 // Partition every tree-shaped river network (each cell drains to at most one cell, no cycle, standard UP - I rows)
-// into single-wave units linked by one-way monthly streams.  handled[c] = 1 for the cells these units route.
+// into single-wave units linked by one-way streams.  handled[c] = 1 for the cells these units route.
 int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
                     const std::vector<int> &comp, int ncomp, std::vector<char> &handled, FlowPlan **out);
 void flow_plan_destroy(FlowPlan *fp);
@@ -28,6 +46,9 @@ void flow_plan_destroy(FlowPlan *fp);
 void flow_plan_info(const FlowPlan *fp, int64_t info[5]);
 // Enqueue the persistent dataflow kernel on `st`. Returns XH_ERR_LIMIT if the units cannot all be resident.
 int flow_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st);
-// Per-unit cycle accounting of the last launch (only when XH_FLOW_STATS=1): 4 words per unit
-// {shader cycles in sub-step loops, shader cycles total, 100 MHz ticks total, shape bits}.
+// Same contract for the time-skewed kernel; XH_ERR_LIMIT also when the schedule does not suit it (months shorter
+// than the deepest lane lag, rows wider than 4 + 1 + 4) -- the caller then uses flow_launch.
+int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st);
+// Per-unit cycle accounting of the last launch (only when XH_FLOW_STATS=1): 6 words per unit
+// {shader cycles in sub-step loops, shader cycles total, 100 MHz ticks total, shape bits, data-wait, ring-wait cycles}.
 int flow_stats_fetch(xh_ctx *ctx, FlowPlan *fp, std::vector<unsigned long long> &out);

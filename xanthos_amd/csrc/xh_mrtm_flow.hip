@@ -38,8 +38,8 @@ namespace {
 
 constexpr int W_MAX = 9;          // terms per row: 8 D8 neighbours + the diagonal
 constexpr int LANES = 64;         // cells per unit (one per lane)
-constexpr int G_MAX = 64;         // imported streams per unit (one ghost slot per lane)
-constexpr int NPAIR = LANES + G_MAX + 1;   // LDS pairs per flow buffer: cells, ghosts, constant zero
+constexpr int G_MAX = 16;         // imported streams per unit (ghost slots; 16 = two block-transfer rounds of the skewed kernel)
+constexpr int NPAIR = 2 * LANES + 1;       // LDS pairs per flow buffer: cells, ghost slots (one per lane), constant zero
 constexpr int RING = 4;           // months of stream kept in HBM per edge
 constexpr int PF = 8;             // sub-steps of ghost prefetch held in registers
 constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2;
@@ -280,12 +280,8 @@ __global__ void __launch_bounds__(LANES) k_mrtm_flow(FlowArgs a) {
     else flow_unit<W_MAX>(a, lds);
 }
 
-struct Buf {
-    void *p = nullptr;
-};
-
 template <typename T>
-int put(xh_ctx *ctx, Buf &b, const std::vector<T> &v) {
+int put(xh_ctx *ctx, FlowBuf &b, const std::vector<T> &v) {
     XH_HIP(ctx, hipMalloc(&b.p, v.empty() ? 16 : v.size() * sizeof(T)));
     if (!v.empty()) XH_HIP(ctx, hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return XH_OK;
@@ -293,20 +289,12 @@ int put(xh_ctx *ctx, Buf &b, const std::vector<T> &v) {
 
 }  // namespace
 
-struct FlowPlan {
-    int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0;
-    Buf d_cell_of_slot, d_ent, d_export_edge, d_ghost_edge, d_edge_cons_unit, d_unit_terms;
-    // per-call exchange buffers (grow-only)
-    void *d_x = nullptr;
-    size_t x_bytes = 0;
-    unsigned long long *d_stats = nullptr;
-};
-
 void flow_plan_destroy(FlowPlan *fp) {
     if (!fp) return;
-    Buf *bufs[] = {&fp->d_cell_of_slot, &fp->d_ent, &fp->d_export_edge, &fp->d_ghost_edge, &fp->d_edge_cons_unit,
-                   &fp->d_unit_terms};
-    for (Buf *b : bufs)
+    FlowBuf *bufs[] = {&fp->d_cell_of_slot, &fp->d_ent,      &fp->d_export_edge, &fp->d_ghost_edge,
+                       &fp->d_edge_cons_unit, &fp->d_unit_terms, &fp->d_lag,        &fp->d_ghost_lag,
+                       &fp->d_ent2,         &fp->d_unit_p,     &fp->d_unit_lmax,   &fp->d_unit_glmax};
+    for (FlowBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (fp->d_x) (void)hipFree(fp->d_x);
     if (fp->d_stats) (void)hipFree(fp->d_stats);
@@ -527,18 +515,107 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
         }
     }
 
+    // ---- time-skewed layout (xh_mrtm_skew.hip).  Lane lags: a cell `h` edges above its piece's outlet runs
+    //      2 * (H - h) sub-steps behind the unit's clock (H = tallest piece of the unit, an imported stream counting as
+    //      one more level), so that every flow a cell gathers was produced exactly two iterations earlier.  The lags
+    //      of a unit are shifted so that its outlets' lag is a multiple of 16 (stream stores of 16 sub-steps never
+    //      wrap inside a group).  Row terms are split at the diagonal: SK_P before, SK_P after.
+    constexpr int SK_P = 4;
+    constexpr unsigned SK_ZERO = 2u * LANES * 16u;
+    bool skew_ok = true;
+    std::vector<int> hgt(n, 0), unit_h(nunit, 0);
+    for (size_t qi = queue.size(); qi-- > 0;) {          // reverse bottom-up order: downstream cells first
+        const int c = queue[qi];
+        if (piece[c] < 0) continue;
+        hgt[c] = (piece_of_root[c] == piece[c]) ? 0 : hgt[ds[c]] + 1;
+        int &uh = unit_h[unit_of_piece[piece[c]]];
+        uh = std::max(uh, hgt[c]);
+    }
+    for (int ed = 0; ed < nedge; ++ed) {
+        int &uh = unit_h[edge_cons_unit[ed]];
+        uh = std::max(uh, hgt[edge_cons_cell[ed]] + 1);
+    }
+    std::vector<int> lag(ts, 0), ghost_lag(ts, 0), unit_p(nunit, 1), unit_lmax(nunit, 0), unit_glmax(nunit, 0);
+    std::vector<unsigned> ent2((size_t)2 * SK_P * ts, SK_ZERO);
+    for (int u = 0; u < nunit; ++u) unit_lmax[u] = (2 * unit_h[u] + 15) & ~15;
+    for (int c = 0; c < n; ++c) {
+        if (piece[c] < 0) continue;
+        const int u = unit_of_piece[piece[c]];
+        const int64_t slot = (int64_t)u * LANES + slot_of_cell[c];
+        lag[slot] = unit_lmax[u] - 2 * hgt[c];
+        int npre = 0, npost = 0;
+        bool past = false;
+        for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {
+            const int src = indices[j];
+            if (src == c) {
+                past = true;
+                continue;
+            }
+            unsigned off;
+            if (piece[src] >= 0 && unit_of_piece[piece[src]] == u) off = (unsigned)slot_of_cell[src] * 16u;
+            else off = (unsigned)(LANES + edge_ghost[edge_of_prod[src]]) * 16u;
+            int &k = past ? npost : npre;
+            if (k >= SK_P) {
+                skew_ok = false;
+                continue;
+            }
+            ent2[(size_t)((past ? SK_P : 0) + k) * ts + slot] = off;
+            ++k;
+        }
+        unit_p[u] = std::max(unit_p[u], std::max(npre, npost));
+    }
+    for (int ed = 0; ed < nedge; ++ed) {
+        const int u = edge_cons_unit[ed];
+        const int gl = unit_lmax[u] - 2 * (hgt[edge_cons_cell[ed]] + 1);
+        ghost_lag[(int64_t)u * LANES + edge_ghost[ed]] = gl;
+        unit_glmax[u] = std::max(unit_glmax[u], gl);
+    }
+
+    std::vector<int> unit_exp(nunit, 0);
+    for (int ed = 0; ed < nedge; ++ed) unit_exp[unit_of_piece[piece[edge_prod_cell[ed]]]]++;
+    if (getenv("XH_FLOW_DEBUG")) {      // partition statistics on stderr
+        std::vector<int> hp(8, 0), hi(9, 0), hx(9, 0), hl(10, 0);
+        auto bucket = [](int v) { return v == 0 ? 0 : v <= 1 ? 1 : v <= 2 ? 2 : v <= 4 ? 3 : v <= 8 ? 4 : v <= 16 ? 5 : v <= 32 ? 6 : 7; };
+        for (int u = 0; u < nunit; ++u) {
+            hp[unit_p[u]]++;
+            hi[bucket(unit_imp_n[u])]++;
+            hx[bucket(unit_exp[u])]++;
+            hl[std::min(unit_lmax[u] / 16, 9)]++;
+        }
+        fprintf(stderr, "flow plan: %d units, %d pieces, %d edges, depth %d, skew_ok %d\n", nunit, npiece, nedge,
+                maxdepth + 1, (int)skew_ok);
+        fprintf(stderr, "  units by P (1..4):");
+        for (int k = 1; k <= 4; ++k) fprintf(stderr, " %d", hp[k]);
+        fprintf(stderr, "\n  units by imports (0,1,2,<=4,<=8,<=16,<=32,more):");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", hi[k]);
+        fprintf(stderr, "\n  units by exports (0,1,2,<=4,<=8,<=16,<=32,more):");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", hx[k]);
+        fprintf(stderr, "\n  units by lmax/16 (0..9+):");
+        for (int k = 0; k < 10; ++k) fprintf(stderr, " %d", hl[k]);
+        fprintf(stderr, "\n");
+    }
+
     FlowPlan *fp = new FlowPlan();
+    fp->skew_ok = skew_ok;
+    fp->skew_lmax = *std::max_element(unit_lmax.begin(), unit_lmax.end());
     fp->n_units = nunit;
     fp->n_edges = nedge;
     fp->depth = maxdepth + 1;
     fp->n_cells = (int)std::count(handled.begin(), handled.end(), (char)1);
     fp->max_imports = *std::max_element(unit_imp_n.begin(), unit_imp_n.end());
+    fp->max_exports = *std::max_element(unit_exp.begin(), unit_exp.end());
     int rc = put(ctx, fp->d_cell_of_slot, cell_of_slot);
     rc |= put(ctx, fp->d_ent, ent);
     rc |= put(ctx, fp->d_export_edge, export_edge);
     rc |= put(ctx, fp->d_ghost_edge, ghost_edge);
     rc |= put(ctx, fp->d_edge_cons_unit, edge_cons_unit);
     rc |= put(ctx, fp->d_unit_terms, unit_terms);
+    rc |= put(ctx, fp->d_lag, lag);
+    rc |= put(ctx, fp->d_ghost_lag, ghost_lag);
+    rc |= put(ctx, fp->d_ent2, ent2);
+    rc |= put(ctx, fp->d_unit_p, unit_p);
+    rc |= put(ctx, fp->d_unit_lmax, unit_lmax);
+    rc |= put(ctx, fp->d_unit_glmax, unit_glmax);
     if (rc) {
         flow_plan_destroy(fp);
         return XH_ERR_HIP;

@@ -1,0 +1,504 @@
+// MRTM routing, time-skewed inside each single-wave unit (gfx950).
+//
+// xh_mrtm_flow.hip removed the workgroup barriers from the sub-step but kept its two LDS round trips: write the flows,
+// read the neighbours' back, sum, and -- when a cell fired (mrtm.py:56-76) -- write the adjusted flows and read them
+// again.  A lone wave waits out every one of those trips, and a unit with a cell that fires most sub-steps (channel
+// shorter than velocity x dt) pays both, ~750 cycles per sub-step; the slowest unit paces the whole chip.
+//
+// The dependency only points downstream, so the lanes of a unit need not be at the same sub-step.  Here a cell `h`
+// edges above its piece's outlet runs 2 (H - h) sub-steps behind the unit's clock: at iteration n it integrates
+// sub-step n - lag.  Everything a cell gathers at iteration n -- the trial flow F AND the adjusted flow F2 of each
+// upstream neighbour, for that same sub-step -- was then written to LDS two iterations earlier, as one 16-byte pair:
+//   - LDS holds a ring of 8 slots (iteration mod 8) of {F, F2} pairs: 64 cells, 64 imported streams ("ghosts"), one
+//     zero;
+//   - the reads for iteration n + 1 are issued at the top of iteration n, a whole iteration ahead of their use, so no
+//     LDS latency sits on the critical path, and both sums of mrtm.py (first with F, second with F2) come from the
+//     same registers: the "fired" path costs one more chain of adds instead of a second round trip;
+//   - the own term -F (the diagonal of UM = UP - I) is taken from registers; the row is summed in its stored order as
+//     [terms before the diagonal] - F [terms after], each side padded with +0.0 (an accumulator that started at +0.0
+//     is never -0.0, so the padding cannot change a bit).  Every operation and its order match scipy's CSR mat-vec,
+//     so results stay bit-identical to numpy/scipy.
+// What remains per sub-step is the recurrence itself (~15 dependent fp64 operations) and ~40 instructions of issue.
+//
+// Streams between units are rings of RS sub-steps indexed by the global sub-step (not by month) and move in blocks
+// of 8 sub-steps, once per 8 iterations, by the whole wave: lane (k, i) stores sub-step i of the unit's k-th outlet
+// from the LDS ring (128 contiguous bytes per outlet), and loads sub-step i of its k-th import two blocks ahead of
+// dropping it into the ghost entries of the ring.  Producers publish and consumers acquire every CH iterations
+// (counters in sub-steps).  Months only matter to a lane when it crosses one: the iterations [G, G + lmax] after the
+// unit's clock passes a month start G run a variant of the loop in which the lanes whose lag puts them on the
+// boundary snapshot their month-end state and pick up the next month's lateral inflow; the month's outputs are
+// formed once, for all lanes, after the last lane has crossed.
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+
+#include "xh_mrtm_flow.h"
+
+namespace {
+
+constexpr int LANES = 64;
+constexpr int SK_P = 4;                       // row terms either side of the diagonal (D8: 4 smaller, 4 larger ids)
+constexpr int NSLOT = 2 * LANES + 1;          // pairs per LDS slot: cells, ghosts, constant zero
+constexpr unsigned SLOTB = NSLOT * 16u;
+constexpr int RING = 8;                       // LDS slots = sub-steps per stream block
+constexpr int GROUP = 16;                     // sub-steps per unrolled group (two blocks)
+constexpr int SK_R = 2;                       // block-transfer rounds: up to 8 * SK_R imports / outlets per unit
+constexpr int CH = 128;                       // iterations between flow-control checks (multiple of GROUP)
+constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2;
+constexpr unsigned long long SPIN_LIMIT_TICKS = 2000000000ull;   // 20 s of the 100 MHz real-time counter
+
+struct SkewArgs {
+    const int *cell_of_slot, *lag, *ghost_lag, *export_edge, *ghost_edge, *edge_cons_unit;
+    const unsigned *ent2;             // [2][SK_P][units*64] LDS byte offsets inside a slot (before / after the diagonal)
+    const int *unit_p, *unit_lmax, *unit_glmax;
+    int64_t total_slots;
+    int nmonths, nit, total;
+    const int *sched_m, *sched_nt, *sched_g;
+    const double *sched_secs;
+    const unsigned char *sched_write;
+    double dt, dtinv;
+    const double *flow_dist, *velocity, *area, *runoff, *S0;
+    double *chs, *avg, *S_end, *F_end;
+    char *xbuf;                       // [edges][RS] {F, F2}
+    unsigned xbytes;                  // size of the rings
+    unsigned ring_mask_b;             // RS * 16 - 1
+    int rs;                           // RS
+    unsigned *ready;                  // [edges] sub-steps published
+    unsigned *done;                   // [units] sub-steps consumed
+    unsigned *fault;
+    unsigned long long *stats;
+};
+
+__device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Lanes with `need` wait until *p >= target (per lane).  False (and the fault word raised) on timeout / fault.
+__device__ __forceinline__ bool wave_wait_ge(bool need, const unsigned *p, unsigned target, unsigned *fault,
+                                             unsigned code) {
+    bool ok = !need;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        if (!ok) ok = ld_relaxed(p) >= target;
+        if (__all(ok)) return true;
+        if (ld_relaxed(fault) != 0) return false;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
+            __hip_atomic_store(fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr int AUX_SC1 = 16;                   // raw-buffer cache policy: agent-coherent (write-through / re-fetching)
+typedef __attribute__((address_space(3))) const char lds_cchar;
+typedef __attribute__((address_space(3))) const v2d lds_cd2;
+typedef __attribute__((address_space(3))) v2d lds_d2;
+
+template <int P, bool HAS_G>
+__device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xtab) {
+    lds_cchar *lds0 = (lds_cchar *)lds;
+    const int lane = threadIdx.x, unit = blockIdx.x;
+    const int64_t slot = (int64_t)unit * LANES + lane;
+
+    const int gc = a.cell_of_slot[slot];
+    const bool valid = gc >= 0;
+    const double tauinv = valid ? a.velocity[gc] / a.flow_dist[gc] : 0.0;      // mrtm.py:40
+    const double area = valid ? a.area[gc] : 0.0;
+    const double S0v = (valid && a.S0) ? a.S0[gc] : 0.0;
+    lds_cchar *epre[P], *epost[P];
+#pragma unroll
+    for (int w = 0; w < P; ++w) {
+        epre[w] = lds0 + a.ent2[(int64_t)w * a.total_slots + slot];
+        epost[w] = lds0 + a.ent2[(int64_t)(SK_P + w) * a.total_slots + slot];
+    }
+    lds_d2 *own = (lds_d2 *)lds + lane;
+    const int xedge = a.export_edge[slot];
+    const int gedge = a.ghost_edge[slot];
+    const bool has_x = xedge >= 0, has_g = gedge >= 0;
+    const unsigned long long xmask = __ballot(has_x), gmask = __ballot(has_g);
+    const bool any_x = xmask != 0, any_g = HAS_G;
+    const int nx_out = __popcll(xmask), ng = __popcll(gmask);       // outlets / imports of this unit
+    const int lmax = a.unit_lmax[unit], glmax = a.unit_glmax[unit];
+    const int lag_g = has_g ? a.ghost_lag[slot] : 0;
+    const unsigned *ready_p = a.ready + (has_g ? gedge : 0);
+    const unsigned *done_p = a.done + (has_x ? a.edge_cons_unit[xedge] : 0);
+    const unsigned maskb = a.ring_mask_b;
+    // The streams are read and written through a buffer resource with the agent-coherent cache policy: stores write
+    // through to memory (whole 128-byte lines per outlet and block), loads re-fetch.  No release / acquire fence is
+    // needed around the counters -- an agent-scope release writes back the whole L2 of the XCD and was measured to slow
+    // every unit on it, importing or not, by ~10 %.
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
+    const int total = a.total, nit = a.nit;
+
+    // ---- block-transfer roles: lane (k = lane / 8 + 8 r, i = lane % 8) moves sub-step i of outlet / import k
+    if (has_x) xtab[__popcll(xmask & ((1ull << lane) - 1ull))] = make_uint2((unsigned)lane, (unsigned)xedge);
+    const int sub = lane & 7, grp = lane >> 3;
+    const int nxr = (nx_out + 7) >> 3;
+    unsigned gbyte[SK_R], xbyte[SK_R];      // byte offset of the ring (+ 16 i for stores)
+    int glag[SK_R];
+    bool gon[SK_R], xon[SK_R];
+    lds_d2 *gdst[SK_R];
+    lds_cd2 *xsrc[SK_R];
+#pragma unroll
+    for (int r = 0; r < SK_R; ++r) {
+        const int k = r * 8 + grp;
+        gon[r] = k < ng;
+        const int ge = gon[r] ? a.ghost_edge[(int64_t)unit * LANES + k] : 0;
+        glag[r] = gon[r] ? a.ghost_lag[(int64_t)unit * LANES + k] : 0;
+        gbyte[r] = (unsigned)ge * (maskb + 1u);
+        gdst[r] = (lds_d2 *)lds + sub * NSLOT + LANES + (k & 63);
+        xon[r] = k < nx_out;
+        const uint2 t = xon[r] ? xtab[k] : make_uint2(0u, 0u);
+        xbyte[r] = t.y * (maskb + 1u) + (unsigned)sub * 16u;
+        xsrc[r] = (lds_cd2 *)lds + sub * NSLOT + t.x;
+    }
+
+#pragma unroll
+    for (int k = 0; k < RING; ++k) {
+        own[k * NSLOT] = v2d{0.0, 0.0};
+        own[k * NSLOT + LANES] = v2d{0.0, 0.0};
+        if (lane == 0) own[k * NSLOT + 2 * LANES] = v2d{0.0, 0.0};
+    }
+
+    const double dt = a.dt, dtinv = a.dtinv;
+    double S = 0.0, F = 0.0, favg = 0.0, erl = 0.0;
+    double snapS = 0.0, snapA = 0.0, snapF = 0.0;
+    int nx = a.lag[slot];                                  // iteration at which this lane enters its next month
+    double erl_n = 0.0, qn = 0.0;                          // lateral inflow of the month to enter / runoff after that
+    {
+        const double q0 = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[0]] : 0.0;
+        erl_n = (q0 * area) * 1000.0 / a.sched_secs[0];                        // mrtm.py:45
+        if (nit > 1) qn = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[1]] : 0.0;
+    }
+    double ob_s[8], ob_a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ob_s[j] = ob_a[j] = 0.0;
+    bool alive = true;
+    unsigned long long cyc_wait_data = 0, cyc_wait_ring = 0, zone_groups = 0;
+    const unsigned long long cyc_begin = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+
+    // ---- flow control, every CH iterations (at a group start: the blocks before n - 8 have been stored)
+    auto check = [&](int n) {
+        const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+        if (any_x) {      // publish the sub-steps stored so far, then make sure the next CH iterations have ring space
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // write-through stores acknowledged
+            const int pub = min(max(n - RING - lmax, 0), total);
+            if (has_x) __hip_atomic_store(a.ready + xedge, (unsigned)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int need = n + CH - lmax - a.rs;
+            if (need > 0) alive = wave_wait_ge(has_x, done_p, (unsigned)min(need, total), a.fault, FAULT_RING_WAIT);
+        }
+        const unsigned long long w1 = __builtin_amdgcn_s_memtime();
+        if (any_g && alive) {   // the next CH iterations load up to sub-step n + CH + GROUP - 1 - lag_g
+            if (lane == 0)    // every import has been consumed up to n - glmax
+                __hip_atomic_store(a.done + unit, (unsigned)min(max(n - glmax, 0), total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            const int need = min(total, n + CH + GROUP - lag_g);
+            alive = wave_wait_ge(has_g && need > 0, ready_p, (unsigned)max(need, 0), a.fault, FAULT_DATA_WAIT);
+            asm volatile("" ::: "memory");      // the stream loads stay behind the poll
+        }
+        cyc_wait_ring += w1 - w0;
+        cyc_wait_data += __builtin_amdgcn_s_memtime() - w1;
+    };
+
+    // ---- month bookkeeping for all lanes at once: outputs of iteration it - 1, lateral inflow of iteration it + 1
+    auto finalize = [&](int it) {
+        if (it >= 1) {
+            const int m = a.sched_m[it - 1], ntp = a.sched_nt[it - 1];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                ob_s[j] = ob_s[j + 1];
+                ob_a[j] = ob_a[j + 1];
+            }
+            ob_s[7] = snapS;
+            ob_a[7] = snapA / (double)ntp;                                     // mrtm.py:80
+            if (a.sched_write[it - 1] && valid) {     // whole 64-byte groups of 8 months per cell
+                if ((m & 7) == 7) {
+                    const int64_t o = (int64_t)gc * a.nmonths + (m - 7);
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        if (a.chs) *reinterpret_cast<v2d *>(a.chs + o + j) = v2d{ob_s[j], ob_s[j + 1]};
+                        if (a.avg) *reinterpret_cast<v2d *>(a.avg + o + j) = v2d{ob_a[j], ob_a[j + 1]};
+                    }
+                } else if (m == a.nmonths - 1) {                                // last, partial group
+                    const int r = (m & 7) + 1;
+                    const int64_t o = (int64_t)gc * a.nmonths + (m + 1 - r);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j >= 8 - r) {
+                            if (a.chs) a.chs[o + j - (8 - r)] = ob_s[j];
+                            if (a.avg) a.avg[o + j - (8 - r)] = ob_a[j];
+                        }
+                }
+            }
+        }
+        if (it + 1 < nit) erl_n = (qn * area) * 1000.0 / a.sched_secs[it + 1];
+        if (it + 2 < nit) qn = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[it + 2]] : 0.0;
+    };
+
+    // gathered pairs of the current sub-step (issued one iteration ago); import blocks in flight (two ahead)
+    v2d ac[P], bc[P], gbuf[2][SK_R];
+#pragma unroll
+    for (int w = 0; w < P; ++w) ac[w] = bc[w] = v2d{0.0, 0.0};
+    auto import_load = [&](int r, int m0) {      // sub-steps of the block that iterations m0 .. m0 + 7 will drop
+        const unsigned pos = ((unsigned)(m0 + sub - glag[r]) * 16u) & maskb;
+        return __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(xr, gbyte[r] | pos, 0, AUX_SC1));
+    };
+    // Block work of the sub-steps m0 = 0 (mod 8), after their gather reads: drop the import block of iterations
+    // m0 .. m0 + 7 into the ghost entries, load the block two ahead, store the outlets' block of m0 - 8 .. m0 - 1.
+    auto block_io = [&](int m0, const int b) {
+        if (HAS_G) {     // both rounds, unconditionally: lanes past the last import read (and ignore) ring 0
+#pragma unroll
+            for (int r = 0; r < SK_R; ++r) {
+                if (gon[r]) *gdst[r] = gbuf[b][r];
+                gbuf[b][r] = import_load(r, m0 + GROUP);
+            }
+        }
+        const unsigned xpos = ((unsigned)(m0 - RING - lmax) * 16u) & maskb;   // 8 sub-steps, never wrapping
+#pragma unroll
+        for (int r = 0; r < SK_R; ++r)
+            if (r < nxr) {
+                if (xon[r])
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, *xsrc[r]), xr, xbyte[r], xpos, AUX_SC1);
+            }
+    };
+
+    check(0);
+#pragma unroll
+    for (int r = 0; r < SK_R; ++r) {
+        gbuf[0][r] = HAS_G ? import_load(r, 0) : v2d{0.0, 0.0};
+        gbuf[1][r] = HAS_G ? import_load(r, RING) : v2d{0.0, 0.0};
+    }
+
+    const int N = (total + lmax + 1 + GROUP - 1) & ~(GROUP - 1);
+    int itz = 0, gz = 0;                 // month whose start zone [gz, gz + lmax] is next (itz == nit: the end zone)
+    int itf = 0, nf = (lmax + 1 + GROUP - 1) & ~(GROUP - 1);     // next month bookkeeping and its iteration
+    int ntz = nit > 0 ? a.sched_nt[0] : 0;
+
+    for (int n = 0; n < N && alive; n += GROUP) {
+        if (n > 0 && (n & (CH - 1)) == 0) {
+            check(n);
+            if (!alive) break;
+        }
+        if (n == nf) {
+            finalize(itf);
+            ++itf;
+            nf = itf <= nit ? ((a.sched_g[itf] + lmax + 1 + GROUP - 1) & ~(GROUP - 1)) : INT_MAX;
+        }
+        const bool zone = itz <= nit && n + GROUP > gz && n <= gz + lmax;
+
+        auto substep = [&](const int j, const bool in_zone) {
+            if (in_zone) {    // lanes crossing a month start (or starting / finishing the series) at this iteration
+                if (nx == n + j) {
+                    snapS = S;
+                    snapA = favg;
+                    snapF = F;
+                    favg = 0.0;
+                    erl = erl_n;
+                    if (itz == 0) S = S0v;
+                    nx = itz < nit ? nx + ntz : INT_MAX;
+                }
+            }
+            // pairs for the NEXT sub-step: produced during the previous iteration
+            v2d an[P], bn[P];
+#pragma unroll
+            for (int w = 0; w < P; ++w) {
+                an[w] = *(lds_cd2 *)(epre[w] + ((j + RING - 1) & (RING - 1)) * SLOTB);
+                bn[w] = *(lds_cd2 *)(epost[w] + ((j + RING - 1) & (RING - 1)) * SLOTB);
+            }
+            if ((j & (RING - 1)) == 0) block_io(n + j, j / RING);
+            const double F0 = S * tauinv;                                      // mrtm.py:50
+            double s1 = 0.0, s2 = 0.0;                                         // UM.dot(F), stored order (mrtm.py:51)
+#pragma unroll
+            for (int w = 0; w < P; ++w) {
+                s1 += ac[w].x;
+                s2 += ac[w].y;
+            }
+            s1 -= F0;
+#pragma unroll
+            for (int w = 0; w < P; ++w) s1 += bc[w].x;
+            const double dsdt = s1 + erl;
+            const bool sx = (dsdt * dt) < (-S);                                // mrtm.py:54
+            const double f2 = sx ? (dsdt + F0) + S * dtinv : F0;               // mrtm.py:60
+            own[(j & (RING - 1)) * NSLOT] = v2d{F0, f2};
+            // second sum with the adjusted flows (mrtm.py:66-69); equal to the first, bit for bit, when nothing it
+            // gathers was adjusted, which is the reference's "no cell fired" branch (mrtm.py:76)
+            s2 -= f2;
+#pragma unroll
+            for (int w = 0; w < P; ++w) s2 += bc[w].y;
+            const double dsdt2 = s2 + erl;
+            S = sx ? 0.0 : S + dsdt2 * dt;                                     // mrtm.py:63, 69
+            F = f2;
+            favg += f2;                                                        // mrtm.py:78
+#pragma unroll
+            for (int w = 0; w < P; ++w) {
+                ac[w] = an[w];
+                bc[w] = bn[w];
+            }
+        };
+
+        if (zone) {
+            ++zone_groups;
+#pragma unroll
+            for (int j = 0; j < GROUP; ++j) substep(j, true);
+            if (n + GROUP > gz + lmax) {      // every lane has crossed: next boundary
+                ++itz;
+                gz = itz <= nit ? a.sched_g[itz] : INT_MAX;
+                ntz = itz < nit ? a.sched_nt[itz] : 0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < GROUP; ++j) substep(j, false);
+        }
+    }
+    if (alive) {
+        while (itf <= nit) finalize(itf++);
+        if (any_x) {      // last block, then everything is published
+            const unsigned xpos = ((unsigned)(N - RING - lmax) * 16u) & maskb;
+#pragma unroll
+            for (int r = 0; r < SK_R; ++r)
+                if (r < nxr) {
+                    if (xon[r])
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, *xsrc[r]), xr, xbyte[r], xpos, AUX_SC1);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // write-through stores acknowledged
+            if (has_x) __hip_atomic_store(a.ready + xedge, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (any_g && lane == 0)
+            __hip_atomic_store(a.done + unit, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (valid) {
+            if (a.S_end) a.S_end[gc] = snapS;
+            if (a.F_end) a.F_end[gc] = snapF;
+        }
+    }
+    if (a.stats && lane == 0) {
+        unsigned long long *st = a.stats + (int64_t)unit * 6;
+        const unsigned long long cyc = __builtin_amdgcn_s_memtime() - cyc_begin;
+        st[0] = cyc - cyc_wait_data - cyc_wait_ring;
+        st[1] = cyc;
+        st[2] = __builtin_amdgcn_s_memrealtime() - rt_begin;
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
+        st[3] = (unsigned long long)(2 * P + 1) | (any_g ? 16u : 0u) | (any_x ? 32u : 0u) |
+                ((unsigned long long)hw << 8) | ((unsigned long long)(xcc & 15u) << 40) | (zone_groups << 44);
+        st[4] = cyc_wait_data;
+        st[5] = cyc_wait_ring;
+    }
+}
+
+// Two waves per SIMD must fit (1,121 units of the 67,420-cell grid on 1,024 SIMDs): at most 256 registers.
+__global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mrtm_skew(SkewArgs a) {
+    __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
+    __shared__ uint2 xtab[LANES];
+    const int p = a.unit_p[blockIdx.x];             // uniform per workgroup
+    const bool g = __any(a.ghost_edge[(int64_t)blockIdx.x * LANES + threadIdx.x] >= 0);
+    if (g) {
+        if (p <= 1) skew_unit<1, true>(a, lds, xtab);
+        else if (p == 2) skew_unit<2, true>(a, lds, xtab);
+        else if (p == 3) skew_unit<3, true>(a, lds, xtab);
+        else skew_unit<4, true>(a, lds, xtab);
+    } else {
+        if (p <= 1) skew_unit<1, false>(a, lds, xtab);
+        else if (p == 2) skew_unit<2, false>(a, lds, xtab);
+        else if (p == 3) skew_unit<3, false>(a, lds, xtab);
+        else skew_unit<4, false>(a, lds, xtab);
+    }
+}
+
+}  // namespace
+
+int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st) {
+    if (!fp || fp->n_units == 0) return XH_OK;
+    // a lane must have left month it - 1 before the unit's clock reaches month it + 1 (one pending snapshot per lane)
+    if (!fp->skew_ok || fp->max_imports > 8 * SK_R || fp->max_exports > 8 * SK_R || s.ntmin < fp->skew_lmax + 2 * GROUP)
+        return XH_ERR_LIMIT;
+    // ring: a consumer asks for ~2 CH + lag sub-steps ahead of its clock, a producer may run RS - CH - lag ahead
+    int rs = 2048;
+    while (rs < 8 * CH + 4 * fp->skew_lmax) rs *= 2;
+    const size_t x_streams = (size_t)std::max(fp->n_edges, 1) * (size_t)rs * sizeof(v2d);
+    if (x_streams >= ((size_t)1 << 32)) return XH_ERR_LIMIT;      // 32-bit ring offsets
+    const size_t x_cnt = ((size_t)(fp->n_edges + fp->n_units) * sizeof(unsigned) + 255) & ~size_t(255);
+    if (x_streams + x_cnt > fp->x_bytes) {
+        if (fp->d_x) {
+            XH_HIP(ctx, hipStreamSynchronize(st));
+            XH_HIP(ctx, hipFree(fp->d_x));
+            fp->d_x = nullptr;
+        }
+        XH_HIP(ctx, hipMalloc(&fp->d_x, x_streams + x_cnt));
+        fp->x_bytes = x_streams + x_cnt;
+    }
+    unsigned *cnt = reinterpret_cast<unsigned *>(static_cast<char *>(fp->d_x) + x_streams);
+    XH_HIP(ctx, hipMemsetAsync(cnt, 0, x_cnt, st));
+
+    // every unit resident at once: see flow_launch for the LDS-share sizing (one workgroup more than the even split)
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    int per_cu = (fp->n_units + cus - 1) / cus + 1;
+    {
+        const char *env = getenv("XH_FLOW_PER_CU_EXTRA");     // experiments only
+        if (env) per_cu += atoi(env);
+    }
+    const size_t lds_static = (size_t)RING * NSLOT * sizeof(v2d) + LANES * sizeof(uint2);
+    const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
+    size_t lds = share > lds_static + 1024 ? share - lds_static : 0;
+    XH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mrtm_skew), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    int resident = 0;
+    XH_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k_mrtm_skew, LANES, lds));
+    if ((int64_t)(resident - 1) * cus < fp->n_units) return XH_ERR_LIMIT;
+
+    SkewArgs a;
+    a.cell_of_slot = static_cast<const int *>(fp->d_cell_of_slot.p);
+    a.lag = static_cast<const int *>(fp->d_lag.p);
+    a.ghost_lag = static_cast<const int *>(fp->d_ghost_lag.p);
+    a.export_edge = static_cast<const int *>(fp->d_export_edge.p);
+    a.ghost_edge = static_cast<const int *>(fp->d_ghost_edge.p);
+    a.edge_cons_unit = static_cast<const int *>(fp->d_edge_cons_unit.p);
+    a.ent2 = static_cast<const unsigned *>(fp->d_ent2.p);
+    a.unit_p = static_cast<const int *>(fp->d_unit_p.p);
+    a.unit_lmax = static_cast<const int *>(fp->d_unit_lmax.p);
+    a.unit_glmax = static_cast<const int *>(fp->d_unit_glmax.p);
+    a.total_slots = (int64_t)fp->n_units * LANES;
+    a.nmonths = s.nmonths;
+    a.nit = s.nit;
+    a.total = s.total;
+    a.sched_m = s.d_m;
+    a.sched_nt = s.d_nt;
+    a.sched_g = s.d_g;
+    a.sched_secs = s.d_secs;
+    a.sched_write = s.d_wr;
+    a.dt = s.dt;
+    a.dtinv = 1.0 / s.dt;
+    a.flow_dist = io.flow_dist;
+    a.velocity = io.velocity;
+    a.area = io.area;
+    a.runoff = io.runoff;
+    a.S0 = io.S0;
+    a.chs = io.chs;
+    a.avg = io.avg;
+    a.S_end = io.S_end;
+    a.F_end = io.F_end;
+    a.xbuf = static_cast<char *>(fp->d_x);
+    a.xbytes = (unsigned)x_streams;
+    a.ring_mask_b = (unsigned)rs * 16u - 1u;
+    a.rs = rs;
+    a.ready = cnt;
+    a.done = cnt + fp->n_edges;
+    unsigned *fault = nullptr;
+    int rc = xh_fault_word(ctx, &fault);
+    if (rc) return rc;
+    a.fault = fault;
+    a.stats = nullptr;
+    {
+        const char *env = getenv("XH_FLOW_STATS");
+        if (env && env[0] == '1') {
+            if (!fp->d_stats) XH_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&fp->d_stats), (size_t)fp->n_units * 48));
+            a.stats = fp->d_stats;
+        }
+    }
+    hipLaunchKernelGGL(k_mrtm_skew, dim3((unsigned)fp->n_units), dim3(LANES), lds, st, a);
+    XH_HIP(ctx, hipGetLastError());
+    return XH_OK;
+}
