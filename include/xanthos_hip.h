@@ -119,8 +119,10 @@ void xh_route_plan_destroy(xh_route_plan *plan);
 /* info[0]=networks, [1]=largest network (cells), [2]=workgroup-per-network units, [3]=cells routed by the global
  * fallback, [4]=largest such unit (cells), [5]=padded slots, [6]=1 if every cell has one downstream cell,
  * [7]=dataflow units, [8]=stream edges between them, [9]=pipeline depth, [10]=cells routed by the dataflow kernel,
- * [11]=most imported streams of one unit */
-int xh_route_plan_info(const xh_route_plan *plan, int64_t info[12]);
+ * [11]=most imported streams of one unit, [12]=deepest lane lag of the time-skewed layout in sub-steps (-1: layout
+ * not available), [13]=kernel that routed the tree networks in the last xh_route_series call on this plan (0 none,
+ * 1 lock-step units with monthly streams, 2 time-skewed units), [14..15]=0 */
+int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]);
 
 /* Diagnostics: with XH_FLOW_STATS=1 in the environment the dataflow kernel records, per unit, {shader cycles inside the
  * sub-step loops, shader cycles total, 100 MHz ticks total, shape bits}; this call waits for the stream and copies

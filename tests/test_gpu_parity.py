@@ -122,7 +122,7 @@ def test_streamrouting_golden_bit_exact(hip, golden, tag, flags):
         assert np.array_equal(F, g['%s_F_%d' % (tag, nday)])
 
 
-@pytest.mark.parametrize('flags', [0, 4])       # dataflow units (default) / one workgroup per network
+@pytest.mark.parametrize('flags', [0, 8, 4])    # time-skewed units (default) / lock-step units / one workgroup per network
 @pytest.mark.parametrize('tag', ['rand', 'tree'])
 def test_route_series_golden_bit_exact(hip, golden, tag, flags):
     from xanthos_amd.routing import mrtm
@@ -147,7 +147,7 @@ def test_route_series_atomic_variant_close(hip, golden):
     close(chs, g[tag + '_series_chstorage'], rtol=1e-9, atol=1e-3)
 
 
-@pytest.mark.parametrize('flags', [0, 4])
+@pytest.mark.parametrize('flags', [0, 8, 4])
 def test_route_synthetic_world_vs_oracle(hip, flags):
     """A 3000-cell world with networks far larger than one unit, 14 months incl. spin-up: bit-exact both as
     dataflow units linked by streams (flags=0) and as one workgroup per network (flags=4)."""
@@ -171,6 +171,7 @@ def test_route_synthetic_world_vs_oracle(hip, flags):
     got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=flags)
     for a, b in zip(got, ref):
         assert np.array_equal(a, b, equal_nan=True)
+    assert um.plan(hip.get_context()).info()['last_tree_kernel'] == {0: 2, 8: 1, 4: 0}[flags]
 
 
 @pytest.mark.parametrize('basin', [0, 1])
@@ -219,7 +220,7 @@ def test_edge_sizes(hip):
     ndays = np.array([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31, 31])
     for spin in (0, 5):
         ref = o_mrtm.route_series(um.tocsr(), L, v, area, q, ndays, spin)
-        for flags in (0, 4, 1):
+        for flags in (0, 8, 4, 1):
             got = mrtm.route_series(um, L, v, area, q, ndays, spin, flags=flags)
             for a, b in zip(got, ref):
                 assert np.array_equal(a, b), (spin, flags)
@@ -267,9 +268,10 @@ def test_writer_aggregation_golden(hip, golden, tmp_path):
     assert np.array_equal(w2.get('q'), w.get('q'), equal_nan=True)
 
 
-@pytest.mark.parametrize('dt', [7200, 17280])
+@pytest.mark.parametrize('dt', [7200, 17280, 86400])
 def test_route_other_time_steps(hip, dt):
-    """Sub-step counts that are not a multiple of the 8-step stream prefetch (tail path), streams between units."""
+    """Sub-step counts that are not a multiple of the 8-step stream blocks, streams between units; with one sub-step a
+    day the months are shorter than the deepest lane lag and the default path must fall back to lock-step units."""
     from types import SimpleNamespace as NS
     from oracle import mrtm as o_mrtm
     from xanthos_amd import synth
@@ -281,10 +283,14 @@ def test_route_other_time_steps(hip, dt):
     ndays = np.array([31, 28, 31, 30, 31])
     assert any(int(d * 86400 / dt) % 8 for d in ndays)
     ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2, dt=dt)
-    for flags in (0, 4):
+    plan = um.plan(hip.get_context())
+    for flags in (0, 8, 4):
         got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, dt=dt, flags=flags)
         for a, b in zip(got, ref):
             assert np.array_equal(a, b), (dt, flags)
+        info = plan.info()
+        short = min(int(d * 86400 / dt) for d in ndays) < info['skew_max_lag'] + 32
+        assert info['last_tree_kernel'] == {0: 1 if short else 2, 8: 1, 4: 0}[flags], (dt, flags, info)
 
 
 def test_calibration_objective_multi_basin(hip, golden):

@@ -70,3 +70,14 @@ idx = np.argsort(-cps)[:10]
 print('slowest units: index, cyc/substep, shape(WU|16 imp|32 exp), waves on its SIMD, units on its CU')
 for i in idx:
     print(' ', i, round(cps[i]), shape[i], share[i], per_cu[cu_key[i]])
+# which units share a SIMD (placement of the blocks past the first 1024)
+order = np.argsort(simd_key, kind='stable')
+pairs = [(order[i], order[i + 1]) for i in range(len(order) - 1) if simd_key[order[i]] == simd_key[order[i + 1]]]
+print('units sharing a SIMD (first 24 pairs):', pairs[:24])
+lo = np.array([min(p) for p in pairs]); hi = np.array([max(p) for p in pairs])
+if len(pairs):
+    print('partner index: low min/max', lo.min(), lo.max(), ' high min/max', hi.min(), hi.max())
+wall = ticks / 1e5
+idx = np.argsort(-wall)[:10]
+print('longest unit walls (ms):', [(int(i), round(float(wall[i]), 2), int(shape[i]), int(share[i])) for i in idx])
+print('xcc of first 16 units', xcc[:16], 'cu', cu[:16], 'simd', simd[:16], 'se', se[:16])

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxanthos_hip.so')
 
-XH_ROUTE_DEFAULT, XH_ROUTE_FORCE_FALLBACK, XH_ROUTE_ATOMIC, XH_ROUTE_NO_DATAFLOW = 0, 1, 2, 4
+XH_ROUTE_DEFAULT, XH_ROUTE_FORCE_FALLBACK, XH_ROUTE_ATOMIC, XH_ROUTE_NO_DATAFLOW, XH_ROUTE_NO_SKEW = 0, 1, 2, 4, 8
 
 
 class HipUnavailable(RuntimeError):
@@ -337,10 +337,11 @@ class RoutePlan:
         self.handle = h.value
 
     def info(self):
-        arr = (c_int64 * 12)()
+        arr = (c_int64 * 16)()
         self.ctx._check(lib().xh_route_plan_info(self.handle, arr))
         keys = ('networks', 'largest_network', 'units', 'fallback_cells', 'largest_unit', 'slots', 'single_downstream',
-                'flow_units', 'flow_edges', 'flow_depth', 'flow_cells', 'flow_max_imports')
+                'flow_units', 'flow_edges', 'flow_depth', 'flow_cells', 'flow_max_imports', 'skew_max_lag',
+                'last_tree_kernel')
         return dict(zip(keys, list(arr)))
 
     def stats(self):

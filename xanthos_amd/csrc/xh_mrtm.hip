@@ -337,6 +337,7 @@ struct xh_route_plan {
     std::vector<int> rest_units[N_CLASS];        // only the units of networks the dataflow kernel does not route
     DevBuf d_rest_units[N_CLASS];
     FlowPlan *flow = nullptr;                    // tree-shaped networks as single-wave dataflow units
+    int last_tree_kernel = 0;                    // last xh_route_series: 0 none, 1 monthly streams, 2 time-skewed
     int64_t n_rest_units = 0, n_fb_rest = 0;
     bool fb_rest_single_ds = true;
     DevBuf d_fbr_cells, d_fbr_ptr, d_fbr_col, d_fbr_sgn, d_fbr_ds;
@@ -663,7 +664,7 @@ extern "C" void xh_route_plan_destroy(xh_route_plan *plan) {
     delete plan;
 }
 
-extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[12]) {
+extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
     if (!plan || !info) return XH_ERR_ARG;
     info[0] = plan->n_networks;
     info[1] = plan->largest_network;
@@ -679,6 +680,9 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[12]) {
     info[9] = fi[2];                  // pipeline depth
     info[10] = fi[3];                 // cells routed by the dataflow kernel
     info[11] = fi[4];                 // most imported streams of a unit
+    info[12] = (plan->flow && plan->flow->skew_ok) ? plan->flow->skew_lmax : -1;     // deepest lane lag (sub-steps)
+    info[13] = plan->last_tree_kernel;
+    info[14] = info[15] = 0;
     return XH_OK;
 }
 
@@ -749,6 +753,7 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
     xh_span sp = xh_span_begin(ctx, "mrtm_route");
     XH_HIP(ctx, hipEventRecord(plan->ev_fork, ctx->stream));
     int njoin = 0;
+    plan->last_tree_kernel = 0;
     if (use_flow) {     // tree-shaped networks: single-wave dataflow units on the context's own stream
         int ntmax = 0, ntmin = INT_MAX;
         for (int v : snt) {
@@ -760,10 +765,15 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
         // time-skewed units first; months shorter than the deepest lane lag (long dt) use the monthly-stream kernel
         static const bool skew_env = !(getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] == '0');
         rc = XH_ERR_LIMIT;
+        plan->last_tree_kernel = 2;
         if (skew_env && (flags & XH_ROUTE_NO_SKEW) == 0) rc = skew_launch(ctx, plan->flow, fs, fio, ctx->stream);
-        if (rc == XH_ERR_LIMIT) rc = flow_launch(ctx, plan->flow, fs, fio, ctx->stream);
+        if (rc == XH_ERR_LIMIT) {
+            plan->last_tree_kernel = 1;
+            rc = flow_launch(ctx, plan->flow, fs, fio, ctx->stream);
+        }
         if (rc == XH_ERR_LIMIT) {
             use_flow = false;   // units cannot all be resident on this device: one workgroup per network instead
+            plan->last_tree_kernel = 0;
         } else if (rc) {
             return rc;
         }

@@ -471,6 +471,54 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     const int nunit = (int)unit_cells_n.size();
     if (nunit == 0) return XH_OK;
 
+    // ---- unit numbering = workgroup id.  With more units than SIMDs some SIMDs hold two waves, and both then run
+    //      ~15 % slower; the slowest unit paces the run.  On MI355X workgroup k and workgroup (SIMDs + k) were
+    //      observed to land on the same SIMD (HW_ID of every unit, tools/flow_stats.py), so the cheapest units take
+    //      the first and the last (units - SIMDs) numbers and the expensive ones get a SIMD of their own.
+    {
+        const int simds = 4 * (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 0);
+        const int extra = nunit - simds;
+        if (simds > 0 && extra > 0 && 2 * extra <= nunit) {
+            std::vector<int> cost(nunit, 0), uexp(nunit, 0);
+            for (int p = 0; p < npiece; ++p)
+                if (ds[closed_roots[p]] >= 0) uexp[unit_of_piece[p]] = 1;
+            for (int c = 0; c < n; ++c) {
+                if (piece[c] < 0) continue;
+                int npre = 0, npost = 0;
+                bool past = false;
+                for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {
+                    if (indices[j] == c) past = true;
+                    else ++(past ? npost : npre);
+                }
+                int &k = cost[unit_of_piece[piece[c]]];             // longest pre side | longest post side << 8
+                k = std::max(k & 255, npre) | (std::max(k >> 8, npost) << 8);
+            }
+            for (int u = 0; u < nunit; ++u)                         // gathered terms dominate
+                cost[u] = 4 * ((cost[u] & 255) + (cost[u] >> 8)) + (unit_imp_n[u] > 0 ? 2 : 0) + uexp[u];
+            std::vector<int> by_cost(nunit);
+            std::iota(by_cost.begin(), by_cost.end(), 0);
+            std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) { return cost[x] < cost[y]; });
+            std::vector<int> newid(nunit, -1);
+            for (int k = 0; k < extra; ++k) {
+                newid[by_cost[2 * k]] = k;                          // cheapest 2 * extra units pair up
+                newid[by_cost[2 * k + 1]] = simds + k;
+            }
+            int next = extra;
+            for (int u = 0; u < nunit; ++u)                         // the rest keep their (depth) order
+                if (newid[u] < 0) newid[u] = next++;
+            for (int p = 0; p < npiece; ++p) unit_of_piece[p] = newid[unit_of_piece[p]];
+            std::vector<int> cn(nunit), in(nunit), dp(nunit);
+            for (int u = 0; u < nunit; ++u) {
+                cn[newid[u]] = unit_cells_n[u];
+                in[newid[u]] = unit_imp_n[u];
+                dp[newid[u]] = unit_depth[u];
+            }
+            unit_cells_n.swap(cn);
+            unit_imp_n.swap(in);
+            unit_depth.swap(dp);
+        }
+    }
+
     // ---- slots, ghosts, gather offsets
     const int64_t ts = (int64_t)nunit * LANES;
     std::vector<int> cell_of_slot(ts, -1), export_edge(ts, -1), ghost_edge(ts, -1), slot_of_cell(n, -1);
@@ -535,7 +583,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
         int &uh = unit_h[edge_cons_unit[ed]];
         uh = std::max(uh, hgt[edge_cons_cell[ed]] + 1);
     }
-    std::vector<int> lag(ts, 0), ghost_lag(ts, 0), unit_p(nunit, 1), unit_lmax(nunit, 0), unit_glmax(nunit, 0);
+    std::vector<int> lag(ts, 0), ghost_lag(ts, 0), unit_p(nunit, 0x11), unit_lmax(nunit, 0), unit_glmax(nunit, 0);
     std::vector<unsigned> ent2((size_t)2 * SK_P * ts, SK_ZERO);
     for (int u = 0; u < nunit; ++u) unit_lmax[u] = (2 * unit_h[u] + 15) & ~15;
     for (int c = 0; c < n; ++c) {
@@ -562,7 +610,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
             ent2[(size_t)((past ? SK_P : 0) + k) * ts + slot] = off;
             ++k;
         }
-        unit_p[u] = std::max(unit_p[u], std::max(npre, npost));
+        unit_p[u] = std::max(unit_p[u] & 15, npre) | (std::max(unit_p[u] >> 4, npost) << 4);
     }
     for (int ed = 0; ed < nedge; ++ed) {
         const int u = edge_cons_unit[ed];
@@ -574,10 +622,11 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     std::vector<int> unit_exp(nunit, 0);
     for (int ed = 0; ed < nedge; ++ed) unit_exp[unit_of_piece[piece[edge_prod_cell[ed]]]]++;
     if (getenv("XH_FLOW_DEBUG")) {      // partition statistics on stderr
-        std::vector<int> hp(8, 0), hi(9, 0), hx(9, 0), hl(10, 0);
+        std::vector<int> hp(8, 0), hi(9, 0), hx(9, 0), hl(10, 0), hpp(25, 0);
         auto bucket = [](int v) { return v == 0 ? 0 : v <= 1 ? 1 : v <= 2 ? 2 : v <= 4 ? 3 : v <= 8 ? 4 : v <= 16 ? 5 : v <= 32 ? 6 : 7; };
         for (int u = 0; u < nunit; ++u) {
-            hp[unit_p[u]]++;
+            hp[std::max(unit_p[u] & 15, unit_p[u] >> 4)]++;
+            hpp[(unit_p[u] & 15) * 5 + (unit_p[u] >> 4)]++;
             hi[bucket(unit_imp_n[u])]++;
             hx[bucket(unit_exp[u])]++;
             hl[std::min(unit_lmax[u] / 16, 9)]++;
@@ -586,6 +635,9 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                 maxdepth + 1, (int)skew_ok);
         fprintf(stderr, "  units by P (1..4):");
         for (int k = 1; k <= 4; ++k) fprintf(stderr, " %d", hp[k]);
+        fprintf(stderr, "\n  units by (pre, post) terms:");
+        for (int a = 1; a <= 4; ++a)
+            for (int b = 1; b <= 4; ++b) fprintf(stderr, " (%d,%d) %d", a, b, hpp[a * 5 + b]);
         fprintf(stderr, "\n  units by imports (0,1,2,<=4,<=8,<=16,<=32,more):");
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", hi[k]);
         fprintf(stderr, "\n  units by exports (0,1,2,<=4,<=8,<=16,<=32,more):");

@@ -97,7 +97,7 @@ typedef __attribute__((address_space(3))) const char lds_cchar;
 typedef __attribute__((address_space(3))) const v2d lds_cd2;
 typedef __attribute__((address_space(3))) v2d lds_d2;
 
-template <int P, bool HAS_G>
+template <int PRE, int POST, bool HAS_G>
 __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xtab) {
     lds_cchar *lds0 = (lds_cchar *)lds;
     const int lane = threadIdx.x, unit = blockIdx.x;
@@ -108,12 +108,11 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
     const double tauinv = valid ? a.velocity[gc] / a.flow_dist[gc] : 0.0;      // mrtm.py:40
     const double area = valid ? a.area[gc] : 0.0;
     const double S0v = (valid && a.S0) ? a.S0[gc] : 0.0;
-    lds_cchar *epre[P], *epost[P];
+    lds_cchar *epre[PRE], *epost[POST];
 #pragma unroll
-    for (int w = 0; w < P; ++w) {
-        epre[w] = lds0 + a.ent2[(int64_t)w * a.total_slots + slot];
-        epost[w] = lds0 + a.ent2[(int64_t)(SK_P + w) * a.total_slots + slot];
-    }
+    for (int w = 0; w < PRE; ++w) epre[w] = lds0 + a.ent2[(int64_t)w * a.total_slots + slot];
+#pragma unroll
+    for (int w = 0; w < POST; ++w) epost[w] = lds0 + a.ent2[(int64_t)(SK_P + w) * a.total_slots + slot];
     lds_d2 *own = (lds_d2 *)lds + lane;
     const int xedge = a.export_edge[slot];
     const int gedge = a.ghost_edge[slot];
@@ -240,9 +239,11 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
     };
 
     // gathered pairs of the current sub-step (issued one iteration ago); import blocks in flight (two ahead)
-    v2d ac[P], bc[P], gbuf[2][SK_R];
+    v2d ac[PRE], bc[POST], gbuf[2][SK_R];
 #pragma unroll
-    for (int w = 0; w < P; ++w) ac[w] = bc[w] = v2d{0.0, 0.0};
+    for (int w = 0; w < PRE; ++w) ac[w] = v2d{0.0, 0.0};
+#pragma unroll
+    for (int w = 0; w < POST; ++w) bc[w] = v2d{0.0, 0.0};
     auto import_load = [&](int r, int m0) {      // sub-steps of the block that iterations m0 .. m0 + 7 will drop
         const unsigned pos = ((unsigned)(m0 + sub - glag[r]) * 16u) & maskb;
         return __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(xr, gbyte[r] | pos, 0, AUX_SC1));
@@ -302,24 +303,27 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
                     nx = itz < nit ? nx + ntz : INT_MAX;
                 }
             }
-            // pairs for the NEXT sub-step: produced during the previous iteration
-            v2d an[P], bn[P];
+            // pairs for the NEXT sub-step: produced during the previous iteration.  The scheduling barriers keep the
+            // reads here, a whole sub-step ahead of the sums that consume them (left alone, the scheduler pulls the next
+            // sub-step's first adds up to ~15 instructions behind the reads and the wave waits out the LDS latency).
+            __builtin_amdgcn_sched_barrier(0);
+            v2d an[PRE], bn[POST];
 #pragma unroll
-            for (int w = 0; w < P; ++w) {
-                an[w] = *(lds_cd2 *)(epre[w] + ((j + RING - 1) & (RING - 1)) * SLOTB);
-                bn[w] = *(lds_cd2 *)(epost[w] + ((j + RING - 1) & (RING - 1)) * SLOTB);
-            }
+            for (int w = 0; w < PRE; ++w) an[w] = *(lds_cd2 *)(epre[w] + ((j + RING - 1) & (RING - 1)) * SLOTB);
+#pragma unroll
+            for (int w = 0; w < POST; ++w) bn[w] = *(lds_cd2 *)(epost[w] + ((j + RING - 1) & (RING - 1)) * SLOTB);
+            __builtin_amdgcn_sched_barrier(0);
             if ((j & (RING - 1)) == 0) block_io(n + j, j / RING);
             const double F0 = S * tauinv;                                      // mrtm.py:50
             double s1 = 0.0, s2 = 0.0;                                         // UM.dot(F), stored order (mrtm.py:51)
 #pragma unroll
-            for (int w = 0; w < P; ++w) {
+            for (int w = 0; w < PRE; ++w) {
                 s1 += ac[w].x;
                 s2 += ac[w].y;
             }
             s1 -= F0;
 #pragma unroll
-            for (int w = 0; w < P; ++w) s1 += bc[w].x;
+            for (int w = 0; w < POST; ++w) s1 += bc[w].x;
             const double dsdt = s1 + erl;
             const bool sx = (dsdt * dt) < (-S);                                // mrtm.py:54
             const double f2 = sx ? (dsdt + F0) + S * dtinv : F0;               // mrtm.py:60
@@ -328,16 +332,15 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
             // gathers was adjusted, which is the reference's "no cell fired" branch (mrtm.py:76)
             s2 -= f2;
 #pragma unroll
-            for (int w = 0; w < P; ++w) s2 += bc[w].y;
+            for (int w = 0; w < POST; ++w) s2 += bc[w].y;
             const double dsdt2 = s2 + erl;
             S = sx ? 0.0 : S + dsdt2 * dt;                                     // mrtm.py:63, 69
             F = f2;
             favg += f2;                                                        // mrtm.py:78
 #pragma unroll
-            for (int w = 0; w < P; ++w) {
-                ac[w] = an[w];
-                bc[w] = bn[w];
-            }
+            for (int w = 0; w < PRE; ++w) ac[w] = an[w];
+#pragma unroll
+            for (int w = 0; w < POST; ++w) bc[w] = bn[w];
         };
 
         if (zone) {
@@ -382,7 +385,7 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
         st[2] = __builtin_amdgcn_s_memrealtime() - rt_begin;
         const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
-        st[3] = (unsigned long long)(2 * P + 1) | (any_g ? 16u : 0u) | (any_x ? 32u : 0u) |
+        st[3] = (unsigned long long)(PRE + POST + 1) | (any_g ? 16u : 0u) | (any_x ? 32u : 0u) |
                 ((unsigned long long)hw << 8) | ((unsigned long long)(xcc & 15u) << 40) | (zone_groups << 44);
         st[4] = cyc_wait_data;
         st[5] = cyc_wait_ring;
@@ -393,19 +396,23 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
 __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mrtm_skew(SkewArgs a) {
     __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
     __shared__ uint2 xtab[LANES];
-    const int p = a.unit_p[blockIdx.x];             // uniform per workgroup
+    const int p = a.unit_p[blockIdx.x];             // uniform per workgroup: terms before | after the diagonal << 4
     const bool g = __any(a.ghost_edge[(int64_t)blockIdx.x * LANES + threadIdx.x] >= 0);
-    if (g) {
-        if (p <= 1) skew_unit<1, true>(a, lds, xtab);
-        else if (p == 2) skew_unit<2, true>(a, lds, xtab);
-        else if (p == 3) skew_unit<3, true>(a, lds, xtab);
-        else skew_unit<4, true>(a, lds, xtab);
-    } else {
-        if (p <= 1) skew_unit<1, false>(a, lds, xtab);
-        else if (p == 2) skew_unit<2, false>(a, lds, xtab);
-        else if (p == 3) skew_unit<3, false>(a, lds, xtab);
-        else skew_unit<4, false>(a, lds, xtab);
+    // one specialisation per (terms before, terms after, imports?): an LDS read costs a lone wave ~17 cycles of issue
+    // whatever its width (tools/micro/substep_cost.hip), so no unit should read padding it does not need
+#define SKEW_CASE(PRE, POST)                                  \
+    case (PRE) | ((POST) << 4):                               \
+        if (g) skew_unit<PRE, POST, true>(a, lds, xtab);      \
+        else skew_unit<PRE, POST, false>(a, lds, xtab);       \
+        break;
+    switch (p) {
+        SKEW_CASE(1, 1) SKEW_CASE(1, 2) SKEW_CASE(1, 3) SKEW_CASE(1, 4)
+        SKEW_CASE(2, 1) SKEW_CASE(2, 2) SKEW_CASE(2, 3) SKEW_CASE(2, 4)
+        SKEW_CASE(3, 1) SKEW_CASE(3, 2) SKEW_CASE(3, 3) SKEW_CASE(3, 4)
+        SKEW_CASE(4, 1) SKEW_CASE(4, 2) SKEW_CASE(4, 3)
+        default: if (g) skew_unit<4, 4, true>(a, lds, xtab); else skew_unit<4, 4, false>(a, lds, xtab);
     }
+#undef SKEW_CASE
 }
 
 }  // namespace
