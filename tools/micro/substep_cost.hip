@@ -24,10 +24,10 @@ __global__ void k(double *out, unsigned long long *cyc, double tauinv, double dt
         for (int j = 0; j < 8; ++j) {
             v2d an[3], bn[3];
             if (MODE >= 3) {
-                __builtin_amdgcn_sched_barrier(0);
+                if (MODE != 6) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int w = 0; w < 3; ++w) {
-                    if (MODE == 3 || w == 0) {
+                    if (MODE == 3 || MODE == 6 || w == 0) {
                         an[w] = e[w][((j + 7) & 7) * 129]; bn[w] = e[3 + w][((j + 7) & 7) * 129];
                     } else if (MODE == 4) {          // rare terms: only a few lanes read them
                         an[w] = bn[w] = v2d{0.0, 0.0};
@@ -37,7 +37,14 @@ __global__ void k(double *out, unsigned long long *cyc, double tauinv, double dt
                         bn[w].x = bn[w].y = ((__attribute__((address_space(3))) double *)e[3 + w])[((j + 7) & 7) * 258];
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (MODE != 6) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MODE == 6) {
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four VALU
+                }
             }
             const double F0 = S * tauinv;
             double s1 = 0.0, s2 = 0.0;
@@ -83,12 +90,13 @@ int main() {
     for (int i = 0; i < 6 * 64; ++i) hp[i] = (i * 37 + 11) % 128;
     (void)hipMalloc(&out, 64 * 8); (void)hipMalloc(&cyc, 8); (void)hipMalloc(&perm, sizeof(hp));
     (void)hipMemcpy(perm, hp, sizeof(hp), hipMemcpyHostToDevice);
-    const char *names[] = {"arithmetic only (20 fp64 ops)", "+ compare and 4 v_cndmask", "+ ds_write_b128", "+ 6 ds_read_b128 a sub-step ahead", "2 full ds_read_b128 + 4 on `nrare` lanes", "2 ds_read_b128 + 4 ds_read_b64"};
+    const char *names[] = {"arithmetic only (20 fp64 ops)", "+ compare and 4 v_cndmask", "+ ds_write_b128", "+ 6 ds_read_b128 a sub-step ahead", "2 full ds_read_b128 + 4 on `nrare` lanes", "2 ds_read_b128 + 4 ds_read_b64", "6 ds_read_b128 interleaved with the VALU work"};
 #define RUN(M) hipLaunchKernelGGL(k<M>, dim3(1), dim3(64), 0, 0, out, cyc, 1e-4, 10800.0, 1.0 / 10800.0, 1e-3, perm, nrare); (void)hipDeviceSynchronize(); \
     (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost); printf("%-40s %.1f cycles per sub-step\n", names[M], (double)h / (2048.0 * 8));
     int nrare = 0;
     RUN(0) RUN(1) RUN(2) RUN(3)
     for (nrare = 1; nrare <= 64; nrare *= 4) { printf("nrare=%d: ", nrare); RUN(4) }
     RUN(5)
+    RUN(6)
     return 0;
 }

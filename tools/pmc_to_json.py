@@ -15,7 +15,7 @@ def read(d):
     for f in glob.glob(d + '/*/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             name = r['Kernel_Name']
-            key = next((k for k in ('k_pm_pet', 'k_abcd<true>', 'k_abcd<false>', 'k_abcd_basin_mean', 'k_mrtm_flow',
+            key = next((k for k in ('k_pm_pet', 'k_abcd<true>', 'k_abcd<false>', 'k_abcd_basin_mean', 'k_mrtm_skew', 'k_mrtm_flow',
                                     'k_mrtm_units', 'k_synth') if k in name), None)
             if key:
                 agg[key].append(float(r['Counter_Value']))
