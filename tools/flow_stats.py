@@ -8,7 +8,8 @@ from xanthos_amd.pipeline import pipeline_from_world
 
 months = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 ctx = _hip.get_context(0)
-w = synth.make_world()
+ncell_env = int(os.environ.get('XH_STATS_NCELL', '67420'))
+w = synth.make_world(ncell=ncell_env, n_basins=max(1, 235 * ncell_env // 67420))
 pipe = pipeline_from_world(ctx, w, months, 1961, 60, 0)
 f = pipe.alloc_forcing()
 ctx.synth_forcing(1, pipe.ncell, pipe.nmonths, ctx.upload(w.latitude), f, nan_frac=0.0)
@@ -27,7 +28,7 @@ print('units', len(st), 'clock GHz median', np.median(clock))
 print('loop cycles/substep: median %.0f  p10 %.0f  p90 %.0f  max %.0f' % tuple(np.percentile(loop / nsub, [50, 10, 90, 100])))
 print('loop share of unit time: median %.2f min %.2f' % (np.median(loop / total), (loop / total).min()))
 print('unit wall ms: median %.2f max %.2f' % (np.median(ticks / 1e5), ticks.max() / 1e5))
-for wu in (3, 5, 7, 9):
+for wu in range(3, 10):
     for flag, name in ((0, 'isolated'), (16, 'imports'), (32, 'exports'), (48, 'both')):
         sel = ((shape & 15) == wu) & ((shape & 48) == flag)
         if sel.any():
@@ -81,3 +82,18 @@ wall = ticks / 1e5
 idx = np.argsort(-wall)[:10]
 print('longest unit walls (ms):', [(int(i), round(float(wall[i]), 2), int(shape[i]), int(share[i])) for i in idx])
 print('xcc of first 16 units', xcc[:16], 'cu', cu[:16], 'simd', simd[:16], 'se', se[:16])
+terms = shape & 15
+for k in sorted(set(per_cu[cu_key])):
+    for t in sorted(set(terms)):
+        sel = (per_cu[cu_key] == k) & (terms == t) & (share == 1)
+        if sel.sum() >= 3:
+            print('units on a CU holding %d, alone on their SIMD, %d terms+1: n=%3d loop cyc/substep median %.0f max %.0f' % (
+                k, t, sel.sum(), np.median(cps[sel]), cps[sel].max()))
+# block index -> CU: which blocks share a CU
+cu_blocks = {}
+for i, ck in enumerate(cu_key):
+    cu_blocks.setdefault(int(ck), []).append(i)
+five = [v for v in cu_blocks.values() if len(v) == 5][:6]
+four = [v for v in cu_blocks.values() if len(v) == 4][:6]
+print('blocks of some 5-unit CUs', five)
+print('blocks of some 4-unit CUs', four)
