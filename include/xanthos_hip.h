@@ -65,7 +65,7 @@ int xh_transpose(xh_ctx *ctx, const double *d_src, int64_t rows, int64_t cols, d
 
 /* HIP-event timing of the kernels each entry point launches, accumulated per kernel name on the context's stream.
  * Names: "pm_pet", "abcd_spinup", "abcd_basin_mean", "abcd_sim", "mrtm_route", "calib_abcd", "calib_kge",
- * "agg_time", "agg_spatial".  xh_timing_get waits for the stream, then returns total milliseconds and launch count. */
+ * "agg_time", "agg_spatial", "drought_thresh", "drought_stats".  xh_timing_get waits for the stream, then returns total milliseconds and launch count. */
 int xh_timing_reset(xh_ctx *ctx);
 int xh_timing_enable(xh_ctx *ctx, int on);
 int xh_timing_get(xh_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
@@ -178,7 +178,9 @@ int xh_calib_objective(xh_ctx *ctx, int64_t ncell_b, int32_t nmonths, int32_t sp
  * xh_agg_time replaces data_writer/out_writer.py:agg_to_year (:237-248) and the mm -> km3 scaling of write()
  * (:111-112): out[c, g] = f(in[c, g*group .. (g+1)*group)) x (d_scale ? d_scale[c] : 1), with f = NaN-skipping sum
  * (mode 0; an all-NaN block gives 0, as pandas does) or NaN-skipping mean (mode 1; all-NaN gives NaN).
- * group = 12 aggregates months to years; group = 1, mode 0 is a plain per-cell scaling (NaN kept).
+ * group = 12 aggregates months to years; group = 1, mode 0 is a plain per-cell scaling (NaN kept).  Mode 2 is
+ * np.sum over the block in numpy's own order (eight accumulators, NaN propagates): the yearly totals of
+ * accessible/accessible.py:41-42, bit for bit.
  * xh_agg_spatial replaces out_writer.py:agg_spatial (:250-265): out[k, t] = NaN-skipping sum over the cells with
  * h_group[c] == k (h_group is 0-based, -1 = cell not aggregated); groups without cells give NaN.            */
 int xh_agg_time(xh_ctx *ctx, int64_t ncell, int32_t ncols, int32_t group, int32_t mode, const double *d_scale,
@@ -188,6 +190,20 @@ int xh_agg_spatial(xh_ctx *ctx, int64_t ncell, int32_t ncols, int32_t n_groups, 
 /* Loader transform on the device: np.nan_to_num in place, as data_load.py applies to the PM forcings
  * and the ABCD tmin (:120-125, :194-195): NaN -> 0, +inf / -inf -> +/- largest finite double.                */
 int xh_nan_to_num(xh_ctx *ctx, double *d_arr, int64_t n);
+
+/* ------------------------------------------------------------------ drought statistics
+ * xh_drought_thresholds replaces drought/drought_stats.py:getthresh (:150-171) as called by calculate_thresholds
+ * (:69-83): for every cell and each of the nper periods of the year, the quantile over the nyear samples
+ * d_hydro[c, month0 + y*nper + p] (y < nyear), by numpy's "linear" method.  The caller passes what depends only on
+ * (nyear, q): the ranks k_prev / k_next of the two order statistics and the weight gamma = (nyear-1) q - k_prev
+ * (xanthos_amd/drought/drought_stats.py computes them the way numpy does).  A NaN sample gives a NaN threshold.
+ *   d_hydro [ncell, nmonths]; d_thresh out [nper, ncell] (the layout of the reference's thresholds file).
+ * xh_drought_stats replaces droughtstats (:85-148): severity / intensity / duration [ncell, nmonths] (any may be
+ * NULL) from d_hydro [ncell, nmonths] and d_thresh [nthresh, ncell]; month t uses threshold row t mod nthresh.   */
+int xh_drought_thresholds(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t month0, int32_t nyear, int32_t nper,
+                          int32_t k_prev, int32_t k_next, double gamma, const double *d_hydro, double *d_thresh);
+int xh_drought_stats(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t nthresh, const double *d_hydro,
+                     const double *d_thresh, double *d_severity, double *d_intensity, double *d_duration);
 
 /* The same objective for SEVERAL basins in one launch, each basin with its own population: one basin alone is only
  * months x ~1.7 us of dependent chain, far too little to fill the chip.  h_ncell [nbasins]; h_pars [nbasins, nmembers,

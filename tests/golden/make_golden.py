@@ -17,6 +17,9 @@ Fixtures written:
   mrtm.npz    streamrouting for 28/29/30/31-day months + Components.calculate_routing (3 spin-up + 5 months)
   kge.npz     objective_kge(basin_runoff) for 16 parameter vectors x 2 basins, both units, with / without tmin
   writer.npz  OutWriter.agg_to_year (sum / mean), mm -> km3 conversion, agg_spatial with an empty id and NaN cells
+  drought.npz DroughtStats.getthresh / calculate_thresholds (nper 1 and 12) and droughtstats (K = 1 and 12) on 80 cells
+              x 30 years with NaN, constant and zero-threshold cells
+  accessible.npz  AccessibleWater end to end (its csv) + RollingWindowFilter / QInGCAMYears / accessible_water pieces
 """
 import importlib.util
 import os
@@ -281,6 +284,85 @@ def golden_writer():
     print('writer.npz', ysum.shape, spatial.shape, int(np.isnan(spatial).sum()))
 
 
+# ----------------------------------------------------------------------------------------------------- drought
+def golden_drought():
+    """drought_stats.py:69-171 on a crafted [ntime, ngrid] series."""
+    from xanthos.drought.drought_stats import DroughtStats
+    rng = np.random.default_rng(707)
+    ncell, nyears = 80, 30
+    nm = nyears * 12
+    season = 1.0 + 0.6 * np.sin(np.arange(nm) * 2 * np.pi / 12)
+    hydro = rng.gamma(2.0, 20.0, (nm, ncell)) * season[:, None]      # [ntime, ngrid]
+    hydro[:, 3] = np.nan                    # a missing-data cell
+    hydro[37, 4] = np.nan                   # one NaN sample
+    hydro[:, 5] = 7.5                       # constant series: never strictly below its own quantile
+    hydro[:, 6] = 0.0                       # zero threshold -> division by zero never reached (0 < 0 is false)
+    hydro[:, 7] = np.round(hydro[:, 7] / 10.0) * 10.0    # many ties
+    out = dict(hydro=hydro, start_year=np.int64(1971))
+    st = bag(StartYear=1971, threshold_start_year=1975, threshold_end_year=1994, threshold_nper=12)
+    out['thresh12'] = DroughtStats.calculate_thresholds(hydro, st)
+    st1 = bag(StartYear=1971, threshold_start_year=1971, threshold_end_year=1990, threshold_nper=1)
+    out['thresh1'] = DroughtStats.calculate_thresholds(hydro, st1)
+    out['thresh12_q25'] = DroughtStats.getthresh(hydro[:240], 12, quantile=0.25)
+    out['thresh4_q50'] = DroughtStats.getthresh(hydro[:240], 4, quantile=0.5)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for tag in ('thresh12', 'thresh1'):
+            S, I, D = DroughtStats.droughtstats(None, hydro, out[tag])
+            out[tag + '_S'], out[tag + '_I'], out[tag + '_D'] = S, I, D
+    np.savez_compressed(os.path.join(HERE, 'drought.npz'), **out)
+    print('drought.npz', out['thresh12'].shape, float(np.nanmax(out['thresh12_D'])))
+
+
+# ----------------------------------------------------------------------------------------------------- accessible water
+def golden_accessible():
+    """accessible.py:25-152 end to end through temporary input files, plus its pieces."""
+    import tempfile
+    from xanthos.accessible import accessible as ref_acc
+    rng = np.random.default_rng(808)
+    ncell, nb, y0, y1 = 500, 9, 1971, 2010
+    nm = (y1 - y0 + 1) * 12
+    runoff = rng.gamma(2.0, 30.0, (ncell, nm))
+    runoff[11, :] = np.nan
+    runoff[12, 30] = np.nan                 # one NaN month: the whole cell-year drops out of the basin total
+    area = rng.uniform(800, 3100, ncell)
+    ids = rng.integers(0, nb + 1, ncell)    # 0 = no basin
+    ids[ids == 4] = 5                       # basin 4 has no cells
+    ids[0] = nb
+    names = np.array(['basin_%02d' % k for k in range(1, nb + 1)])
+    res = rng.uniform(0.0, 3.0, nb)
+    bfi = rng.uniform(0.2, 0.9, nb)
+    with tempfile.TemporaryDirectory() as d:
+        np.savetxt(os.path.join(d, 'res.csv'), res, fmt='%.17g')
+        with open(os.path.join(d, 'bfi.csv'), 'w') as fh:
+            fh.write('basin_id,bfi_avg\n')
+            for k in range(nb):
+                fh.write('%d,%.17g\n' % (k + 1, bfi[k]))
+        st = bag(ResCapacityFile=os.path.join(d, 'res.csv'), BfiFile=os.path.join(d, 'bfi.csv'), nmonths=nm, ncell=ncell,
+                 MovingMeanWindow=9, StartYear=y0, EndYear=y1, HistEndYear=2001, GCAM_StartYear=1975, GCAM_EndYear=2005,
+                 GCAM_YearStep=5, Env_FlowPercent=0.1, OutputFolder=d, OutputNameStr='gold')
+        ref = bag(basin_names=names, area=area, basin_ids=ids)
+        ref_acc.AccessibleWater(st, ref, runoff)
+        import pandas as pd                  # what the reference holds in memory: pandas' fast float parser is not
+        res_parsed = pd.read_csv(st.ResCapacityFile, header=None, names=['res_capacity']).values[:, 0]   # round-trip exact
+        bfi_parsed = pd.read_csv(st.BfiFile)['bfi_avg'].values
+        with open(st.ResCapacityFile) as fh:
+            res_text = fh.read()
+        with open(st.BfiFile) as fh:
+            bfi_text = fh.read()
+        with open(os.path.join(d, 'accessible_water_km3peryr_gold.csv')) as fh:
+            lines = fh.read().splitlines()
+    table = np.array([[float(v) for v in ln.split(',')[2:]] for ln in lines[1:]])
+    demo = rng.gamma(2.0, 5.0, (nb, 40))
+    out = dict(runoff=runoff, area=area, ids=ids, res=res_parsed, bfi=bfi_parsed, res_text=np.array(res_text),
+               bfi_text=np.array(bfi_text), table=table, header=np.array(lines[0]), csv=np.array(lines),
+               names=names, settings=np.array([y0, y1, 2001, 1975, 2005, 5, 9]), env_pct=np.float64(0.1), demo=demo,
+               demo_roll5=ref_acc.RollingWindowFilter(demo, 5), demo_roll9=ref_acc.RollingWindowFilter(demo, 9))
+    np.savez_compressed(os.path.join(HERE, 'accessible.npz'), **out)
+    print('accessible.npz', table.shape, lines[0])
+
+
 if __name__ == '__main__':
     import warnings
     warnings.simplefilter('ignore')
@@ -290,6 +372,8 @@ if __name__ == '__main__':
     golden_mrtm(topo, w)
     golden_kge()
     golden_writer()
+    golden_drought()
+    golden_accessible()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')

@@ -229,3 +229,37 @@ def test_calibrate_all_lockstep(example, tmp_path):
         assert kge > 0.98, (b, kge)
         assert np.load(str(tmp_path / 'kge_result_basin_{}.npy'.format(b)))[0] == kge
         assert np.load(str(tmp_path / 'abcdm_parameters_basin_{}.npy'.format(b))).shape == (1, 5)
+
+
+def test_run_model_with_post_processors(tmp_path):
+    """CalculateDroughtStats / CalculateAccessibleWater = 1 in the ini: the files the reference would write, with the
+    values the oracle gives for the run's own runoff (thresholds run, then the statistics run from its file)."""
+    import os
+    from oracle import accessible as o_ac, drought as o_dr
+    from xanthos_amd import Xanthos, synth
+    root = str(tmp_path)
+    w = synth.make_world(nrow=36, ncol=72, ncell=900, n_basins=7, seed=34)
+    f = synth.make_forcing(w, 72)
+    ini = synth.write_example(root, w, f, 1971, 1976, runoff_spinup=25, routing_spinup=6, post=True)
+    res = Xanthos(ini).execute()
+    out = os.path.join(root, 'output', 'pm_abcd_mrtm_synth')
+    th = np.load(os.path.join(out, 'drought_thresholds_pm_abcd_mrtm_synth.npy'))
+    assert np.array_equal(th, o_dr.calculate_thresholds(res.Q.T, 1971, 1971, 1976, 12), equal_nan=True)
+    import pandas as pd
+    acc = os.path.join(root, 'input', 'accessible')
+    cap = pd.read_csv(os.path.join(acc, 'total_reservoir_storage.csv'), header=None).values
+    bfi = pd.read_csv(os.path.join(acc, 'bfi_per_basin.csv'))['bfi_avg'].values
+    table, _ = o_ac.accessible_water(res.Q, res.data.area, res.data.basin_ids, bfi, cap, 1971, 1976, 1976, 1971, 1976, 1, 3, 0.1)
+    lines = open(os.path.join(out, 'accessible_water_km3peryr_pm_abcd_mrtm_synth.csv')).read().splitlines()
+    assert lines[0] == 'id,name,1971,1972,1973,1974,1975,1976' and lines[1].startswith('1,Basin 001,')
+    got = np.array([[float(v) for v in ln.split(',')[2:]] for ln in lines[1:]])
+    assert np.array_equal(got, table)
+    # second run: statistics from the thresholds file of the first
+    x = Xanthos(ini)
+    stats = x.execute({'drought_thresholds': os.path.join(out, 'drought_thresholds_pm_abcd_mrtm_synth.npy'),
+                       'CalculateAccessibleWater': 0, 'OutputFormat': 4})
+    S, I, D = o_dr.droughtstats(stats.Q.T, th)
+    for name, ref in (('severity', S), ('intensity', I), ('duration', D)):
+        got = np.load(os.path.join(out, 'drought_{}_pm_abcd_mrtm_synth.npy'.format(name)))
+        assert np.array_equal(got.T, ref)
+    assert D.max() >= 1

@@ -109,3 +109,39 @@ def test_lockstep_multi_basin_de_driver():
     assert np.allclose(x, targets, atol=6e-2) and (fun < 2e-2).all()
     assert seen[0] == (0, 1, 2) and all(set(a) <= {0, 1, 2} for a in seen)
     assert (nfev == 45 * (nit + 1)).all()
+
+
+def test_post_processor_ini_sections(tmp_path):
+    """[Drought] / [AccessibleWater] parsing and validation (ini_reader.py:460-486, :547-551); other post-processors
+    are rejected by name."""
+    from xanthos_amd import synth
+    from xanthos_amd.drought.drought_stats import quantile_plan
+    from xanthos_amd.ini_reader import ConfigReader, ValidationException, parse_ini
+    w = synth.make_world(nrow=24, ncol=48, ncell=300, n_basins=4, seed=2)
+    f = synth.make_forcing(w, 36)
+    ini = synth.write_example(str(tmp_path), w, f, 1971, 1973, runoff_spinup=25, routing_spinup=6, post=True)
+    c = ConfigReader(ini)
+    assert (c.CalculateDroughtStats, c.CalculateAccessibleWater) == (1, 1)
+    assert c.drought_var == 'q' and c.drought_thresholds is None and c.threshold_nper == 12
+    assert (c.threshold_start_year, c.threshold_end_year) == (1971, 1973)
+    assert c.ResCapacityFile.endswith('input/accessible/total_reservoir_storage.csv')
+    assert (c.GCAM_StartYear, c.GCAM_EndYear, c.GCAM_YearStep, c.MovingMeanWindow, c.Env_FlowPercent) == (1971, 1973, 1, 3, 0.1)
+    d = parse_ini(ini)
+    d['Drought']['threshold_end_year'] = '1990'
+    with pytest.raises(ValidationException, match='Drought threshold year range'):
+        ConfigReader(d)
+    d = parse_ini(ini)
+    d['AccessibleWater']['GCAM_StartYear'] = '1960'
+    with pytest.raises(ValidationException, match='outside the range of years'):
+        ConfigReader(d)
+    d = parse_ini(ini)
+    d['Project']['PerformDiagnostics'] = '1'
+    with pytest.raises(ValidationException, match='PerformDiagnostics'):
+        ConfigReader(d)
+    # numpy's linear quantile: (k_prev, k_next, weight) for the sample sizes the thresholds use
+    import numpy as np
+    for n, q in ((20, 0.1), (30, 0.1), (20, 0.25), (60, 0.5), (5, 0.1), (1, 0.1), (11, 1.0)):
+        k0, k1, g = quantile_plan(n, (q * 100) / 100.0)
+        x = np.sort(np.random.default_rng(n).normal(size=n))
+        lerp = x[k0] + (x[k1] - x[k0]) * g if g < 0.5 else x[k1] - (x[k1] - x[k0]) * (1 - g)
+        assert lerp == np.percentile(x, q * 100)

@@ -146,3 +146,33 @@ def test_writer_aggregation_matches_reference(golden):
     sp = o_writer.agg_spatial(o_writer.mm_to_km3(o_writer.agg_to_year(g['q'], 'sum'), g['area']), g['ids'], 8)
     assert np.allclose(sp, g['spatial'], rtol=1e-13, atol=0, equal_nan=True)
     assert np.isnan(sp[4]).all() and np.isnan(sp[7]).all()          # ids 5 and 8 have no cells
+
+
+def test_drought_matches_reference(golden):
+    """oracle/drought.py against DroughtStats.getthresh / calculate_thresholds / droughtstats of the reference."""
+    from oracle import drought as o_dr
+    g = golden('drought')
+    h = g['hydro']
+    y0 = int(g['start_year'])
+    assert np.array_equal(o_dr.calculate_thresholds(h, y0, 1975, 1994, 12), g['thresh12'], equal_nan=True)
+    assert np.array_equal(o_dr.calculate_thresholds(h, y0, 1971, 1990, 1), g['thresh1'], equal_nan=True)
+    assert np.array_equal(o_dr.getthresh(h[:240], 12, quantile=0.25), g['thresh12_q25'], equal_nan=True)
+    assert np.array_equal(o_dr.getthresh(h[:240], 4, quantile=0.5), g['thresh4_q50'], equal_nan=True)
+    for tag in ('thresh12', 'thresh1'):
+        S, I, D = o_dr.droughtstats(h, g[tag])
+        assert np.array_equal(S, g[tag + '_S']) and np.array_equal(I, g[tag + '_I']) and np.array_equal(D, g[tag + '_D'])
+    assert g['thresh12_D'].max() >= 5 and (g['thresh12_D'][:, 3] == 0).all()       # droughts occur; NaN cell has none
+
+
+def test_accessible_water_matches_reference(golden):
+    """oracle/accessible.py against the csv the reference's AccessibleWater wrote, and its moving mean."""
+    from oracle import accessible as o_ac
+    g = golden('accessible')
+    y0, y1, hist, g0, g1, step, window = (int(v) for v in g['settings'])
+    table, totals = o_ac.accessible_water(g['runoff'], g['area'], g['ids'], g['bfi'], g['res'].reshape(-1, 1), y0, y1, hist,
+                                          g0, g1, step, window, float(g['env_pct']))
+    assert table.shape == g['table'].shape
+    assert np.array_equal(table, g['table'])            # the csv holds shortest round-trip decimals (ndarray.astype(str))
+    assert (totals[3] == 0).all() and table.max() > 0   # basin 4 has no cells
+    assert np.array_equal(o_ac.rolling_mean_rows(g['demo'], 5), g['demo_roll5'])
+    assert np.array_equal(o_ac.rolling_mean_rows(g['demo'], 9), g['demo_roll9'])

@@ -68,6 +68,8 @@ SIGNATURES = {
     'xh_agg_time': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
     'xh_agg_spatial': (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
     'xh_nan_to_num': (c_int, [_P, _P, c_int64]),
+    'xh_drought_thresholds': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_double, _P, _P]),
+    'xh_drought_stats': (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     'xh_synth_forcing': (c_int, [_P, c_uint64, c_double, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
@@ -312,6 +314,14 @@ class Context:
         """In-place np.nan_to_num of a DeviceArray."""
         self._check(lib().xh_nan_to_num(self.handle, _dptr(arr), arr.size))
         return arr
+
+    def drought_thresholds(self, ncell, nmonths, month0, nyear, nper, k_prev, k_next, gamma, hydro, thresh):
+        self._check(lib().xh_drought_thresholds(self.handle, ncell, nmonths, month0, nyear, nper, k_prev, k_next,
+                                                float(gamma), _dptr(hydro), _dptr(thresh)))
+
+    def drought_stats(self, ncell, nmonths, nthresh, hydro, thresh, severity, intensity, duration):
+        self._check(lib().xh_drought_stats(self.handle, ncell, nmonths, nthresh, _dptr(hydro), _dptr(thresh),
+                                           _dptr(severity), _dptr(intensity), _dptr(duration)))
 
     # ---- bench support
     def synth_forcing(self, seed, ncell, nmonths, lat, out, nan_frac=0.001):

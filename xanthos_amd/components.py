@@ -139,6 +139,24 @@ class Components:
         pet_out = self.calculate_pet()
         calib_mod.calibrate_all(settings=self.s, data=self.data, pet=pet_out, router_function=self.calculate_routing)
 
+    def drought(self):
+        """Drought statistics of runoff or soil moisture (components.py:391-399)."""
+        if self.s.CalculateDroughtStats:
+            from .drought.drought_stats import DroughtStats
+            logging.info('---Start Drought Statistics:')
+            t0 = time.time()
+            DroughtStats(self.s, self.Q, self.Sav)
+            logging.info('---Drought Statistics has finished successfully: %s seconds ------' % (time.time() - t0))
+
+    def accessible_water(self):
+        """Accessible water per basin (components.py:401-409)."""
+        if self.s.CalculateAccessibleWater:
+            from .accessible.accessible import AccessibleWater
+            logging.info('---Start Accessible Water:')
+            t0 = time.time()
+            AccessibleWater(self.s, self.data, self.Q)
+            logging.info('---Accessible Water has finished successfully: %s seconds ------' % (time.time() - t0))
+
     def output_simulation(self):
         """Aggregate / convert on the device and write the selected variables (components.py:441-474)."""
         from .data_writer.out_writer import OutWriter

@@ -26,4 +26,6 @@ class ConfigRunner:
         c.simulation(run_pet=self.run_pet, run_runoff=self.run_runoff, run_routing=self.run_routing,
                      pet_num_steps=0, runoff_num_steps=0, routing_num_steps=0, notify='Simulation')
         c.output_simulation()
+        c.accessible_water()          # post-processors in the reference's order (configurations.py:117-124)
+        c.drought()
         return c

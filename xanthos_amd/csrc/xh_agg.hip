@@ -13,6 +13,29 @@
 
 namespace {
 
+// np.sum of n <= 128 contiguous doubles, in numpy's order (pairwise_sum of numpy/_core/src/umath/loops_utils.h.src,
+// numpy >= 1.9): fewer than 8 values are added left to right; otherwise eight accumulators take the values 8 at a
+// time, are combined as ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), and the remaining n % 8 values are added one by one.
+// NaN propagates (accessible.py:42 relies on that to drop whole cell-years).
+__device__ __forceinline__ double np_sum(const double *p, int n) {
+    if (n < 8) {
+        double r = 0.0;                       // numpy starts from the identity written to the output (-0.0 aside)
+        for (int i = 0; i < n; ++i) r += p[i];
+        return r;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = p[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += p[i + j];
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += p[i];
+    return 0.0 + res;                         // the reduction starts from the identity: -0.0 totals come out +0.0
+}
+
 // thread <-> (cell, group of `group` consecutive columns)
 __global__ void __launch_bounds__(256) k_agg_time(int64_t ncell, int ncols, int group, int mode,
                                                   const double *__restrict__ scale, const double *__restrict__ in,
@@ -34,6 +57,7 @@ __global__ void __launch_bounds__(256) k_agg_time(int64_t ncell, int ncols, int 
         }
         double r = mode == 0 ? sum : (cnt ? sum / (double)cnt : NAN);     // pandas: sum skips NaN (all-NaN -> 0), mean -> NaN
         if (group == 1 && mode == 0) r = p[0];                             // plain conversion keeps NaN
+        if (mode == 2) r = np_sum(p, group);                               // np.sum along a contiguous axis
         if (scale) r = r * scale[c];
         out[i] = r;
     }
@@ -83,7 +107,8 @@ extern "C" int xh_agg_time(xh_ctx *ctx, int64_t ncell, int32_t ncols, int32_t gr
     if (!ctx) return XH_ERR_ARG;
     XH_REQUIRE(ctx, d_in && d_out && ncell >= 0 && ncols > 0, "xh_agg_time: bad argument");
     XH_REQUIRE(ctx, group >= 1 && ncols % group == 0, "xh_agg_time: ncols (%d) is not a multiple of group (%d)", ncols, group);
-    XH_REQUIRE(ctx, mode == 0 || mode == 1, "xh_agg_time: mode must be 0 (sum) or 1 (mean)");
+    XH_REQUIRE(ctx, mode >= 0 && mode <= 2, "xh_agg_time: mode must be 0 (sum), 1 (mean) or 2 (numpy sum)");
+    XH_REQUIRE(ctx, mode != 2 || group <= 128, "xh_agg_time: numpy-order sums are implemented for blocks of <= 128 values");
     if (ncell == 0) return XH_OK;
     const int64_t total = ncell * (int64_t)(ncols / group);
     int64_t blocks = (total + 255) / 256;

@@ -64,6 +64,12 @@ class DataLoader:
         self.coords = np.asarray(load_file(s.Coord), dtype=float)
         self.basin_ids = np.asarray(load_file(s.BasinIDs, 1)).reshape(-1).astype(int)
         self.latitude = np.copy(self.coords[:, 2])
+        names = getattr(s, 'BasinNames', None)                   # one basin name per line (data_load.py:57, :366-368)
+        if names and os.path.isfile(names):
+            with open(names) as fh:
+                self.basin_names = np.array(fh.read().splitlines())
+        else:
+            self.basin_names = np.array(['basin_{}'.format(k) for k in range(1, s.n_basins + 1)])
 
         if s.pet_module == 'pm':
             et = np.asarray(load_file(s.pm_params), dtype=float)

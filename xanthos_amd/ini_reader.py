@@ -113,6 +113,19 @@ class ConfigReader:
         if self.mod_cfg == 'none_none_none':
             raise ValidationException('No PET, Runoff, or Routing model selected.')
         self.configure_reference_data()
+        # post-processors next to the hot path (ini_reader.py:85-98, 178-184)
+        if c.get('Drought') and self.CalculateDroughtStats:
+            self.configure_drought_stats(c['Drought'])
+        if c.get('AccessibleWater') and self.CalculateAccessibleWater:
+            if 'AccWatDir' not in p:
+                raise ValidationException('CalculateAccessibleWater = 1 needs AccWatDir in [Project].')
+            self.AccWatDir = os.path.join(self.InputFolder, p['AccWatDir'])
+            self.configure_acc_water(c['AccessibleWater'])
+        for flag in ('PerformDiagnostics', 'CreateTimeSeriesPlot', 'CalculateHydropowerPotential',
+                     'CalculateHydropowerActual'):
+            if getattr(self, flag):
+                raise ValidationException("{} = 1: this post-processor belongs to the reference's host-side modules and "
+                                          "is not part of this package.".format(flag))
         if self.calibrate:
             if 'Calibrate' not in c:
                 raise ValidationException('Calibrate = 1 but no [Calibrate] section.')
@@ -210,6 +223,37 @@ class ConfigReader:
             self.Area = os.path.join(self.Reference, 'Grid_Areas_ID.csv')
             self.Coord = os.path.join(self.Reference, 'coordinates.csv')
             self.BasinIDs = os.path.join(self.Reference, 'basin.csv')
+            self.BasinNames = os.path.join(self.Reference, 'BasinNames235.txt')
+
+    def configure_drought_stats(self, cfg):
+        """[Drought] (ini_reader.py:460-471)."""
+        self.drought_var = cfg['drought_var']
+        self.drought_thresholds = cfg.get('drought_thresholds')            # optional: thresholds file of an earlier run
+        if self.drought_thresholds is None:
+            self.threshold_nper = int(cfg['threshold_nper'])
+            self.threshold_start_year = int(cfg['threshold_start_year'])
+            self.threshold_end_year = int(cfg['threshold_end_year'])
+            if self.StartYear > self.threshold_start_year or self.EndYear < self.threshold_end_year:
+                raise ValidationException('Drought threshold year range is outside the output year range.')
+
+    def configure_acc_water(self, cfg):
+        """[AccessibleWater] (ini_reader.py:473-486)."""
+        self.ResCapacityFile = os.path.join(self.AccWatDir, cfg['ResCapacityFile'])
+        self.BfiFile = os.path.join(self.AccWatDir, cfg['BfiFile'])
+        self.HistEndYear = int(cfg['HistEndYear'])
+        self.GCAM_StartYear = self.ck_year(int(cfg['GCAM_StartYear']))
+        self.GCAM_EndYear = int(cfg['GCAM_EndYear'])
+        self.GCAM_YearStep = int(cfg['GCAM_YearStep'])
+        self.MovingMeanWindow = int(cfg['MovingMeanWindow'])
+        self.Env_FlowPercent = float(cfg['Env_FlowPercent'])
+        if self.StartYear > self.GCAM_StartYear or self.EndYear < self.GCAM_EndYear:
+            raise ValidationException('Accessible water range of GCAM years are outside the range of years in climate data.')
+
+    def ck_year(self, yr):
+        """A year inside the run (ini_reader.py:547-551)."""
+        if yr < self.StartYear or yr > self.EndYear:
+            raise ValidationException('Accessible water year {0} is outside the range of years in the climate data.'.format(yr))
+        return yr
 
     def configure_calibration(self, cfg):
         """[Calibrate] (ini_reader.py:506-519)."""

@@ -215,12 +215,14 @@ def data_bag(world, forcing):
 
 
 def write_example(root, world, forcing, start_year, end_year, project='pm_abcd_mrtm_synth', runoff_spinup=36,
-                  routing_spinup=None, output_vars=('q', 'avgchflow'), obs=None):
+                  routing_spinup=None, output_vars=('q', 'avgchflow'), obs=None, post=False):
     """Write ``world`` + ``forcing`` as a Xanthos-style input tree under ``root`` and return the .ini path.
 
     Layout and file names follow the reference's example (ini_reader.py:254-279, 353-381, 399-416, 425-437):
     input/reference/{Grid_Areas_ID.csv, coordinates.csv, basin.csv}, input/pet/penman_monteith/*.npy + gcam_*.csv,
     input/runoff/abcd/{pars.npy, pr.npy, tmin.npy}, input/routing/mrtm/{velocity.npy, flow_dist.npy, flow_dir.npy}.
+    ``post=True`` also switches on the drought-threshold and accessible-water post-processors (basin names, reservoir
+    capacity and base-flow index tables under input/reference and input/accessible; ini_reader.py:460-486).
     """
     import os
     inp = os.path.join(root, 'input')
@@ -255,6 +257,23 @@ def write_example(root, world, forcing, start_year, end_year, project='pm_abcd_m
         np.savetxt(obs_file, obs, delimiter=',', fmt='%.17g')
         calib = ('\n[Calibrate]\nset_calibrate = 0\nobserved = {}\nobs_unit = km3_per_mth\ncalib_out_dir = {}\n'
                  'calibration_basins = 1-2\n').format(obs_file, os.path.join(root, 'calib_out'))
+    post_project = post_sections = ''
+    if post:
+        acc = os.path.join(inp, 'accessible')
+        os.makedirs(acc, exist_ok=True)
+        nb = world.n_basins
+        with open(os.path.join(dirs['ref'], 'BasinNames235.txt'), 'w') as fh:
+            fh.write('\n'.join('Basin {:03d}'.format(k) for k in range(1, nb + 1)) + '\n')
+        cap = uniform(splitmix64(np.arange(nb, dtype=np.uint64) + np.uint64(77001)), 0.0, 5.0)
+        bfi = uniform(splitmix64(np.arange(nb, dtype=np.uint64) + np.uint64(77002)), 0.2, 0.9)
+        np.savetxt(os.path.join(acc, 'total_reservoir_storage.csv'), cap, fmt='%.17g')
+        with open(os.path.join(acc, 'bfi_per_basin.csv'), 'w') as fh:
+            fh.write('basin_id,bfi_avg\n' + ''.join('{},{!r}\n'.format(k + 1, float(bfi[k])) for k in range(nb)))
+        post_project = 'AccWatDir = accessible\nCalculateDroughtStats = 1\nCalculateAccessibleWater = 1\n'
+        post_sections = ('\n[Drought]\ndrought_var = q\nthreshold_nper = 12\nthreshold_start_year = {y0}\n'
+                         'threshold_end_year = {y1}\n\n[AccessibleWater]\nResCapacityFile = total_reservoir_storage.csv\n'
+                         'BfiFile = bfi_per_basin.csv\nHistEndYear = {y1}\nGCAM_StartYear = {y0}\nGCAM_EndYear = {y1}\n'
+                         'GCAM_YearStep = 1\nMovingMeanWindow = 3\nEnv_FlowPercent = 0.1\n').format(y0=start_year, y1=end_year)
     with open(ini, 'w') as fh:
         fh.write('''[Project]
 # synthetic pm_abcd_mrtm example written by xanthos_amd.synth.write_example
@@ -278,7 +297,7 @@ OutputFormat = 1
 OutputUnit = 0
 OutputInYear = 0
 Calibrate = {cal}
-
+{post_project}
 [PET]
 pet_module = pm
 [[penman-monteith]]
@@ -313,7 +332,7 @@ routing_spinup = {rtsp}
 channel_velocity = velocity.npy
 flow_distance = flow_dist.npy
 flow_direction = flow_dir.npy
-{calib}'''.format(project=project, root=root, nb=world.n_basins, ncell=world.ncell, nrow=world.nrow, ncol=world.ncol,
+{calib}{post_sections}'''.format(post_project=post_project, post_sections=post_sections, project=project, root=root, nb=world.n_basins, ncell=world.ncell, nrow=world.nrow, ncol=world.ncol,
                   y0=start_year, y1=end_year, ov=', '.join(output_vars), cal=int(obs is not None), nlcs=world.nlcs,
                   lcy=', '.join(str(y) for y in world.lc_years), rsp=runoff_spinup,
                   rtsp=nmonths if routing_spinup is None else routing_spinup,
