@@ -76,6 +76,9 @@ SIGNATURES = {
 _lib = None
 
 
+ABI_VERSION = 2        # xh_abi_version() of the library these signatures describe
+
+
 def lib():
     """Load libxanthos_hip.so (once) and declare every signature. Raises HipUnavailable if it is not built."""
     global _lib
@@ -92,6 +95,9 @@ def lib():
             fn = getattr(handle, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
+        if handle.xh_abi_version() != ABI_VERSION:
+            raise HipUnavailable('{} has ABI version {}, this package binds version {}: rebuild it (make -C xanthos_amd/csrc)'
+                                 .format(LIB_PATH, handle.xh_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 
