@@ -315,3 +315,46 @@ def test_calibration_objective_multi_basin(hip, golden):
         tag = 'snow' if with_tmin else 'nosnow'
         close(ed[0], g['ed_0_km3_per_mth_' + tag], rtol=1e-9, atol=1e-12)
         close(ed[1], g['ed_1_km3_per_mth_' + tag][::-1], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('flags', [0, 8])
+def test_route_long_chain_deep_lags(hip, flags):
+    """A 1,500-cell main stem with short side branches and cells that fire every other sub-step: pieces are 64-cell
+    chains, so lane lags reach the maximum (128 sub-steps) and every month boundary is crossed lane by lane; initial
+    storage given, 11 months (one 8-month output group + a partial one), spin-up 3."""
+    from oracle import mrtm as o_mrtm
+    from xanthos_amd.routing import mrtm
+    rng = np.random.default_rng(77)
+    n_main, n = 1500, 1500 + 300
+    ds = np.full(n, -1)
+    ds[1:n_main] = np.arange(0, n_main - 1)                       # cell k drains to k - 1; cell 0 is the outlet
+    ds[n_main:] = rng.integers(5, n_main, n - n_main)             # side cells drain into the main stem
+    perm = rng.permutation(n)                                     # scramble the ids: row order != river order
+    ds_p = np.full(n, -1)
+    ds_p[perm] = np.where(ds >= 0, perm[np.clip(ds, 0, None)], -1)
+    rows = [[] for _ in range(n)]
+    for c in range(n):
+        rows[c].append((c, -1))
+        if ds_p[c] >= 0:
+            rows[ds_p[c]].append((c, 1))
+    indptr, indices, data = [0], [], []
+    for r in rows:
+        for col, sgn in sorted(r):
+            indices.append(col)
+            data.append(sgn)
+        indptr.append(len(indices))
+    um = mrtm.UpstreamMatrix(indptr, indices, data)
+    info = um.plan(hip.get_context()).info()
+    assert info['flow_cells'] == n and info['skew_max_lag'] >= 112 and info['flow_depth'] >= 10
+    L = rng.uniform(20e3, 60e3, n)
+    L[rng.random(n) < 0.03] = 4e3                                  # velocity x dt > length: these cells fire
+    v = rng.uniform(0.4, 1.5, n)
+    area = rng.uniform(800, 3100, n)
+    q = rng.gamma(2.0, 30.0, (n, 11))
+    S0 = rng.uniform(0.0, 5e7, n)
+    ndays = np.array([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30])
+    ref = o_mrtm.route_series(um.tocsr(), L, v, area, q, ndays, 3, S0=S0)
+    got = mrtm.route_series(um, L, v, area, q, ndays, 3, S0=S0, flags=flags)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    assert um.plan(hip.get_context()).info()['last_tree_kernel'] == (2 if flags == 0 else 1)
