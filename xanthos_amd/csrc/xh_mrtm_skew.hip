@@ -44,6 +44,7 @@ constexpr int RING = 8;                       // LDS slots = sub-steps per strea
 constexpr int GROUP = 16;                     // sub-steps per unrolled group (two blocks)
 constexpr int SK_R = 2;                       // block-transfer rounds: up to 8 * SK_R imports / outlets per unit
 constexpr int CH = 128;                       // iterations between flow-control checks (multiple of GROUP)
+constexpr int PUBLAG = 64;                    // a check publishes the stores older than this many iterations
 constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2;
 constexpr unsigned long long SPIN_LIMIT_TICKS = 2000000000ull;   // 20 s of the 100 MHz real-time counter
 
@@ -73,13 +74,19 @@ __device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Lanes with `need` wait until *p >= target (per lane).  False (and the fault word raised) on timeout / fault.
-__device__ __forceinline__ bool wave_wait_ge(bool need, const unsigned *p, unsigned target, unsigned *fault,
-                                             unsigned code) {
-    bool ok = !need;
+// Lanes with `need` wait until *p >= target (per lane); `seen` keeps the last value each lane read, so that the next
+// check can skip the poll (a counter only grows; one poll is an agent-coherent load, ~1-2 us).  False (and the fault
+// word raised) on timeout / fault.
+__device__ __forceinline__ bool wave_wait_ge(bool need, const unsigned *p, unsigned target, unsigned &seen,
+                                             unsigned *fault, unsigned code) {
+    bool ok = !need || seen >= target;
+    if (__all(ok)) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-        if (!ok) ok = ld_relaxed(p) >= target;
+        if (!ok) {
+            seen = ld_relaxed(p);
+            ok = seen >= target;
+        }
         if (__all(ok)) return true;
         if (ld_relaxed(fault) != 0) return false;
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
@@ -180,15 +187,19 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
     const unsigned long long cyc_begin = __builtin_amdgcn_s_memtime();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
 
-    // ---- flow control, every CH iterations (at a group start: the blocks before n - 8 have been stored)
+    // ---- flow control, every CH iterations, at a group start.  Every block of 8 iterations issues at least one
+    //      stream access, so "all but the 8 youngest memory operations have completed" covers every store older than
+    //      PUBLAG iterations without draining the loads that are two blocks ahead.
+    unsigned seen_ready = 0, seen_done = 0;
     auto check = [&](int n) {
         const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-        if (any_x) {      // publish the sub-steps stored so far, then make sure the next CH iterations have ring space
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // write-through stores acknowledged
-            const int pub = min(max(n - RING - lmax, 0), total);
+        if (any_x) {      // publish what has certainly been stored, then make sure the next CH iterations have ring space
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // write-through stores of older blocks acknowledged
+            const int pub = min(max(n - PUBLAG - RING - lmax, 0), total);
             if (has_x) __hip_atomic_store(a.ready + xedge, (unsigned)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int need = n + CH - lmax - a.rs;
-            if (need > 0) alive = wave_wait_ge(has_x, done_p, (unsigned)min(need, total), a.fault, FAULT_RING_WAIT);
+            if (need > 0)
+                alive = wave_wait_ge(has_x, done_p, (unsigned)min(need, total), seen_done, a.fault, FAULT_RING_WAIT);
         }
         const unsigned long long w1 = __builtin_amdgcn_s_memtime();
         if (any_g && alive) {   // the next CH iterations load up to sub-step n + CH + GROUP - 1 - lag_g
@@ -196,7 +207,7 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
                 __hip_atomic_store(a.done + unit, (unsigned)min(max(n - glmax, 0), total), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             const int need = min(total, n + CH + GROUP - lag_g);
-            alive = wave_wait_ge(has_g && need > 0, ready_p, (unsigned)max(need, 0), a.fault, FAULT_DATA_WAIT);
+            alive = wave_wait_ge(has_g && need > 0, ready_p, (unsigned)max(need, 0), seen_ready, a.fault, FAULT_DATA_WAIT);
             asm volatile("" ::: "memory");      // the stream loads stay behind the poll
         }
         cyc_wait_ring += w1 - w0;
