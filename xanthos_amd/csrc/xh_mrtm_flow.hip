@@ -493,8 +493,8 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                 int &k = cost[unit_of_piece[piece[c]]];             // longest pre side | longest post side << 8
                 k = std::max(k & 255, npre) | (std::max(k >> 8, npost) << 8);
             }
-            for (int u = 0; u < nunit; ++u)                         // gathered terms dominate
-                cost[u] = 4 * ((cost[u] & 255) + (cost[u] >> 8)) + (unit_imp_n[u] > 0 ? 2 : 0) + uexp[u];
+            for (int u = 0; u < nunit; ++u)     // measured (tools/flow_stats.py): ~25 cycles per gathered term, ~30 for
+                cost[u] = 25 * ((cost[u] & 255) + (cost[u] >> 8)) + (unit_imp_n[u] > 0 ? 30 : 0) + 20 * uexp[u];   // imports, ~20 for outlets
             std::vector<int> by_cost(nunit);
             std::iota(by_cost.begin(), by_cost.end(), 0);
             std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) { return cost[x] < cost[y]; });
@@ -633,6 +633,29 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
         }
         fprintf(stderr, "flow plan: %d units, %d pieces, %d edges, depth %d, skew_ok %d\n", nunit, npiece, nedge,
                 maxdepth + 1, (int)skew_ok);
+        {   // pieces by the longest (pre, post) side of their rows, and the cells per class
+            std::vector<int> ppre(npiece, 0), ppost(npiece, 0), hpc(25, 0), hcells(25, 0);
+            for (int c = 0; c < n; ++c) {
+                if (piece[c] < 0) continue;
+                int a = 0, b = 0;
+                bool past = false;
+                for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {
+                    if (indices[j] == c) past = true;
+                    else ++(past ? b : a);
+                }
+                ppre[piece[c]] = std::max(ppre[piece[c]], a);
+                ppost[piece[c]] = std::max(ppost[piece[c]], b);
+            }
+            for (int q = 0; q < npiece; ++q) {
+                hpc[ppre[q] * 5 + ppost[q]]++;
+                hcells[ppre[q] * 5 + ppost[q]] += piece_size[q];
+            }
+            fprintf(stderr, "  pieces (cells) by (pre, post):");
+            for (int a = 0; a <= 4; ++a)
+                for (int b = 0; b <= 4; ++b)
+                    if (hpc[a * 5 + b]) fprintf(stderr, " (%d,%d) %d (%d)", a, b, hpc[a * 5 + b], hcells[a * 5 + b]);
+            fprintf(stderr, "\n");
+        }
         fprintf(stderr, "  units by P (1..4):");
         for (int k = 1; k <= 4; ++k) fprintf(stderr, " %d", hp[k]);
         fprintf(stderr, "\n  units by (pre, post) terms:");
