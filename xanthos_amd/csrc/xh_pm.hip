@@ -8,7 +8,10 @@
 // Algorithmic HBM traffic: 6 x 8 B forcing + 8 B PET per cell-month (+ land cover, amortised) = 61.3 B.
 //
 // Arithmetic follows the reference expression by expression (same association order; compiled with
-// -ffp-contract=off); differences come from the exp/log/sqrt implementations and from fdiv() below (a few ulp each).
+// -ffp-contract=off) except where a quotient is only ever used as a divisor again: the parallel resistances and their
+// caps are carried as reciprocals (1/ra = 1/rc + 1/rr, min -> max), per-class constants are multiplied by their
+// host-computed reciprocals, and 1/cc is formed as gsum / numerator.  Differences from numpy therefore come from the
+// exp/log/sqrt implementations, from fdiv() below and from those regroupings -- a few ulp each, 5e-13 in PET overall.
 #include <algorithm>
 
 #include "xh_common.h"
@@ -23,7 +26,7 @@ constexpr double GAMMA = 0.67;       // :80
 
 // rows of the per-class parameter block
 enum { V_CL = 0, V_BETA, V_RSLIMIT, V_TOPEN, V_TCLOSE, V_TSPAN, V_VCLOSE, V_VOPEN, V_VSPAN, V_RBLMIN, V_RBLMAX,
-       V_RBLSPAN, V_RC, V_INVRC, V_EMISS, PM_NVEC };
+       V_RBLSPAN, V_RC, V_INVRC, V_EMISS, V_INVTSPAN, V_INVVSPAN, V_INVBETA, V_INVRSLIMIT, PM_NVEC };
 
 struct PmTablesDev {
     int nlcs, n_lc_years, water_idx, snow_idx, start_year, nyears;
@@ -46,8 +49,8 @@ __device__ __forceinline__ int days_in_month(int year, int moy) {
 // a / b as a * (1 / b), the reciprocal from v_rcp_f64 refined by two Newton steps: within ~2 ulp of the IEEE quotient
 // for the magnitudes that occur here (no scaling for operands near the exponent limits; b == 0 gives NaN, not an
 // infinity -- every denominator below is guarded or strictly positive) in 6 instructions instead of the ~13 of the
-// correctly rounded sequence.  The kernel is bound by its ~145 divisions per cell-month: 4.9 ms -> 3.7 ms per
-// 67,420 x 600 launch.  PET still agrees with numpy to 5e-13 relative (exp / log dominate; tolerance 1e-6).
+// correctly rounded sequence.  The kernel is bound by its divisions (~145 per cell-month as written in the reference,
+// ~50 after the regroupings above): 4.9 ms -> 3.7 ms -> 3.1 ms per 67,420 x 600 launch.  PET still agrees with numpy to 5e-13 relative (exp / log dominate; tolerance 1e-6).
 __device__ __forceinline__ double fdiv(double a, double b) {
     double r = __builtin_amdgcn_rcp(b);
     r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
@@ -92,6 +95,8 @@ __device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_i
     const double rho = fdiv(p, tk * 287.058);
     const double rr = fdiv(rho * CP, 4.0 * SIGMA2 * (tk * tk * tk));
     const double rho_cp = rho * CP;
+    const double inv_rr = fdiv(1.0, rr);
+    const double inv_secs = fdiv(1.0, secs);
     const double log_r100 = log(r100);
     const double one_m_fwet = 1.0 - fwet;
 
@@ -128,23 +133,23 @@ __device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_i
             double mtmin = 0.0;                                       // calc_mtmin :102-114
             mtmin = TN >= topen ? 1.0 : mtmin;
             mtmin = TN <= tclose ? 0.1 : mtmin;
-            mtmin = (TN < topen && TN > tclose) ? fdiv(TN - tclose, L.vec[V_TSPAN][l]) : mtmin;
-            const double vclose = L.vec[V_VCLOSE][l], vopen = L.vec[V_VOPEN][l], vspan = L.vec[V_VSPAN][l];
+            mtmin = (TN < topen && TN > tclose) ? (TN - tclose) * L.vec[V_INVTSPAN][l] : mtmin;
+            const double vclose = L.vec[V_VCLOSE][l], vopen = L.vec[V_VOPEN][l], inv_vspan = L.vec[V_INVVSPAN][l];
             const bool vmid = (vpd > vopen) && (vpd < vclose);
             double mvpd = vpd;                                        // calc_vpd :117-129
             mvpd = vpd <= vopen ? 1.0 : mvpd;
             mvpd = vpd >= vclose ? 0.1 : mvpd;
-            mvpd = vmid ? fdiv(vclose - vpd, vspan) : mvpd;
+            mvpd = vmid ? (vclose - vpd) * inv_vspan : mvpd;
             const double gs1 = L.vec[V_CL][l] * mtmin * mvpd * rcorr;    // :242
             const double rblmin = L.vec[V_RBLMIN][l], rblmax = L.vec[V_RBLMAX][l];
             double rtotc = 0.0;                                       // calc_rtotc :132-145
             rtotc = vpd <= vopen ? rblmax : rtotc;
             rtotc = vpd >= vclose ? rblmin : rtotc;
-            rtotc = vmid ? rblmax - fdiv(L.vec[V_RBLSPAN][l] * (vclose - vpd), vspan) : rtotc;
+            rtotc = vmid ? rblmax - L.vec[V_RBLSPAN][l] * (vclose - vpd) * inv_vspan : rtotc;
 
             const double rnl = sig_t4 * L.vec[V_EMISS][l] * dz - rl_term;  // calc_a :148-162
             const double rn = oma * RS * 86400.0 * dz - rnl;
-            const double a = fdiv(rn, secs);
+            const double a = rn * inv_secs;
 
             const double lai = L.lai[l][moy], fc = L.fc[l][moy];
             const double ac = fc * a;
@@ -152,35 +157,42 @@ __device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_i
             double rtot = rtotc * rcorr;
             rtot = rtot > 80.0 ? 80.0 : rtot;
             const double rc = L.vec[V_RC][l], inv_rc = L.vec[V_INVRC][l], rslimit = L.vec[V_RSLIMIT][l];
-            double ra = fdiv(rc * rr, rc + rr);
-            ra = ra > rtot ? rtot : ra;
+            // Resistances in parallel / capped: only their reciprocals are used below, so they are formed directly:
+            // 1 / (x rr / (x + rr)) = 1/x + 1/rr, and min(r, rtot) becomes max(1/r, 1/rtot) (same NaN selection).
+            const double inv_rtot = fdiv(1.0, rtot);
+            double inv_ra = inv_rc + inv_rr;                          // 1 / (rc rr / (rc + rr))
+            inv_ra = inv_ra < inv_rtot ? inv_rtot : inv_ra;           // ra = min(ra, rtot)
 
             const double gsum = gs1 + inv_rc + gcu;                   // calc_cc :192-197
             double cc = gsum < 0.0001 ? 10000.0 : (fwet == 1.0 ? 0.00001 : (lai < 0.0001 ? 0.00001 : 0.0));
-            cc = cc == 0.0 ? fdiv(inv_rc * (gs1 + gcu) * lai * one_m_fwet, gsum) : cc;
-            double rs = cc == 0.0 ? 100000.0 : fdiv(1.0, cc);              // :285-291
+            const double cnum = inv_rc * (gs1 + gcu) * lai * one_m_fwet;      // cc = cnum / gsum in the general case
+            double rs = cc != 0.0 ? (cc == 10000.0 ? 0.0001 : 100000.0)       // 1 / cc for the two fixed values of cc
+                                  : (cnum == 0.0 ? 100000.0 : fdiv(gsum, cnum));   // :285-291 (cc == 0 -> 1e5)
             rs = rs > rslimit ? rslimit : rs;
 
             const double lf = lai * fwet;                             // :296-301
             const double lai_fwet = lf == 0.0 ? 1.0 : lf;
+            const double inv_rslimit = L.vec[V_INVRSLIMIT][l];
             double rhc = lai > 0.00001 ? fdiv(rc, lai_fwet) : rslimit;
+            double inv_rhc = lai > 0.00001 ? lai_fwet * inv_rc : inv_rslimit;
+            inv_rhc = rhc > rslimit ? inv_rslimit : inv_rhc;
             rhc = rhc > rslimit ? rslimit : rhc;
-            double rhrc = fdiv(rhc * rr, rhc + rr);
-            rhrc = rhrc > rtot ? rtot : rhrc;
+            double inv_rhrc = inv_rhc + inv_rr;                       // 1 / (rhc rr / (rhc + rr))
+            inv_rhrc = inv_rhrc < inv_rtot ? inv_rtot : inv_rhrc;     // rhrc = min(rhrc, rtot)
 
-            const double apres = fdiv(dz * 86400.0 * (sx * ac + fdiv(rho_cp * vpd * fc, rhrc)) * fwet,
-                                      (sx + fdiv(p * 0.01 * CP * rhc, LAMBDA1 * 0.622 * rhrc)) * LAMBDA1);   // :306-307
+            const double apres = fdiv(dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_rhrc) * fwet,
+                                      (sx + p * 0.01 * CP * rhc * inv_rhrc * (1.0 / (LAMBDA1 * 0.622))) * LAMBDA1);   // :306-307
             const double ewet_c = rh >= 70.0 ? apres : 0.0;
 
-            const double rasoil = fdiv(rtot * rr, rtot + rr);
-            const double soil_num = 86400.0 * dz * (sx * asoil + fdiv(rho_cp * (1.0 - fc) * vpd, rasoil));
-            const double soil_den = (sx + fdiv(GAMMA * rtot, rasoil)) * LAMBDA1;
+            const double inv_rasoil = inv_rtot + inv_rr;              // 1 / (rtot rr / (rtot + rr))
+            const double soil_num = 86400.0 * dz * (sx * asoil + rho_cp * (1.0 - fc) * vpd * inv_rasoil);
+            const double soil_den = (sx + GAMMA * rtot * inv_rasoil) * LAMBDA1;
             const double ewet_soil = fdiv(soil_num * fwet, soil_den);      // :314-315
             const double esoilpot = fdiv(soil_num * one_m_fwet, soil_den); // :316-317
-            const double esoil = ewet_soil + esoilpot * exp(fdiv(vpd, L.vec[V_BETA][l]) * log_r100);   // pow(rh/100, vpd/beta) :323
+            const double esoil = ewet_soil + esoilpot * exp(vpd * L.vec[V_INVBETA][l] * log_r100);   // pow(rh/100, vpd/beta) :323
 
-            double trans = fdiv(dz * 86400.0 * (sx * ac + fdiv(rho_cp * vpd * fc, ra)) * one_m_fwet,
-                                (sx + GAMMA * (1.0 + fdiv(rs, ra))) * LAMBDA1);                  // :326-327
+            double trans = fdiv(dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_ra) * one_m_fwet,
+                                (sx + GAMMA * (1.0 + rs * inv_ra)) * LAMBDA1);                   // :326-327
             trans = fc == 0.0 ? 0.0 : trans;
             et = trans + ewet_c + esoil;
             et = et < 0.0 ? 0.0 : et;
@@ -312,6 +324,10 @@ extern "C" int xh_pm_pet(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int3
         h.vec[V_RC][l] = t->rc[l];
         h.vec[V_INVRC][l] = 1.0 / t->rc[l];
         h.vec[V_EMISS][l] = t->emiss[l];
+        h.vec[V_INVTSPAN][l] = 1.0 / h.vec[V_TSPAN][l];          // reciprocals of per-class constants: the kernel multiplies
+        h.vec[V_INVVSPAN][l] = 1.0 / h.vec[V_VSPAN][l];
+        h.vec[V_INVBETA][l] = 1.0 / t->beta[l];
+        h.vec[V_INVRSLIMIT][l] = 1.0 / t->rslimit[l];
         for (int m = 0; m < 12; ++m) {
             const double lai = t->lai[l * 12 + m], lmin = t->laimin[l * 12 + m], lmax = t->laimax[l * 12 + m];
             double den = exp(-0.5 * lmin) - exp(-0.5 * lmax);           // :257-261
