@@ -32,7 +32,7 @@ for wu in range(3, 10):
     for flag, name in ((0, 'isolated'), (16, 'imports'), (32, 'exports'), (48, 'both')):
         sel = ((shape & 15) == wu) & ((shape & 48) == flag)
         if sel.any():
-            print('WU=%d %-9s n=%4d loop cyc/substep median %.0f' % (wu, name, sel.sum(), np.median(loop[sel] / nsub)))
+            print('%d gathered terms %-9s n=%4d loop cyc/substep median %.0f' % (wu - 1, name, sel.sum(), np.median(loop[sel] / nsub)))
 nit = pipe.nmonths + pipe.routing_spinup
 ovh = (total - loop) / nit / clock / 1e3     # us per month outside the sub-step loops
 for flag, name in ((0, 'isolated'), (16, 'imports'), (32, 'exports'), (48, 'both')):
@@ -68,7 +68,7 @@ for k in sorted(set(share)):
     sel = share == k
     print('units on a SIMD holding %d wave(s): n=%d loop cyc/substep median %.0f max %.0f' % (k, sel.sum(), np.median(cps[sel]), cps[sel].max()))
 idx = np.argsort(-cps)[:10]
-print('slowest units: index, cyc/substep, shape(WU|16 imp|32 exp), waves on its SIMD, units on its CU')
+print('slowest units: index, cyc/substep, shape(terms+1 | 16 imports | 32 outlets), waves on its SIMD, units on its CU')
 for i in idx:
     print(' ', i, round(cps[i]), shape[i], share[i], per_cu[cu_key[i]])
 # which units share a SIMD (placement of the blocks past the first 1024)
@@ -87,8 +87,8 @@ for k in sorted(set(per_cu[cu_key])):
     for t in sorted(set(terms)):
         sel = (per_cu[cu_key] == k) & (terms == t) & (share == 1)
         if sel.sum() >= 3:
-            print('units on a CU holding %d, alone on their SIMD, %d terms+1: n=%3d loop cyc/substep median %.0f max %.0f' % (
-                k, t, sel.sum(), np.median(cps[sel]), cps[sel].max()))
+            print('units on a CU holding %d, alone on their SIMD, %d gathered terms: n=%3d loop cyc/substep median %.0f max %.0f' % (
+                k, t - 1, sel.sum(), np.median(cps[sel]), cps[sel].max()))
 # block index -> CU: which blocks share a CU
 cu_blocks = {}
 for i, ck in enumerate(cu_key):

@@ -10,7 +10,28 @@ constexpr double TSNOW = 0.6;   // abcd.py:100
 
 struct AbcdPar {
     double a2, b, b_over_a, c, d, d1, m;
+    double inv_a2, inv_b, inv_d1;      // reciprocals of the three per-cell divisors of the month update (see finish_par)
 };
+
+// The month update divides by 2a, b and d + 1 -- constants of the cell (or calibration member) -- and the division by
+// 2a sits on the sequential chain of the march (13 dependent instructions as an IEEE quotient).  The reciprocals are
+// taken once per march; quot() then forms x / d as x * (1/d) plus one residual correction, three dependent
+// instructions, which gives the correctly rounded quotient (the last step of the IEEE sequence, without its scaling
+// for extreme exponents).  A bare x * (1/d) is not good enough here: y = rpt - sqrt(rpt^2 - w b / a) cancels, and one
+// ulp in rpt showed up as 1e-11 in soil moisture against numpy.
+__device__ __forceinline__ void finish_par(AbcdPar &P, double a) {
+    P.a2 = a * 2.0;                                                   // :54-56
+    P.b_over_a = P.b / a;
+    P.d1 = P.d + 1.0;
+    P.inv_a2 = 1.0 / P.a2;
+    P.inv_b = 1.0 / P.b;
+    P.inv_d1 = 1.0 / P.d1;
+}
+
+__device__ __forceinline__ double quot(double x, double d, double inv_d) {
+    const double q = x * inv_d;
+    return __builtin_fma(__builtin_fma(-d, q, x), inv_d, q);
+}
 
 struct AbcdState {
     double snowpack, sm, gw;
@@ -29,7 +50,7 @@ struct AbcdPre {
 __device__ __forceinline__ AbcdPre abcd_pre(const AbcdPar &P, bool snow_on, double pet, double precip, double tmin) {
     AbcdPre r;
     r.pet = pet;
-    r.decay = exp(-pet / P.b);                                        // :211
+    r.decay = exp(quot(-pet, P.b, P.inv_b));                          // :211
     r.rain = precip;
     r.snow = 0.0;
     r.frac = 0.0;
@@ -63,12 +84,12 @@ __device__ __forceinline__ void abcd_step(const AbcdPar &P, AbcdState &s, bool s
         s.snowpack = s.snowpack - snm;                                // :197
     }
     const double w = first ? r.rain + s.sm : r.rain + s.sm + snm;     // :200-203
-    const double rpt = (w + P.b) / P.a2;                              // :206-207
+    const double rpt = quot(w + P.b, P.a2, P.inv_a2);                 // :206-207
     const double y = rpt - sqrt(rpt * rpt - (w * P.b_over_a));        // :208
     const double sm1 = y * r.decay;                                   // :211
     const double awet = w - y;
     const double c_awet = P.c * awet;
-    s.gw = (s.gw + c_awet) / P.d1;                                    // :219-221
+    s.gw = quot(s.gw + c_awet, P.d1, P.inv_d1);                       // :219-221
     double e = y - sm1;                                               // :224-226
     e = (0.0 >= e) ? 0.0 : e;                                         // np.maximum(0, e): NaN e stays NaN
     e = (r.pet <= e || r.pet != r.pet) ? r.pet : e;                   // np.minimum(pet, e): NaN propagates
@@ -91,9 +112,7 @@ __device__ __forceinline__ AbcdPar load_par(const double *__restrict__ pars, int
     P.c = p[2];
     P.d = p[3];
     P.m = snow_on ? p[4] : 0.0;
-    P.a2 = a * 2.0;                                                   // :54-56
-    P.b_over_a = P.b / a;
-    P.d1 = P.d + 1.0;
+    finish_par(P, a);
     return P;
 }
 

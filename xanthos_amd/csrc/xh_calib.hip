@@ -59,9 +59,7 @@ __device__ __forceinline__ AbcdPar member_par(const double *__restrict__ pars, i
     P.c = p[2];
     P.d = p[3];
     P.m = npar > 4 ? p[4] : 0.0;
-    P.a2 = a * 2.0;
-    P.b_over_a = P.b / a;
-    P.d1 = P.d + 1.0;
+    xh_abcd_dev::finish_par(P, a);
     return P;
 }
 
@@ -119,7 +117,7 @@ __global__ void __launch_bounds__(64) k_calib_march(const CalibBasin *__restrict
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
             double aet, q;
-            if (j > 0) pre.decay = exp(-pet_c / P[j].b);
+            if (j > 0) pre.decay = exp(quot(-pet_c, P[j].b, P[j].inv_b));
             abcd_step(P[j], s[j], snow_on, m == 0, pre, aet, q);
             if (SPINUP) {
                 if (k >= 0) {                                    // wave-uniform
