@@ -38,7 +38,7 @@ namespace {
 
 constexpr int W_MAX = 9;          // terms per row: 8 D8 neighbours + the diagonal
 constexpr int LANES = 64;         // cells per unit (one per lane)
-constexpr int G_MAX = 16;         // imported streams per unit (ghost slots; 16 = two block-transfer rounds of the skewed kernel)
+constexpr int G_MAX = 16;         // imported streams, and outlets, per unit (16 = two block-transfer rounds of the skewed kernel)
 constexpr int NPAIR = 2 * LANES + 1;       // LDS pairs per flow buffer: cells, ghost slots (one per lane), constant zero
 constexpr int RING = 4;           // months of stream kept in HBM per edge
 constexpr int PF = 8;             // sub-steps of ghost prefetch held in registers
@@ -441,7 +441,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
         return piece_depth[x] != piece_depth[y] ? piece_depth[x] < piece_depth[y] : piece_size[x] > piece_size[y];
     });
-    std::vector<int> unit_of_piece(npiece, -1), unit_cells_n, unit_imp_n, unit_depth;
+    std::vector<int> unit_of_piece(npiece, -1), unit_cells_n, unit_imp_n, unit_depth, unit_out_n;   // outlets: <= G_MAX too
     {
         size_t first_open = 0;
         int cur_depth = -1;
@@ -452,7 +452,8 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
             }
             int u = -1;
             for (size_t b = first_open; b < unit_cells_n.size(); ++b)
-                if (unit_cells_n[b] + piece_size[p] <= LANES && unit_imp_n[b] + piece_imp[p] <= G_MAX) {
+                if (unit_cells_n[b] + piece_size[p] <= LANES && unit_imp_n[b] + piece_imp[p] <= G_MAX &&
+                    unit_out_n[b] + (ds[closed_roots[p]] >= 0 ? 1 : 0) <= G_MAX) {
                     u = (int)b;
                     break;
                 }
@@ -460,11 +461,13 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                 u = (int)unit_cells_n.size();
                 unit_cells_n.push_back(0);
                 unit_imp_n.push_back(0);
+                unit_out_n.push_back(0);
                 unit_depth.push_back(cur_depth);
             }
             unit_of_piece[p] = u;
             unit_cells_n[u] += piece_size[p];
             unit_imp_n[u] += piece_imp[p];
+            unit_out_n[u] += ds[closed_roots[p]] >= 0 ? 1 : 0;
             while (first_open < unit_cells_n.size() && unit_cells_n[first_open] >= LANES) ++first_open;
         }
     }
