@@ -278,7 +278,8 @@ def main():
     roofline = {'kernel': dominant, 'bound': 'hbm', 'achieved': kernels[dominant]['achieved_GBs'],
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dominant]['frac_of_hbm_peak'],
                 'traffic': kernels[dominant].get('traffic_bytes'), 'traffic_source': traffic_src,
-                'note': 'mrtm_route is bound by sub-step latency (on-chip LDS exchange), not by HBM; see DESIGN.md'
+                'note': 'mrtm_route is bound by the instruction issue of one wave per sub-step (about 36 instructions for the '
+                        'median unit, 8-term rows pace the run), not by HBM; see DESIGN.md 4.3'
                 if dominant == 'mrtm_route' else ''}
     if dominant == 'mrtm_route':
         nsub = int(sum(int(d * 86400 / 10800) for d in pipe.ndays)) + \
@@ -286,6 +287,7 @@ def main():
         roofline['substeps'] = nsub
         roofline['us_per_substep'] = kernels['mrtm_route']['avg_ms'] * 1e3 / nsub
         roofline['cell_substeps_per_s'] = pipe.ncell * nsub / (kernels['mrtm_route']['avg_ms'] * 1e-3)
+        roofline['cycles_per_substep_at_2.4GHz'] = roofline['us_per_substep'] * 2400.0
 
     result = {
         'metric': 'cell-months/sec (pm_abcd_mrtm, 67,420 cells)' if args.workload == 'pm_abcd_mrtm'
