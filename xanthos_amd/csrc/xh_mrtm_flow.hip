@@ -1,4 +1,7 @@
-// MRTM routing as a dataflow of single-wave units (gfx950).
+// MRTM routing as a dataflow of single-wave units (gfx950): the partition of the tree networks into units
+// (flow_plan_build, also used by the time-skewed kernel of xh_mrtm_skew.hip, which is the default) and the lock-step
+// kernel k_mrtm_flow, kept for schedules whose months are shorter than the skewed kernel's lane lags and as an
+// independently written second implementation that the tests hold to the same bits.
 //
 // One workgroup per river network (xh_mrtm.hip) is bounded by the largest network: all of its cells share one CU,
 // which then issues ~70 instructions x (cells / 64) per sub-step while 200 other CUs idle.  But the dependency in
@@ -26,7 +29,7 @@
 //     Every spin is bounded by the 100 MHz real-time counter and raises the context's fault word instead of hanging.
 //
 // Throughput is then set by the sub-step latency of ONE wave (a few hundred cycles) instead of the instruction
-// issue of the largest network, and the whole chip is busy: ~1,500 units over 256 CUs for the 67,420-cell grid.
+// issue of the largest network, and the whole chip is busy: 1,121 units over 256 CUs for the 67,420-cell grid.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
