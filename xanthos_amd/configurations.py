@@ -25,7 +25,7 @@ class ConfigRunner:
         c = Components(self.config)
         c.simulation(run_pet=self.run_pet, run_runoff=self.run_runoff, run_routing=self.run_routing,
                      pet_num_steps=0, runoff_num_steps=0, routing_num_steps=0, notify='Simulation')
-        c.output_simulation()
-        c.accessible_water()          # post-processors in the reference's order (configurations.py:117-124)
+        c.accessible_water()          # post-processors, then the outputs: the reference's order (configurations.py:117-136)
         c.drought()
+        c.output_simulation()
         return c
