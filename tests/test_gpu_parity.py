@@ -358,3 +358,16 @@ def test_route_long_chain_deep_lags(hip, flags):
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
     assert um.plan(hip.get_context()).info()['last_tree_kernel'] == (2 if flags == 0 else 1)
+
+
+def test_route_differential_fuzz(hip):
+    """tools/fuzz_routing.py, 25 seeded cases: random tree worlds (12 .. 6,000 cells), month counts, spin-ups, time steps,
+    NaN runoff, stagnant and over-fast channels, initial storage -- all three network kernels bit-exact against the oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('fuzz_routing', os.path.join(os.path.dirname(__file__), '..', 'tools', 'fuzz_routing.py'))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(31337)
+    used = [fz.one_case(rng, k)[4][0] for k in range(25)]
+    assert 2 in used                      # the time-skewed kernel was exercised
