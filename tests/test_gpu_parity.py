@@ -371,3 +371,16 @@ def test_route_differential_fuzz(hip):
     rng = np.random.default_rng(31337)
     used = [fz.one_case(rng, k)[4][0] for k in range(25)]
     assert 2 in used                      # the time-skewed kernel was exercised
+
+
+def test_pm_abcd_parity_fuzz(hip):
+    """tools/fuzz_pm_abcd.py, 10 seeded cases with hostile forcing (zeros from nan_to_num, saturated air, -60 K spikes, NaN
+    precipitation, with / without snow): PET / AET / Q / Sav within 1 % of the 1e-6 north-star gate."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('fuzz_pm_abcd', os.path.join(os.path.dirname(__file__), '..', 'tools', 'fuzz_pm_abcd.py'))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(4242)
+    worst = max(max(fz.one_case(rng, k)[3]) for k in range(10))
+    assert worst < 1e-2, worst
