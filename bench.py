@@ -136,12 +136,121 @@ def cpu_baseline(pipe, world, args, log):
             'stage_rates': res}, parity
 
 
+FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector fp64 peak (MI355X_MICROARCH.md)
+CALIB_FLOP_PER_MCM = 120.0      # flop-equivalents per member-cell-month ("Calibration")
+
+
+def bench_calib(args, ctx, rank, world_size, dist, torch, backend, log):
+    """BASELINE configs[4]: one step = one differential-evolution generation (trial vectors, objective of every member
+    of every basin over spin-up + simulation months, selection, convergence test) of all 235 basins, entirely on the
+    device.  N > 1: the basins are dealt to the ranks by size (strong scaling) and the results gathered at the end."""
+    from xanthos_amd import synth
+    from xanthos_amd.calibrate.calibrate_abcd import assign_basins, gather_results
+    from xanthos_amd.calibrate.config5 import Config5
+    world = synth.make_world()
+    counts = np.bincount(world.basin_ids, minlength=world.n_basins + 1)[1:]
+    owner = assign_basins(counts * (args.months + args.abcd_spinup), world_size)
+    mine = [b + 1 for b in range(world.n_basins) if owner[b] == rank]
+    t0 = time.perf_counter()
+    cfg = Config5(ctx, nmembers=args.members, nmonths=args.months, spinup=args.abcd_spinup, seed=synth.MASTER_SEED,
+                  world=world, basins=mine)
+    log('config 5 on rank 0: {} basins, {} cells, {} members, {}+{} months, set up in {:.1f} s'.format(
+        len(mine), int(cfg.counts.sum()), args.members, args.months, args.abcd_spinup, time.perf_counter() - t0))
+    de = cfg.de
+    de.init()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.sync()
+    # tol = 0: no basin converges, every step is a full generation of every basin
+    if args.warmup:
+        de.step(args.warmup, tol=0.0)
+    ctx.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    de.step(args.steps, tol=0.0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    x, fun, nfev, nit, _ = de.result()
+    table = np.column_stack([x, fun, nfev, nit])
+    if dist is not None:
+        table = gather_results(table, owner, dist)
+    total_mcm = args.members * NCELL * (args.months + args.abcd_spinup)
+    value = total_mcm * args.steps / elapsed
+    ms = {k: ctx.timing(k) for k in ('calib_abcd', 'calib_kge', 'calib_de')}
+    kern_ms = ms['calib_abcd'][0] / args.steps            # spin-up march + basin means + simulation march
+    local_mcm = cfg.member_cell_months
+    achieved = local_mcm * CALIB_FLOP_PER_MCM / (kern_ms * 1e-3) / 1e12
+    result = {
+        'metric': 'member-cell-months/sec (ABCD DE calibration, {} members x {} basins)'.format(args.members, NBASINS),
+        'value': value, 'unit': 'member-cell-months/s', 'n_gpus': world_size, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'calib: differential evolution (best1bin, deferred) of ABCD a,b,c,d,m; {} members x {} '
+                               'basins ({} cells) x {}+{} months, set_calibrate 0, km3_per_mth; step = one generation'
+                               .format(args.members, NBASINS, NCELL, args.months, args.abcd_spinup),
+                   'parallelism': 'basins dealt by size over {} GPU(s), results gathered once'.format(world_size)},
+        'objective_evaluations_per_s': args.members * NBASINS * args.steps / elapsed,
+        'roofline': {'kernel': 'calib_abcd (k_calib_march spin-up + simulation)', 'bound': 'fp64 valu',
+                     'achieved': achieved, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / FP64_VALU_PEAK_TFLOPS, 'traffic': None,
+                     'note': '{} flop-equivalents per member-cell-month (SURVEY 8(d)); no dense contraction, so the '
+                             'vector fp64 peak is the ceiling, not MFMA'.format(CALIB_FLOP_PER_MCM)},
+        'kernels': {k: {'avg_ms': v[0] / args.steps, 'launches': v[1]} for k, v in ms.items()},
+        'host_share_of_step': 1.0 - sum(v[0] for v in ms.values()) / (1e3 * elapsed),
+    }
+    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+        from oracle import calib as o_calib, de as o_de
+        pop, en = de.state(0)
+        lo, hi = np.array([b[0] for b in cfg_bounds()]), np.array([b[1] for b in cfg_bounds()])
+        order = np.argsort(-cfg.counts)
+        picks = [int(order[i * len(order) // args.cpu_calib_evals]) for i in range(args.cpu_calib_evals)]
+        cells, t_cpu, worst = 0, 0.0, 0.0
+        for i, b in enumerate(picks):
+            host = cfg.host_basin(b)
+            xs = o_de.scale_parameters(pop[b, i], lo, hi)
+            t1 = time.perf_counter()
+            ref = o_calib.objective_kge(xs, 0, host['pet'], host['precip'], host['tmin'], args.months, args.abcd_spinup,
+                                        'km3_per_mth', host['area'], cfg.obs[b])
+            t_cpu += time.perf_counter() - t1
+            cells += int(cfg.counts[b])
+            worst = max(worst, abs(cfg.evaluate_one(b, xs[None])[0] - ref) / abs(ref))
+        cpu = cells * (args.months + args.abcd_spinup) / t_cpu
+        result['cpu_baseline'] = {'value': cpu, 'unit': 'member-cell-months/s', 'cores': 1, 'kind': 'port',
+                                  'sample': 'numpy oracle objective_kge (basin_runoff + KGE, as the reference evaluates '
+                                            'one member at a time): {} evaluations on basins of {}..{} cells, {:.1f} s'
+                                            .format(len(picks), int(cfg.counts[picks].min()),
+                                                    int(cfg.counts[picks].max()), t_cpu)}
+        result['parity'] = {'objective_max_rel_err_vs_oracle': worst}
+        result['speedup_vs_cpu_baseline'] = value / cpu
+        log('cpu baseline: ' + result['cpu_baseline']['sample'])
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    cfg.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cfg_bounds():
+    from xanthos_amd.calibrate.config5 import BOUNDS
+    return BOUNDS
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='pm_abcd_mrtm', choices=['pm_abcd_mrtm', 'pm_abcd'])
+    ap.add_argument('--workload', default='pm_abcd_mrtm', choices=['pm_abcd_mrtm', 'pm_abcd', 'calib'])
+    ap.add_argument('--members', type=int, default=512, help='calib: population per basin')
+    ap.add_argument('--cpu-calib-evals', type=int, default=24, help='calib: oracle objective evaluations to time')
     ap.add_argument('--months', type=int, default=600)
     ap.add_argument('--start-year', type=int, default=1961)
     ap.add_argument('--abcd-spinup', type=int, default=120)
@@ -155,6 +264,8 @@ def main():
     ap.add_argument('--route-flags', type=int, default=0)
     args = ap.parse_args()
     args.stages = ('pm', 'abcd', 'mrtm') if args.workload == 'pm_abcd_mrtm' else ('pm', 'abcd')
+    if args.workload == 'calib' and args.months == 600:
+        args.months = 480                                       # BASELINE configs[4]: 480 + 120 spin-up months
 
     rank = int(os.environ.get('RANK', '0'))
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
@@ -185,6 +296,9 @@ def main():
     from xanthos_amd.pipeline import FORCING, pipeline_from_world, topology_from_world
     ctx = _hip.get_context(local_rank)
     log('device: ' + ctx.name())
+
+    if args.workload == 'calib':
+        return bench_calib(args, ctx, rank, world_size, dist, torch, backend, log)
 
     t0 = time.perf_counter()
     world = synth.make_world()

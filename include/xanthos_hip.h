@@ -64,7 +64,7 @@ int xh_scatter_rows(xh_ctx *ctx, const double *d_src, const int64_t *d_rows, int
 int xh_transpose(xh_ctx *ctx, const double *d_src, int64_t rows, int64_t cols, double *d_dst);
 
 /* HIP-event timing of the kernels each entry point launches, accumulated per kernel name on the context's stream.
- * Names: "pm_pet", "abcd_spinup", "abcd_basin_mean", "abcd_sim", "mrtm_route", "calib_abcd", "calib_kge",
+ * Names: "pm_pet", "abcd_spinup", "abcd_basin_mean", "abcd_sim", "mrtm_route", "calib_abcd", "calib_kge", "calib_de",
  * "agg_time", "agg_spatial", "drought_thresh", "drought_stats".  xh_timing_get waits for the stream, then returns total milliseconds and launch count. */
 int xh_timing_reset(xh_ctx *ctx);
 int xh_timing_enable(xh_ctx *ctx, int on);
@@ -125,8 +125,8 @@ void xh_route_plan_destroy(xh_route_plan *plan);
 int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]);
 
 /* Diagnostics: with XH_FLOW_STATS=1 in the environment the dataflow kernel records, per unit, {shader cycles inside the
- * sub-step loops, shader cycles total, 100 MHz ticks total, shape bits}; this call waits for the stream and copies
- * up to max_words 64-bit words (4 per unit) of the last xh_route_series launch. */
+ * sub-step loops, shader cycles total, 100 MHz ticks total, shape bits + placement, cycles waiting for data, cycles waiting for ring space}; this call waits for the
+ * stream and copies up to max_words 64-bit words (6 per unit) of the last xh_route_series launch. */
 int xh_route_plan_stats(xh_route_plan *plan, int64_t max_words, uint64_t *h_words, int64_t *n_words);
 
 /* Host-side topology (integer work, no device needed).
@@ -214,6 +214,40 @@ int xh_calib_objective_multi(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncel
                              int32_t nmembers, int32_t npar, const double *h_pars, const double *const *h_pet_t,
                              const double *const *h_precip_t, const double *const *h_tmin_t,
                              const double *const *h_area, const double *h_obs, double *h_ed, double *h_series);
+
+/* ------------------------------------------------------------------ differential evolution on the device
+ * Replaces the scipy.optimize.differential_evolution call of calibrate/calibrate_abcd.py:calibrate_basin (:103-112,
+ * SciPy defaults: best1bin, Latin-hypercube start, dither (0.5, 1), recombination 0.7, tol 0.01, polish off) AND the
+ * serial loop over basins of calibrate_all (:256-262): all basins of the session search at once in lock-step
+ * generations; populations, trial vectors, energies and convergence flags stay in HBM and a generation is five
+ * kernel launches with no host work.  Selection is generation-synchronous (SciPy's updating='deferred').
+ * Random numbers are counter-based on (seed, h_basin_key[b], generation, member): a basin's search does not depend
+ * on the other basins of the session or on the device, so basin-sharded multi-GPU runs reproduce one-GPU runs.
+ *   xh_calib_de_create : basins as for xh_calib_objective_multi (device forcing [nmonths, ncell_b] per basin, which
+ *                        must outlive the session); h_basin_key [nbasins] or NULL (= 0..nbasins-1); h_lo / h_hi
+ *                        [npar] parameter bounds (:62-64); nmembers = popsize x npar in SciPy's terms
+ *   xh_calib_de_init   : Latin-hypercube population and its energies
+ *   xh_calib_de_step   : ngen generations; a basin stops when std(E) <= atol + tol |mean(E)| (SciPy's test);
+ *                        *h_n_active = basins still searching after the last generation
+ *   xh_calib_de_result : h_x [nbasins, npar] best parameters, h_fun [nbasins] = ED = 1 - KGE, h_nfev, h_nit,
+ *                        h_active (each may be NULL)
+ *   xh_calib_de_state  : which = 0 population + energies, 1 last trial vectors + their energies (unit cube),
+ *                        2 last trial vectors scaled to parameter space; [nbasins, nmembers, npar] / [nbasins, nmembers]
+ *   xh_calib_de_set_state : overwrite population and energies and re-activate every basin (tests, restarts)   */
+typedef struct xh_calib_de xh_calib_de;
+int xh_calib_de_create(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, const uint64_t *h_basin_key,
+                       int32_t nmonths, int32_t spinup, int32_t nmembers, int32_t npar,
+                       const double *const *h_pet_t, const double *const *h_precip_t, const double *const *h_tmin_t,
+                       const double *const *h_area, const double *h_obs, const double *h_lo, const double *h_hi,
+                       uint64_t seed, xh_calib_de **out);
+void xh_calib_de_destroy(xh_calib_de *de);
+int xh_calib_de_init(xh_calib_de *de);
+int xh_calib_de_step(xh_calib_de *de, int32_t ngen, double tol, double atol, double mut_lo, double mut_hi,
+                     double recombination, int32_t *h_n_active);
+int xh_calib_de_result(xh_calib_de *de, double *h_x, double *h_fun, int64_t *h_nfev, int32_t *h_nit,
+                       int32_t *h_active);
+int xh_calib_de_state(xh_calib_de *de, int32_t which, double *h_vectors, double *h_energy);
+int xh_calib_de_set_state(xh_calib_de *de, const double *h_pop, const double *h_energy, int32_t generation);
 
 /* ------------------------------------------------------------------ bench support (not on the hot path)
  * Fills the eight forcing arrays of the synthetic benchmark world on the device (same distributions as

@@ -75,3 +75,67 @@ def test_gather_to_root_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert 'GATHER_OK' in outs[0]
+
+
+CALIB_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+from types import SimpleNamespace as NS
+import numpy as np, torch.distributed as dist
+from xanthos_amd.calibrate import calibrate_abcd as cal
+dist.init_process_group(backend='gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+rank = dist.get_rank()
+rng = np.random.default_rng(2)
+basin_ids = rng.integers(1, 8, 400)                 # 7 basins of different sizes; basin 8 requested but empty
+nm = 30
+settings = NS(set_calibrate=0, obs_unit='km3_per_mth', cal_basins=['1-8'], nmonths=nm, runoff_spinup=25,
+              calib_out_dir=sys.argv[2], device=0)
+obs = np.concatenate([np.stack([np.full(nm, b), np.arange(nm) + b], axis=1) for b in range(1, 9)])
+data = NS(basin_ids=basin_ids, area=np.ones(400), precip=np.ones((400, nm)), tmin=np.ones((400, nm)), cal_obs=obs)
+seen = []
+
+def fake_local(mine, settings, data, pet, seed, popsize, nmembers):     # stands in for the GPU search of this rank
+    seen.extend(mine)
+    rows = np.array([[b + 0.1, b + 0.2, b + 0.3, b + 0.4, b + 0.5, 1.0 / b, 75 * b, b] for b in mine]).reshape(-1, 8)
+    return rows, {}
+cal._calibrate_local = fake_local
+res = cal.calibrate_all(settings, data, np.ones((400, nm)), seed=1, dist=dist)
+sizes = np.array([(basin_ids == b).sum() for b in range(1, 8)])
+owner = cal.assign_basins(sizes * nm, 2)
+assert seen == [b for b, r in zip(range(1, 8), owner) if r == rank] and 0 < len(seen) < 7
+if rank == 0:
+    assert sorted(res) == list(range(1, 8))
+    for b, (x, kge) in res.items():
+        assert np.array_equal(x, b + np.array([0.1, 0.2, 0.3, 0.4, 0.5])) and kge == 1 - 1.0 / b
+        assert np.load(os.path.join(sys.argv[2], 'kge_result_basin_%d.npy' % b))[0] == kge
+        assert np.array_equal(np.load(os.path.join(sys.argv[2], 'abcdm_parameters_basin_%d.npy' % b))[0], x)
+    print('CALIB_FANOUT_OK', owner.tolist())
+else:
+    assert res == {}
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _run_two_ranks(tmp_path, text, *extra):
+    script = tmp_path / 'worker.py'
+    script.write_text(text)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT] + list(extra), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    return outs
+
+
+def test_calibration_fanout_two_ranks_gloo(tmp_path):
+    """calibrate_all over 2 ranks: basins dealt by size, each rank searches only its share (the GPU search is
+    replaced by a stand-in), ONE collective brings the [n_basins, n_par + 3] table to rank 0, which writes the files."""
+    out = tmp_path / 'calib_out'
+    outs = _run_two_ranks(tmp_path, CALIB_WORKER, str(out))
+    assert 'CALIB_FANOUT_OK' in outs[0]

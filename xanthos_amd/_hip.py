@@ -65,6 +65,14 @@ SIGNATURES = {
     'xh_route_series': (c_int, [_P, _P, c_int32, c_int32, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32]),
     'xh_calib_objective': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'xh_calib_objective_multi': (c_int, [_P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'xh_calib_de_create': (c_int, [_P, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P,
+                                   c_uint64, POINTER(c_void_p)]),
+    'xh_calib_de_destroy': (None, [_P]),
+    'xh_calib_de_init': (c_int, [_P]),
+    'xh_calib_de_step': (c_int, [_P, c_int32, c_double, c_double, c_double, c_double, c_double, POINTER(c_int32)]),
+    'xh_calib_de_result': (c_int, [_P, _P, _P, _P, _P, _P]),
+    'xh_calib_de_state': (c_int, [_P, c_int32, _P, _P]),
+    'xh_calib_de_set_state': (c_int, [_P, _P, _P, c_int32]),
     'xh_agg_time': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
     'xh_agg_spatial': (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
     'xh_nan_to_num': (c_int, [_P, _P, c_int64]),
@@ -76,7 +84,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 2        # xh_abi_version() of the library these signatures describe
+ABI_VERSION = 3        # xh_abi_version() of the library these signatures describe
 
 
 def lib():
@@ -361,7 +369,7 @@ class RoutePlan:
         return dict(zip(keys, list(arr)))
 
     def stats(self):
-        """[units, 4] uint64 cycle accounting of the last launch (needs XH_FLOW_STATS=1), or None."""
+        """[units, 6] uint64 per-unit accounting of the last launch (needs XH_FLOW_STATS=1), or None."""
         n = c_int64(0)
         self.ctx._check(lib().xh_route_plan_stats(self.handle, 0, None, byref(n)))
         if n.value == 0:
@@ -373,6 +381,75 @@ class RoutePlan:
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:
             lib().xh_route_plan_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CalibDE:
+    """Device-side differential evolution over several basins in lock-step (xh_calib_de).
+
+    ncells [nb]; pet_t / precip_t / tmin_t / area: lists of DeviceArrays ([nmonths, ncell_b]; tmin_t / area may be
+    None) that must stay alive as long as the session; obs [nb, nmonths]; bounds [(lo, hi)] * npar; keys [nb] RNG
+    stream of each basin (e.g. the basin number) so that a basin's search does not depend on its companions."""
+
+    def __init__(self, ctx, ncells, nmonths, spinup, nmembers, bounds, pet_t, precip_t, tmin_t, area, obs, seed=0,
+                 keys=None):
+        self.ctx = ctx
+        nc = np.ascontiguousarray(ncells, dtype=np.int64)
+        self.nb, self.n, self.d = int(nc.size), int(nmembers), len(bounds)
+        obs = as_f64(obs)
+        if obs.shape != (self.nb, nmonths):
+            raise ValueError('obs must be [nbasins, nmonths]')
+        lo, hi = as_f64([b[0] for b in bounds]), as_f64([b[1] for b in bounds])
+        kk = None if keys is None else np.ascontiguousarray(keys, dtype=np.uint64)
+        ptrs = lambda lst: None if lst is None else (c_void_p * self.nb)(*[_dptr(x) for x in lst])
+        self._keep = (pet_t, precip_t, tmin_t, area)
+        h = c_void_p()
+        ctx._check(lib().xh_calib_de_create(ctx.handle, self.nb, _host_ptr(nc), None if kk is None else _host_ptr(kk),
+                                            nmonths, spinup, self.n, self.d, ptrs(pet_t), ptrs(precip_t), ptrs(tmin_t),
+                                            ptrs(area), _host_ptr(obs), _host_ptr(lo), _host_ptr(hi),
+                                            int(seed) & 0xFFFFFFFFFFFFFFFF, byref(h)))
+        self.handle = h.value
+
+    def init(self):
+        self.ctx._check(lib().xh_calib_de_init(self.handle))
+
+    def step(self, ngen=1, tol=0.01, atol=0.0, mutation=(0.5, 1.0), recombination=0.7):
+        """Run ``ngen`` generations; returns the number of basins still searching."""
+        left = c_int32(0)
+        self.ctx._check(lib().xh_calib_de_step(self.handle, int(ngen), float(tol), float(atol), float(mutation[0]),
+                                               float(mutation[1]), float(recombination), byref(left)))
+        return left.value
+
+    def result(self):
+        """(x [nb, d], fun [nb], nfev [nb], nit [nb], active [nb])."""
+        x, fun = np.empty((self.nb, self.d)), np.empty(self.nb)
+        nfev, nit, act = np.empty(self.nb, dtype=np.int64), np.empty(self.nb, dtype=np.int32), \
+            np.empty(self.nb, dtype=np.int32)
+        self.ctx._check(lib().xh_calib_de_result(self.handle, _host_ptr(x), _host_ptr(fun), _host_ptr(nfev),
+                                                 _host_ptr(nit), _host_ptr(act)))
+        return x, fun, nfev, nit, act
+
+    def state(self, which=0):
+        """which: 0 population + energies, 1 last trial (unit cube) + energies, 2 last trial scaled + energies."""
+        v, e = np.empty((self.nb, self.n, self.d)), np.empty((self.nb, self.n))
+        self.ctx._check(lib().xh_calib_de_state(self.handle, int(which), _host_ptr(v), _host_ptr(e)))
+        return v, e
+
+    def set_state(self, pop, energies, generation=0):
+        pop, energies = as_f64(pop), as_f64(energies)
+        if pop.shape != (self.nb, self.n, self.d) or energies.shape != (self.nb, self.n):
+            raise ValueError('bad state shape')
+        self.ctx._check(lib().xh_calib_de_set_state(self.handle, _host_ptr(pop), _host_ptr(energies), int(generation)))
+
+    def close(self):
+        if self.handle is not None and self.ctx.handle is not None:
+            lib().xh_calib_de_destroy(self.handle)
         self.handle = None
 
     def __del__(self):

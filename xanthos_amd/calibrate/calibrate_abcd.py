@@ -3,10 +3,14 @@
 The reference wraps ``scipy.optimize.differential_evolution`` around ``objective_kge`` (:103-112, :176-213), which
 runs ABCD on one basin for ONE parameter vector per call.  Here the objective is evaluated for a whole population
 per call by ``xh_calib_objective`` (csrc/xh_calib.hip: members x cells on the GPU, forcing transposed once per basin
-and kept in HBM), and the differential-evolution driver is a generation-synchronous ``best1bin`` with the same
-defaults as SciPy's (popsize 15 x n_parameters members, Latin-hypercube start, dithered mutation in (0.5, 1),
-recombination 0.7, tol 0.01, maxiter 1000).  SciPy's driver is unseeded and updates the population in place, so the
-reference's search trajectory is not reproducible; only the objective is a parity target (tests/golden/kge.npz).
+and kept in HBM), and the differential evolution itself runs on the device too (csrc/xh_calib_de.hip): ``best1bin``
+with SciPy's defaults (popsize 15 x n_parameters members, Latin-hypercube start, dithered mutation in (0.5, 1),
+recombination 0.7, tol 0.01, maxiter 1000, the two sampled members distinct from the candidate), generation-synchronous
+like SciPy's ``updating='deferred'``, for ALL requested basins at once instead of the reference's serial basin loop
+(:256-262).  With several ranks (``torch.distributed``) the basins are dealt to the ranks largest-first and the
+``[n_basins, n_par + 1]`` results gathered on rank 0.  SciPy's driver is unseeded, so the reference's search
+trajectory is not reproducible; the objective is the parity target (tests/golden/kge.npz) and the generation step is
+checked against a numpy restatement of SciPy's (oracle/de.py).
 
 ``set_calibrate = 1`` (calibrate against routed stream flow) is not offered: in the reference that branch hands the
 whole ``[ncell, nmonths]`` Avg_ChFlow array to ``np.corrcoef`` against a 1-D observation series (:165-173, :196-213),
@@ -39,7 +43,8 @@ class BasinObjective:
         self.npar = 4 if self.nosnow else 5
         tr = lambda a: self.ctx.upload(np.ascontiguousarray(np.asarray(a, dtype=np.float64)[:, :n_months].T))
         self.d_pet, self.d_precip = tr(pet), tr(precip)
-        self.d_tmin = None if self.nosnow else tr(tmin)
+        # the loader's np.nan_to_num of TempMinFile (data_load.py:194-195); precipitation keeps its NaNs (:186)
+        self.d_tmin = None if self.nosnow else self.ctx.nan_to_num(tr(tmin))
         self.d_area = self.ctx.upload(bsn_areas) if obs_unit == 'km3_per_mth' else None
         self.obs = np.ascontiguousarray(np.asarray(bsn_robs, dtype=np.float64)[:n_months])
         self.nfev = 0
@@ -56,42 +61,65 @@ class BasinObjective:
                 b.free()
 
 
-def differential_evolution_batched(func, bounds, popsize=15, maxiter=1000, tol=0.01, atol=0.0, mutation=(0.5, 1.0),
-                                   recombination=0.7, seed=None):
-    """Generation-synchronous DE/best/1/bin. ``func(P[n, d]) -> energies[n]``. Returns (x, fun, nfev, nit)."""
-    rng = np.random.default_rng(seed)
-    lo = np.array([b[0] for b in bounds], dtype=float)
-    hi = np.array([b[1] for b in bounds], dtype=float)
-    d = len(bounds)
-    n = max(5, popsize * d)
-    # Latin hypercube start, as SciPy's init='latinhypercube'
-    seg = (np.arange(n)[:, None] + rng.random((n, d))) / n
-    pop = np.empty((n, d))
-    for j in range(d):
-        pop[:, j] = seg[rng.permutation(n), j]
-    energies = np.asarray(func(lo + pop * (hi - lo)), dtype=float)
-    energies = np.where(np.isfinite(energies), energies, np.inf)
-    nfev, nit = n, 0
-    for nit in range(1, maxiter + 1):
-        finite = energies[np.isfinite(energies)]
-        if finite.size == n and np.std(finite) <= atol + tol * np.abs(np.mean(finite)):
-            break
-        best = pop[np.argmin(energies)]
-        scale = rng.uniform(mutation[0], mutation[1])                  # dither once per generation
-        r = np.array([rng.choice(n, 2, replace=False) for _ in range(n)])
-        mutant = best + scale * (pop[r[:, 0]] - pop[r[:, 1]])
-        cross = rng.random((n, d)) < recombination
-        cross[np.arange(n), rng.integers(0, d, n)] = True
-        trial = np.where(cross, mutant, pop)
-        out = (trial < 0) | (trial > 1)
-        trial[out] = rng.random(int(out.sum()))                        # SciPy re-draws out-of-bounds entries
-        e_trial = np.asarray(func(lo + trial * (hi - lo)), dtype=float)
-        e_trial = np.where(np.isfinite(e_trial), e_trial, np.inf)
-        nfev += n
-        better = e_trial <= energies
-        pop[better], energies[better] = trial[better], e_trial[better]
-    k = int(np.argmin(energies))
-    return lo + pop[k] * (hi - lo), float(energies[k]), nfev, nit
+class BasinSet:
+    """Several basins prepared for the device: forcing transposed to [month, cell] in HBM, observations, bounds."""
+
+    def __init__(self, cals, n_months, runoff_spinup, obs_unit, device=0):
+        self.cals = cals
+        self.objs = [c.objective() for c in cals]
+        self.ctx = self.objs[0].ctx
+        self.nosnow, self.npar = self.objs[0].nosnow, self.objs[0].npar
+        self.n_months, self.spinup = int(n_months), int(runoff_spinup)
+        self.obs = np.stack([o.obs for o in self.objs])
+        self.bounds = cals[0].bounds
+
+    def args(self):
+        o = self.objs
+        return ([x.ncell for x in o], [x.d_pet for x in o], [x.d_precip for x in o],
+                None if self.nosnow else [x.d_tmin for x in o],
+                None if o[0].d_area is None else [x.d_area for x in o])
+
+    def evaluate(self, pars):
+        """ED for parameter sets pars [nbasins, nmembers, npar] in ONE launch."""
+        nc, pet, pr, tn, ar = self.args()
+        return self.ctx.calib_objective_multi(nc, self.n_months, self.spinup, np.asarray(pars)[:, :, :self.npar], pet,
+                                              pr, tn, ar, self.obs)
+
+    def solver(self, nmembers, seed=0):
+        nc, pet, pr, tn, ar = self.args()
+        return _hip.CalibDE(self.ctx, nc, self.n_months, self.spinup, nmembers, self.bounds, pet, pr, tn, ar, self.obs,
+                            seed=seed, keys=[c.basin_num for c in self.cals])
+
+    def close(self):
+        for o in self.objs:
+            o.close()
+
+
+def differential_evolution_device(bset, popsize=15, maxiter=1000, tol=0.01, atol=0.0, mutation=(0.5, 1.0),
+                                  recombination=0.7, seed=None, nmembers=None, check_every=4):
+    """DE/best/1/bin for every basin of ``bset`` at once, entirely on the device (csrc/xh_calib_de.hip).
+
+    SciPy's defaults as the reference uses them (calibrate_abcd.py:103-112): ``popsize x n_parameters`` members,
+    Latin-hypercube start, dither (0.5, 1), recombination 0.7, tol 0.01, maxiter 1000, no polish; selection is
+    generation-synchronous (SciPy's ``updating='deferred'``).  The host only enqueues generations, ``check_every`` at
+    a time, and reads back how many basins are still searching.  Returns (x [nb, d], fun [nb], nfev [nb], nit [nb]).
+    """
+    d = len(bset.bounds)
+    n = int(nmembers) if nmembers else max(5, popsize * d)
+    if seed is None:
+        seed = int.from_bytes(os.urandom(8), 'little')       # unseeded like the reference; pass a seed to reproduce
+    de = bset.solver(n, seed=seed)
+    try:
+        de.init()
+        done, left = 0, len(bset.cals)
+        while done < maxiter and left > 0:
+            k = min(check_every, maxiter - done)
+            left = de.step(k, tol=tol, atol=atol, mutation=mutation, recombination=recombination)
+            done += k
+        x, fun, nfev, nit, _ = de.result()
+    finally:
+        de.close()
+    return x, fun, nfev, nit
 
 
 class Calibrate:
@@ -125,26 +153,34 @@ class Calibrate:
 
     def calibrate_basin(self, popsize=15, polish=False):
         """Optimise (a, b, c, d[, m]) for maximum KGE and save the results (:90-131)."""
+        if polish:
+            raise NotImplementedError('polish=True (L-BFGS-B after the search) is not offered; the reference default is False')
         st = time.time()
-        obj = self.objective()
+        bset = BasinSet([self], self.n_months, self.runoff_spinup, self.obs_unit)
         try:
-            x, ed, nfev, nit = differential_evolution_batched(obj, self.bounds, popsize=popsize, seed=self.seed)
+            x, ed, nfev, nit = differential_evolution_device(bset, popsize=popsize, seed=self.seed)
         finally:
-            obj.close()
+            bset.close()
+        self._store(x[0], ed[0], int(nfev[0]))
+        logging.debug('\t\tFinished calibration for basin {0} which contains {1} grid cells.'.format(
+            self.basin_num, self.basin_idx[0].shape[0]))
+        logging.debug('\t\tPopulation size:  {}'.format(popsize))
+        logging.debug('\t\tParameter values ({}):  {}'.format(','.join(list(self.par_names())), x[0]))
+        logging.debug('\t\tKGE:  {}'.format(1 - ed[0]))
+        logging.debug('\t\tNumber of function evaluations:  {} in {} generations'.format(int(nfev[0]), int(nit[0])))
+        logging.debug('\t\tCalibration time (seconds):  {}'.format(time.time() - st))
+
+    def par_names(self):
+        return 'abcd' + 'm' * (not self.nosnow)
+
+    def _store(self, x, ed, nfev, save=True):
         self.all_pars[0, :] = x
         self.kge_vals[0] = 1 - ed
         self.nfev = nfev
-        par_names = 'abcd' + 'm' * (not self.nosnow)
-        logging.debug('\t\tFinished calibration for basin {0} which contains {1} grid cells.'.format(
-            self.basin_num, self.basin_idx[0].shape[0]))
-        logging.debug('\t\tParameter values ({}):  {}'.format(','.join(list(par_names)), x))
-        logging.debug('\t\tKGE:  {}'.format(1 - ed))
-        logging.debug('\t\tNumber of function evaluations:  {} in {} generations'.format(nfev, nit))
-        logging.debug('\t\tCalibration time (seconds):  {}'.format(time.time() - st))
-        if self.out_dir is not None:
+        if save and self.out_dir is not None:
             os.makedirs(self.out_dir, exist_ok=True)
             np.save('{}/kge_result_basin_{}.npy'.format(self.out_dir, self.basin_num), self.kge_vals)
-            np.save('{}/{}_parameters_basin_{}.npy'.format(self.out_dir, par_names, self.basin_num), self.all_pars)
+            np.save('{}/{}_parameters_basin_{}.npy'.format(self.out_dir, self.par_names(), self.basin_num), self.all_pars)
 
 
 def objective_kge(pars, pet, precip, tmin, n_months, runoff_spinup, obs_unit, bsn_areas, bsn_robs, device=0):
@@ -178,104 +214,88 @@ def process_basin(basin_num, settings, data, pet, router_function=None):
     return cal
 
 
-def differential_evolution_multi(func, bounds, nbasins, popsize=15, maxiter=1000, tol=0.01, atol=0.0,
-                                 mutation=(0.5, 1.0), recombination=0.7, seed=None):
-    """Lock-step DE/best/1/bin for ``nbasins`` independent problems with a shared generation clock.
-
-    ``func(active, P)``: ``active`` = indices of the basins still searching, ``P`` [len(active), n, d] their trial
-    populations; returns energies [len(active), n].  One call = one generation of every active basin, which is what
-    the multi-basin GPU objective evaluates in a single launch.  Returns (x [nb, d], fun [nb], nfev [nb], nit [nb]).
-    """
-    rng = np.random.default_rng(seed)
-    lo = np.array([b[0] for b in bounds], dtype=float)
-    hi = np.array([b[1] for b in bounds], dtype=float)
-    d = len(bounds)
-    n = max(5, popsize * d)
-    pop = np.empty((nbasins, n, d))
-    for b in range(nbasins):                                             # Latin hypercube per basin
-        seg = (np.arange(n)[:, None] + rng.random((n, d))) / n
-        for j in range(d):
-            pop[b, :, j] = seg[rng.permutation(n), j]
-    clean = lambda e: np.where(np.isfinite(e), e, np.inf)
-    active = np.arange(nbasins)
-    energies = clean(np.asarray(func(active, lo + pop * (hi - lo)), dtype=float))
-    nfev = np.full(nbasins, n)
-    nit = np.zeros(nbasins, dtype=int)
-    for it in range(1, maxiter + 1):
-        fin = np.isfinite(energies).all(axis=1)
-        spread = np.std(np.where(np.isfinite(energies), energies, 0.0), axis=1)
-        conv = fin & (spread <= atol + tol * np.abs(np.mean(np.where(np.isfinite(energies), energies, 0.0), axis=1)))
-        active = np.nonzero(~conv)[0]
-        if len(active) == 0:
-            break
-        k = len(active)
-        best = pop[active, np.argmin(energies[active], axis=1)]           # [k, d]
-        scale = rng.uniform(mutation[0], mutation[1], size=(k, 1, 1))
-        r = np.stack([np.stack([rng.choice(n, 2, replace=False) for _ in range(n)]) for _ in range(k)])   # [k, n, 2]
-        pa = np.take_along_axis(pop[active], r[:, :, :1].repeat(d, axis=2), axis=1)
-        pb = np.take_along_axis(pop[active], r[:, :, 1:].repeat(d, axis=2), axis=1)
-        mutant = best[:, None, :] + scale * (pa - pb)
-        cross = rng.random((k, n, d)) < recombination
-        jj = rng.integers(0, d, (k, n))
-        cross[np.arange(k)[:, None], np.arange(n)[None, :], jj] = True
-        trial = np.where(cross, mutant, pop[active])
-        out = (trial < 0) | (trial > 1)
-        trial[out] = rng.random(int(out.sum()))
-        e_trial = clean(np.asarray(func(active, lo + trial * (hi - lo)), dtype=float))
-        nfev[active] += n
-        nit[active] = it
-        better = e_trial <= energies[active]
-        pa2, ea2 = pop[active], energies[active]
-        pa2[better], ea2[better] = trial[better], e_trial[better]
-        pop[active], energies[active] = pa2, ea2
-    kbest = np.argmin(energies, axis=1)
-    x = lo + pop[np.arange(nbasins), kbest] * (hi - lo)
-    return x, energies[np.arange(nbasins), kbest], nfev, nit
+def assign_basins(sizes, n_ranks):
+    """Largest-first onto the least-loaded rank (LPT) by ``sizes`` (cells x months). Returns rank of each basin."""
+    sizes = np.asarray(sizes, dtype=np.int64)
+    load = np.zeros(n_ranks, dtype=np.int64)
+    owner = np.empty(len(sizes), dtype=np.int64)
+    for b in np.argsort(-sizes, kind='stable'):
+        r = int(np.argmin(load))
+        owner[b] = r
+        load[r] += sizes[b]
+    return owner
 
 
-def calibrate_all(settings, data, pet, router_function=None, seed=None, popsize=15):
+def gather_results(local, owner, dist, root=0):
+    """Gather per-basin result rows to ``root``: local [n_local, w] in the rank's basin order -> [n_basins, w].
+
+    ONE collective of ``n_basins x (n_par + 3)`` doubles: every rank contributes a full-size table
+    that is zero outside its own basins, so a sum-reduce to the root IS the gather (x + 0 is exact)."""
+    import torch
+    rank = dist.get_rank()
+    owner = np.asarray(owner)
+    table = np.zeros((len(owner), local.shape[1]))
+    table[np.nonzero(owner == rank)[0]] = local
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.from_numpy(table).to(dev)
+    dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy() if rank == root else None
+
+
+def _make_calibrate(b, settings, data, pet):
+    return Calibrate(basin_num=b, set_calibrate=0, obs_unit=settings.obs_unit, basin_ids=data.basin_ids,
+                     basin_areas=data.area, precip=data.precip, pet=pet, obs=data.cal_obs, tmin=data.tmin,
+                     n_months=settings.nmonths, runoff_spinup=settings.runoff_spinup, out_dir=settings.calib_out_dir,
+                     device=getattr(settings, 'device', 0))
+
+
+def _calibrate_local(mine, settings, data, pet, seed, popsize, nmembers):
+    """This rank's share: rows [len(mine), npar + 3] = (parameters, ED, nfev, nit) and {basin: Calibrate}."""
+    npar = 5 if data.tmin is not None else 4
+    if not mine:
+        return np.zeros((0, npar + 3)), {}
+    cals = [_make_calibrate(b, settings, data, pet) for b in mine]
+    bset = BasinSet(cals, settings.nmonths, settings.runoff_spinup, settings.obs_unit)
+    try:
+        x, ed, nfev, nit = differential_evolution_device(bset, popsize=popsize, seed=seed, nmembers=nmembers)
+    finally:
+        bset.close()
+    return np.column_stack([x, ed, nfev, nit]), dict(zip(mine, cals))
+
+
+def calibrate_all(settings, data, pet, router_function=None, seed=None, popsize=15, nmembers=None, dist=None):
     """Calibrate every requested basin (:256-262).
 
-    All basins search in lock-step: each generation is ONE multi-basin launch of the objective
-    (xh_calib_objective_multi), ~3x faster than one launch per basin because a single basin cannot fill the chip.
-    Writes the reference's two files per basin (:130-131) and returns {basin: (parameters, kge)}.
+    All basins search in lock-step on the device (differential_evolution_device).  ``dist`` = an initialised
+    ``torch.distributed`` module: the basins are dealt to the ranks by size (every rank needs the same ``seed``), each
+    rank calibrates its share on its own GPU, and rank 0 receives all results in one collective.  Writes the
+    reference's two files per basin (:130-131; on rank 0) and returns {basin: (parameters, kge)} (rank 0; {} elsewhere).
     """
     if settings.set_calibrate != 0:
         raise NotImplementedError('set_calibrate = 1 (stream flow) is not supported; see the module docstring')
     basins = expand_str_range(settings.cal_basins)
-    cals = [Calibrate(basin_num=b, set_calibrate=0, obs_unit=settings.obs_unit, basin_ids=data.basin_ids,
-                      basin_areas=data.area, precip=data.precip, pet=pet, obs=data.cal_obs, tmin=data.tmin,
-                      n_months=settings.nmonths, runoff_spinup=settings.runoff_spinup, out_dir=settings.calib_out_dir,
-                      device=getattr(settings, 'device', 0)) for b in basins]
-    cals = [c for c in cals if c.basin_idx[0].size > 0]
-    if not cals:
+    basin_ids = np.asarray(data.basin_ids)
+    sizes = np.array([(basin_ids == b).sum() for b in basins])
+    basins = [b for b, n in zip(basins, sizes) if n > 0]
+    sizes = sizes[sizes > 0]
+    if not basins:
         return {}
-    objs = [c.objective() for c in cals]
-    ctx, nosnow = objs[0].ctx, objs[0].nosnow
-    npar = objs[0].npar
-    obs = np.stack([o.obs for o in objs])
-
-    def func(active, P):
-        sel = [objs[i] for i in active]
-        return ctx.calib_objective_multi([o.ncell for o in sel], settings.nmonths, settings.runoff_spinup,
-                                         P[:, :, :npar], [o.d_pet for o in sel], [o.d_precip for o in sel],
-                                         None if nosnow else [o.d_tmin for o in sel],
-                                         None if objs[0].d_area is None else [o.d_area for o in sel], obs[active])
+    rank, n_ranks = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    if n_ranks > 1 and seed is None:
+        raise ValueError('a multi-rank calibration needs the same explicit seed on every rank')
+    owner = assign_basins(sizes * settings.nmonths, n_ranks)
+    mine = [b for b, r in zip(basins, owner) if r == rank]
     st = time.time()
-    try:
-        x, ed, nfev, nit = differential_evolution_multi(func, cals[0].bounds, len(cals), popsize=popsize, seed=seed)
-    finally:
-        for o in objs:
-            o.close()
-    logging.info('\tCalibrated {} basins in {:.1f} s ({} objective evaluations)'.format(len(cals), time.time() - st,
-                                                                                     int(nfev.sum())))
-    par_names = 'abcd' + 'm' * (not nosnow)
+    npar = 5 if data.tmin is not None else 4
+    local, cals = _calibrate_local(mine, settings, data, pet, seed, popsize, nmembers)
+    table = gather_results(local, owner, dist) if n_ranks > 1 else local
+    if rank != 0:
+        return {}
+    logging.info('\tCalibrated {} basins on {} GPU(s) in {:.1f} s ({} objective evaluations)'.format(
+        len(basins), n_ranks, time.time() - st, int(table[:, npar + 1].sum())))
     results = {}
-    for i, c in enumerate(cals):
-        c.all_pars[0, :], c.kge_vals[0], c.nfev = x[i], 1 - ed[i], int(nfev[i])
-        results[c.basin_num] = (x[i], 1 - ed[i])
-        if c.out_dir is not None:
-            os.makedirs(c.out_dir, exist_ok=True)
-            np.save('{}/kge_result_basin_{}.npy'.format(c.out_dir, c.basin_num), c.kge_vals)
-            np.save('{}/{}_parameters_basin_{}.npy'.format(c.out_dir, par_names, c.basin_num), c.all_pars)
+    for b, row in zip(basins, table):
+        c = cals[b] if b in cals else _make_calibrate(b, settings, data, pet)
+        c._store(row[:npar], row[npar], int(row[npar + 1]))
+        results[b] = (row[:npar].copy(), 1 - row[npar])
     return results

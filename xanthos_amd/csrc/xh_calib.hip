@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "xh_abcd_dev.h"
+#include "xh_calib.h"
 #include "xh_common.h"
 
 namespace {
@@ -63,17 +64,15 @@ __device__ __forceinline__ AbcdPar member_par(const double *__restrict__ pars, i
     return P;
 }
 
-struct CalibBasin {
-    int ncell, chunk0, nchunks, pad;
-    const double *pet, *pr, *tn, *area;      // [month, cell] forcing of this basin; area may be NULL (mm_per_mth)
-};
+using CalibBasin = xh_calib_basin;
 
 // grid.x = 64-cell chunks of ALL basins of the call, grid.y = member blocks of MB; block = 64 threads (one wave).
 // Every basin carries its own population (pars[basin][member][npar]), so one launch evaluates a whole generation of
 // every basin: a single basin is only months x 1.7 us of dependent chain, far too little to fill the chip.
 template <bool SPINUP>
 __global__ void __launch_bounds__(64) k_calib_march(const CalibBasin *__restrict__ basins,
-                                                    const int *__restrict__ chunk_basin, int nsteps, int nmembers,
+                                                    const int *__restrict__ chunk_basin,
+                                                    const int *__restrict__ active, int nsteps, int nmembers,
                                                     int npar, const double *__restrict__ pars,
                                                     const double *__restrict__ sm0, const double *__restrict__ gw0,
                                                     double *__restrict__ dec_sum,    // [chunk][member][6]
@@ -81,6 +80,7 @@ __global__ void __launch_bounds__(64) k_calib_march(const CalibBasin *__restrict
                                                     double *__restrict__ part) {     // [chunk][member][nsteps]
     const int chunk = blockIdx.x, lane = threadIdx.x;
     const int b = chunk_basin[chunk];
+    if (active && !active[b]) return;                                // basin already converged (device-side DE)
     const CalibBasin B = basins[b];
     const int ncell = B.ncell;
     const int c = (chunk - B.chunk0) * 64 + lane;
@@ -144,12 +144,14 @@ __global__ void __launch_bounds__(64) k_calib_march(const CalibBasin *__restrict
 }
 
 // one thread per (basin, member): basin mean of the three Decembers over the basin's chunks, in chunk order
-__global__ void __launch_bounds__(64) k_calib_init(const CalibBasin *__restrict__ basins, int nbasins, int nmembers,
+__global__ void __launch_bounds__(64) k_calib_init(const CalibBasin *__restrict__ basins,
+                                                   const int *__restrict__ active, int nbasins, int nmembers,
                                                    const double *__restrict__ dec_sum, const int *__restrict__ dec_cnt,
                                                    double *__restrict__ sm0, double *__restrict__ gw0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nbasins * nmembers) return;
     const int b = i / nmembers, mem = i - b * nmembers;
+    if (active && !active[b]) return;
     const CalibBasin B = basins[b];
     double sum[6] = {0, 0, 0, 0, 0, 0};
     long long cnt[6] = {0, 0, 0, 0, 0, 0};
@@ -169,13 +171,15 @@ __global__ void __launch_bounds__(64) k_calib_init(const CalibBasin *__restrict_
 }
 
 // series[basin][member][month] = sum over the basin's chunks of part[chunk][member][month]
-__global__ void __launch_bounds__(256) k_calib_series(const CalibBasin *__restrict__ basins, int nbasins, int nmembers,
+__global__ void __launch_bounds__(256) k_calib_series(const CalibBasin *__restrict__ basins,
+                                                      const int *__restrict__ active, int nbasins, int nmembers,
                                                       int nmonths, const double *__restrict__ part,
                                                       double *__restrict__ series) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t per_basin = (int64_t)nmembers * nmonths;
     if (i >= per_basin * nbasins) return;
     const int b = (int)(i / per_basin);
+    if (active && !active[b]) return;
     const int64_t r = i - (int64_t)b * per_basin;                // member * nmonths + month
     const CalibBasin B = basins[b];
     double acc = 0.0;
@@ -196,10 +200,12 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 }
 
 // one workgroup per member: ED = sqrt((r-1)^2 + (sd_m/sd_o - 1)^2 + (mean_m/mean_o - 1)^2) (:196-213)
-__global__ void __launch_bounds__(256) k_calib_kge(int nmonths, int nmembers, const double *__restrict__ series,
+__global__ void __launch_bounds__(256) k_calib_kge(const int *__restrict__ active, int nmonths, int nmembers,
+                                                   const double *__restrict__ series,
                                                    const double *__restrict__ obs_all, double *__restrict__ ed) {
     __shared__ double sh[256];
     const int mem = blockIdx.x;                          // basin * nmembers + member
+    if (active && !active[mem / nmembers]) return;       // block-uniform
     const double *x = series + (int64_t)mem * nmonths;
     const double *obs = obs_all + (int64_t)(mem / nmembers) * nmonths;
     double sx = 0.0, so = 0.0;
@@ -231,26 +237,23 @@ __global__ void __launch_bounds__(256) k_calib_kge(int nmonths, int nmembers, co
 
 }  // namespace
 
-extern "C" int xh_calib_objective_multi(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, int32_t nmonths,
-                                        int32_t spinup, int32_t nmembers, int32_t npar, const double *h_pars,
-                                        const double *const *h_pet_t, const double *const *h_precip_t,
-                                        const double *const *h_tmin_t, const double *const *h_area,
-                                        const double *h_obs, double *h_ed, double *h_series) {
-    if (!ctx) return XH_ERR_ARG;
-    XH_REQUIRE(ctx, nbasins > 0 && h_ncell && h_pars && h_pet_t && h_precip_t && h_obs && h_ed,
-               "xh_calib_objective: NULL argument");
+int xh_calib_problem_plan(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, int32_t nmonths, int32_t spinup,
+                          int32_t nmembers, int32_t npar, const double *const *h_pet_t,
+                          const double *const *h_precip_t, const double *const *h_tmin_t,
+                          const double *const *h_area, std::vector<xh_calib_basin> &basins,
+                          std::vector<int> &chunk_basin, size_t *bytes) {
+    XH_REQUIRE(ctx, nbasins > 0 && h_ncell && h_pet_t && h_precip_t, "xh_calib_objective: NULL argument");
     XH_REQUIRE(ctx, nmonths > 1 && nmembers > 0, "xh_calib_objective: bad size");
     XH_REQUIRE(ctx, npar == 4 || npar == 5, "xh_calib_objective: npar must be 4 (no snow) or 5");
     XH_REQUIRE(ctx, (npar == 5) == (h_tmin_t != nullptr), "xh_calib_objective: npar = 5 requires tmin and vice versa");
     XH_REQUIRE(ctx, spinup >= 25 && spinup <= nmonths, "xh_calib_objective: spin-up must be in [25, nmonths]");
-
-    std::vector<CalibBasin> basins(nbasins);
-    std::vector<int> chunk_basin;
+    basins.assign(nbasins, xh_calib_basin());
+    chunk_basin.clear();
     for (int b = 0; b < nbasins; ++b) {
         XH_REQUIRE(ctx, h_ncell[b] > 0 && h_ncell[b] < ((int64_t)1 << 24), "xh_calib_objective: basin %d has %lld cells",
                    b, (long long)h_ncell[b]);
         XH_REQUIRE(ctx, h_pet_t[b] && h_precip_t[b] && (npar == 4 || h_tmin_t[b]), "xh_calib_objective: NULL forcing");
-        CalibBasin &B = basins[b];
+        xh_calib_basin &B = basins[b];
         B.ncell = (int)h_ncell[b];
         B.chunk0 = (int)chunk_basin.size();
         B.nchunks = (B.ncell + 63) / 64;
@@ -261,59 +264,107 @@ extern "C" int xh_calib_objective_multi(xh_ctx *ctx, int32_t nbasins, const int6
         B.area = h_area ? h_area[b] : nullptr;
         chunk_basin.insert(chunk_basin.end(), B.nchunks, b);
     }
-    const size_t nchunks = chunk_basin.size();
-    const int nmblocks = (nmembers + MB - 1) / MB;
-    XH_REQUIRE(ctx, nmblocks <= 65535, "xh_calib_objective: too many members");
-    const size_t nbm = (size_t)nbasins * nmembers;
-    const size_t n_part = nchunks * nmembers * (size_t)nmonths;
-    const size_t n_dec = nchunks * nmembers * 6;
-    const size_t dbl = nbm * npar + (size_t)nbasins * nmonths + 2 * nbm + n_dec + n_part + nbm * nmonths + nbm;
-    const size_t tab_bytes = ((sizeof(CalibBasin) * nbasins + sizeof(int) * nchunks) + 255) & ~size_t(255);
-    void *buf = nullptr;
-    int rc = xh_scratch(ctx, 1, dbl * sizeof(double) + n_dec * sizeof(int) + tab_bytes + 256, &buf);
-    if (rc) return rc;
-    double *d_pars = static_cast<double *>(buf);
-    double *d_obs = d_pars + nbm * npar;
-    double *d_sm0 = d_obs + (size_t)nbasins * nmonths;
-    double *d_gw0 = d_sm0 + nbm;
-    double *d_dec = d_gw0 + nbm;
-    double *d_part = d_dec + n_dec;
-    double *d_series = d_part + n_part;
-    double *d_ed = d_series + nbm * nmonths;
-    CalibBasin *d_basins = reinterpret_cast<CalibBasin *>(d_ed + nbm);
-    int *d_chunk_basin = reinterpret_cast<int *>(d_basins + nbasins);
-    int *d_cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(d_basins) + tab_bytes);
-    XH_HIP(ctx, hipMemcpyAsync(d_pars, h_pars, sizeof(double) * nbm * npar, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_obs, h_obs, sizeof(double) * nbasins * nmonths, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_basins, basins.data(), sizeof(CalibBasin) * nbasins, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_chunk_basin, chunk_basin.data(), sizeof(int) * nchunks, hipMemcpyHostToDevice, ctx->stream));
+    XH_REQUIRE(ctx, (nmembers + MB - 1) / MB <= 65535, "xh_calib_objective: too many members");
+    const size_t nchunks = chunk_basin.size(), nbm = (size_t)nbasins * nmembers;
+    const size_t dbl = (size_t)nbasins * nmonths + 2 * nbm + nchunks * nmembers * 6 + nchunks * nmembers * (size_t)nmonths +
+                       nbm * nmonths;
+    const size_t tab_bytes = ((sizeof(xh_calib_basin) * nbasins + sizeof(int) * nchunks) + 255) & ~size_t(255);
+    *bytes = dbl * sizeof(double) + nchunks * nmembers * 6 * sizeof(int) + tab_bytes + 256;
+    return XH_OK;
+}
 
-    const dim3 grid((unsigned)nchunks, (unsigned)nmblocks), block(64);
+int xh_calib_problem_place(xh_ctx *ctx, xh_calib_problem &P, int32_t nmonths, int32_t spinup, int32_t nmembers,
+                           int32_t npar, const std::vector<xh_calib_basin> &basins,
+                           const std::vector<int> &chunk_basin, const double *h_obs, void *buf) {
+    XH_REQUIRE(ctx, h_obs != nullptr, "xh_calib_objective: obs is NULL");
+    const int nbasins = (int)basins.size();
+    const size_t nchunks = chunk_basin.size(), nbm = (size_t)nbasins * nmembers;
+    const size_t n_dec = nchunks * nmembers * 6, n_part = nchunks * nmembers * (size_t)nmonths;
+    const size_t tab_bytes = ((sizeof(xh_calib_basin) * nbasins + sizeof(int) * nchunks) + 255) & ~size_t(255);
+    P.nbasins = nbasins;
+    P.nmonths = nmonths;
+    P.spinup = spinup;
+    P.nmembers = nmembers;
+    P.npar = npar;
+    P.nchunks = nchunks;
+    P.d_obs = static_cast<double *>(buf);
+    P.d_sm0 = P.d_obs + (size_t)nbasins * nmonths;
+    P.d_gw0 = P.d_sm0 + nbm;
+    P.d_dec = P.d_gw0 + nbm;
+    P.d_part = P.d_dec + n_dec;
+    P.d_series = P.d_part + n_part;
+    P.d_basins = reinterpret_cast<xh_calib_basin *>(P.d_series + nbm * nmonths);
+    P.d_chunk_basin = reinterpret_cast<int *>(P.d_basins + nbasins);
+    P.d_cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(P.d_basins) + tab_bytes);
+    XH_HIP(ctx, hipMemcpyAsync(P.d_obs, h_obs, sizeof(double) * nbasins * nmonths, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(P.d_basins, basins.data(), sizeof(xh_calib_basin) * nbasins, hipMemcpyHostToDevice,
+                               ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(P.d_chunk_basin, chunk_basin.data(), sizeof(int) * nchunks, hipMemcpyHostToDevice,
+                               ctx->stream));
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));                  // the host tables are the caller's locals
+    return XH_OK;
+}
+
+int xh_calib_enqueue(xh_ctx *ctx, const xh_calib_problem &P, const double *d_pars, const int *d_active, double *d_ed) {
+    const int nmblocks = (P.nmembers + MB - 1) / MB;
+    const size_t nbm = (size_t)P.nbasins * P.nmembers;
+    const dim3 grid((unsigned)P.nchunks, (unsigned)nmblocks), block(64);
     {
         xh_span sp = xh_span_begin(ctx, "calib_abcd");
-        hipLaunchKernelGGL(k_calib_march<true>, grid, block, 0, ctx->stream, d_basins, d_chunk_basin, (int)spinup,
-                           (int)nmembers, (int)npar, d_pars, (const double *)nullptr, (const double *)nullptr, d_dec,
-                           d_cnt, (double *)nullptr);
-        hipLaunchKernelGGL(k_calib_init, dim3((unsigned)((nbm + 63) / 64)), dim3(64), 0, ctx->stream, d_basins,
-                           (int)nbasins, (int)nmembers, d_dec, d_cnt, d_sm0, d_gw0);
-        hipLaunchKernelGGL(k_calib_march<false>, grid, block, 0, ctx->stream, d_basins, d_chunk_basin, (int)nmonths,
-                           (int)nmembers, (int)npar, d_pars, d_sm0, d_gw0, (double *)nullptr, (int *)nullptr, d_part);
+        hipLaunchKernelGGL(k_calib_march<true>, grid, block, 0, ctx->stream, P.d_basins, P.d_chunk_basin, d_active,
+                           P.spinup, P.nmembers, P.npar, d_pars, (const double *)nullptr, (const double *)nullptr,
+                           P.d_dec, P.d_cnt, (double *)nullptr);
+        hipLaunchKernelGGL(k_calib_init, dim3((unsigned)((nbm + 63) / 64)), dim3(64), 0, ctx->stream, P.d_basins,
+                           d_active, P.nbasins, P.nmembers, P.d_dec, P.d_cnt, P.d_sm0, P.d_gw0);
+        hipLaunchKernelGGL(k_calib_march<false>, grid, block, 0, ctx->stream, P.d_basins, P.d_chunk_basin, d_active,
+                           P.nmonths, P.nmembers, P.npar, d_pars, P.d_sm0, P.d_gw0, (double *)nullptr, (int *)nullptr,
+                           P.d_part);
         xh_span_end(sp);
     }
     {
         xh_span sp = xh_span_begin(ctx, "calib_kge");
-        const int64_t n = (int64_t)nbm * nmonths;
-        hipLaunchKernelGGL(k_calib_series, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_basins,
-                           (int)nbasins, (int)nmembers, (int)nmonths, d_part, d_series);
-        hipLaunchKernelGGL(k_calib_kge, dim3((unsigned)nbm), dim3(256), 0, ctx->stream, (int)nmonths, (int)nmembers,
-                           d_series, d_obs, d_ed);
+        const int64_t n = (int64_t)nbm * P.nmonths;
+        hipLaunchKernelGGL(k_calib_series, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P.d_basins,
+                           d_active, P.nbasins, P.nmembers, P.nmonths, P.d_part, P.d_series);
+        hipLaunchKernelGGL(k_calib_kge, dim3((unsigned)nbm), dim3(256), 0, ctx->stream, d_active, P.nmonths,
+                           P.nmembers, P.d_series, P.d_obs, d_ed);
         xh_span_end(sp);
     }
     XH_HIP(ctx, hipGetLastError());
+    return XH_OK;
+}
+
+extern "C" int xh_calib_objective_multi(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, int32_t nmonths,
+                                        int32_t spinup, int32_t nmembers, int32_t npar, const double *h_pars,
+                                        const double *const *h_pet_t, const double *const *h_precip_t,
+                                        const double *const *h_tmin_t, const double *const *h_area,
+                                        const double *h_obs, double *h_ed, double *h_series) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, h_pars && h_obs && h_ed, "xh_calib_objective: NULL argument");
+    std::vector<xh_calib_basin> basins;
+    std::vector<int> chunk_basin;
+    size_t bytes = 0;
+    int rc = xh_calib_problem_plan(ctx, nbasins, h_ncell, nmonths, spinup, nmembers, npar, h_pet_t, h_precip_t, h_tmin_t,
+                                   h_area, basins, chunk_basin, &bytes);
+    if (rc) return rc;
+    const size_t nbm = (size_t)nbasins * nmembers;
+    const size_t io_bytes = ((nbm * npar + nbm) * sizeof(double) + 255) & ~size_t(255);
+    void *buf = nullptr;
+    rc = xh_scratch(ctx, 1, io_bytes + bytes, &buf);
+    if (rc) return rc;
+    double *d_pars = static_cast<double *>(buf);
+    double *d_ed = d_pars + nbm * npar;
+    xh_calib_problem P;
+    XH_HIP(ctx, hipMemcpyAsync(d_pars, h_pars, sizeof(double) * nbm * npar, hipMemcpyHostToDevice, ctx->stream));
+    rc = xh_calib_problem_place(ctx, P, nmonths, spinup, nmembers, npar, basins, chunk_basin, h_obs,
+                                static_cast<char *>(buf) + io_bytes);
+    if (rc) return rc;
+    rc = xh_calib_enqueue(ctx, P, d_pars, nullptr, d_ed);
+    if (rc) return rc;
     XH_HIP(ctx, hipMemcpyAsync(h_ed, d_ed, sizeof(double) * nbm, hipMemcpyDeviceToHost, ctx->stream));
     if (h_series)
-        XH_HIP(ctx, hipMemcpyAsync(h_series, d_series, sizeof(double) * nbm * nmonths, hipMemcpyDeviceToHost, ctx->stream));
-    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host tables and result buffers are the caller's / locals
+        XH_HIP(ctx, hipMemcpyAsync(h_series, P.d_series, sizeof(double) * nbm * nmonths, hipMemcpyDeviceToHost, ctx->stream));
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // result buffers are the caller's
     return XH_OK;
 }
 

@@ -86,7 +86,7 @@ void xh_span_end(xh_span &s) {
 
 extern "C" {
 
-int xh_abi_version(void) { return 2; }
+int xh_abi_version(void) { return 3; }
 
 int xh_device_count(int *n) {
     if (!n) return XH_ERR_ARG;
