@@ -8,10 +8,12 @@ ABCD runoff (spin-up + simulation) -> MRTM routing (spin-up + simulation at 3-ho
 x 600 months (BASELINE.json configs[2]; ``--workload pm_abcd`` runs configs[1]).  Forcing is synthetic
 (xanthos_amd/synth.py distributions), generated on the device and resident in HBM before the timed region.
 
-N > 1 (launched with torch.distributed.run, one rank per GPU): every rank routes its own 67,420-cell scenario
-(different forcing seed) -- weak scaling, no data-path collective; the timed region is bracketed by a barrier and a
-device synchronise on both sides and the slowest rank's time is used.  ``--strong`` instead shards the 235 basins of
-ONE world over the ranks (BASELINE.json configs[3]) with a single gather of the six outputs to rank 0.
+N > 1 (launched with torch.distributed.run, one rank per GPU): the 235 basins of ONE world are sharded over the ranks
+(BASELINE.json configs[3]; strong scaling) and every step ends with a single gather of the six outputs to rank 0; the
+timed region is bracketed by a barrier and a device synchronise on both sides and the slowest rank's time is used.
+The figure for N independent whole-world scenarios (one per GPU, no collective) is measured afterwards and printed as
+the secondary object ``replicas``; ``--replicas`` makes that mode the primary one (weak scaling).
+``--workload calib`` runs BASELINE configs[4] (one step = one differential-evolution generation of all 235 basins).
 
 Rank 0 prints ONE JSON line: metric cell-months/s (whole job), the roofline object for the dominant kernel
 (HIP-event durations measured on the library's stream inside this run), per-kernel figures, and -- at N = 1 -- the
@@ -44,96 +46,136 @@ def algorithmic_bytes(ncell, nmonths, nlcs, abcd_spinup, routing_spinup):
 
 
 def cpu_baseline(pipe, world, args, log):
-    """Time the numpy oracle (port of the reference) on a bounded sample; check the GPU outputs on the same cells."""
+    """Time the numpy oracle (a port of the reference's algorithm) on this host and check the GPU outputs against it.
+
+    Sizes: PM on the FULL grid for the first ``--cpu-pm-years`` years (it is linear in years), 1 thread
+    like the reference; ABCD at FULL size (67,420 cells x all months + spin-up) on joblib threads like the reference's
+    ``jobs = -1``; MRTM on the full grid (networks cannot be sampled) for ``--cpu-mrtm-months`` months, 1 thread,
+    scipy CSR like the reference -- ``--cpu-full`` routes the whole series (spin-up + all months, ~3-4 min) and
+    compares every value of the run's ChStorage / Avg_ChFlow bit for bit."""
+    from types import SimpleNamespace
     from oracle import abcd as o_abcd, mrtm as o_mrtm, pm as o_pm
     from xanthos_amd import synth
     nm, y0 = pipe.nmonths, pipe.start_year
-    res, parity = {}, {}
-
-    # ---- PM: a contiguous block of cells (tairprev = previous cell), first pm_years years
-    n_pm, pm_years = args.cpu_pm_cells, min(args.cpu_pm_years, nm // 12)
-    cells = np.arange(n_pm)
-    f = {k: pipe.rows(pipe.forcing[k], cells)[:, :12 * pm_years] for k in ('tas', 'tmin', 'rhs', 'wind', 'rsds', 'rlds')}
-    from types import SimpleNamespace
-    sub = SimpleNamespace(**{k: getattr(world, k) for k in ('cL', 'beta', 'rslimit', 'ae', 'be', 'Tminopen',
-                                                                  'Tminclose', 'VPDclose', 'VPDopen', 'RBLmin',
-                                                                  'RBLmax', 'rc', 'emiss', 'alpha', 'lai', 'laimax',
-                                                                  'laimin')})
-    sub.elev, sub.lct = world.elev[:n_pm], world.lct[:n_pm]
-    d = synth.data_bag(sub, f)
-    t = time.perf_counter()
-    ref_pet = o_pm.run_pmpet(d, n_pm, world.nlcs, y0, y0 + pm_years - 1, 0, 6, world.lc_years)
-    t_pm = time.perf_counter() - t
-    res['pm'] = n_pm * 12 * pm_years / t_pm
-    got = pipe.rows(pipe.out['pet'], cells)[:, :12 * pm_years]
+    res, parity = {}, {'tolerance_used': {}}
 
     def gate(x, ref):
         """Worst |x - ref| as a fraction of the north-star tolerance 1e-6 |ref| + 1e-9 (must stay <= 1)."""
         m = ~np.isnan(ref)
         assert np.array_equal(np.isnan(x), np.isnan(ref))
         return float(np.max(np.abs(x[m] - ref[m]) / (1e-6 * np.abs(ref[m]) + 1e-9)))
-    parity['pet'] = float(np.nanmax(np.abs(got - ref_pet) / (np.abs(ref_pet) + 1e-9)))
-    parity['tolerance_used'] = {'pet': gate(got, ref_pet)}
 
-    # ---- ABCD: whole basins up to ~cpu_abcd_cells cells, full series, joblib threads like the reference
-    order = np.argsort(-np.bincount(world.basin_ids, minlength=world.n_basins + 1))
-    chosen, count = [], 0
-    for b in order[3:]:
-        if b == 0:
-            continue
-        chosen.append(b)
-        count += int((world.basin_ids == b).sum())
-        if count >= args.cpu_abcd_cells:
-            break
-    bcells = np.nonzero(np.isin(world.basin_ids, chosen))[0]
-    pet_rows = pipe.rows(pipe.out['pet'], bcells)
-    pr_rows = pipe.rows(pipe.forcing['precip'], bcells)
-    tn_rows = pipe.rows(pipe.forcing['abcd_tmin'], bcells)
-    bid = world.basin_ids[bcells]
-    remap = {b: i + 1 for i, b in enumerate(sorted(chosen))}
-    bid_local = np.array([remap[b] for b in bid])
-    pars_local = world.abcd_pars[np.array(sorted(chosen)) - 1]
+    def relerr(x, ref):
+        m = ~np.isnan(ref)
+        return float(np.max(np.abs(x[m] - ref[m]) / (np.abs(ref[m]) + 1e-9)))
+
+    # ---- PM: the whole grid, first pm_years years
+    pm_years = min(args.cpu_pm_years, nm // 12)
+    k = 12 * pm_years
+    f = {name: pipe.forcing[name].download()[:, :k].copy() for name in ('tas', 'tmin', 'rhs', 'wind', 'rsds', 'rlds')}
+    d = synth.data_bag(world, f)
     t = time.perf_counter()
-    aet, q, sav = o_abcd.abcd_parallel(len(chosen), pars_local, bid_local, pet_rows, pr_rows, tn_rows, nm,
+    ref_pet = o_pm.run_pmpet(d, world.ncell, world.nlcs, y0, y0 + pm_years - 1, 0, 6, world.lc_years)
+    t_pm = time.perf_counter() - t
+    res['pm'] = world.ncell * k / t_pm
+    got_pet = pipe.out['pet'].download()
+    parity['pet'] = relerr(got_pet[:, :k], ref_pet)
+    parity['tolerance_used']['pet'] = gate(got_pet[:, :k], ref_pet)
+    del f, d, ref_pet
+
+    # ---- ABCD: full size, from the run's own PET (so that the comparison isolates this stage)
+    pr, tn = pipe.forcing['precip'].download(), pipe.forcing['abcd_tmin'].download()
+    t = time.perf_counter()
+    aet, q, sav = o_abcd.abcd_parallel(world.n_basins, world.abcd_pars, world.basin_ids, got_pet, pr, tn, nm,
                                        pipe.abcd_spinup, jobs=-1)
     t_abcd = time.perf_counter() - t
-    res['abcd'] = len(bcells) * nm / t_abcd
+    res['abcd'] = world.ncell * nm / t_abcd
     for name, ref in (('aet', aet), ('q', q), ('sav', sav)):
-        got = pipe.rows(pipe.out[name], bcells)
-        m = ~np.isnan(ref)
-        assert np.array_equal(np.isnan(got), np.isnan(ref)), name
-        parity[name] = float(np.max(np.abs(got[m] - ref[m]) / (np.abs(ref[m]) + 1e-9)))
+        got = pipe.out[name].download()
+        parity[name] = relerr(got, ref)
         parity['tolerance_used'][name] = gate(got, ref)
+    del aet, sav, pr, tn, got_pet
 
-    # ---- MRTM: the whole grid (networks cannot be sampled), a few months, scipy CSR like the reference
+    # ---- MRTM: the whole grid, scipy CSR like the reference, from the run's own runoff
     if 'mrtm' in args.stages:
         from xanthos_amd.routing import mrtm
-        k = args.cpu_mrtm_months
-        q_host = pipe.out['q'].download()[:, :k].copy()
+        q_run = pipe.out['q'].download()
         um = pipe.um.tocsr()
-        t = time.perf_counter()
-        r_chs, r_avg, _ = o_mrtm.route_series(um, world.flow_dist, world.velocity, world.area, q_host, pipe.ndays[:k], 0)
-        t_mrtm = time.perf_counter() - t
-        res['mrtm'] = world.ncell * k / t_mrtm
-        g_chs, g_avg, _ = mrtm.route_series(pipe.um, world.flow_dist, world.velocity, world.area, q_host,
-                                            pipe.ndays[:k], 0)
-        parity['routing_bit_exact'] = bool(np.array_equal(g_chs, r_chs, equal_nan=True) and
-                                           np.array_equal(g_avg, r_avg, equal_nan=True))
+        if args.cpu_full:
+            t = time.perf_counter()
+            r_chs, r_avg, _ = o_mrtm.route_series(um, world.flow_dist, world.velocity, world.area, q_run, pipe.ndays,
+                                                  pipe.routing_spinup)
+            t_mrtm = time.perf_counter() - t
+            res['mrtm'] = world.ncell * (nm + pipe.routing_spinup) / t_mrtm
+            parity['routing_bit_exact'] = bool(np.array_equal(pipe.out['chs'].download(), r_chs, equal_nan=True) and
+                                               np.array_equal(pipe.out['avg'].download(), r_avg, equal_nan=True))
+            parity['routing_months_checked'] = '{} spin-up + {} (the whole run)'.format(pipe.routing_spinup, nm)
+        else:
+            km = min(args.cpu_mrtm_months, nm)
+            q_host = q_run[:, :km].copy()
+            t = time.perf_counter()
+            r_chs, r_avg, _ = o_mrtm.route_series(um, world.flow_dist, world.velocity, world.area, q_host,
+                                                  pipe.ndays[:km], 0)
+            t_mrtm = time.perf_counter() - t
+            res['mrtm'] = world.ncell * km / t_mrtm
+            g_chs, g_avg, _ = mrtm.route_series(pipe.um, world.flow_dist, world.velocity, world.area, q_host,
+                                                pipe.ndays[:km], 0)
+            parity['routing_bit_exact'] = bool(np.array_equal(g_chs, r_chs, equal_nan=True) and
+                                               np.array_equal(g_avg, r_avg, equal_nan=True))
+            parity['routing_months_checked'] = '{} (no spin-up); --cpu-full checks the whole run'.format(km)
     inv = 1.0 / res['pm'] + 1.0 / res['abcd']        # the ABCD rate already includes its spin-up pass
     if 'mrtm' in res:
-        inv += (1.0 + pipe.routing_spinup / nm) / res['mrtm']
+        inv += (1.0 + pipe.routing_spinup / nm) / res['mrtm'] if not args.cpu_full else \
+            (1.0 + pipe.routing_spinup / nm) / res['mrtm']
     value = 1.0 / inv
-    sample = ('numpy oracle: PM {} cells x {} months 1 thread = {:.3g} cm/s; ABCD {} cells ({} basins) x {}+{} months '
-              'joblib {} threads = {:.3g} cm/s'.format(n_pm, 12 * pm_years, res['pm'], len(bcells), len(chosen), nm,
-                                                      pipe.abcd_spinup, os.cpu_count(), res['abcd']))
+    sample = ('numpy oracle on the full 67,420-cell grid: PM {} months 1 thread = {:.3g} cm/s ({:.1f} s); ABCD {}+{} '
+              'months joblib {} threads = {:.3g} cm/s ({:.1f} s)'.format(k, res['pm'], t_pm, nm, pipe.abcd_spinup,
+                                                                       os.cpu_count(), res['abcd'], t_abcd))
     if 'mrtm' in res:
-        sample += '; MRTM {} cells x {} months 1 thread = {:.3g} cm/s (x{:.2f} for routing spin-up)'.format(
-            world.ncell, args.cpu_mrtm_months, res['mrtm'], 1.0 + pipe.routing_spinup / nm)
-    sample += '; value = harmonic composition of the stage rates'
+        sample += '; MRTM {} 1 thread = {:.3g} cm/s ({:.1f} s), x{:.2f} for routing spin-up'.format(
+            'whole series' if args.cpu_full else '{} months'.format(min(args.cpu_mrtm_months, nm)), res['mrtm'],
+            t_mrtm, 1.0 + pipe.routing_spinup / nm)
+    sample += '; value = harmonic composition of the stage rates per simulated cell-month'
     log('cpu baseline: ' + sample)
-    log('parity on the sample: ' + json.dumps(parity))
+    log('parity: ' + json.dumps(parity))
     return {'value': value, 'unit': 'cell-months/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': sample,
             'stage_rates': res}, parity
+
+
+def end_to_end(ctx, pipe, args, log):
+    """PCIe-inclusive rate (never `value`): the eight forcing arrays start in page-locked host memory and the six outputs
+    end there, as a loader / writer around the boundary would hold them: H2D + loader transform (nan_to_num) + the
+    pipeline + D2H, ``steps`` times."""
+    from xanthos_amd.pipeline import FORCING, OUTPUTS
+    names = [k for k in FORCING if k in pipe.forcing]
+    outs = [k for k in OUTPUTS if ('mrtm' in args.stages or k not in ('chs', 'avg'))]
+    h_in = {k: ctx.pinned((pipe.ncell, pipe.nmonths)) for k in names}
+    h_out = {k: ctx.pinned((pipe.ncell, pipe.nmonths)) for k in outs}
+    for k in names:
+        pipe.forcing[k].download(h_in[k])
+    ctx.sync()
+    times = []
+    for _ in range(max(args.steps, 2)):
+        t0 = time.perf_counter()
+        for k in names:
+            ctx.h2d_async(pipe.forcing[k], h_in[k])
+            if k != 'precip':
+                ctx.nan_to_num(pipe.forcing[k])
+        pipe.run(args.stages)
+        for k in outs:
+            ctx.d2h_async(h_out[k], pipe.out[k])
+        ctx.sync()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    nbytes = (len(names) + len(outs)) * pipe.ncell * pipe.nmonths * 8
+    for a in list(h_in.values()) + list(h_out.values()):
+        ctx.free_pinned(a)
+    r = {'value': pipe.ncell * pipe.nmonths / t, 'unit': 'cell-months/s', 'ms_per_step': 1e3 * t,
+         'pcie_bytes_per_step': nbytes, 'pcie_GBs_if_serial': nbytes / max(t - args._kernel_s, 1e-9) / 1e9,
+         'note': 'pinned-host H2D of {} forcing arrays + nan_to_num + pipeline + D2H of {} outputs, one stream, no '
+                 'overlap; median of {} runs'.format(len(names), len(outs), len(times))}
+    log('end to end (PCIe-inclusive): ' + json.dumps(r))
+    return r
 
 
 FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector fp64 peak (MI355X_MICROARCH.md)
@@ -210,17 +252,21 @@ def bench_calib(args, ctx, rank, world_size, dist, torch, backend, log):
         pop, en = de.state(0)
         lo, hi = np.array([b[0] for b in cfg_bounds()]), np.array([b[1] for b in cfg_bounds()])
         order = np.argsort(-cfg.counts)
-        picks = [int(order[i * len(order) // args.cpu_calib_evals]) for i in range(args.cpu_calib_evals)]
-        cells, t_cpu, worst = 0, 0.0, 0.0
-        for i, b in enumerate(picks):
+        picks, cells, t_cpu, worst = [], 0, 0.0, 0.0
+        for i in range(100000):
+            if t_cpu > args.cpu_calib_seconds:
+                break
+            b = int(order[(i * 37) % len(order)])          # strides through big and small basins alike
+            picks.append(b)
             host = cfg.host_basin(b)
-            xs = o_de.scale_parameters(pop[b, i], lo, hi)
+            xs = o_de.scale_parameters(pop[b, i % args.members], lo, hi)
             t1 = time.perf_counter()
             ref = o_calib.objective_kge(xs, 0, host['pet'], host['precip'], host['tmin'], args.months, args.abcd_spinup,
                                         'km3_per_mth', host['area'], cfg.obs[b])
             t_cpu += time.perf_counter() - t1
             cells += int(cfg.counts[b])
-            worst = max(worst, abs(cfg.evaluate_one(b, xs[None])[0] - ref) / abs(ref))
+            if i < 24:
+                worst = max(worst, abs(cfg.evaluate_one(b, xs[None])[0] - ref) / abs(ref))
         cpu = cells * (args.months + args.abcd_spinup) / t_cpu
         result['cpu_baseline'] = {'value': cpu, 'unit': 'member-cell-months/s', 'cores': 1, 'kind': 'port',
                                   'sample': 'numpy oracle objective_kge (basin_runoff + KGE, as the reference evaluates '
@@ -250,17 +296,21 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='pm_abcd_mrtm', choices=['pm_abcd_mrtm', 'pm_abcd', 'calib'])
     ap.add_argument('--members', type=int, default=512, help='calib: population per basin')
-    ap.add_argument('--cpu-calib-evals', type=int, default=24, help='calib: oracle objective evaluations to time')
+    ap.add_argument('--cpu-calib-seconds', type=float, default=15.0, help='calib: seconds of oracle evaluations to time')
     ap.add_argument('--months', type=int, default=600)
     ap.add_argument('--start-year', type=int, default=1961)
     ap.add_argument('--abcd-spinup', type=int, default=120)
     ap.add_argument('--routing-spinup', type=int, default=120)
-    ap.add_argument('--strong', action='store_true', help='shard ONE world by basins over the ranks (configs[3])')
+    ap.add_argument('--replicas', action='store_true',
+                    help='N > 1: every rank runs its own whole world (weak scaling) instead of sharding ONE world')
+    ap.add_argument('--strong', action='store_true', help='(default for N > 1; kept for compatibility)')
+    ap.add_argument('--no-replica-figure', action='store_true', help='N > 1: skip the secondary replica measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-pm-cells', type=int, default=4096)
-    ap.add_argument('--cpu-pm-years', type=int, default=25)
-    ap.add_argument('--cpu-abcd-cells', type=int, default=12000)
-    ap.add_argument('--cpu-mrtm-months', type=int, default=24)
+    ap.add_argument('--no-end-to-end', action='store_true')
+    ap.add_argument('--cpu-full', action='store_true', help='CPU baseline routes the whole series (3-4 min) and '
+                                                            'checks every routed value of the run bit for bit')
+    ap.add_argument('--cpu-pm-years', type=int, default=5)
+    ap.add_argument('--cpu-mrtm-months', type=int, default=60)
     ap.add_argument('--route-flags', type=int, default=0)
     args = ap.parse_args()
     args.stages = ('pm', 'abcd', 'mrtm') if args.workload == 'pm_abcd_mrtm' else ('pm', 'abcd')
@@ -284,7 +334,7 @@ def main():
     backend = os.environ.get('XH_BENCH_BACKEND', 'nccl')       # "gloo" + XH_BENCH_ONE_DEVICE=1: dry-run of the N > 1
     if os.environ.get('XH_BENCH_ONE_DEVICE') == '1':           # code path with every rank on GPU 0 (1-GPU test boxes)
         local_rank = 0
-    if world_size > 1:
+    if world_size > 1:                                         # ranks were started by the launcher before any GPU call
         import torch
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -293,7 +343,7 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
 
     from xanthos_amd import _hip, synth
-    from xanthos_amd.pipeline import FORCING, pipeline_from_world, topology_from_world
+    from xanthos_amd.pipeline import pipeline_from_world, topology_from_world
     ctx = _hip.get_context(local_rank)
     log('device: ' + ctx.name())
 
@@ -305,28 +355,7 @@ def main():
     um = topology_from_world(world)
     log('synthetic world: {} cells, {} basins, built in {:.1f} s'.format(world.ncell, world.n_basins,
                                                                           time.perf_counter() - t0))
-    shard = None
-    if args.strong and world_size > 1:
-        from xanthos_amd import dist as xdist
-        shards = xdist.make_shards(world, um, world_size)
-        shard = shards[rank]
-        run_world, run_um = xdist.sub_world(world, um, shard)
-    else:
-        run_world, run_um = world, um
-    pipe = pipeline_from_world(ctx, run_world, args.months, args.start_year, args.abcd_spinup, args.routing_spinup,
-                               um=run_um, route_flags=args.route_flags)
-    info = pipe.plan.info()
-    log('routing plan: ' + json.dumps(info))
-
-    # forcing: generated on the device, resident before the timed region
-    forcing = pipe.alloc_forcing()
-    d_lat = ctx.upload(run_world.latitude)
-    seed = synth.MASTER_SEED + 1 + (0 if args.strong else rank)
-    if shard is None:
-        ctx.synth_forcing(seed, pipe.ncell, pipe.nmonths, d_lat, forcing, nan_frac=0.0)
-    else:                                   # generate the full world, keep this rank's rows (incl. tairprev rows)
-        xdist.fill_shard_forcing(ctx, world, shard, pipe, seed)
-    ctx.sync()
+    sharded = world_size > 1 and not args.replicas
 
     def barrier():
         if dist is not None:
@@ -334,28 +363,68 @@ def main():
             torch.cuda.synchronize()
         ctx.sync()
 
-    for _ in range(args.warmup):
-        pipe.run(args.stages)
-    ctx.sync()
-    ctx.timing_reset()
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.run(args.stages)
-        if shard is not None:
-            gathered = xdist.gather_outputs(ctx, pipe, shard, shards, world, dist, torch)
-            torch.cuda.synchronize()
-            del gathered
-    ctx.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
 
-    units_per_step = NCELL * args.months * (1 if args.strong else world_size)
+    def whole_world_pipeline(seed):
+        pipe = pipeline_from_world(ctx, world, args.months, args.start_year, args.abcd_spinup, args.routing_spinup,
+                                   um=um, route_flags=args.route_flags)
+        d_lat = ctx.upload(world.latitude)
+        ctx.synth_forcing(seed, pipe.ncell, pipe.nmonths, d_lat, pipe.alloc_forcing(), nan_frac=0.0)
+        # tairprev[c] = tas[c - 1], zeros for cell 0 (data_load.py:128-129)
+        pipe.d_tairprev = ctx.empty((pipe.ncell, pipe.nmonths)).zero()
+        ctx._check(_hip.lib().xh_memcpy_d2d(ctx.handle, pipe.d_tairprev.ptr + pipe.nmonths * 8, pipe.forcing['tas'].ptr,
+                                            (pipe.ncell - 1) * pipe.nmonths * 8))
+        ctx.sync()
+        d_lat.free()
+        return pipe
+
+    def timed(pipe, after_step=None):
+        for _ in range(args.warmup):
+            pipe.run(args.stages)
+            if after_step:
+                after_step()
+        ctx.sync()
+        ctx.timing_reset()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.run(args.stages)
+            if after_step:
+                after_step()
+        ctx.sync()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    shard = None
+    if sharded:
+        # BASELINE configs[3]: the 235 basins of ONE world over the ranks, one gather of the six outputs to rank 0
+        from xanthos_amd import dist as xdist
+        shards = xdist.make_shards(world, um, world_size)
+        shard = shards[rank]
+        run_world, run_um = xdist.sub_world(world, um, shard)
+        pipe = pipeline_from_world(ctx, run_world, args.months, args.start_year, args.abcd_spinup,
+                                   args.routing_spinup, um=run_um, route_flags=args.route_flags)
+        xdist.fill_shard_forcing(ctx, world, shard, pipe, synth.MASTER_SEED + 1)
+        gather = xdist.OutputGather(ctx, pipe, shards, rank, world.ncell, dist, torch,
+                                    names=('pet', 'aet', 'q', 'sav') + (('chs', 'avg') if 'mrtm' in args.stages else ()))
+        elapsed = timed(pipe, gather.run)
+        units_per_step = NCELL * args.months
+        parallelism = '{} basins of one world sharded over {} GPUs ({} cells on rank 0), one gather of {} outputs ' \
+                      'per step ({})'.format(NBASINS, world_size, pipe.ncell, len(gather.names), gather.kind)
+    else:
+        run_world = world
+        pipe = whole_world_pipeline(synth.MASTER_SEED + 1 + rank)
+        elapsed = timed(pipe)
+        units_per_step = NCELL * args.months * world_size
+        parallelism = ('{} independent scenarios, one per GPU'.format(world_size) if world_size > 1 else
+                       'one world on one GPU')
+    info = pipe.plan.info() if pipe.plan is not None else {}
+    log('routing plan: ' + json.dumps(info))
     value = units_per_step * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
@@ -371,6 +440,7 @@ def main():
                 k['achieved_GBs'] = algo[name] / (ms / n * 1e-3) / 1e9
                 k['frac_of_hbm_peak'] = k['achieved_GBs'] / HBM_PEAK_GBS
             kernels[name] = k
+    args._kernel_s = sum(k['avg_ms'] for k in kernels.values()) * 1e-3
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/roundN/
     # pmc_traffic.json, made by tools/pmc_to_json.py): counters cannot be read from inside the run itself
     traffic, traffic_src = {}, None
@@ -384,7 +454,7 @@ def main():
             traffic_src = os.path.relpath(f, ROOT)
         except (OSError, ValueError):
             pass
-    full_config = (args.months == 600 and args.abcd_spinup == 120 and args.routing_spinup == 120 and not args.strong)
+    full_config = (args.months == 600 and args.abcd_spinup == 120 and args.routing_spinup == 120 and not sharded)
     for k, v in traffic.items():
         if k in kernels and v and full_config:
             kernels[k]['traffic_bytes'] = v
@@ -392,9 +462,8 @@ def main():
     roofline = {'kernel': dominant, 'bound': 'hbm', 'achieved': kernels[dominant]['achieved_GBs'],
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dominant]['frac_of_hbm_peak'],
                 'traffic': kernels[dominant].get('traffic_bytes'), 'traffic_source': traffic_src,
-                'note': 'mrtm_route is bound by the instruction issue of one wave per sub-step (about 36 instructions for the '
-                        'median unit, 8-term rows pace the run), not by HBM; see DESIGN.md 4.3'
-                if dominant == 'mrtm_route' else ''}
+                'note': 'mrtm_route is bound by the sub-step latency / instruction issue of one wave per unit, not by '
+                        'HBM; see DESIGN.md 4.3' if dominant == 'mrtm_route' else ''}
     if dominant == 'mrtm_route':
         nsub = int(sum(int(d * 86400 / 10800) for d in pipe.ndays)) + \
             int(sum(int(d * 86400 / 10800) for d in pipe.ndays[:args.routing_spinup]))
@@ -407,20 +476,36 @@ def main():
         'metric': 'cell-months/sec (pm_abcd_mrtm, 67,420 cells)' if args.workload == 'pm_abcd_mrtm'
         else 'cell-months/sec (pm_abcd, 67,420 cells)',
         'value': value, 'unit': 'cell-months/s', 'n_gpus': world_size, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak',
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak' if args.replicas else 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': '{}: {} cells x {} months, {} basins, nlcs {}, abcd spin-up {}, routing spin-up {}, '
                                'dt 10800 s'.format(args.workload, NCELL, args.months, NBASINS, run_world.nlcs,
                                                    args.abcd_spinup, args.routing_spinup),
-                   'parallelism': ('basins sharded over {} GPUs + gather'.format(world_size) if args.strong else
-                                   '{} independent scenario(s), one per GPU'.format(world_size))},
+                   'parallelism': parallelism},
         'roofline': roofline, 'kernels': kernels, 'routing_plan': info,
     }
-    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
-        base, parity = cpu_baseline(pipe, world, args, log)
-        result['cpu_baseline'] = base
-        result['parity'] = parity
-        result['speedup_vs_cpu_baseline'] = value / base['value']
+    if sharded:
+        result['gather'] = gather.report()
+        if not args.no_replica_figure:
+            # secondary figure: N independent whole-world scenarios, one per GPU (no collective on the data path)
+            gather.close()
+            for a in list(pipe.out.values()) + list(pipe.forcing.values()):
+                a.free()
+            rpipe = whole_world_pipeline(synth.MASTER_SEED + 1 + rank)
+            r_elapsed = timed(rpipe)
+            result['replicas'] = {'value': NCELL * args.months * world_size * args.steps / r_elapsed,
+                                  'unit': 'cell-months/s', 'ms_per_step': 1e3 * r_elapsed / args.steps,
+                                  'scaling': 'weak', 'note': '{} independent scenarios, one per GPU'.format(world_size)}
+    if rank == 0 and world_size == 1:
+        if not args.no_end_to_end:
+            result['end_to_end'] = end_to_end(ctx, pipe, args, log)
+            pipe.run(args.stages)                      # outputs of the resident run again, for the parity check below
+            ctx.sync()
+        if not args.no_cpu_baseline:
+            base, parity = cpu_baseline(pipe, world, args, log)
+            result['cpu_baseline'] = base
+            result['parity'] = parity
+            result['speedup_vs_cpu_baseline'] = value / base['value']
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -53,6 +53,12 @@ int xh_free(xh_ctx *ctx, void *d_ptr);
 int xh_memcpy_h2d(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int xh_memcpy_d2h(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* waits for the stream */
 int xh_memcpy_d2d(xh_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+/* Page-locked host memory and transfers that do not wait: a loader / writer that keeps its arrays in xh_host_alloc
+ * memory moves them at PCIe rate and overlaps them with kernels; the buffers must stay untouched until xh_sync. */
+int xh_host_alloc(xh_ctx *ctx, size_t bytes, void **h_ptr);
+int xh_host_free(xh_ctx *ctx, void *h_ptr);
+int xh_memcpy_h2d_async(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int xh_memcpy_d2h_async(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int xh_memset(xh_ctx *ctx, void *d_ptr, int value, size_t bytes);
 int xh_sync(xh_ctx *ctx);
 /* Gather / scatter whole rows of a [nrows_total, ncols] device array by row index (shard packing, samples). */
@@ -121,7 +127,8 @@ void xh_route_plan_destroy(xh_route_plan *plan);
  * [7]=dataflow units, [8]=stream edges between them, [9]=pipeline depth, [10]=cells routed by the dataflow kernel,
  * [11]=most imported streams of one unit, [12]=deepest lane lag of the time-skewed layout in sub-steps (-1: layout
  * not available), [13]=kernel that routed the tree networks in the last xh_route_series call on this plan (0 none,
- * 1 lock-step units with monthly streams, 2 time-skewed units), [14..15]=0 */
+ * 1 lock-step units with monthly streams, 2 time-skewed units), [14]=calls of this plan re-run with one workgroup per
+ * network after a device fault, [15]=0 */
 int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]);
 
 /* Diagnostics: with XH_FLOW_STATS=1 in the environment the dataflow kernel records, per unit, {shader cycles inside the
@@ -150,12 +157,19 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
  *   h_ndays[nmonths]; d_runoff [ncell, nmonths] (mm/month); d_flow_dist, d_velocity, d_area [ncell]
  *   d_S0 [ncell] or NULL (zeros); outputs d_chstorage / d_avgchflow [ncell, nmonths] (either may be NULL),
  *   d_S_end / d_F_end [ncell] optional.  streamrouting() itself is the nmonths = 1, spinup = 0 case.
- * flags: XH_ROUTE_ATOMIC routes with global fp64 atomic scatter-adds (non bit-reproducible variant).       */
+ * flags: XH_ROUTE_ATOMIC routes with global fp64 atomic scatter-adds (non bit-reproducible variant).
+ * The dataflow kernels (tree networks) keep every unit resident and let units wait for each other, bounded by a
+ * timeout proportional to the run's length.  On a device shared with another routing call the units may not all fit:
+ * the timeout then raises a sticky device fault, and the next synchronising call (xh_sync, xh_memcpy_d2h) re-routes
+ * every call enqueued since the last synchronisation with one workgroup per network (no waits between workgroups)
+ * before it returns -- XH_OK if nothing else was enqueued behind the routing, XH_ERR_DEVICE (routing outputs valid,
+ * later results not) otherwise.  xh_route_plan_info[14] counts such re-runs.                                  */
 #define XH_ROUTE_DEFAULT 0
 #define XH_ROUTE_FORCE_FALLBACK 1   /* route every network with the global-memory kernels (testing)        */
 #define XH_ROUTE_ATOMIC 2           /* with the fallback: scatter-add outflow with global_atomic_add_f64   */
 #define XH_ROUTE_NO_DATAFLOW 4      /* one workgroup per network even for tree-shaped networks (testing)   */
 #define XH_ROUTE_NO_SKEW 8          /* dataflow units in lock-step with monthly streams, not time-skewed   */
+#define XH_ROUTE_TEST_FAULT 16      /* testing: the dataflow kernel raises its fault word as a timed-out wait would */
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,
                     const double *d_flow_dist, const double *d_velocity, const double *d_area,
@@ -249,11 +263,33 @@ int xh_calib_de_result(xh_calib_de *de, double *h_x, double *h_fun, int64_t *h_n
 int xh_calib_de_state(xh_calib_de *de, int32_t which, double *h_vectors, double *h_energy);
 int xh_calib_de_set_state(xh_calib_de *de, const double *h_pop, const double *h_energy, int32_t generation);
 
+/* ------------------------------------------------------------------ multi-GPU write-out (RCCL over xGMI)
+ * The reference has no distributed path; BASELINE's north star shards the 235 basins over the GPUs of a node with a
+ * single RCCL gather at write-out.  One process per GPU; the launcher (torchrun, mpirun, anything) starts the ranks
+ * and carries the 128-byte id from rank 0 to the others.  RCCL is bound at run time (dlopen of librccl.so.1).
+ *   xh_comm_unique_id   : ncclGetUniqueId (rank 0); len >= 128
+ *   xh_comm_create      : ncclCommInitRank on the context's device (collective over all ranks)
+ *   xh_comm_gather_rows : every rank contributes nvar device arrays [h_counts[rank], ncols] (h_d_local: host array of
+ *                         nvar device pointers -- the pipeline's own output buffers, nothing is staged or padded on the
+ *                         senders); grouped ncclSend / ncclRecv of the exact sizes on the context's stream.  On the root
+ *                         d_perm [sum h_counts] (device) holds, rank-major, the destination row of every gathered row and
+ *                         h_d_out the nvar device arrays [total rows, ncols] that receive them in grid order.
+ *                         Asynchronous like every call: xh_sync to wait.                                       */
+typedef struct xh_comm xh_comm;
+int xh_comm_unique_id(char *id, size_t len);
+int xh_comm_create(xh_ctx *ctx, int32_t nranks, int32_t rank, const char *id, size_t len, xh_comm **out);
+void xh_comm_destroy(xh_comm *comm);
+int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *comm, int32_t root, int32_t nvar, const double *const *h_d_local,
+                        int64_t ncols, const int64_t *h_counts, const int64_t *d_perm, double *const *h_d_out);
+
 /* ------------------------------------------------------------------ bench support (not on the hot path)
  * Fills the eight forcing arrays of the synthetic benchmark world on the device (same distributions as
- * xanthos_amd/synth.py:make_forcing); d_lat [ncell] degrees; nan_frac = share of cells whose precipitation is NaN.                                             */
+ * xanthos_amd/synth.py:make_forcing); d_lat [ncell] degrees; nan_frac = share of cells whose precipitation is NaN.
+ * d_cell_ids [ncell] or NULL: GLOBAL cell index of each row (the random streams are keyed on it, so a rank can generate
+ * just its shard of a world; -1 = no cell: a row of zeros).  With only d_tas non-NULL, only temperature is generated
+ * (the tairprev rows of a shard: the previous GLOBAL cell's temperature, data_load.py:128-129).             */
 int xh_synth_forcing(xh_ctx *ctx, uint64_t seed, double nan_frac, int64_t ncell, int32_t nmonths, const double *d_lat,
-                     double *d_tas, double *d_tmin, double *d_rhs, double *d_wind, double *d_rsds,
+                     const int64_t *d_cell_ids, double *d_tas, double *d_tmin, double *d_rhs, double *d_wind, double *d_rsds,
                      double *d_rlds, double *d_precip, double *d_abcd_tmin);
 
 #ifdef __cplusplus

@@ -20,6 +20,10 @@ Fixtures written:
   drought.npz DroughtStats.getthresh / calculate_thresholds (nper 1 and 12) and droughtstats (K = 1 and 12) on 80 cells
               x 30 years with NaN, constant and zero-threshold cells
   accessible.npz  AccessibleWater end to end (its csv) + RollingWindowFilter / QInGCAMYears / accessible_water pieces
+  loader.npz  the reference's DataLoader driven by THIS package's ConfigReader on a small pm_abcd_mrtm input tree on
+              the real 360 x 720 geometry (150 cells, 280 x 720 DRT-style routing maps, NaN / inf in the forcing,
+              short flow distances, negative velocities, cells outside the maps, region / country tables, calibration
+              observations, future-mode channel storage): every attribute the hot path reads + the input tree (zip)
 """
 import importlib.util
 import os
@@ -363,6 +367,68 @@ def golden_accessible():
     print('accessible.npz', table.shape, lines[0])
 
 
+# ----------------------------------------------------------------------------------------------------- loader
+def golden_loader():
+    """Reference DataLoader (data_load.py:27-438) on a generated input tree; settings from xanthos_amd.ini_reader."""
+    import io
+    import tempfile
+    import zipfile
+    from xanthos.data_reader.data_load import DataLoader as RefLoader
+    from xanthos_amd.ini_reader import ConfigReader
+    rng = np.random.default_rng(404)
+    w = synth.make_world(nrow=360, ncol=720, ncell=150, n_basins=4, seed=3)
+    nm, y0, y1 = 24, 1971, 1972
+    w.coords[10, 4], w.coords[11, 4] = 20, 355          # two cells north / south of the rows the DRT maps cover
+    f = synth.make_forcing(w, nm)
+    for k in ('tas', 'tmin', 'rhs', 'wind', 'rsds', 'rlds', 'abcd_tmin', 'precip'):
+        holes = rng.random(f[k].shape) < 0.03
+        f[k][holes] = np.nan
+    f['tas'][5, 3], f['rsds'][6, 4], f['abcd_tmin'][7, 5] = np.inf, -np.inf, np.inf
+    w.lct[3, 2, 1] = np.nan
+    w.elev = np.array(w.elev, dtype=float)
+    w.elev.reshape(-1)[4] = np.nan
+    obs = np.stack([np.repeat([1, 2], nm), np.zeros(2 * nm), np.zeros(2 * nm), rng.uniform(1, 9, 2 * nm)], axis=1)
+    chs = rng.uniform(0, 1e6, (w.ncell, 7))
+    with tempfile.TemporaryDirectory() as root:
+        ini = synth.write_example(root, w, f, y0, y1, runoff_spinup=24, routing_spinup=6, obs=obs, aggregates=True,
+                                  hist_flag=False, ch_storage=chs)
+        # names with different word counts, like the real BasinNames235.txt: np.genfromtxt fails on them and the reference
+        # falls back to reading the lines (data_load.py:366-368)
+        with open(os.path.join(root, 'input', 'reference', 'BasinNames235.txt'), 'w') as fh:
+            fh.write('Amazon\nUpper Nile Basin\nRio de la Plata\nYukon\n')
+        # routing inputs as 280 x 720 DRT-style maps (north to south, 68 rows up from the bottom, -9999 = no data)
+        rt = os.path.join(root, 'input', 'routing', 'mrtm')
+        r_map = 280 - 1 - (w.coords[:, 4].astype(int) - 1 - 68)
+        c_map = w.coords[:, 3].astype(int) - 1
+        inside = (r_map >= 0) & (r_map < 280)
+        dist, vel, fdir = w.flow_dist.copy(), w.velocity.copy(), w.flow_dir.copy()
+        dist[::9] = 500.0                # shorter than 1 km -> 1000 (data_load.py:204-205 via rep_val)
+        vel[::11] = -3.0                 # negative velocity -> 0
+        for name, vec in (('flow_dist', dist), ('velocity', vel), ('flow_dir', fdir)):
+            m = np.full((280, 720), -9999.0)
+            m[r_map[inside], c_map[inside]] = vec[inside]
+            np.save(os.path.join(rt, name + '.npy'), m)
+        buf = io.BytesIO()
+        with zipfile.ZipFile(buf, 'w', zipfile.ZIP_DEFLATED) as z:
+            for d, _, files in os.walk(root):
+                for fn in files:
+                    full = os.path.join(d, fn)
+                    z.write(full, os.path.relpath(full, root))
+        settings = ConfigReader(ini)
+        ref = RefLoader(settings)
+        out = {k: np.asarray(getattr(ref, k)) for k in (
+            'area', 'coords', 'basin_ids', 'basin_names', 'region_ids', 'region_names', 'country_ids', 'country_names',
+            'latitude', 'cL', 'beta', 'rslimit', 'ae', 'be', 'Tminopen', 'Tminclose', 'VPDclose', 'VPDopen', 'RBLmin',
+            'RBLmax', 'rc', 'emiss', 'alpha', 'lai', 'laimax', 'laimin', 'tair_load', 'TMIN_load', 'rhs_load',
+            'wind_load', 'rsds_load', 'rlds_load', 'tairprev_load', 'lct_load', 'elev', 'precip', 'tmin', 'flow_dist',
+            'flow_dir', 'str_velocity', 'instream_flow', 'chs_prev', 'cal_obs')}
+        assert (~inside).sum() == 2
+    np.savez_compressed(os.path.join(HERE, 'loader.npz'), tree_zip=np.frombuffer(buf.getvalue(), dtype=np.uint8),
+                        old_root=np.array(root), ini_name=np.array(os.path.basename(ini)), **out)
+    print('loader.npz', {k: v.shape for k, v in out.items() if v.ndim == 2 and v.shape[1] == nm},
+          'cells outside the maps:', int((~inside).sum()), 'chs_prev max', float(out['chs_prev'].max()))
+
+
 if __name__ == '__main__':
     import warnings
     warnings.simplefilter('ignore')
@@ -374,6 +440,7 @@ if __name__ == '__main__':
     golden_writer()
     golden_drought()
     golden_accessible()
+    golden_loader()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')

@@ -170,42 +170,9 @@ def test_basin_sharded_run_equals_whole_world():
         assert np.array_equal(got[k], ref[k], equal_nan=True), k
 
 
-def test_dataflow_routing_long_run_under_load():
-    """Full grid, 600 months + 120 spin-up: the dataflow kernel (streams between 1,100+ units, ring slots reused 180
-    times) must reproduce the one-workgroup-per-network kernel bit for bit, also while another context keeps the GPU
-    busy (uneven timing between producers and consumers), and twice in a row (no state leaks between launches)."""
-    from xanthos_amd import _hip, synth
-    from xanthos_amd.pipeline import pipeline_from_world
-    ctx = _hip.get_context(0)
-    w = synth.make_world()
-    nm = 600
-    pipe = pipeline_from_world(ctx, w, nm, 1961, 120, 120)
-    ctx.synth_forcing(3, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.0)
-    pipe.run(('pm', 'abcd'))
-    pipe.route_flags = 4                                   # one workgroup per network: no streams
-    pipe.run_mrtm()
-    ref = pipe.download(('chs', 'avg'))
-    assert np.isfinite(ref['avg']).all() and ref['avg'].max() > 0
-    pipe.route_flags = 0
-    other = _hip.Context(0)                                # second stream on the same device: background load
-    bg = pipeline_from_world(other, w, 120, 1961, 30, 0)
-    other.synth_forcing(4, w.ncell, 120, other.upload(w.latitude), bg.alloc_forcing(), nan_frac=0.0)
-    for rep in range(2):
-        pipe.out['chs'].zero()
-        pipe.out['avg'].zero()
-        if rep == 1:
-            for _ in range(40):
-                bg.run(('pm', 'abcd'))                     # ~50 ms of PM/ABCD kernels racing the routing kernel
-        pipe.run_mrtm()
-        got = pipe.download(('chs', 'avg'))
-        other.sync()
-        assert np.array_equal(got['chs'], ref['chs']) and np.array_equal(got['avg'], ref['avg']), rep
-    other.close()
-
-
 def test_calibrate_all_lockstep(example, tmp_path):
-    """calibrate_all: every basin of the example searched in lock-step through the multi-basin objective; the files
-    the reference writes per basin (calibrate_abcd.py:130-131) appear and KGE is high where data is clean."""
+    """calibrate_all: every basin of the example searched in lock-step by the device-side DE; the files the
+    reference writes per basin (calibrate_abcd.py:130-131) appear and KGE is high where data is clean."""
     from types import SimpleNamespace as NS
     from oracle import calib as o_calib
     from xanthos_amd.calibrate.calibrate_abcd import calibrate_all
@@ -263,3 +230,45 @@ def test_run_model_with_post_processors(tmp_path):
         got = np.load(os.path.join(out, 'drought_{}_pm_abcd_mrtm_synth.npy'.format(name)))
         assert np.array_equal(got.T, ref)
     assert D.max() >= 1
+
+
+def test_run_model_aggregates_and_future_mode(tmp_path):
+    """AggregateRunoffBasin / Country / GCAMRegion = 1 (out_writer.py:126-158: one row per NAME, basins and regions from
+    id 1, countries from id 0, a name without cells gives NaN) and HistFlag = False with a ChStorageFile: routing starts
+    from the last column of the historical channel storage (data_load.py:427-438)."""
+    import os
+    from oracle import months as o_months, mrtm as o_mrtm
+    from xanthos_amd import Xanthos, synth
+    root = str(tmp_path)
+    w = synth.make_world(nrow=36, ncol=72, ncell=900, n_basins=7, seed=35)
+    f = synth.make_forcing(w, 36)
+    chs0 = np.random.default_rng(2).uniform(0, 5e7, (w.ncell, 4))
+    ini = synth.write_example(root, w, f, 1971, 1973, runoff_spinup=25, routing_spinup=6, aggregates=True,
+                              hist_flag=False, ch_storage=chs0)
+    res = Xanthos(ini).execute()
+    assert np.array_equal(res.data.chs_prev, chs0[:, -1])
+    st = SimpleNamespace(ngridrow=w.nrow, ngridcol=w.ncol)
+    um = o_mrtm.upstream_genmatrix(o_mrtm.upstream(w.coords, o_mrtm.downstream(w.coords, w.flow_dir, st), st))
+    ndays = o_months.set_month_arrays(36, 1971, 1973)[:, 2]
+    chs, avg, _ = o_mrtm.route_series(um, res.data.flow_dist, res.data.str_velocity, res.data.area, res.Q, ndays, 6,
+                                      S0=chs0[:, -1])
+    assert np.array_equal(res.ChStorage, chs, equal_nan=True) and np.array_equal(res.Avg_ChFlow, avg, equal_nan=True)
+    zero = o_mrtm.route_series(um, res.data.flow_dist, res.data.str_velocity, res.data.area, res.Q, ndays, 6)[0]
+    assert not np.array_equal(zero, chs, equal_nan=True)
+    out = os.path.join(root, 'output', 'pm_abcd_mrtm_synth')
+    for fname, ids, first, n in (('Basin_runoff', w.basin_ids, 1, 7), ('Country_runoff', w.basin_ids % 9, 0, 10),
+                                 ('GCAMRegion_runoff', w.basin_ids % 6 + 1, 1, 7)):
+        lines = open(os.path.join(out, fname + '_mmpermonth_pm_abcd_mrtm_synth.csv')).read().splitlines()
+        assert lines[0].startswith('id,name,197101,197102') and len(lines) == n + 1
+        for k, ln in enumerate(lines[1:]):
+            cols = ln.split(',')
+            assert int(cols[0]) == first + k
+            sel = ids == first + k
+            vals = np.array([float(v) if v != '' else np.nan for v in cols[2:]])
+            if sel.any():
+                want = np.nansum(res.Q[sel], axis=0)
+                assert np.allclose(vals, want, rtol=1e-12, atol=1e-12), (fname, k)
+            else:
+                assert np.isnan(vals).all(), (fname, k)                 # a name without cells
+    assert open(os.path.join(out, 'Country_runoff_mmpermonth_pm_abcd_mrtm_synth.csv')).read().splitlines()[1] \
+        .startswith('0,Country 0,')

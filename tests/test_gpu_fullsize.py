@@ -1,0 +1,200 @@
+"""GPU tests (-m gpu) at BASELINE.json's full sizes: the 67,420-cell grid through every configuration.
+
+* config 3: 600 + 120 months of routing on the full grid, the dataflow kernel against the ORACLE (scipy CSR, ~3 min of
+  host time, computed once per module), then 20 repetitions, a second context routing concurrently on the same device,
+  background load, and the forced-fault re-route;
+* config 1: ``run_model()`` through a generated ``.ini`` on the full grid against the oracle chain;
+* config 4: 480 months, the 235 basins in 8 network-closed shards run one after the other on this GPU and reassembled:
+  bit-identical to the unsharded run (what rank 0 holds after the gather on an 8-GPU node).
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(x, ref):
+    assert np.array_equal(np.isnan(x), np.isnan(ref))
+    m = ~np.isnan(ref)
+    return float(np.max(np.abs(x[m] - ref[m]) / (np.abs(ref[m]) + 1e-9))) if m.any() else 0.0
+
+
+@pytest.fixture(scope='module')
+def full():
+    """Full-grid pipeline, 600 months, PM -> ABCD run once; the oracle's routing of the run's own runoff."""
+    from oracle import mrtm as o_mrtm
+    from xanthos_amd import _hip, synth
+    from xanthos_amd.pipeline import pipeline_from_world
+    ctx = _hip.get_context(0)
+    w = synth.make_world()
+    nm = 600
+    pipe = pipeline_from_world(ctx, w, nm, 1961, 120, 120)
+    ctx.synth_forcing(3, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.0)
+    pipe.run(('pm', 'abcd'))
+    q = pipe.out['q'].download()
+    chs, avg, _ = o_mrtm.route_series(pipe.um.tocsr(), w.flow_dist, w.velocity, w.area, q, pipe.ndays, 120)
+    assert np.isfinite(avg).all() and avg.max() > 0
+    return SimpleNamespace(ctx=ctx, w=w, pipe=pipe, chs=chs, avg=avg)
+
+
+def _check(full, pipe=None, tag=''):
+    got = (pipe or full.pipe).download(('chs', 'avg'))
+    assert np.array_equal(got['chs'], full.chs), tag
+    assert np.array_equal(got['avg'], full.avg), tag
+
+
+def test_config3_full_length_routing_equals_oracle(full):
+    """67,420 cells x (120 spin-up + 600) months = 175,312 sub-steps: the time-skewed dataflow kernel, the lock-step
+    dataflow kernel and the workgroup-per-network kernel are each bit-identical to the oracle (scipy CSR mat-vec)."""
+    for flags, kernel in ((0, 2), (8, 1), (4, 0)):
+        full.pipe.route_flags = flags
+        full.pipe.out['chs'].zero()
+        full.pipe.out['avg'].zero()
+        full.pipe.run_mrtm()
+        _check(full, tag=flags)
+        assert full.pipe.plan.info()['last_tree_kernel'] == kernel
+    full.pipe.route_flags = 0
+
+
+def test_config3_twenty_repetitions_and_background_load(full):
+    """No state leaks between launches (stream rings and counters are reused 20 times), also while another context
+    keeps the GPU busy with PM / ABCD kernels (uneven timing between producers and consumers)."""
+    from xanthos_amd import _hip
+    from xanthos_amd.pipeline import pipeline_from_world
+    other = _hip.Context(0)
+    bg = pipeline_from_world(other, full.w, 120, 1961, 30, 0)
+    other.synth_forcing(4, full.w.ncell, 120, other.upload(full.w.latitude), bg.alloc_forcing(), nan_frac=0.0)
+    for rep in range(20):
+        full.pipe.out['chs'].zero()
+        full.pipe.out['avg'].zero()
+        if rep % 5 == 4:
+            for _ in range(40):
+                bg.run(('pm', 'abcd'))
+        full.pipe.run_mrtm()
+        _check(full, tag=rep)
+        other.sync()
+    assert full.pipe.plan.info()['reroutes'] == 0
+    other.close()
+
+
+def test_config3_two_contexts_route_concurrently(full):
+    """Two contexts (two streams, as two host threads or two processes would own) route the full grid on device 0 at
+    the same time, three rounds: the dataflow units of both launches cannot all be resident, so either the launches
+    serialise or a bounded wait times out and the library re-routes with the workgroup-per-network kernel -- in both
+    cases both contexts end with the oracle's values and no error."""
+    from xanthos_amd import _hip
+    from xanthos_amd.pipeline import pipeline_from_world
+    other = _hip.Context(0)
+    p2 = pipeline_from_world(other, full.w, 600, 1961, 120, 120)
+    other._check(_hip.lib().xh_memcpy_d2d(other.handle, p2.out['q'].ptr, full.pipe.out['q'].ptr, p2.out['q'].nbytes))
+    other.sync()
+    for rep in range(3):
+        for p in (full.pipe, p2):
+            p.out['chs'].zero()
+            p.out['avg'].zero()
+        full.ctx.sync()
+        other.sync()
+        full.pipe.run_mrtm()              # asynchronous: both kernels are in flight together
+        p2.run_mrtm()
+        _check(full, tag=('a', rep))
+        _check(full, pipe=p2, tag=('b', rep))
+    print('re-routes: ctx A %d, ctx B %d' % (full.pipe.plan.info()['reroutes'], p2.plan.info()['reroutes']))
+    other.close()
+
+
+def test_config3_forced_fault_is_rerouted(full):
+    """XH_ROUTE_TEST_FAULT makes unit 0 of the dataflow kernel raise the device fault word as a timed-out wait would:
+    the next synchronising call re-runs the routing with one workgroup per network and the caller sees valid outputs
+    (XH_OK when nothing else was enqueued behind the routing, XH_ERR_DEVICE with valid routing outputs otherwise)."""
+    from xanthos_amd import _hip
+    pipe = full.pipe
+    before = pipe.plan.info()['reroutes']
+    for flags in (_hip.XH_ROUTE_TEST_FAULT, _hip.XH_ROUTE_TEST_FAULT | _hip.XH_ROUTE_NO_SKEW):
+        pipe.out['chs'].zero()
+        pipe.out['avg'].zero()
+        pipe.route_flags = flags
+        pipe.run_mrtm()
+        pipe.route_flags = 0
+        _check(full, tag=flags)                               # the download is the synchronising call
+    assert pipe.plan.info()['reroutes'] == before + 2
+    # two faulting calls in flight, then a kernel that read the invalid outputs: the error is reported, not lost
+    pipe.out['chs'].zero()
+    pipe.route_flags = _hip.XH_ROUTE_TEST_FAULT
+    pipe.run_mrtm()
+    pipe.route_flags = 0
+    pipe.run_mrtm()                                           # gives up at once: the fault word is sticky
+    tmp = full.ctx.empty((pipe.ncell, 50))
+    full.ctx.agg_time(pipe.ncell, 600, 12, 0, None, pipe.out['avg'], tmp)
+    with pytest.raises(_hip.HipError, match='must be recomputed'):
+        full.ctx.sync()
+    _check(full, tag='after error')                           # routing outputs were recomputed all the same
+    assert pipe.plan.info()['reroutes'] == before + 4
+    pipe.run_mrtm()                                           # and the dataflow kernel works again afterwards
+    _check(full, tag='recovered')
+    assert pipe.plan.info()['last_tree_kernel'] == 2 and pipe.plan.info()['reroutes'] == before + 4
+    tmp.free()
+
+
+def test_config1_run_model_full_grid(tmp_path):
+    """BASELINE config 1's workload on HIP: run_model() through a generated pm_abcd_mrtm .ini on the full 67,420-cell
+    grid (3 years: ABCD needs >= 25 spin-up months, abcd.py:258-266; config 1's 12 months are the first year), every
+    output against the oracle chain."""
+    from oracle import abcd as o_abcd, months as o_months, mrtm as o_mrtm, pm as o_pm
+    from xanthos_amd import run_model, synth
+    w = synth.make_world()
+    nm = 36
+    f = synth.make_forcing(w, nm)
+    ini = synth.write_example(str(tmp_path), w, f, 1971, 1973, runoff_spinup=25, routing_spinup=12)
+    res = run_model(ini)
+    assert res.Q.shape == (67420, nm) and res.Avg_ChFlow.shape == (67420, nm)
+    d = synth.data_bag(w, f)
+    pet = o_pm.run_pmpet(d, w.ncell, w.nlcs, 1971, 1973, 0, 6, w.lc_years)
+    assert rel(res.PET, pet) < 1e-9
+    _, aet, q, sav = o_abcd.abcd_execute(w.n_basins, w.basin_ids, res.PET, f['precip'], np.nan_to_num(f['abcd_tmin']),
+                                         w.abcd_pars, nm, 25, -1)
+    assert rel(res.AET, aet) < 1e-9 and rel(res.Q, q) < 1e-9 and rel(res.Sav, sav) < 1e-9
+    assert np.nanmin(res.Q) >= 0 and np.isnan(res.Q).any()                  # NaN-precipitation cells stay NaN
+    st = SimpleNamespace(ngridrow=w.nrow, ngridcol=w.ncol)
+    um = o_mrtm.upstream_genmatrix(o_mrtm.upstream(w.coords, o_mrtm.downstream(w.coords, w.flow_dir, st), st))
+    ndays = o_months.set_month_arrays(nm, 1971, 1973)[:, 2]
+    chs, avg, _ = o_mrtm.route_series(um, res.data.flow_dist, res.data.str_velocity, res.data.area, res.Q, ndays, 12)
+    assert np.array_equal(res.ChStorage, chs, equal_nan=True) and np.array_equal(res.Avg_ChFlow, avg, equal_nan=True)
+
+
+def test_config4_eight_shards_480_months():
+    """BASELINE config 4's workload emulated on one GPU: 1971-2010, the 235 basins packed into 8 network-closed shards,
+    each shard's pipeline run on this GPU with shard-local forcing generation, outputs reassembled in grid order:
+    bit-identical to the unsharded run for all six outputs."""
+    from xanthos_amd import _hip, synth
+    from xanthos_amd.dist import fill_shard_forcing, make_shards, sub_world
+    from xanthos_amd.pipeline import OUTPUTS, pipeline_from_world, topology_from_world
+    ctx = _hip.get_context(0)
+    w = synth.make_world()
+    um = topology_from_world(w)
+    nm, seed = 480, 41
+    whole = pipeline_from_world(ctx, w, nm, 1971, 120, 120, um=um)
+    d_lat = ctx.upload(w.latitude)
+    ctx.synth_forcing(seed, w.ncell, nm, d_lat, whole.alloc_forcing(), nan_frac=0.001)
+    whole.run()
+    ref = whole.download()
+    for a in list(whole.out.values()) + list(whole.forcing.values()):
+        a.free()
+    shards = make_shards(w, um, 8)
+    sizes = np.array([len(s.cells) for s in shards])
+    assert sizes.min() > 0 and sizes.max() - sizes.min() < 0.05 * w.ncell          # LPT balance
+    seen = np.zeros(w.ncell, dtype=bool)
+    for s in shards:
+        sw, sum_ = sub_world(w, um, s)
+        pipe = pipeline_from_world(ctx, sw, nm, 1971, 120, 120, um=sum_)
+        fill_shard_forcing(ctx, w, s, pipe, seed, nan_frac=0.001)
+        pipe.run()
+        out = pipe.download()
+        for k in OUTPUTS:
+            assert np.array_equal(out[k], ref[k][s.cells], equal_nan=True), (k, s.rank)
+        seen[s.cells] = True
+        for a in list(pipe.out.values()) + list(pipe.forcing.values()) + [pipe.d_tairprev]:
+            a.free()
+        pipe.plan.close()
+    assert seen.all()

@@ -69,6 +69,57 @@ def test_pm_synthetic_vs_oracle(hip):
     assert np.array_equal(d_pet.download(), got)
 
 
+@pytest.mark.parametrize('years', [(1899, 1901), (2099, 2101)])
+def test_two_leap_year_rules_on_the_device(hip, years):
+    """1900 and 2100 are the years where the reference's two calendars disagree: Penman-Monteith takes days per month
+    from calendar.isleap (penman_monteith.py:57: February has 28 days), the routing month table from year % 4
+    (utils/general.py:37: February has 29 days, 232 sub-steps).  The HIP kernels follow each rule where the reference
+    does: PET against the oracle (a 29-day February would change dz and every radiation term), routing bit-exact."""
+    from oracle import months as o_months, mrtm as o_mrtm, pm as o_pm
+    from xanthos_amd import synth, utils
+    from xanthos_amd.pet import penman_monteith as pm
+    from xanthos_amd.routing import mrtm
+    y0, y1 = years
+    w = synth.make_world(nrow=36, ncol=72, ncell=700, n_basins=5, seed=19)
+    nm = 36
+    f = synth.make_forcing(w, nm)
+    d = synth.data_bag(w, f)
+    ref = o_pm.run_pmpet(d, w.ncell, w.nlcs, y0, y1, 0, 6, w.lc_years)
+    got = pm.run_pmpet(d, w.ncell, w.nlcs, y0, y1, 0, 6, w.lc_years)
+    close(got, ref)
+    wrong = o_pm.run_pmpet(d, w.ncell, w.nlcs, y0 + 4, y1 + 4, 0, 6, w.lc_years)      # 1904 / 2104 ARE leap years
+    feb = 12 + 1
+    assert np.max(np.abs(wrong[:, feb] - ref[:, feb]) / (np.abs(ref[:, feb]) + 1e-9)) > 1e-3
+    tab = utils.set_month_arrays(nm, y0, y1)
+    assert np.array_equal(tab, o_months.set_month_arrays(nm, y0, y1)) and tab[feb, 2] == 29
+    st = SimpleNamespace(ngridrow=w.nrow, ngridcol=w.ncol)
+    um = mrtm.upstream_genmatrix(mrtm.upstream(w.coords, mrtm.downstream(w.coords, w.flow_dir, st), st))
+    runoff = np.random.default_rng(5).gamma(2.0, 30.0, (w.ncell, nm))
+    r = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, tab[:, 2], 3)
+    g = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, tab[:, 2], 3)
+    assert np.array_equal(g[0], r[0]) and np.array_equal(g[1], r[1])
+
+
+def test_comm_single_rank_gather(hip):
+    """The RCCL write-out gather with one rank: librccl is bound at run time, the communicator initialises, and the
+    root's own rows go to their grid positions (the send / receive pairs need several GPUs; tests/test_dist_gloo.py
+    covers the N > 1 bookkeeping on the CPU)."""
+    ctx = hip.get_context()
+    comm = hip.Comm(ctx, 1, 0, hip.comm_unique_id())
+    rng = np.random.default_rng(0)
+    n, nm = 300, 40
+    perm = rng.permutation(n)
+    local = [ctx.upload(rng.random((n, nm))) for _ in range(3)]
+    out = [ctx.empty((n, nm)).zero() for _ in range(3)]
+    comm.gather_rows(local, [n], nm, perm=ctx.upload(perm, dtype=np.int64), out=out, root=0)
+    ctx.sync()
+    for a, b in zip(local, out):
+        want = np.empty((n, nm))
+        want[perm] = a.download()
+        assert np.array_equal(b.download(), want)
+    comm.close()
+
+
 @pytest.mark.parametrize('tag', ['snow', 'nosnow'])
 def test_abcd_golden(hip, golden, tag):
     from xanthos_amd.runoff import abcd

@@ -129,3 +129,41 @@ def test_post_processor_ini_sections(tmp_path):
         x = np.sort(np.random.default_rng(n).normal(size=n))
         lerp = x[k0] + (x[k1] - x[k0]) * g if g < 0.5 else x[k1] - (x[k1] - x[k0]) * (1 - g)
         assert lerp == np.percentile(x, q * 100)
+
+
+def test_data_loader_matches_reference_golden(tmp_path, golden):
+    """xanthos_amd.data_load.DataLoader against the reference's DataLoader (tests/golden/loader.npz, made by driving
+    the reference with this package's ConfigReader): ha -> km2, the DRT map flattening (vectorize) incl. cells outside
+    the maps, flow distance < 1000 m, negative velocities, nan_to_num policy per array (precipitation keeps NaN),
+    tairprev = previous cell, region / country tables, calibration observations, future-mode channel storage."""
+    import io
+    import zipfile
+    from xanthos_amd.data_load import DataLoader
+    g = golden('loader')
+    root = str(tmp_path)
+    zipfile.ZipFile(io.BytesIO(g['tree_zip'].tobytes())).extractall(root)
+    ini = os.path.join(root, str(g['ini_name']))
+    text = open(ini).read().replace(str(g['old_root']), root)
+    open(ini, 'w').write(text)
+    s = ConfigReader(ini)
+    assert str(s.HistFlag) == 'False' and s.ChStorageFile.endswith('ch_storage.npy')
+    s.device_transforms = False                     # host-side nan_to_num, as the reference loader does it
+    d = DataLoader(s)
+    exact = ('area', 'coords', 'basin_ids', 'region_ids', 'country_ids', 'latitude', 'cL', 'beta', 'rslimit', 'ae',
+             'be', 'Tminopen', 'Tminclose', 'VPDclose', 'VPDopen', 'RBLmin', 'RBLmax', 'rc', 'emiss', 'alpha', 'lai',
+             'laimax', 'laimin', 'tair_load', 'TMIN_load', 'rhs_load', 'wind_load', 'rsds_load', 'rlds_load',
+             'tairprev_load', 'lct_load', 'elev', 'precip', 'tmin', 'flow_dist', 'flow_dir', 'str_velocity',
+             'instream_flow', 'chs_prev', 'cal_obs')
+    for k in exact:
+        got, ref = np.asarray(getattr(d, k)), g[k]
+        assert got.shape == ref.shape or got.reshape(ref.shape).shape == ref.shape, k
+        assert np.array_equal(got.reshape(ref.shape), ref, equal_nan=True), k
+    for k in ('basin_names', 'region_names', 'country_names'):
+        assert [str(x) for x in getattr(d, k)] == [str(x) for x in g[k]], k
+    assert np.isnan(d.precip).any() and not np.isnan(d.tmin).any() and not np.isnan(d.tair_load).any()
+    assert (d.flow_dist >= 1000).all() and (d.str_velocity >= 0).all() and d.chs_prev.max() > 0
+    assert d.flow_dist[10] == 1000 and d.flow_dir[11] == -9999            # cells outside the maps: -9999 -> rep_val
+    # device_transforms (the default): the big arrays keep their NaNs on the host and lose them on the device
+    s2 = ConfigReader(ini)
+    d2 = DataLoader(s2)
+    assert np.isnan(d2.tair_load).any() and np.array_equal(np.nan_to_num(d2.tair_load), g['tair_load'])

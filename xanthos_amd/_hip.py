@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxanthos_hip.so')
 
 XH_ROUTE_DEFAULT, XH_ROUTE_FORCE_FALLBACK, XH_ROUTE_ATOMIC, XH_ROUTE_NO_DATAFLOW, XH_ROUTE_NO_SKEW = 0, 1, 2, 4, 8
+XH_ROUTE_TEST_FAULT = 16
 
 
 class HipUnavailable(RuntimeError):
@@ -44,6 +45,10 @@ SIGNATURES = {
     'xh_memcpy_h2d': (c_int, [_P, _P, _P, c_size_t]),
     'xh_memcpy_d2h': (c_int, [_P, _P, _P, c_size_t]),
     'xh_memcpy_d2d': (c_int, [_P, _P, _P, c_size_t]),
+    'xh_host_alloc': (c_int, [_P, c_size_t, POINTER(c_void_p)]),
+    'xh_host_free': (c_int, [_P, _P]),
+    'xh_memcpy_h2d_async': (c_int, [_P, _P, _P, c_size_t]),
+    'xh_memcpy_d2h_async': (c_int, [_P, _P, _P, c_size_t]),
     'xh_memset': (c_int, [_P, _P, c_int, c_size_t]),
     'xh_sync': (c_int, [_P]),
     'xh_gather_rows': (c_int, [_P, _P, _P, c_int64, c_int64, _P]),
@@ -73,12 +78,16 @@ SIGNATURES = {
     'xh_calib_de_result': (c_int, [_P, _P, _P, _P, _P, _P]),
     'xh_calib_de_state': (c_int, [_P, c_int32, _P, _P]),
     'xh_calib_de_set_state': (c_int, [_P, _P, _P, c_int32]),
+    'xh_comm_unique_id': (c_int, [ctypes.c_char_p, c_size_t]),
+    'xh_comm_create': (c_int, [_P, c_int32, c_int32, ctypes.c_char_p, c_size_t, POINTER(c_void_p)]),
+    'xh_comm_destroy': (None, [_P]),
+    'xh_comm_gather_rows': (c_int, [_P, _P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     'xh_agg_time': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
     'xh_agg_spatial': (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
     'xh_nan_to_num': (c_int, [_P, _P, c_int64]),
     'xh_drought_thresholds': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_double, _P, _P]),
     'xh_drought_stats': (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
-    'xh_synth_forcing': (c_int, [_P, c_uint64, c_double, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'xh_synth_forcing': (c_int, [_P, c_uint64, c_double, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None
@@ -190,6 +199,7 @@ class Context:
         self.handle = h.value
         self.device = int(device)
         self._live = set()
+        self._pinned = {}
 
     # ---- plumbing
     def _check(self, rc):
@@ -206,6 +216,9 @@ class Context:
         if self.handle is not None:
             for a in list(self._live):
                 a.free()
+            for p in list(self._pinned.values()):
+                lib().xh_host_free(self.handle, p)
+            self._pinned = {}
             lib().xh_ctx_destroy(self.handle)
             self.handle = None
 
@@ -224,6 +237,29 @@ class Context:
     def upload(self, host, dtype=np.float64):
         host = np.ascontiguousarray(host, dtype=dtype)
         return DeviceArray(self, host.shape, dtype).upload(host)
+
+    def pinned(self, shape, dtype=np.float64):
+        """A numpy array in page-locked host memory (xh_host_alloc); release it with free_pinned()."""
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+        p = c_void_p()
+        self._check(lib().xh_host_alloc(self.handle, nbytes, byref(p)))
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def free_pinned(self, arr):
+        p = self._pinned.pop(arr.ctypes.data, None)
+        if p is not None and self.handle is not None:
+            self._check(lib().xh_host_free(self.handle, p))
+
+    def h2d_async(self, dst, host):
+        """Enqueue host -> device without waiting; ``host`` must stay alive and unchanged until sync()."""
+        self._check(lib().xh_memcpy_h2d_async(self.handle, _dptr(dst), _host_ptr(host), host.nbytes))
+
+    def d2h_async(self, host, src):
+        self._check(lib().xh_memcpy_d2h_async(self.handle, _host_ptr(host), _dptr(src), host.nbytes))
 
     def timing_reset(self):
         self._check(lib().xh_timing_reset(self.handle))
@@ -338,12 +374,13 @@ class Context:
                                            _dptr(severity), _dptr(intensity), _dptr(duration)))
 
     # ---- bench support
-    def synth_forcing(self, seed, ncell, nmonths, lat, out, nan_frac=0.001):
-        """out: dict name -> DeviceArray for synth.FORCING_NAMES."""
-        self._check(lib().xh_synth_forcing(self.handle, int(seed), float(nan_frac), ncell, nmonths, _dptr(lat), _dptr(out['tas']),
-                                           _dptr(out['tmin']), _dptr(out['rhs']), _dptr(out['wind']),
-                                           _dptr(out['rsds']), _dptr(out['rlds']), _dptr(out['precip']),
-                                           _dptr(out['abcd_tmin'])))
+    def synth_forcing(self, seed, ncell, nmonths, lat, out, nan_frac=0.001, cell_ids=None):
+        """out: dict name -> DeviceArray for synth.FORCING_NAMES (or only 'tas'). cell_ids: device int64 [ncell]
+        global cell of each row (None = 0..ncell-1; -1 = a row of zeros)."""
+        g = lambda k: _dptr(out.get(k))
+        self._check(lib().xh_synth_forcing(self.handle, int(seed), float(nan_frac), ncell, nmonths, _dptr(lat),
+                                           _dptr(cell_ids), g('tas'), g('tmin'), g('rhs'), g('wind'), g('rsds'),
+                                           g('rlds'), g('precip'), g('abcd_tmin')))
 
 
 class RoutePlan:
@@ -365,7 +402,7 @@ class RoutePlan:
         self.ctx._check(lib().xh_route_plan_info(self.handle, arr))
         keys = ('networks', 'largest_network', 'units', 'fallback_cells', 'largest_unit', 'slots', 'single_downstream',
                 'flow_units', 'flow_edges', 'flow_depth', 'flow_cells', 'flow_max_imports', 'skew_max_lag',
-                'last_tree_kernel')
+                'last_tree_kernel', 'reroutes')
         return dict(zip(keys, list(arr)))
 
     def stats(self):
@@ -381,6 +418,44 @@ class RoutePlan:
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:
             lib().xh_route_plan_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id():
+    """128-byte RCCL id made on rank 0; the launcher carries it to the other ranks (xh_comm_unique_id)."""
+    buf = ctypes.create_string_buffer(128)
+    _check_host(lib().xh_comm_unique_id(buf, 128))
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of one rank for the write-out gather (xh_comm)."""
+
+    def __init__(self, ctx, nranks, rank, unique_id):
+        self.ctx, self.nranks, self.rank = ctx, int(nranks), int(rank)
+        h = c_void_p()
+        ctx._check(lib().xh_comm_create(ctx.handle, self.nranks, self.rank, unique_id, len(unique_id), byref(h)))
+        self.handle = h.value
+
+    def gather_rows(self, local, counts, ncols, perm=None, out=None, root=0):
+        """local: list of DeviceArrays [counts[rank], ncols]; on the root ``perm`` (device int64, rank-major destination
+        rows) and ``out`` (list of DeviceArrays [sum(counts), ncols]). Asynchronous."""
+        nvar = len(local)
+        cn = np.ascontiguousarray(counts, dtype=np.int64)
+        p_local = (c_void_p * nvar)(*[_dptr(x) for x in local])
+        p_out = None if out is None else (c_void_p * nvar)(*[_dptr(x) for x in out])
+        self.ctx._check(lib().xh_comm_gather_rows(self.ctx.handle, self.handle, int(root), nvar, p_local, int(ncols),
+                                                  _host_ptr(cn), _dptr(perm), p_out))
+
+    def close(self):
+        if self.handle is not None:
+            lib().xh_comm_destroy(self.handle)
         self.handle = None
 
     def __del__(self):

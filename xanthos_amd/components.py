@@ -117,7 +117,8 @@ class Components:
                               flow_dist=d.flow_dist if um is not None else np.zeros(s.ncell),
                               velocity=d.str_velocity if um is not None else np.zeros(s.ncell), area=d.area,
                               abcd_spinup=s.runoff_spinup, routing_spinup=getattr(s, 'routing_spinup', 0),
-                              water_idx=s.pm_water_idx, snow_idx=s.pm_snow_idx, use_snow=d.tmin is not None)
+                              water_idx=s.pm_water_idx, snow_idx=s.pm_snow_idx, use_snow=d.tmin is not None,
+                              chs_prev=getattr(d, 'chs_prev', None))
         pipe.set_forcing({'tas': d.tair_load, 'tmin': d.TMIN_load, 'rhs': d.rhs_load, 'wind': d.wind_load,
                           'rsds': d.rsds_load, 'rlds': d.rlds_load, 'precip': d.precip, 'abcd_tmin': d.tmin},
                          tairprev=d.tairprev_load)
@@ -166,6 +167,6 @@ class Components:
         writer.write()
         self.q = writer.get('q') if 'q' in writer.output_names else self.Q
         self.ac = writer.get('avgchflow') if 'avgchflow' in writer.output_names else self.Avg_ChFlow
-        if 'q' in writer.output_names and self.s.AggregateRunoffBasin:
-            ref = type('Ref', (), {'basin_ids': self.data.basin_ids, 'n_basin_names': self.s.n_basins})
-            writer.write_aggregates(ref, self.q, self.s.AggregateRunoffBasin, 0, 0)
+        # always from the written runoff, or from self.Q when 'q' is not among the output variables (:461-472)
+        writer.write_aggregates(self.data, self.q, self.s.AggregateRunoffBasin, self.s.AggregateRunoffCountry,
+                                self.s.AggregateRunoffGCAMRegion)

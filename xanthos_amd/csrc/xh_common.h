@@ -18,6 +18,21 @@ struct xh_timer_slot {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
+// A routing call that ran on the dataflow kernels and has not been confirmed fault-free by a synchronisation yet.
+// If the device fault word turns out to be set (units of two dataflow kernels could not all be resident and a bounded
+// wait timed out), the synchronising call re-runs these calls with one workgroup per network (XH_ROUTE_NO_DATAFLOW),
+// which has no dependencies between workgroups.
+struct xh_route_record {
+    xh_route_plan *plan = nullptr;
+    int32_t nmonths = 0, spinup_months = 0, flags = 0;
+    std::vector<int32_t> ndays;
+    double dt = 0.0;
+    const double *flow_dist = nullptr, *velocity = nullptr, *area = nullptr, *runoff = nullptr, *S0 = nullptr;
+    double *chs = nullptr, *avg = nullptr, *S_end = nullptr, *F_end = nullptr;
+    uint64_t seq_after = 0;        // ctx->work_seq right after the call was enqueued
+};
+int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r);      // xh_mrtm.hip
+
 struct xh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -33,10 +48,14 @@ struct xh_ctx {
     unsigned *d_fault = nullptr;
     unsigned *h_fault = nullptr;
     bool fault_pending = false;
+    std::vector<xh_route_record> pending_routes;
+    uint64_t work_seq = 0;         // bumped by every kernel-launching entry point (xh_span_begin)
+    int64_t reroutes = 0;          // routing calls re-run after a device fault
 };
 
 // Device fault word: kernels set it non-zero instead of hanging; the next synchronising call reports XH_ERR_DEVICE.
-int xh_fault_word(xh_ctx *ctx, unsigned **d_word);   // lazily allocated, zeroed on the stream
+int xh_fault_word(xh_ctx *ctx, unsigned **d_word);   // lazily allocated and zeroed ONCE: the word is sticky until a check clears it
+unsigned long long xh_spin_limit_ticks(int64_t total_substeps);   // bound of a wait between routing units, 100 MHz ticks
 int xh_fault_collect(xh_ctx *ctx);                   // enqueue device -> pinned host copy after the kernel
 int xh_fault_check(xh_ctx *ctx);                     // after a stream sync: XH_ERR_DEVICE if the word was set
 

@@ -37,10 +37,21 @@ int xh_fault_word(xh_ctx *ctx, unsigned **d_word) {
         XH_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_fault), 64));
         XH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_fault), 64, hipHostMallocDefault));
         *ctx->h_fault = 0;
+        // zeroed once: a fault stays set (and makes later dataflow launches give up at once) until xh_fault_check
+        // has seen it, so a second call enqueued behind a faulting one cannot wipe the evidence
+        XH_HIP(ctx, hipMemsetAsync(ctx->d_fault, 0, 64, ctx->stream));
     }
-    XH_HIP(ctx, hipMemsetAsync(ctx->d_fault, 0, 64, ctx->stream));
     *d_word = ctx->d_fault;
     return XH_OK;
+}
+
+// A unit waits for another only while that one is behind, i.e. at most about the run time of the whole kernel
+// (~0.2 us per sub-step): allow 100x that, at least half a second, at most 20 s.
+unsigned long long xh_spin_limit_ticks(int64_t total_substeps) {
+    const double expected_s = (double)total_substeps * 0.25e-6;
+    double limit = 100.0 * expected_s;
+    limit = limit < 0.5 ? 0.5 : (limit > 20.0 ? 20.0 : limit);
+    return (unsigned long long)(limit * 1e8);
 }
 
 int xh_fault_collect(xh_ctx *ctx) {
@@ -55,14 +66,36 @@ int xh_fault_check(xh_ctx *ctx) {
     ctx->fault_pending = false;
     const unsigned code = *ctx->h_fault;
     *ctx->h_fault = 0;
-    if (code)
-        return xh_fail(ctx, XH_ERR_DEVICE, "routing kernel fault %u: a bounded wait between routing units timed out "
-                       "(units not co-resident or a producer stalled); outputs of that call are invalid", code);
+    std::vector<xh_route_record> pending;
+    pending.swap(ctx->pending_routes);
+    if (!code) return XH_OK;
+    // A bounded wait between routing units timed out: the dataflow kernels of these calls left invalid outputs.
+    // Clear the word and route them again with one workgroup per network (no waits between workgroups).
+    XH_HIP(ctx, hipMemsetAsync(ctx->d_fault, 0, 64, ctx->stream));
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t seq_now = ctx->work_seq;
+    const bool later_work = !pending.empty() && seq_now != pending.back().seq_after;
+    fprintf(stderr, "[libxanthos_hip] routing fault %u (a bounded wait between routing units timed out: the device is "
+            "shared and the units were not all resident); re-routing %zu call(s) with one workgroup per network\n",
+            code, pending.size());
+    for (const xh_route_record &r : pending) {
+        int rc = xh_route_rerun(ctx, r);
+        if (rc) return rc;
+        ctx->reroutes += 1;
+    }
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (pending.empty())
+        return xh_fail(ctx, XH_ERR_DEVICE, "routing kernel fault %u and no record of the call: outputs are invalid", code);
+    if (later_work)
+        return xh_fail(ctx, XH_ERR_DEVICE, "routing kernel fault %u: the routing outputs were recomputed with the "
+                       "workgroup-per-network kernel and are valid now, but results of calls enqueued after "
+                       "xh_route_series read the invalid ones and must be recomputed", code);
     return XH_OK;
 }
 
 xh_span xh_span_begin(xh_ctx *ctx, const char *name) {
     xh_span s{ctx, name};
+    ctx->work_seq += 1;
     if (!ctx->timing) return s;
     auto take = [&](hipEvent_t &e) {
         if (!ctx->event_pool.empty()) {
@@ -179,6 +212,33 @@ int xh_memcpy_d2h(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     XH_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return xh_fault_check(ctx);
+}
+
+int xh_host_alloc(xh_ctx *ctx, size_t bytes, void **h_ptr) {
+    if (!ctx || !h_ptr) return XH_ERR_ARG;
+    XH_HIP(ctx, hipSetDevice(ctx->device));
+    XH_HIP(ctx, hipHostMalloc(h_ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return XH_OK;
+}
+
+int xh_host_free(xh_ctx *ctx, void *h_ptr) {
+    if (!ctx) return XH_ERR_ARG;
+    if (!h_ptr) return XH_OK;
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    XH_HIP(ctx, hipHostFree(h_ptr));
+    return XH_OK;
+}
+
+int xh_memcpy_h2d_async(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !h_src))) return XH_ERR_ARG;
+    XH_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return XH_OK;
+}
+
+int xh_memcpy_d2h_async(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    if (!ctx || (bytes && (!h_dst || !d_src))) return XH_ERR_ARG;
+    XH_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return XH_OK;
 }
 
 int xh_memcpy_d2d(xh_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {

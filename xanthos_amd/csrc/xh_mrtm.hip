@@ -338,6 +338,7 @@ struct xh_route_plan {
     DevBuf d_rest_units[N_CLASS];
     FlowPlan *flow = nullptr;                    // tree-shaped networks as single-wave dataflow units
     int last_tree_kernel = 0;                    // last xh_route_series: 0 none, 1 monthly streams, 2 time-skewed
+    int64_t reroutes = 0;                        // calls re-run with one workgroup per network after a device fault
     int64_t n_rest_units = 0, n_fb_rest = 0;
     bool fb_rest_single_ds = true;
     DevBuf d_fbr_cells, d_fbr_ptr, d_fbr_col, d_fbr_sgn, d_fbr_ds;
@@ -645,7 +646,7 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
 
 extern "C" void xh_route_plan_destroy(xh_route_plan *plan) {
     if (!plan) return;
-    (void)hipStreamSynchronize(plan->ctx->stream);
+    (void)xh_sync(plan->ctx);                    // settles (and if needed re-runs) routing calls still in flight
     for (int k = 0; k < N_CLASS; ++k) {
         free_buf(plan->d_class_units[k]);
         free_buf(plan->d_rest_units[k]);
@@ -682,7 +683,8 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
     info[11] = fi[4];                 // most imported streams of a unit
     info[12] = (plan->flow && plan->flow->skew_ok) ? plan->flow->skew_lmax : -1;     // deepest lane lag (sub-steps)
     info[13] = plan->last_tree_kernel;
-    info[14] = info[15] = 0;
+    info[14] = plan->reroutes;
+    info[15] = 0;
     return XH_OK;
 }
 
@@ -697,11 +699,54 @@ extern "C" int xh_route_plan_stats(xh_route_plan *plan, int64_t max_words, uint6
     return XH_OK;
 }
 
+static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
+                             const int32_t *h_ndays, double dt, const double *d_flow_dist, const double *d_velocity,
+                             const double *d_area, const double *d_runoff, const double *d_S0, double *d_chstorage,
+                             double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow);
+
 extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                                const int32_t *h_ndays, double dt, const double *d_flow_dist,
                                const double *d_velocity, const double *d_area, const double *d_runoff,
                                const double *d_S0, double *d_chstorage, double *d_avgchflow, double *d_S_end,
                                double *d_F_end, int32_t flags) {
+    bool used_flow = false;
+    int rc = route_series_impl(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff,
+                               d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end, flags, &used_flow);
+    if (rc || !used_flow) return rc;
+    // remember the call until a synchronisation has confirmed that no bounded wait timed out (xh_fault_check)
+    xh_route_record r;
+    r.plan = plan;
+    r.nmonths = nmonths;
+    r.spinup_months = spinup_months;
+    r.flags = flags;
+    r.ndays.assign(h_ndays, h_ndays + nmonths);
+    r.dt = dt;
+    r.flow_dist = d_flow_dist;
+    r.velocity = d_velocity;
+    r.area = d_area;
+    r.runoff = d_runoff;
+    r.S0 = d_S0;
+    r.chs = d_chstorage;
+    r.avg = d_avgchflow;
+    r.S_end = d_S_end;
+    r.F_end = d_F_end;
+    r.seq_after = ctx->work_seq;
+    ctx->pending_routes.push_back(std::move(r));
+    return xh_fault_collect(ctx);
+}
+
+int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r) {
+    bool used_flow = false;
+    r.plan->reroutes += 1;
+    return route_series_impl(ctx, r.plan, r.nmonths, r.spinup_months, r.ndays.data(), r.dt, r.flow_dist, r.velocity,
+                             r.area, r.runoff, r.S0, r.chs, r.avg, r.S_end, r.F_end,
+                             (r.flags | XH_ROUTE_NO_DATAFLOW) & ~XH_ROUTE_TEST_FAULT, &used_flow);
+}
+
+static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
+                             const int32_t *h_ndays, double dt, const double *d_flow_dist, const double *d_velocity,
+                             const double *d_area, const double *d_runoff, const double *d_S0, double *d_chstorage,
+                             double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow) {
     if (!ctx || !plan) return XH_ERR_ARG;
     XH_REQUIRE(ctx, plan->ctx == ctx, "xh_route_series: plan belongs to another context");
     XH_REQUIRE(ctx, h_ndays && d_flow_dist && d_velocity && d_area && d_runoff, "xh_route_series: NULL argument");
@@ -760,7 +805,8 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
             ntmax = std::max(ntmax, v);
             ntmin = std::min(ntmin, v);
         }
-        const FlowSched fs{nmonths, nit, ntmax, ntmin, sg[nit], d_m, d_nt, d_g, d_secs, d_wr, dt};
+        const FlowSched fs{nmonths, nit, ntmax, ntmin, sg[nit], d_m, d_nt, d_g, d_secs, d_wr, dt,
+                           (flags & XH_ROUTE_TEST_FAULT) != 0};
         const FlowIO fio{d_flow_dist, d_velocity, d_area, d_runoff, d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end};
         // time-skewed units first; months shorter than the deepest lane lag (long dt) use the monthly-stream kernel
         static const bool skew_env = !(getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] == '0');
@@ -892,6 +938,6 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
         XH_HIP(ctx, hipStreamWaitEvent(ctx->stream, plan->ev_join[N_CLASS], 0));
     }
     xh_span_end(sp);
-    if (use_flow) return xh_fault_collect(ctx);
+    *used_flow = use_flow;
     return XH_OK;
 }

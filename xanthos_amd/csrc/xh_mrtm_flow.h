@@ -30,6 +30,7 @@ struct FlowSched {
     const double *d_secs;             // [nit]
     const unsigned char *d_wr;        // [nit] 1 = simulation pass (store outputs)
     double dt;
+    bool test_fault;                  // XH_ROUTE_TEST_FAULT: unit 0 raises the fault word and stops (tests of the re-route)
 };
 
 struct FlowIO {

@@ -46,7 +46,7 @@ constexpr int SK_R = 2;                       // block-transfer rounds: up to 8 
 constexpr int CH = 128;                       // iterations between flow-control checks (multiple of GROUP)
 constexpr int PUBLAG = 64;                    // a check publishes the stores older than this many iterations
 constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2;
-constexpr unsigned long long SPIN_LIMIT_TICKS = 2000000000ull;   // 20 s of the 100 MHz real-time counter
+constexpr unsigned FAULT_TEST = 99;
 
 struct SkewArgs {
     const int *cell_of_slot, *lag, *ghost_lag, *export_edge, *ghost_edge, *edge_cons_unit;
@@ -67,6 +67,8 @@ struct SkewArgs {
     unsigned *ready;                  // [edges] sub-steps published
     unsigned *done;                   // [units] sub-steps consumed
     unsigned *fault;
+    unsigned long long spin_limit;    // bound of one wait, 100 MHz ticks (xh_spin_limit_ticks)
+    int test_fault;
     unsigned long long *stats;
 };
 
@@ -78,7 +80,7 @@ __device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
 // check can skip the poll (a counter only grows; one poll is an agent-coherent load, ~1-2 us).  False (and the fault
 // word raised) on timeout / fault.
 __device__ __forceinline__ bool wave_wait_ge(bool need, const unsigned *p, unsigned target, unsigned &seen,
-                                             unsigned *fault, unsigned code) {
+                                             unsigned *fault, unsigned code, unsigned long long limit) {
     bool ok = !need || seen >= target;
     if (__all(ok)) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -89,7 +91,7 @@ __device__ __forceinline__ bool wave_wait_ge(bool need, const unsigned *p, unsig
         }
         if (__all(ok)) return true;
         if (ld_relaxed(fault) != 0) return false;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit) {
             __hip_atomic_store(fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -199,7 +201,8 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
             if (has_x) __hip_atomic_store(a.ready + xedge, (unsigned)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int need = n + CH - lmax - a.rs;
             if (need > 0)
-                alive = wave_wait_ge(has_x, done_p, (unsigned)min(need, total), seen_done, a.fault, FAULT_RING_WAIT);
+                alive = wave_wait_ge(has_x, done_p, (unsigned)min(need, total), seen_done, a.fault, FAULT_RING_WAIT,
+                                     a.spin_limit);
         }
         const unsigned long long w1 = __builtin_amdgcn_s_memtime();
         if (any_g && alive) {   // the next CH iterations load up to sub-step n + CH + GROUP - 1 - lag_g
@@ -207,7 +210,8 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
                 __hip_atomic_store(a.done + unit, (unsigned)min(max(n - glmax, 0), total), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             const int need = min(total, n + CH + GROUP - lag_g);
-            alive = wave_wait_ge(has_g && need > 0, ready_p, (unsigned)max(need, 0), seen_ready, a.fault, FAULT_DATA_WAIT);
+            alive = wave_wait_ge(has_g && need > 0, ready_p, (unsigned)max(need, 0), seen_ready, a.fault, FAULT_DATA_WAIT,
+                                 a.spin_limit);
             asm volatile("" ::: "memory");      // the stream loads stay behind the poll
         }
         cyc_wait_ring += w1 - w0;
@@ -278,7 +282,11 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
             }
     };
 
-    check(0);
+    if (a.test_fault && unit == 0) {      // XH_ROUTE_TEST_FAULT: behave as if a wait had timed out
+        if (lane == 0) __hip_atomic_store(a.fault, FAULT_TEST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        alive = false;
+    }
+    if (alive) check(0);
 #pragma unroll
     for (int r = 0; r < SK_R; ++r) {
         gbuf[0][r] = HAS_G ? import_load(r, 0) : v2d{0.0, 0.0};
@@ -508,6 +516,8 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     int rc = xh_fault_word(ctx, &fault);
     if (rc) return rc;
     a.fault = fault;
+    a.spin_limit = xh_spin_limit_ticks(s.total);
+    a.test_fault = s.test_fault ? 1 : 0;
     a.stats = nullptr;
     {
         const char *env = getenv("XH_FLOW_STATS");

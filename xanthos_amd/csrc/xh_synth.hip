@@ -28,13 +28,18 @@ __device__ __forceinline__ double nrm(uint64_t seed, uint64_t stream, uint64_t i
 }
 
 __global__ void __launch_bounds__(256) k_synth(uint64_t seed, double nan_frac, int64_t ncell, int nmonths, const double *__restrict__ lat,
-                                               double *tas, double *tmin, double *rhs, double *wind, double *rsds,
+                                               const int64_t *__restrict__ cell_ids, double *tas, double *tmin, double *rhs, double *wind, double *rsds,
                                                double *rlds, double *precip, double *abcd_tmin) {
     const int64_t total = ncell * (int64_t)nmonths;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t c = i / nmonths;
         const int m = (int)(i - c * nmonths);
-        const uint64_t idx = (uint64_t)c * 4096ull + (uint64_t)m;
+        const int64_t gcid = cell_ids ? cell_ids[c] : c;            // global cell: the random streams follow it
+        if (gcid < 0) {                                             // "no such cell" (tairprev row of cell 0): zeros
+            if (tas) tas[i] = 0.0;
+            continue;
+        }
+        const uint64_t idx = (uint64_t)gcid * 4096ull + (uint64_t)m;
         const double la = lat[c];
         const double coslat = cos(la * (M_PI / 180.0));
         const double hemi = la > 0.0 ? 1.0 : (la < 0.0 ? -1.0 : 0.0);
@@ -43,14 +48,15 @@ __global__ void __launch_bounds__(256) k_synth(uint64_t seed, double nan_frac, i
         const double tn = t - (2.0 + 8.0 * uni(seed, 4, idx));
         double rh = 65.0 + 20.0 * nrm(seed, 3, idx);
         rh = rh < 5.0 ? 5.0 : (rh > 100.0 ? 100.0 : rh);
-        tas[i] = t;
+        if (tas) tas[i] = t;
+        if (!tmin) continue;                                        // tas only (tairprev rows of a shard)
         tmin[i] = tn;
         rhs[i] = rh;
         wind[i] = 0.5 + 7.5 * uni(seed, 10, idx);
         rsds[i] = 30.0 + 300.0 * uni(seed, 11, idx);
         rlds[i] = 150.0 + 280.0 * uni(seed, 12, idx);
         double pr = -40.0 * (log(1.0 - uni(seed, 13, idx)) + log(1.0 - uni(seed, 14, idx)));
-        if (uni(seed, 15, (uint64_t)c) < nan_frac) pr = NAN;        // missing-data cells (precip keeps NaN, data_load.py:186)
+        if (uni(seed, 15, (uint64_t)gcid) < nan_frac) pr = NAN;     // missing-data cells (precip keeps NaN, data_load.py:186)
         precip[i] = pr;
         abcd_tmin[i] = tn;
     }
@@ -59,11 +65,12 @@ __global__ void __launch_bounds__(256) k_synth(uint64_t seed, double nan_frac, i
 }  // namespace
 
 extern "C" int xh_synth_forcing(xh_ctx *ctx, uint64_t seed, double nan_frac, int64_t ncell, int32_t nmonths, const double *d_lat,
-                                double *d_tas, double *d_tmin, double *d_rhs, double *d_wind, double *d_rsds,
+                                const int64_t *d_cell_ids, double *d_tas, double *d_tmin, double *d_rhs, double *d_wind, double *d_rsds,
                                 double *d_rlds, double *d_precip, double *d_abcd_tmin) {
     if (!ctx) return XH_ERR_ARG;
-    XH_REQUIRE(ctx, d_lat && d_tas && d_tmin && d_rhs && d_wind && d_rsds && d_rlds && d_precip && d_abcd_tmin,
-               "xh_synth_forcing: NULL argument");
+    const bool all = d_tmin && d_rhs && d_wind && d_rsds && d_rlds && d_precip && d_abcd_tmin;
+    const bool none = !d_tmin && !d_rhs && !d_wind && !d_rsds && !d_rlds && !d_precip && !d_abcd_tmin;
+    XH_REQUIRE(ctx, d_lat && d_tas && (all || none), "xh_synth_forcing: NULL argument (all eight arrays, or d_tas only)");
     XH_REQUIRE(ctx, ncell >= 0 && nmonths > 0 && nmonths < 4096, "xh_synth_forcing: bad size");
     if (ncell == 0) return XH_OK;
     const int64_t total = ncell * (int64_t)nmonths;
@@ -71,7 +78,7 @@ extern "C" int xh_synth_forcing(xh_ctx *ctx, uint64_t seed, double nan_frac, int
     const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 16;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, seed, nan_frac, ncell, (int)nmonths, d_lat,
-                       d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds, d_precip, d_abcd_tmin);
+                       d_cell_ids, d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds, d_precip, d_abcd_tmin);
     XH_HIP(ctx, hipGetLastError());
     return XH_OK;
 }

@@ -47,12 +47,23 @@ def load_file(fn, header_num=0, key=None):
     raise RuntimeError('File {} has unrecognized extension'.format(fn))
 
 
+def _present(f):
+    return isinstance(f, np.ndarray) or (isinstance(f, str) and os.path.isfile(f))
+
+
 def vectorize(data, ngridrow, ngridcol, map_index, skip=68):
     """2-D DRT map (rows north to south) -> per-cell vector (data_load.py:415-425)."""
-    new = np.zeros((ngridrow, ngridcol), dtype=float) - 9999
-    for i in range(data.shape[0]):
-        new[i + skip, :] = data[data.shape[0] - 1 - i, :]
-    return new.reshape((ngridrow * ngridcol,), order='F')[map_index]
+    # row i of the map (south to north after the flip) lands on grid row i + skip; map_index addresses the grid in
+    # column-major order, so cell k reads new[r, c] with r = map_index % ngridrow, c = map_index // ngridrow: one
+    # index gather per cell instead of assembling (and re-ordering) the whole 360 x 720 grid
+    data = np.asarray(data, dtype=float)
+    map_index = np.asarray(map_index)
+    r, c = map_index % ngridrow, map_index // ngridrow
+    src = data.shape[0] - 1 - (r - skip)
+    inside = (r >= skip) & (r < skip + data.shape[0])
+    out = np.full(map_index.shape, -9999.0)
+    out[inside] = data[src[inside], c[inside]]
+    return out
 
 
 class DataLoader:
@@ -70,6 +81,26 @@ class DataLoader:
                 self.basin_names = np.array(fh.read().splitlines())
         else:
             self.basin_names = np.array(['basin_{}'.format(k) for k in range(1, s.n_basins + 1)])
+        # GCAM region and country maps with their names (data_load.py:59-69, :275-286): only read by the spatial
+        # aggregation of the writer, so they are loaded when present and demanded only if that aggregation is on
+        self.region_ids = self.region_names = self.country_ids = self.country_names = None
+        rid, rnm = getattr(s, 'GCAMRegionIDs', None), getattr(s, 'GCAMRegionNames', None)
+        if _present(rid) and _present(rnm):
+            self.region_ids = np.asarray(load_file(rid, 1)).reshape(-1).astype(int)
+            with open(rnm) as fh:
+                fh.readline()
+                self.region_names = np.array([ln.split(',')[0] for ln in fh.read().split('\n') if ln != ''])
+        cid, cnm = getattr(s, 'CountryIDs', None), getattr(s, 'CountryNames', None)
+        if _present(cid) and _present(cnm):
+            self.country_ids = np.asarray(load_file(cid, 1)).reshape(-1).astype(int)
+            with open(cnm) as fh:
+                self.country_names = np.array([ln.split(',')[1] for ln in fh.read().splitlines()])
+        if getattr(s, 'AggregateRunoffGCAMRegion', 0) and self.region_ids is None:
+            raise ValidationException('AggregateRunoffGCAMRegion = 1 needs region32_grids.csv and Rgn32Names.csv in '
+                                      'the reference directory')
+        if getattr(s, 'AggregateRunoffCountry', 0) and self.country_ids is None:
+            raise ValidationException('AggregateRunoffCountry = 1 needs country.csv and country-names.csv in the '
+                                      'reference directory')
 
         if s.pet_module == 'pm':
             et = np.asarray(load_file(s.pm_params), dtype=float)
@@ -102,10 +133,24 @@ class DataLoader:
             self.flow_dir = self.load_routing_data(s.flow_direction)
             self.str_velocity = self.load_routing_data(s.strm_veloc, rep_val=0)
             self.instream_flow = np.zeros((s.ncell,), dtype=float)
-            self.chs_prev = np.zeros((s.ncell,), dtype=float)      # historic mode (data_load.py:427-438)
+            self.chs_prev = self.load_chs_data()
 
         if s.calibrate:
             self.cal_obs = np.asarray(load_file(s.cal_observed, 0))[:, [0, 3]]
+
+    def load_chs_data(self):
+        """Initial channel storage (data_load.py:427-438): zeros in historic mode; in future mode the last column of the
+        historical run's channel storage file."""
+        s = self.s
+        f = getattr(s, 'ChStorageFile', None)
+        if str(getattr(s, 'HistFlag', 'True')) == 'True' or f is None:
+            return np.zeros((s.ncell,), dtype=float)
+        arr = np.asarray(load_file(f, 0, getattr(s, 'ChStorageVarName', None)), dtype=float)
+        if arr.ndim == 1:
+            arr = arr[:, None]
+        if arr.shape[0] != s.ncell:
+            raise ValidationException('ChStorageFile has {} cells, expected {}'.format(arr.shape[0], s.ncell))
+        return np.ascontiguousarray(arr[:, -1])
 
     def load_to_array(self, f, var_name, nan_to_num=False, key=None):
         arr = np.asarray(load_file(f, key=key), dtype=float)

@@ -101,32 +101,48 @@ class OutWriter:
             self.write_data(filename, var, self.outputs[i], self.time_steps, first_id=1)
 
     def write_aggregates(self, ref, values, basin, country, region):
-        """Spatial sums of ``values`` (the written runoff) by basin / country / region (:126-158)."""
+        """Spatial sums of ``values`` (the written runoff) by basin / country / GCAM region (:126-158).
+
+        As in the reference's ``agg_spatial`` (:250-265) there is one row per NAME: basins and regions are numbered from
+        1 (``inc_name_idx=True``), countries from 0 (the names table keeps its 0-based index there); ids without a
+        name are dropped, names without cells give NaN.  The csv carries the ``id`` and ``name`` columns the
+        reference's DataFrame has."""
         filepath = os.path.join(self.out_folder, '{}_' + '{}_{}'.format(self.out_unit_str, self.proj_name))
         jobs = []
         if basin:
-            jobs.append(('Basin_runoff', ref.basin_ids, getattr(ref, 'n_basin_names', int(np.max(ref.basin_ids)))))
-        if country and hasattr(ref, 'country_ids'):
-            jobs.append(('Country_runoff', ref.country_ids, int(np.max(ref.country_ids))))
-        if region and hasattr(ref, 'region_ids'):
-            jobs.append(('GCAMRegion_runoff', ref.region_ids, int(np.max(ref.region_ids))))
+            names = getattr(ref, 'basin_names', None)
+            n = len(names) if names is not None else getattr(ref, 'n_basin_names', int(np.max(ref.basin_ids)))
+            jobs.append(('Basin_runoff', ref.basin_ids, n, 1, names))
+        if country:
+            if getattr(ref, 'country_ids', None) is None:
+                raise ValueError('AggregateRunoffCountry needs country ids and names (country.csv, country-names.csv)')
+            jobs.append(('Country_runoff', ref.country_ids, len(ref.country_names), 0, ref.country_names))
+        if region:
+            if getattr(ref, 'region_ids', None) is None:
+                raise ValueError('AggregateRunoffGCAMRegion needs region ids and names (region32_grids.csv, '
+                                 'Rgn32Names.csv)')
+            jobs.append(('GCAMRegion_runoff', ref.region_ids, len(ref.region_names), 1, ref.region_names))
         out = {}
-        for name, ids, n in jobs:
-            out[name] = self.agg_spatial(values, ids, n)
-            self.write_data(filepath.format(name), name, out[name], self.time_steps, first_id=1)
+        for name, ids, n, first, names in jobs:
+            logging.info('Aggregating by ' + name.split('_')[0])
+            out[name] = self.agg_spatial(values, ids, n, first_id=first)
+            self.write_data(filepath.format(name), name, out[name], self.time_steps, first_id=first, names=names)
+        logging.info('Aggregated unit is {}'.format(self.out_unit_str))
         return out
 
-    def write_data(self, filename, var, data, col_names, first_id=1):
+    def write_data(self, filename, var, data, col_names, first_id=1, names=None):
         os.makedirs(self.out_folder, exist_ok=True)
         if self.out_format == FORMAT_NPY:
             np.save(filename + '.npy', data)
         elif self.out_format == FORMAT_CSV:
             ids = np.arange(first_id, first_id + data.shape[0])
-            header = 'id,' + ','.join(col_names[:data.shape[1]])
+            header = 'id,' + ('name,' if names is not None else '') + ','.join(col_names[:data.shape[1]])
+            fmt = lambda v: '' if v != v else repr(float(v))                    # pandas writes NaN as an empty field
             with open(filename + '.csv', 'w') as fh:
                 fh.write(header + '\n')
-                for i, row in zip(ids, data):
-                    fh.write(str(i) + ',' + ','.join(repr(float(v)) for v in row) + '\n')
+                for k, (i, row) in enumerate(zip(ids, data)):
+                    label = '' if names is None else str(names[k]) + ','
+                    fh.write(str(i) + ',' + label + ','.join(fmt(v) for v in row) + '\n')
         else:
             raise RuntimeError('OutputFormat {} (NetCDF / MATLAB / parquet) is written by the reference\'s pandas '
                                'writers, outside the MI355X hot path; use 1 (csv) or 4 (npy)'.format(self.out_format))

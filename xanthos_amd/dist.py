@@ -9,9 +9,12 @@ abcd.py:357-391).  What shards naturally on this path:
 
 So the unit of sharding is a connected component of "same basin OR linked by a flow edge".  Components are packed onto
 the ranks largest-first onto the least-loaded rank (LPT), each rank runs the unchanged single-GPU pipeline on its
-cells (no collective on the data path), and the six ``[n_local, nmonths]`` outputs travel to rank 0 in ONE padded
-gather over RCCL/xGMI (``torch.distributed`` backend "nccl"; "gloo" in the CPU tests), where rows are scattered back to
-grid order.
+cells (no collective on the data path), and the six ``[n_local, nmonths]`` outputs travel to rank 0 in ONE gather over
+RCCL/xGMI, where rows are scattered back to grid order.  The gather is the library's own (``xh_comm_gather_rows``:
+grouped ncclSend / ncclRecv of the exact shard sizes straight from the pipeline's output buffers, csrc/xh_comm.hip);
+``torch.distributed`` is only the launcher and carries the RCCL id.  ``gather_to_root`` (a padded
+``torch.distributed.gather``) remains for the gloo CPU tests and as the fallback when RCCL cannot be initialised
+(e.g. the dry run with every rank on one GPU).
 """
 from types import SimpleNamespace
 
@@ -89,24 +92,21 @@ def sub_world(world, um, shard):
 
 
 def fill_shard_forcing(ctx, world, shard, pipe, seed, nan_frac=0.0):
-    """Generate the whole world's forcing on this device, keep the shard's rows (+ tairprev rows of cell - 1)."""
-    nm = pipe.nmonths
-    full = {k: ctx.empty((world.ncell, nm)) for k in pipe.alloc_forcing()}
-    d_lat = ctx.upload(world.latitude)
-    ctx.synth_forcing(seed, world.ncell, nm, d_lat, full, nan_frac=nan_frac)
-    d_rows = ctx.upload(shard.cells, dtype=np.int64)
-    for k, dst in pipe.forcing.items():
-        ctx.gather_rows(full[k], d_rows, len(shard.cells), nm, dst)
-    # tairprev[c] = tas[c - 1] in GLOBAL cell order, zeros for cell 0 (data_load.py:128-129)
-    prev = np.maximum(shard.cells - 1, 0)
+    """Generate THIS shard's rows of the world's forcing on the device (the random streams are keyed on the global
+    cell index, so the rows equal those of a whole-world generation) and its tairprev rows = temperature of the
+    previous GLOBAL cell, zeros for cell 0 (data_load.py:128-129)."""
+    nm, n = pipe.nmonths, len(shard.cells)
+    forcing = pipe.alloc_forcing()
+    d_lat = ctx.upload(world.latitude[shard.cells])
+    d_ids = ctx.upload(shard.cells, dtype=np.int64)
+    ctx.synth_forcing(seed, n, nm, d_lat, forcing, nan_frac=nan_frac, cell_ids=d_ids)
+    prev = shard.cells - 1                                    # -1 for global cell 0: a row of zeros
     d_prev = ctx.upload(prev, dtype=np.int64)
-    pipe.d_tairprev = ctx.empty((len(shard.cells), nm))
-    ctx.gather_rows(full['tas'], d_prev, len(shard.cells), nm, pipe.d_tairprev)
-    if len(shard.cells) and shard.cells[0] == 0:
-        from . import _hip
-        ctx._check(_hip.lib().xh_memset(ctx.handle, pipe.d_tairprev.ptr, 0, nm * 8))
+    d_plat = ctx.upload(world.latitude[np.maximum(prev, 0)])
+    pipe.d_tairprev = ctx.empty((n, nm))
+    ctx.synth_forcing(seed, n, nm, d_plat, {'tas': pipe.d_tairprev}, nan_frac=nan_frac, cell_ids=d_prev)
     ctx.sync()
-    for b in list(full.values()) + [d_lat, d_rows, d_prev]:
+    for b in (d_lat, d_ids, d_prev, d_plat):
         b.free()
 
 
@@ -146,3 +146,62 @@ def gather_outputs(ctx, pipe, shard, shards, world, dist, torch, names=('pet', '
     if dist.get_backend() != 'nccl':
         local = local.cpu()          # gloo dry runs gather on the host
     return gather_to_root(local, shards, world.ncell, dist)
+
+
+class OutputGather:
+    """The write-out gather of a sharded run, set up once and run after every pipeline pass.
+
+    kind "rccl": xh_comm_gather_rows on the library's stream -- no torch tensor, no staging copy on the senders, no
+    padding; rank 0 ends up with ``names`` as device arrays ``[ncell, nmonths]`` in grid order (``self.out``).
+    kind "torch": padded ``torch.distributed.gather`` of a stacked copy (gloo dry runs; RCCL unavailable)."""
+
+    def __init__(self, ctx, pipe, shards, rank, ncell, dist, torch, names=('pet', 'aet', 'q', 'sav', 'chs', 'avg'),
+                 root=0):
+        from . import _hip
+        self.ctx, self.pipe, self.shards, self.rank, self.ncell = ctx, pipe, shards, rank, int(ncell)
+        self.dist, self.torch, self.names, self.root = dist, torch, tuple(names), root
+        self.counts = np.array([len(s.cells) for s in shards], dtype=np.int64)
+        self.out, self.d_perm, self.comm, self.kind, self.why = None, None, None, 'torch', ''
+        self.bytes = int(self.counts.sum()) * pipe.nmonths * 8 * len(self.names)
+        if dist.get_backend() == 'nccl':
+            try:
+                uid = [_hip.comm_unique_id() if rank == root else None]
+                dist.broadcast_object_list(uid, src=root)
+                self.comm = _hip.Comm(ctx, len(shards), rank, uid[0])
+                self.kind = 'rccl'
+            except (_hip.HipError, RuntimeError) as exc:          # e.g. two ranks on one GPU in a dry run
+                self.why = str(exc)
+            ok = torch.tensor([1 if self.kind == 'rccl' else 0], device='cuda')
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)             # all ranks take the same path
+            if int(ok.item()) == 0 and self.kind == 'rccl':
+                self.comm.close()
+                self.comm, self.kind = None, 'torch'
+        if self.kind == 'rccl' and rank == root:
+            self.d_perm = ctx.upload(np.concatenate([s.cells for s in shards]), dtype=np.int64)
+            self.out = {k: ctx.empty((self.ncell, pipe.nmonths)) for k in self.names}
+
+    def run(self):
+        if self.kind == 'rccl':
+            self.comm.gather_rows([self.pipe.out[k] for k in self.names], self.counts, self.pipe.nmonths,
+                                  perm=self.d_perm, out=None if self.out is None else [self.out[k] for k in self.names],
+                                  root=self.root)
+            return None
+        world = SimpleNamespace(ncell=self.ncell)
+        got = gather_outputs(self.ctx, self.pipe, self.shards[self.rank], self.shards, world, self.dist, self.torch,
+                             names=self.names)
+        if self.torch.cuda.is_available() and self.dist.get_backend() == 'nccl':
+            self.torch.cuda.synchronize()
+        return got
+
+    def report(self):
+        return {'kind': self.kind, 'bytes_per_step': self.bytes, 'variables': list(self.names),
+                'rows_per_rank': self.counts.tolist(), 'fallback_reason': self.why}
+
+    def close(self):
+        if self.comm is not None:
+            self.ctx.sync()
+            self.comm.close()
+            self.comm = None
+        for a in (list(self.out.values()) if self.out else []) + ([self.d_perm] if self.d_perm is not None else []):
+            a.free()
+        self.out, self.d_perm = None, None

@@ -108,7 +108,8 @@ class DroughtStats:
             cols = [str(x) for x in range(nm)]                       # the reference names the columns 0 .. ntime-1
             for varname, arr in zip(('severity', 'intensity', 'duration'),
                                     (self.severity, self.intensity, self.duration)):
-                out_writer.write_data(output_path.format(varname), varname, arr, cols)
+                # a fresh DataFrame's index starts at 0 (drought_stats.py:64-65): ids 0 .. ncell-1, unlike write()'s 1-based ids
+                out_writer.write_data(output_path.format(varname), varname, arr, cols, first_id=0)
 
     @classmethod
     def _window(cls, settings):

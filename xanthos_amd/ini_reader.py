@@ -187,6 +187,13 @@ class ConfigReader:
             self.PrecipVarName = m.get('PrecipVarName')
             self.TempMinFile = m.get('TempMinFile')
             self.TempMinVarName = m.get('TempMinVarName')
+            # Future mode (HistFlag = False): channel storage at the end of the historical run.  The reference reads these
+            # two keys only in its gwam section (ini_reader.py:322-338), so with abcd its loader silently starts from
+            # zeros (data_load.py:427-438); here they are honoured in the abcd section as well.
+            self.ChStorageFile = self.ChStorageVarName = None
+            if str(self.HistFlag) == 'False':
+                self.ChStorageFile = m.get('ChStorageFile')
+                self.ChStorageVarName = m.get('ChStorageVarName')
         elif self.runoff_module == 'none':
             pass
         elif self.runoff_module in self.RUNOFF_OTHER:
@@ -224,6 +231,10 @@ class ConfigReader:
             self.Coord = os.path.join(self.Reference, 'coordinates.csv')
             self.BasinIDs = os.path.join(self.Reference, 'basin.csv')
             self.BasinNames = os.path.join(self.Reference, 'BasinNames235.txt')
+            self.GCAMRegionIDs = os.path.join(self.Reference, 'region32_grids.csv')
+            self.GCAMRegionNames = os.path.join(self.Reference, 'Rgn32Names.csv')
+            self.CountryIDs = os.path.join(self.Reference, 'country.csv')
+            self.CountryNames = os.path.join(self.Reference, 'country-names.csv')
 
     def configure_drought_stats(self, cfg):
         """[Drought] (ini_reader.py:460-471)."""

@@ -21,7 +21,7 @@ class DevicePipeline:
 
     def __init__(self, ctx, *, ncell, nmonths, start_year, basin_ids, abcd_pars, pm_tables, lct, elev, lc_years,
                  um, flow_dist, velocity, area, abcd_spinup, routing_spinup, water_idx=0, snow_idx=6, use_snow=True,
-                 route_flags=0):
+                 route_flags=0, chs_prev=None):
         self.ctx = ctx
         self.ncell, self.nmonths, self.start_year = int(ncell), int(nmonths), int(start_year)
         self.end_year = self.start_year + self.nmonths // 12 - 1
@@ -42,6 +42,8 @@ class DevicePipeline:
         self.d_elev = up(np.asarray(elev, dtype=np.float64).reshape(-1))
         self.um = um
         self.d_flow_dist, self.d_velocity, self.d_area = up(flow_dist), up(velocity), up(area)
+        # initial channel storage (future mode, data_load.py:427-438); None = zeros
+        self.d_S0 = up(chs_prev) if chs_prev is not None and np.any(np.asarray(chs_prev) != 0) else None
         self.ndays = set_month_arrays(self.nmonths, self.start_year, self.end_year)[:, 2]
         self.forcing = {}
         self.d_tairprev = None
@@ -87,7 +89,7 @@ class DevicePipeline:
 
     def run_mrtm(self, runoff=None):
         self.ctx.route_series(self.plan, self.nmonths, self.routing_spinup, self.ndays, 10800.0, self.d_flow_dist,
-                              self.d_velocity, self.d_area, self.out['q'] if runoff is None else runoff, None,
+                              self.d_velocity, self.d_area, self.out['q'] if runoff is None else runoff, self.d_S0,
                               self.out['chs'], self.out['avg'], flags=self.route_flags)
 
     def run(self, stages=('pm', 'abcd', 'mrtm')):

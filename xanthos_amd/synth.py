@@ -215,7 +215,8 @@ def data_bag(world, forcing):
 
 
 def write_example(root, world, forcing, start_year, end_year, project='pm_abcd_mrtm_synth', runoff_spinup=36,
-                  routing_spinup=None, output_vars=('q', 'avgchflow'), obs=None, post=False):
+                  routing_spinup=None, output_vars=('q', 'avgchflow'), obs=None, post=False, aggregates=False,
+                  hist_flag=True, ch_storage=None):
     """Write ``world`` + ``forcing`` as a Xanthos-style input tree under ``root`` and return the .ini path.
 
     Layout and file names follow the reference's example (ini_reader.py:254-279, 353-381, 399-416, 425-437):
@@ -223,6 +224,10 @@ def write_example(root, world, forcing, start_year, end_year, project='pm_abcd_m
     input/runoff/abcd/{pars.npy, pr.npy, tmin.npy}, input/routing/mrtm/{velocity.npy, flow_dist.npy, flow_dir.npy}.
     ``post=True`` also switches on the drought-threshold and accessible-water post-processors (basin names, reservoir
     capacity and base-flow index tables under input/reference and input/accessible; ini_reader.py:460-486).
+    ``aggregates=True`` writes GCAM-region and country maps with their name tables (7 regions / 10 countries, the last
+    name of each without cells; countries numbered from 0) and switches the three runoff aggregations on.
+    ``hist_flag=False`` + ``ch_storage`` (array [ncell]): future mode starting from a saved channel storage file
+    (ini_reader.py HistFlag / ChStorageFile, data_load.py:427-438).
     """
     import os
     inp = os.path.join(root, 'input')
@@ -274,6 +279,22 @@ def write_example(root, world, forcing, start_year, end_year, project='pm_abcd_m
                          'threshold_end_year = {y1}\n\n[AccessibleWater]\nResCapacityFile = total_reservoir_storage.csv\n'
                          'BfiFile = bfi_per_basin.csv\nHistEndYear = {y1}\nGCAM_StartYear = {y0}\nGCAM_EndYear = {y1}\n'
                          'GCAM_YearStep = 1\nMovingMeanWindow = 3\nEnv_FlowPercent = 0.1\n').format(y0=start_year, y1=end_year)
+    if aggregates:
+        names = os.path.join(dirs['ref'], 'BasinNames235.txt')
+        if not os.path.isfile(names):
+            with open(names, 'w') as fh:
+                fh.write('\n'.join('Basin {:03d}'.format(k) for k in range(1, world.n_basins + 1)) + '\n')
+        np.savetxt(os.path.join(dirs['ref'], 'region32_grids.csv'), np.concatenate([[0], world.basin_ids % 6 + 1]), fmt='%d')
+        with open(os.path.join(dirs['ref'], 'Rgn32Names.csv'), 'w') as fh:
+            fh.write('region,region_id\n' + '\n'.join('Region {},{}'.format(k, k) for k in range(1, 8)))
+        np.savetxt(os.path.join(dirs['ref'], 'country.csv'), np.concatenate([[0], world.basin_ids % 9]), fmt='%d')
+        with open(os.path.join(dirs['ref'], 'country-names.csv'), 'w') as fh:
+            fh.write(''.join('{},Country {}\n'.format(k, k) for k in range(10)))
+        post_project += 'AggregateRunoffBasin = 1\nAggregateRunoffCountry = 1\nAggregateRunoffGCAMRegion = 1\n'
+    chs_lines = ''
+    if not hist_flag:
+        np.save(os.path.join(dirs['rt'], 'ch_storage.npy'), np.asarray(ch_storage, dtype=float))
+        chs_lines = 'ChStorageFile = {}\nChStorageVarName = chs\n'.format(os.path.join(dirs['rt'], 'ch_storage.npy'))
     with open(ini, 'w') as fh:
         fh.write('''[Project]
 # synthetic pm_abcd_mrtm example written by xanthos_amd.synth.write_example
@@ -285,7 +306,7 @@ RefDir = reference
 pet_dir = pet
 RunoffDir = runoff
 RoutingDir = routing
-HistFlag = True
+HistFlag = {hist}
 n_basins = {nb}
 ncell = {ncell}
 ngridrow = {nrow}
@@ -323,7 +344,7 @@ runoff_spinup = {rsp}
 jobs = -1
 PrecipitationFile = {pr}
 TempMinFile = {tn}
-
+{chs}
 [Routing]
 routing_module = mrtm
 [[mrtm]]
@@ -332,7 +353,7 @@ routing_spinup = {rtsp}
 channel_velocity = velocity.npy
 flow_distance = flow_dist.npy
 flow_direction = flow_dir.npy
-{calib}{post_sections}'''.format(post_project=post_project, post_sections=post_sections, project=project, root=root, nb=world.n_basins, ncell=world.ncell, nrow=world.nrow, ncol=world.ncol,
+{calib}{post_sections}'''.format(chs=chs_lines, hist='True' if hist_flag else 'False', post_project=post_project, post_sections=post_sections, project=project, root=root, nb=world.n_basins, ncell=world.ncell, nrow=world.nrow, ncol=world.ncol,
                   y0=start_year, y1=end_year, ov=', '.join(output_vars), cal=int(obs is not None), nlcs=world.nlcs,
                   lcy=', '.join(str(y) for y in world.lc_years), rsp=runoff_spinup,
                   rtsp=nmonths if routing_spinup is None else routing_spinup,
