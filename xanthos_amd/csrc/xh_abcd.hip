@@ -17,6 +17,7 @@
 // (+ 24 x spinup/nmonths for the spin-up pass) = 52.8 B at spinup 120 / 600 months.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "xh_abcd_dev.h"
 #include "xh_common.h"
@@ -126,6 +127,166 @@ __global__ void __launch_bounds__(64) k_abcd(int64_t ncell, int nmonths, int nst
     }
 }
 
+// ---------------------------------------------------------------------------------------------- tiled kernel
+// Same march, different data movement.  In k_abcd a wave's 16-byte load touches 64 different cache lines (one per
+// cell row) and its stores are quarter-line fragments; the texture-address path then serialises ~64 line requests per
+// instruction and, with one wave per SIMD, nothing hides it.  Here ONE WAVE owns CPW cells and moves whole 128-byte
+// lines: lane (r, k) = (lane / 8, lane % 8) copies the 16-byte chunk k of row r (+ 8 rows per pass), so an
+// instruction covers 8 complete lines; tiles of 16 months are staged in LDS ([cell][17] doubles: conflict-free both
+// for the copy lanes and for the compute lanes), the lanes < CPW march their cell through the tile reading month j at
+// [cell][j], results overwrite the inputs in place (PET -> AET, precipitation -> Q, tmin -> soil moisture) and leave
+// as whole lines.  Rows start at byte c x nmonths x 8, which is a multiple of 128 only for every other cell at 600
+// months, so each row's tiles are shifted by s(c) = (c x nmonths) mod 16 months: tile t of cell c holds months
+// [16 t - s, 16 t - s + 16) and EVERY global access is a full aligned line.  The next tile's lines are loaded into
+// registers while the current one is computed.  CPW = 32 gives twice the waves (two per SIMD), whose dependent chains
+// overlap.
+constexpr int TMS = 16;            // months per LDS tile = one 128-byte line per row and array
+constexpr int TLD = TMS + 1;       // padded row length (doubles)
+
+template <bool SPINUP, int CPW>
+__global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, int nsteps,
+                                                  const int *__restrict__ par_index, const int *__restrict__ basin_index,
+                                                  const double *__restrict__ pars, const double *__restrict__ pet,
+                                                  const double *__restrict__ precip, const double *__restrict__ tmin,
+                                                  const double *__restrict__ sm0, const double *__restrict__ gw0,
+                                                  double *__restrict__ dec, double *__restrict__ aet,
+                                                  double *__restrict__ q, double *__restrict__ sav) {
+    constexpr int NP = CPW / 8;                          // copy passes per tile (8 rows each)
+    __shared__ double T[3][CPW * TLD];
+    const int lane = threadIdx.x;
+    const int64_t cell0 = (int64_t)blockIdx.x * CPW;
+    const bool snow_on = tmin != nullptr;
+    const double *__restrict__ src[3] = {pet, precip, tmin ? tmin : precip};
+    double *__restrict__ dst[3] = {aet, q, sav};
+
+    // ---- copy role
+    const int ck = lane & 7, cr = lane >> 3;
+    int64_t crow[NP];                                    // element offset of the row, or -1
+    int cshift[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int64_t c = cell0 + p * 8 + cr;
+        crow[p] = c < ncell ? c * (int64_t)nmonths : -1;
+        cshift[p] = c < ncell ? (int)((c * (int64_t)nmonths) & (TMS - 1)) : 0;
+    }
+    const int ntiles = (nsteps + (TMS - 2) + TMS - 1) / TMS;     // enough for the largest shift (14)
+    double2 R[3][NP];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int m = t * TMS - cshift[p] + 2 * ck;           // first of the chunk's two months
+            const bool ok = crow[p] >= 0 && m >= 0 && m < nsteps;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                R[a][p] = ok ? *reinterpret_cast<const double2 *>(src[a] + crow[p] + m) : make_double2(0.0, 0.0);
+        }
+    };
+
+    // ---- compute role
+    const int64_t c = cell0 + lane;
+    const bool mine = lane < CPW && c < ncell;
+    const int64_t cc = mine ? c : (ncell - 1);
+    const AbcdPar P = load_par(pars, par_index[cc], snow_on);
+    const int shift = (int)((cc * (int64_t)nmonths) & (TMS - 1));
+    AbcdState s;
+    s.snowpack = 0.0;
+    if (SPINUP) {
+        s.sm = 100.0;
+        s.gw = 500.0;
+    } else {
+        const int b = basin_index[cc];
+        s.sm = sm0[b];
+        s.gw = gw0[b];
+    }
+    double *mypet = &T[0][(lane < CPW ? lane : 0) * TLD], *mypr = &T[1][(lane < CPW ? lane : 0) * TLD],
+           *mytn = &T[2][(lane < CPW ? lane : 0) * TLD];
+
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        // registers -> LDS (the previous tile's write-out has finished: barrier at the bottom)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int o = (p * 8 + cr) * TLD + 2 * ck;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                T[a][o] = R[a][p].x;
+                T[a][o + 1] = R[a][p].y;
+            }
+        }
+        if (t + 1 < ntiles) load_tile(t + 1);            // in flight while this tile is computed
+        __syncthreads();
+        if (mine) {
+            const int mbase = t * TMS - shift;
+#pragma unroll
+            for (int h = 0; h < TMS; h += 8) {
+                double ipet[8], ipr[8], itn[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    ipet[j] = mypet[h + j];
+                    ipr[j] = mypr[h + j];
+                    itn[j] = mytn[h + j];
+                }
+                if (mbase + h >= 0 && mbase + h + 8 <= nsteps) {                  // all eight months exist
+                    AbcdPre pre[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pre[j] = abcd_pre(P, snow_on, ipet[j], ipr[j], itn[j]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int m = mbase + h + j;
+                        double oa, oq;
+                        abcd_step(P, s, snow_on, m == 0, pre[j], oa, oq);
+                        if (SPINUP) {
+                            const int k = (m == nsteps - 1) ? 0 : ((m == nsteps - 13) ? 1 : ((m == nsteps - 25) ? 2 : -1));
+                            if (k >= 0) {
+                                dec[(int64_t)k * ncell + c] = s.sm;
+                                dec[(int64_t)(3 + k) * ncell + c] = s.gw;
+                            }
+                        } else {
+                            mypet[h + j] = oa;
+                            mypr[h + j] = oq;
+                            mytn[h + j] = s.sm;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int m = mbase + h + j;
+                        if (m >= 0 && m < nsteps) {
+                            double oa, oq;
+                            abcd_month(P, s, snow_on, m == 0, ipet[j], ipr[j], itn[j], oa, oq);
+                            if (SPINUP) {
+                                const int k = (m == nsteps - 1) ? 0 : ((m == nsteps - 13) ? 1 : ((m == nsteps - 25) ? 2 : -1));
+                                if (k >= 0) {
+                                    dec[(int64_t)k * ncell + c] = s.sm;
+                                    dec[(int64_t)(3 + k) * ncell + c] = s.gw;
+                                }
+                            } else {
+                                mypet[h + j] = oa;
+                                mypr[h + j] = oq;
+                                mytn[h + j] = s.sm;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!SPINUP) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int m = t * TMS - cshift[p] + 2 * ck;
+                if (crow[p] >= 0 && m >= 0 && m < nsteps) {
+                    const int o = (p * 8 + cr) * TLD + 2 * ck;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                        if (dst[a]) *reinterpret_cast<double2 *>(dst[a] + crow[p] + m) = make_double2(T[a][o], T[a][o + 1]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // set_vals (:246-282): per basin, mean over the Decembers {-1,-13,-25} of nanmean over the basin's cells.
 // One workgroup per basin; cells of basin b are cells[ptr[b] .. ptr[b+1]).
 __global__ void __launch_bounds__(256) k_abcd_basin_mean(const int *__restrict__ ptr, const int *__restrict__ cells,
@@ -223,8 +384,28 @@ extern "C" int xh_abcd(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spin
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host vectors die at return
 
     const unsigned blocks = (unsigned)((ncell + 63) / 64);
+    // Simulation: the tiled kernel (whole-line traffic; 0.61 ms against 0.81 ms for 67,420 x 600).  Spin-up: the
+    // thread-per-cell kernel -- it writes nothing, so staging its reads through LDS only adds work (0.09 ms against
+    // 0.18 ms for 120 months).  XH_ABCD_KERNEL = 0 / 32 / 64 forces one kernel (or cells per wave) for both passes
+    // (profiling); the results are identical.
+    static const int abcd_env = [] {
+        const char *e = getenv("XH_ABCD_KERNEL");
+        const int v = e ? atoi(e) : -1;
+        return (v == 0 || v == 32 || v == 64) ? v : -1;
+    }();
+    int abcd_mode = abcd_env < 0 ? 0 : abcd_env;                 // spin-up pass
+    const unsigned blocks32 = (unsigned)((ncell + 31) / 32);
     {
         xh_span sp = xh_span_begin(ctx, "abcd_spinup");
+        if (abcd_mode == 32)
+            hipLaunchKernelGGL((k_abcd_tile<true, 32>), dim3(blocks32), dim3(64), 0, ctx->stream, ncell, (int)nmonths,
+                               (int)spinup, d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, (const double *)nullptr,
+                               (const double *)nullptr, d_dec, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+        else if (abcd_mode == 64)
+            hipLaunchKernelGGL((k_abcd_tile<true, 64>), dim3(blocks), dim3(64), 0, ctx->stream, ncell, (int)nmonths,
+                               (int)spinup, d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, (const double *)nullptr,
+                               (const double *)nullptr, d_dec, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+        else
         hipLaunchKernelGGL(k_abcd<true>, dim3(blocks), dim3(64), 0, ctx->stream, ncell, (int)nmonths, (int)spinup,
                            d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, (const double *)nullptr,
                            (const double *)nullptr, d_dec, (double *)nullptr, (double *)nullptr, (double *)nullptr);
@@ -238,6 +419,16 @@ extern "C" int xh_abcd(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spin
     }
     {
         xh_span sp = xh_span_begin(ctx, "abcd_sim");
+        abcd_mode = abcd_env < 0 ? 32 : abcd_env;                // simulation pass
+        if (abcd_mode == 32)
+            hipLaunchKernelGGL((k_abcd_tile<false, 32>), dim3(blocks32), dim3(64), 0, ctx->stream, ncell, (int)nmonths,
+                               (int)nmonths, d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, d_sm0, d_gw0,
+                               (double *)nullptr, d_aet, d_q, d_sav);
+        else if (abcd_mode == 64)
+            hipLaunchKernelGGL((k_abcd_tile<false, 64>), dim3(blocks), dim3(64), 0, ctx->stream, ncell, (int)nmonths,
+                               (int)nmonths, d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, d_sm0, d_gw0,
+                               (double *)nullptr, d_aet, d_q, d_sav);
+        else
         hipLaunchKernelGGL(k_abcd<false>, dim3(blocks), dim3(64), 0, ctx->stream, ncell, (int)nmonths, (int)nmonths,
                            d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, d_sm0, d_gw0, (double *)nullptr, d_aet, d_q,
                            d_sav);

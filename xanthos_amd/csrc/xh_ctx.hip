@@ -209,9 +209,14 @@ int xh_memcpy_h2d(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
 
 int xh_memcpy_d2h(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (!ctx || (bytes && (!h_dst || !d_src))) return XH_ERR_ARG;
+    int rc = XH_OK;
+    if (ctx->fault_pending) {      // settle routing calls in flight first: a re-route must precede the copy
+        XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rc = xh_fault_check(ctx);
+    }
     XH_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return xh_fault_check(ctx);
+    return rc;
 }
 
 int xh_host_alloc(xh_ctx *ctx, size_t bytes, void **h_ptr) {
