@@ -176,6 +176,39 @@ int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t s
                     const double *d_runoff, const double *d_S0,
                     double *d_chstorage, double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags);
 
+/* ------------------------------------------------------------------ the whole path as one pipelined call
+ * xh_run_fused replaces the stage-after-stage hand-over of components.py:simulation (:344-370: calculate_pet ->
+ * calculate_runoff -> calculate_routing): Penman-Monteith, ABCD (spin-up, basin means, simulation) and MRTM are enqueued
+ * together and overlap on the device -- PM runs in blocks of `block_months` months, the ABCD march follows one block
+ * behind (PET still in cache; state carried from block to block), and routing starts on the first block of runoff and
+ * polls a device word for the months it has not seen yet.  Results are bit-identical to xh_pm_pet + xh_abcd +
+ * xh_route_series with the same arguments (same kernels, same arithmetic).  Arguments mean what they mean there.
+ * d_pet and d_q must be given (they are the stages' hand-over and outputs of the model); d_aet, d_sav, d_chstorage,
+ * d_avgchflow may be NULL; plan = NULL stops after the runoff.  block_months = 0 picks the default (96); it must be a
+ * multiple of 48.  Asynchronous; on return the context's stream is ordered after every output.                    */
+typedef struct xh_fused_args {
+    int64_t ncell;
+    int32_t nmonths, start_year;
+    const xh_pm_tables *pm;
+    int32_t n_lc_years;
+    const int32_t *h_lc_years;
+    int32_t water_idx, snow_idx;
+    const double *d_tas, *d_tmin, *d_rhs, *d_wind, *d_rsds, *d_rlds, *d_tairprev, *d_lct, *d_elev;
+    int32_t abcd_spinup, n_groups;
+    const int32_t *h_basin_index, *h_par_index;
+    int64_t npar_rows;
+    const double *d_pars, *d_precip, *d_abcd_tmin;
+    xh_route_plan *plan;
+    int32_t routing_spinup;
+    const int32_t *h_ndays;
+    double dt;
+    const double *d_flow_dist, *d_velocity, *d_area, *d_S0;
+    int32_t route_flags;
+    double *d_pet, *d_aet, *d_q, *d_sav, *d_chstorage, *d_avgchflow;
+    int32_t block_months;
+} xh_fused_args;
+int xh_run_fused(xh_ctx *ctx, const xh_fused_args *args);
+
 /* ------------------------------------------------------------------ calibration objective
  * Replaces calibrate/calibrate_abcd.py:basin_runoff + objective_kge (:134-213) for set_calibrate = 0, batched
  * over a population: every member runs ABCD on the basin's cells, the simulated runoff is summed over cells per

@@ -272,3 +272,33 @@ def test_run_model_aggregates_and_future_mode(tmp_path):
                 assert np.isnan(vals).all(), (fname, k)                 # a name without cells
     assert open(os.path.join(out, 'Country_runoff_mmpermonth_pm_abcd_mrtm_synth.csv')).read().splitlines()[1] \
         .startswith('0,Country 0,')
+
+
+@pytest.mark.parametrize('nm,block', [(120, 48), (36, 48), (96, 96)])
+def test_fused_pipeline_equals_stage_by_stage(nm, block):
+    """xh_run_fused (PM blocks, the ABCD march one block behind with its state carried across blocks, routing started on
+    the first block of runoff and polling for the months behind it) gives bit for bit what xh_pm_pet + xh_abcd +
+    xh_route_series give, for series of several blocks, of less than one block, and of exactly one."""
+    from xanthos_amd import _hip, synth
+    from xanthos_amd.pipeline import OUTPUTS, pipeline_from_world
+    ctx = _hip.get_context(0)
+    w = synth.make_world(nrow=60, ncol=120, ncell=4000, n_basins=11, seed=8)
+    pipe = pipeline_from_world(ctx, w, nm, 1971, 25, 6)
+    ctx.synth_forcing(17, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.002)
+    pipe.run(fused=False)
+    ref = pipe.download()
+    for rep in range(3):
+        for k in OUTPUTS:
+            pipe.out[k].zero()
+        pipe.run_fused(block_months=block)
+        got = pipe.download()
+        for k in OUTPUTS:
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (k, rep)
+    assert pipe.plan.info()['reroutes'] == 0
+    # PM + ABCD only
+    for k in OUTPUTS:
+        pipe.out[k].zero()
+    pipe.run(('pm', 'abcd'))
+    got = pipe.download(('pet', 'aet', 'q', 'sav'))
+    for k in ('pet', 'aet', 'q', 'sav'):
+        assert np.array_equal(got[k], ref[k], equal_nan=True), k

@@ -32,7 +32,7 @@ def full():
     nm = 600
     pipe = pipeline_from_world(ctx, w, nm, 1961, 120, 120)
     ctx.synth_forcing(3, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.0)
-    pipe.run(('pm', 'abcd'))
+    pipe.run(('pm', 'abcd'), fused=False)
     q = pipe.out['q'].download()
     chs, avg, _ = o_mrtm.route_series(pipe.um.tocsr(), w.flow_dist, w.velocity, w.area, q, pipe.ndays, 120)
     assert np.isfinite(avg).all() and avg.max() > 0
@@ -56,6 +56,20 @@ def test_config3_full_length_routing_equals_oracle(full):
         _check(full, tag=flags)
         assert full.pipe.plan.info()['last_tree_kernel'] == kernel
     full.pipe.route_flags = 0
+
+
+def test_config3_fused_pipeline_equals_oracle(full):
+    """The pipelined call (PM blocks || ABCD march || routing polling for months) on the full grid, five times in a
+    row: PET / AET / Q / Sav identical to the stage-by-stage run, routing identical to the oracle."""
+    keep = {k: full.pipe.out[k].download() for k in ('pet', 'aet', 'q', 'sav')}
+    for rep in range(5):
+        for k in full.pipe.out:
+            full.pipe.out[k].zero()
+        full.pipe.run_fused()
+        _check(full, tag=rep)
+        for k, ref in keep.items():
+            assert np.array_equal(full.pipe.out[k].download(), ref, equal_nan=True), (k, rep)
+    assert full.pipe.plan.info()['reroutes'] == 0 and full.pipe.plan.info()['last_tree_kernel'] == 2
 
 
 def test_config3_twenty_repetitions_and_background_load(full):

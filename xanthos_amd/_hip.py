@@ -31,6 +31,21 @@ class PmTables(Structure):
         'alpha', 'lai', 'laimin', 'laimax')]
 
 
+class FusedArgs(Structure):
+    """xh_fused_args (include/xanthos_hip.h)."""
+    _fields_ = ([('ncell', c_int64), ('nmonths', c_int32), ('start_year', c_int32), ('pm', POINTER(PmTables)),
+                 ('n_lc_years', c_int32), ('h_lc_years', c_void_p), ('water_idx', c_int32), ('snow_idx', c_int32)] +
+                [(n, c_void_p) for n in ('d_tas', 'd_tmin', 'd_rhs', 'd_wind', 'd_rsds', 'd_rlds', 'd_tairprev', 'd_lct',
+                                         'd_elev')] +
+                [('abcd_spinup', c_int32), ('n_groups', c_int32), ('h_basin_index', c_void_p), ('h_par_index', c_void_p),
+                 ('npar_rows', c_int64), ('d_pars', c_void_p), ('d_precip', c_void_p), ('d_abcd_tmin', c_void_p),
+                 ('plan', c_void_p), ('routing_spinup', c_int32), ('h_ndays', c_void_p), ('dt', c_double),
+                 ('d_flow_dist', c_void_p), ('d_velocity', c_void_p), ('d_area', c_void_p), ('d_S0', c_void_p),
+                 ('route_flags', c_int32)] +
+                [(n, c_void_p) for n in ('d_pet', 'd_aet', 'd_q', 'd_sav', 'd_chstorage', 'd_avgchflow')] +
+                [('block_months', c_int32)])
+
+
 _P = c_void_p
 # name -> (restype, argtypes); mirrors include/xanthos_hip.h one to one
 SIGNATURES = {
@@ -68,6 +83,7 @@ SIGNATURES = {
     'xh_mrtm_upstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     'xh_mrtm_um_csr': (c_int, [c_int64, _P, _P, _P, _P]),
     'xh_route_series': (c_int, [_P, _P, c_int32, c_int32, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32]),
+    'xh_run_fused': (c_int, [_P, POINTER(FusedArgs)]),
     'xh_calib_objective': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'xh_calib_objective_multi': (c_int, [_P, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'xh_calib_de_create': (c_int, [_P, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P,
@@ -279,9 +295,9 @@ class Context:
         self._check(lib().xh_transpose(self.handle, _dptr(src), rows, cols, _dptr(dst)))
 
     # ---- Penman-Monteith
-    def pm_pet(self, tables, ncell, nmonths, start_year, lc_years, water_idx, snow_idx, tas, tmin, rhs, wind, rsds,
-               rlds, tairprev, lct, elev, pet):
-        """tables: dict of host arrays (cL ... laimax); the rest device arrays / pointers."""
+    @staticmethod
+    def _pm_tables(tables):
+        """dict of host arrays (cL ... laimax) -> (PmTables, arrays to keep alive)."""
         keep = []
         t = PmTables()
         t.nlcs = int(np.asarray(tables['cL']).shape[0])
@@ -292,6 +308,41 @@ class Context:
                 raise ValueError('PM table {} has {} values, expected {}'.format(name, a.size, want))
             keep.append(a)
             setattr(t, name, a.ctypes.data_as(POINTER(c_double)))
+        return t, keep
+
+    def run_fused(self, *, tables, ncell, nmonths, start_year, lc_years, water_idx, snow_idx, tas, tmin, rhs, wind, rsds,
+                  rlds, tairprev, lct, elev, abcd_spinup, n_groups, basin_index, par_index, npar_rows, pars, precip,
+                  abcd_tmin, pet, aet, q, sav, plan=None, routing_spinup=0, ndays=None, dt=10800.0, flow_dist=None,
+                  velocity=None, area=None, S0=None, chs=None, avg=None, route_flags=0, block_months=0):
+        """PM -> ABCD -> MRTM as one pipelined call (xh_run_fused); arguments as in pm_pet / abcd / route_series."""
+        t, keep = self._pm_tables(tables)
+        lcy = np.ascontiguousarray(lc_years, dtype=np.int32)
+        bi = np.ascontiguousarray(basin_index, dtype=np.int32)
+        pi = np.ascontiguousarray(par_index, dtype=np.int32)
+        nd = None if ndays is None else np.ascontiguousarray(ndays, dtype=np.int32)
+        if plan is not None and (nd is None or nd.size != nmonths):
+            raise ValueError('ndays must have nmonths entries')
+        a = FusedArgs()
+        a.ncell, a.nmonths, a.start_year = ncell, nmonths, start_year
+        a.pm = ctypes.pointer(t)
+        a.n_lc_years, a.h_lc_years, a.water_idx, a.snow_idx = len(lcy), lcy.ctypes.data, water_idx, snow_idx
+        for name, v in (('d_tas', tas), ('d_tmin', tmin), ('d_rhs', rhs), ('d_wind', wind), ('d_rsds', rsds),
+                        ('d_rlds', rlds), ('d_tairprev', tairprev), ('d_lct', lct), ('d_elev', elev), ('d_pars', pars),
+                        ('d_precip', precip), ('d_abcd_tmin', abcd_tmin), ('d_flow_dist', flow_dist),
+                        ('d_velocity', velocity), ('d_area', area), ('d_S0', S0), ('d_pet', pet), ('d_aet', aet),
+                        ('d_q', q), ('d_sav', sav), ('d_chstorage', chs), ('d_avgchflow', avg)):
+            setattr(a, name, _dptr(v))
+        a.abcd_spinup, a.n_groups, a.npar_rows = abcd_spinup, n_groups, npar_rows
+        a.h_basin_index, a.h_par_index = bi.ctypes.data, pi.ctypes.data
+        a.plan = None if plan is None else plan.handle
+        a.routing_spinup, a.dt, a.route_flags, a.block_months = routing_spinup, float(dt), int(route_flags), int(block_months)
+        a.h_ndays = None if nd is None else nd.ctypes.data
+        self._check(lib().xh_run_fused(self.handle, byref(a)))
+
+    def pm_pet(self, tables, ncell, nmonths, start_year, lc_years, water_idx, snow_idx, tas, tmin, rhs, wind, rsds,
+               rlds, tairprev, lct, elev, pet):
+        """tables: dict of host arrays (cL ... laimax); the rest device arrays / pointers."""
+        t, keep = self._pm_tables(tables)
         lcy = np.ascontiguousarray(lc_years, dtype=np.int32)
         self._check(lib().xh_pm_pet(self.handle, byref(t), ncell, nmonths, start_year, len(lcy), _host_ptr(lcy),
                                     water_idx, snow_idx, _dptr(tas), _dptr(tmin), _dptr(rhs), _dptr(wind),

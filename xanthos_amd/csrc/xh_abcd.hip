@@ -21,6 +21,7 @@
 
 #include "xh_abcd_dev.h"
 #include "xh_common.h"
+#include "xh_stage.h"
 
 namespace {
 
@@ -144,7 +145,8 @@ constexpr int TMS = 16;            // months per LDS tile = one 128-byte line pe
 constexpr int TLD = TMS + 1;       // padded row length (doubles)
 
 template <bool SPINUP, int CPW>
-__global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, int nsteps,
+__global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, int nsteps, int m_begin, int m_end,
+                                                  double *__restrict__ state,      // [3][ncell] carried between month blocks
                                                   const int *__restrict__ par_index, const int *__restrict__ basin_index,
                                                   const double *__restrict__ pars, const double *__restrict__ pet,
                                                   const double *__restrict__ precip, const double *__restrict__ tmin,
@@ -169,13 +171,14 @@ __global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, in
         crow[p] = c < ncell ? c * (int64_t)nmonths : -1;
         cshift[p] = c < ncell ? (int)((c * (int64_t)nmonths) & (TMS - 1)) : 0;
     }
-    const int ntiles = (nsteps + (TMS - 2) + TMS - 1) / TMS;     // enough for the largest shift (14)
+    // months [m_begin, m_end) of the march (both even): tiles that can hold one of them for some shift (0 .. 14)
+    const int tile0 = m_begin / TMS, ntiles = (m_end + (TMS - 2) + TMS - 1) / TMS;
     double2 R[3][NP];
     auto load_tile = [&](int t) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int m = t * TMS - cshift[p] + 2 * ck;           // first of the chunk's two months
-            const bool ok = crow[p] >= 0 && m >= 0 && m < nsteps;
+            const bool ok = crow[p] >= 0 && m >= m_begin && m < m_end;
 #pragma unroll
             for (int a = 0; a < 3; ++a)
                 R[a][p] = ok ? *reinterpret_cast<const double2 *>(src[a] + crow[p] + m) : make_double2(0.0, 0.0);
@@ -190,7 +193,11 @@ __global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, in
     const int shift = (int)((cc * (int64_t)nmonths) & (TMS - 1));
     AbcdState s;
     s.snowpack = 0.0;
-    if (SPINUP) {
+    if (m_begin > 0) {                                   // a later block of months: the state the previous block left
+        s.snowpack = state[cc];
+        s.sm = state[ncell + cc];
+        s.gw = state[2 * ncell + cc];
+    } else if (SPINUP) {
         s.sm = 100.0;
         s.gw = 500.0;
     } else {
@@ -201,8 +208,8 @@ __global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, in
     double *mypet = &T[0][(lane < CPW ? lane : 0) * TLD], *mypr = &T[1][(lane < CPW ? lane : 0) * TLD],
            *mytn = &T[2][(lane < CPW ? lane : 0) * TLD];
 
-    load_tile(0);
-    for (int t = 0; t < ntiles; ++t) {
+    load_tile(tile0);
+    for (int t = tile0; t < ntiles; ++t) {
         // registers -> LDS (the previous tile's write-out has finished: barrier at the bottom)
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -226,7 +233,7 @@ __global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, in
                     ipr[j] = mypr[h + j];
                     itn[j] = mytn[h + j];
                 }
-                if (mbase + h >= 0 && mbase + h + 8 <= nsteps) {                  // all eight months exist
+                if (mbase + h >= m_begin && mbase + h + 8 <= m_end) {             // all eight months belong to this block
                     AbcdPre pre[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pre[j] = abcd_pre(P, snow_on, ipet[j], ipr[j], itn[j]);
@@ -251,7 +258,7 @@ __global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, in
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int m = mbase + h + j;
-                        if (m >= 0 && m < nsteps) {
+                        if (m >= m_begin && m < m_end) {
                             double oa, oq;
                             abcd_month(P, s, snow_on, m == 0, ipet[j], ipr[j], itn[j], oa, oq);
                             if (SPINUP) {
@@ -275,7 +282,7 @@ __global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, in
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int m = t * TMS - cshift[p] + 2 * ck;
-                if (crow[p] >= 0 && m >= 0 && m < nsteps) {
+                if (crow[p] >= 0 && m >= m_begin && m < m_end) {
                     const int o = (p * 8 + cr) * TLD + 2 * ck;
 #pragma unroll
                     for (int a = 0; a < 3; ++a)
@@ -284,6 +291,11 @@ __global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, in
             }
             __syncthreads();
         }
+    }
+    if (state && mine) {
+        state[c] = s.snowpack;
+        state[ncell + c] = s.sm;
+        state[2 * ncell + c] = s.gw;
     }
 }
 
@@ -335,18 +347,19 @@ __global__ void __launch_bounds__(256) k_abcd_basin_mean(const int *__restrict__
 
 }  // namespace
 
-extern "C" int xh_abcd(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spinup, int32_t n_groups,
-                       const int32_t *h_basin_index, const int32_t *h_par_index, int64_t npar_rows,
-                       const double *d_pars, const double *d_pet, const double *d_precip, const double *d_tmin,
-                       double *d_aet, double *d_q, double *d_sav, double *d_sm0_out, double *d_gw0_out) {
-    if (!ctx) return XH_ERR_ARG;
-    XH_REQUIRE(ctx, h_basin_index && h_par_index && d_pars && d_pet && d_precip, "xh_abcd: NULL argument");
+int xh_abcd_prepare(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spinup, int32_t n_groups,
+                    const int32_t *h_basin_index, const int32_t *h_par_index, int64_t npar_rows, xh_abcd_setup *out) {
+    XH_REQUIRE(ctx, h_basin_index && h_par_index, "xh_abcd: NULL argument");
     XH_REQUIRE(ctx, ncell >= 0 && nmonths > 0 && nmonths % 2 == 0, "xh_abcd: nmonths must be positive and even");
     XH_REQUIRE(ctx, ncell < (int64_t)1 << 31, "xh_abcd: too many cells");
     // the reference indexes rows -1, -13, -25 of the spin-up series and raises IndexError below 25 (:258-266)
     XH_REQUIRE(ctx, spinup >= 25, "xh_abcd: spin-up of %d months is too short (needs >= 25; abcd.py:258-266)", spinup);
     XH_REQUIRE(ctx, spinup <= nmonths, "xh_abcd: spin-up (%d) exceeds the number of months (%d)", spinup, nmonths);
     XH_REQUIRE(ctx, n_groups >= 1, "xh_abcd: n_groups must be >= 1");
+    out->ncell = ncell;
+    out->nmonths = nmonths;
+    out->spinup = spinup;
+    out->n_groups = n_groups;
     if (ncell == 0) return XH_OK;
 
     // CSR of cells per basin (host, tiny) + index arrays -> scratch
@@ -366,76 +379,116 @@ extern "C" int xh_abcd(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spin
     }
     const size_t n_int = (size_t)(n_groups + 1) + 3 * (size_t)ncell;
     const size_t int_bytes = (n_int * sizeof(int) + 255) & ~size_t(255);
-    const size_t dbl = (6 * (size_t)ncell + 2 * (size_t)n_groups) * sizeof(double);
+    const size_t dbl = (9 * (size_t)ncell + 2 * (size_t)n_groups) * sizeof(double);
     void *buf = nullptr;
     int rc = xh_scratch(ctx, 1, int_bytes + dbl, &buf);
     if (rc) return rc;
-    int *d_ptr = static_cast<int *>(buf);
-    int *d_cells = d_ptr + (n_groups + 1);
-    int *d_bidx = d_cells + ncell;
-    int *d_pidx = d_bidx + ncell;
-    double *d_dec = reinterpret_cast<double *>(static_cast<char *>(buf) + int_bytes);
-    double *d_sm0 = d_dec + 6 * ncell;
-    double *d_gw0 = d_sm0 + n_groups;
-    XH_HIP(ctx, hipMemcpyAsync(d_ptr, ptr.data(), sizeof(int) * (n_groups + 1), hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_cells, cells.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_bidx, bidx.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_pidx, pidx.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
+    out->d_ptr = static_cast<int *>(buf);
+    out->d_cells = out->d_ptr + (n_groups + 1);
+    out->d_bidx = out->d_cells + ncell;
+    out->d_pidx = out->d_bidx + ncell;
+    out->d_dec = reinterpret_cast<double *>(static_cast<char *>(buf) + int_bytes);
+    out->d_state = out->d_dec + 6 * ncell;
+    out->d_sm0 = out->d_state + 3 * ncell;
+    out->d_gw0 = out->d_sm0 + n_groups;
+    XH_HIP(ctx, hipMemcpyAsync(out->d_ptr, ptr.data(), sizeof(int) * (n_groups + 1), hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(out->d_cells, cells.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(out->d_bidx, bidx.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(out->d_pidx, pidx.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host vectors die at return
+    return XH_OK;
+}
 
-    const unsigned blocks = (unsigned)((ncell + 63) / 64);
-    // Simulation: the tiled kernel (whole-line traffic; 0.61 ms against 0.81 ms for 67,420 x 600).  Spin-up: the
-    // thread-per-cell kernel -- it writes nothing, so staging its reads through LDS only adds work (0.09 ms against
-    // 0.18 ms for 120 months).  XH_ABCD_KERNEL = 0 / 32 / 64 forces one kernel (or cells per wave) for both passes
-    // (profiling); the results are identical.
-    static const int abcd_env = [] {
+// XH_ABCD_KERNEL = 0 / 32 / 64 forces the thread-per-cell kernel or the tiled kernel with that many cells per wave for
+// both passes (profiling; results are identical).  Default: spin-up on the thread-per-cell kernel -- it writes nothing,
+// so staging its reads through LDS only adds work (0.09 ms against 0.18 ms for 120 months) -- and the simulation on the
+// tiled kernel (whole-line traffic: 0.61 ms against 0.81 ms for 67,420 x 600).
+static int abcd_env() {
+    static const int v = [] {
         const char *e = getenv("XH_ABCD_KERNEL");
-        const int v = e ? atoi(e) : -1;
-        return (v == 0 || v == 32 || v == 64) ? v : -1;
+        const int x = e ? atoi(e) : -1;
+        return (x == 0 || x == 32 || x == 64) ? x : -1;
     }();
-    int abcd_mode = abcd_env < 0 ? 0 : abcd_env;                 // spin-up pass
-    const unsigned blocks32 = (unsigned)((ncell + 31) / 32);
+    return v;
+}
+
+int xh_abcd_enqueue_spinup(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, const double *d_pars,
+                           const double *d_pet, const double *d_precip, const double *d_tmin) {
+    if (s.ncell == 0) return XH_OK;
+    const int64_t ncell = s.ncell;
+    const unsigned blocks = (unsigned)((ncell + 63) / 64), blocks32 = (unsigned)((ncell + 31) / 32);
+    const int mode = abcd_env() < 0 ? 0 : abcd_env();
     {
-        xh_span sp = xh_span_begin(ctx, "abcd_spinup");
-        if (abcd_mode == 32)
-            hipLaunchKernelGGL((k_abcd_tile<true, 32>), dim3(blocks32), dim3(64), 0, ctx->stream, ncell, (int)nmonths,
-                               (int)spinup, d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, (const double *)nullptr,
-                               (const double *)nullptr, d_dec, (double *)nullptr, (double *)nullptr, (double *)nullptr);
-        else if (abcd_mode == 64)
-            hipLaunchKernelGGL((k_abcd_tile<true, 64>), dim3(blocks), dim3(64), 0, ctx->stream, ncell, (int)nmonths,
-                               (int)spinup, d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, (const double *)nullptr,
-                               (const double *)nullptr, d_dec, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+        xh_span sp = xh_span_begin_on(ctx, "abcd_spinup", st);
+        if (mode == 32)
+            hipLaunchKernelGGL((k_abcd_tile<true, 32>), dim3(blocks32), dim3(64), 0, st, ncell, s.nmonths, s.spinup, 0,
+                               s.spinup, (double *)nullptr, s.d_pidx, s.d_bidx, d_pars, d_pet, d_precip, d_tmin,
+                               (const double *)nullptr, (const double *)nullptr, s.d_dec, (double *)nullptr,
+                               (double *)nullptr, (double *)nullptr);
+        else if (mode == 64)
+            hipLaunchKernelGGL((k_abcd_tile<true, 64>), dim3(blocks), dim3(64), 0, st, ncell, s.nmonths, s.spinup, 0,
+                               s.spinup, (double *)nullptr, s.d_pidx, s.d_bidx, d_pars, d_pet, d_precip, d_tmin,
+                               (const double *)nullptr, (const double *)nullptr, s.d_dec, (double *)nullptr,
+                               (double *)nullptr, (double *)nullptr);
         else
-        hipLaunchKernelGGL(k_abcd<true>, dim3(blocks), dim3(64), 0, ctx->stream, ncell, (int)nmonths, (int)spinup,
-                           d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, (const double *)nullptr,
-                           (const double *)nullptr, d_dec, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+            hipLaunchKernelGGL(k_abcd<true>, dim3(blocks), dim3(64), 0, st, ncell, s.nmonths, s.spinup, s.d_pidx,
+                               s.d_bidx, d_pars, d_pet, d_precip, d_tmin, (const double *)nullptr,
+                               (const double *)nullptr, s.d_dec, (double *)nullptr, (double *)nullptr,
+                               (double *)nullptr);
         xh_span_end(sp);
     }
     {
-        xh_span sp = xh_span_begin(ctx, "abcd_basin_mean");
-        hipLaunchKernelGGL(k_abcd_basin_mean, dim3((unsigned)n_groups), dim3(256), 0, ctx->stream, d_ptr, d_cells, ncell,
-                           d_dec, d_sm0, d_gw0);
-        xh_span_end(sp);
-    }
-    {
-        xh_span sp = xh_span_begin(ctx, "abcd_sim");
-        abcd_mode = abcd_env < 0 ? 32 : abcd_env;                // simulation pass
-        if (abcd_mode == 32)
-            hipLaunchKernelGGL((k_abcd_tile<false, 32>), dim3(blocks32), dim3(64), 0, ctx->stream, ncell, (int)nmonths,
-                               (int)nmonths, d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, d_sm0, d_gw0,
-                               (double *)nullptr, d_aet, d_q, d_sav);
-        else if (abcd_mode == 64)
-            hipLaunchKernelGGL((k_abcd_tile<false, 64>), dim3(blocks), dim3(64), 0, ctx->stream, ncell, (int)nmonths,
-                               (int)nmonths, d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, d_sm0, d_gw0,
-                               (double *)nullptr, d_aet, d_q, d_sav);
-        else
-        hipLaunchKernelGGL(k_abcd<false>, dim3(blocks), dim3(64), 0, ctx->stream, ncell, (int)nmonths, (int)nmonths,
-                           d_pidx, d_bidx, d_pars, d_pet, d_precip, d_tmin, d_sm0, d_gw0, (double *)nullptr, d_aet, d_q,
-                           d_sav);
+        xh_span sp = xh_span_begin_on(ctx, "abcd_basin_mean", st);
+        hipLaunchKernelGGL(k_abcd_basin_mean, dim3((unsigned)s.n_groups), dim3(256), 0, st, s.d_ptr, s.d_cells, ncell,
+                           s.d_dec, s.d_sm0, s.d_gw0);
         xh_span_end(sp);
     }
     XH_HIP(ctx, hipGetLastError());
-    if (d_sm0_out) XH_HIP(ctx, hipMemcpyAsync(d_sm0_out, d_sm0, sizeof(double) * n_groups, hipMemcpyDeviceToDevice, ctx->stream));
-    if (d_gw0_out) XH_HIP(ctx, hipMemcpyAsync(d_gw0_out, d_gw0, sizeof(double) * n_groups, hipMemcpyDeviceToDevice, ctx->stream));
+    return XH_OK;
+}
+
+int xh_abcd_enqueue_sim(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, int m_begin, int m_end,
+                        const double *d_pars, const double *d_pet, const double *d_precip, const double *d_tmin,
+                        double *d_aet, double *d_q, double *d_sav) {
+    if (s.ncell == 0 || m_end <= m_begin) return XH_OK;
+    XH_REQUIRE(ctx, m_begin >= 0 && m_end <= s.nmonths && m_begin % 2 == 0 && m_end % 2 == 0, "xh_abcd: bad month block");
+    const int64_t ncell = s.ncell;
+    const unsigned blocks = (unsigned)((ncell + 63) / 64), blocks32 = (unsigned)((ncell + 31) / 32);
+    const bool whole = m_begin == 0 && m_end == s.nmonths;
+    int mode = abcd_env() < 0 ? 32 : abcd_env();
+    if (mode == 0 && !whole) mode = 32;                          // only the tiled kernel marches blocks of months
+    double *state = whole ? nullptr : s.d_state;
+    xh_span sp = xh_span_begin_on(ctx, "abcd_sim", st);
+    if (mode == 32)
+        hipLaunchKernelGGL((k_abcd_tile<false, 32>), dim3(blocks32), dim3(64), 0, st, ncell, s.nmonths, s.nmonths, m_begin,
+                           m_end, state, s.d_pidx, s.d_bidx, d_pars, d_pet, d_precip, d_tmin, s.d_sm0, s.d_gw0,
+                           (double *)nullptr, d_aet, d_q, d_sav);
+    else if (mode == 64)
+        hipLaunchKernelGGL((k_abcd_tile<false, 64>), dim3(blocks), dim3(64), 0, st, ncell, s.nmonths, s.nmonths, m_begin,
+                           m_end, state, s.d_pidx, s.d_bidx, d_pars, d_pet, d_precip, d_tmin, s.d_sm0, s.d_gw0,
+                           (double *)nullptr, d_aet, d_q, d_sav);
+    else
+        hipLaunchKernelGGL(k_abcd<false>, dim3(blocks), dim3(64), 0, st, ncell, s.nmonths, s.nmonths, s.d_pidx, s.d_bidx,
+                           d_pars, d_pet, d_precip, d_tmin, s.d_sm0, s.d_gw0, (double *)nullptr, d_aet, d_q, d_sav);
+    xh_span_end(sp);
+    XH_HIP(ctx, hipGetLastError());
+    return XH_OK;
+}
+
+extern "C" int xh_abcd(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spinup, int32_t n_groups,
+                       const int32_t *h_basin_index, const int32_t *h_par_index, int64_t npar_rows,
+                       const double *d_pars, const double *d_pet, const double *d_precip, const double *d_tmin,
+                       double *d_aet, double *d_q, double *d_sav, double *d_sm0_out, double *d_gw0_out) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, d_pars && d_pet && d_precip, "xh_abcd: NULL argument");
+    xh_abcd_setup s;
+    int rc = xh_abcd_prepare(ctx, ncell, nmonths, spinup, n_groups, h_basin_index, h_par_index, npar_rows, &s);
+    if (rc || ncell == 0) return rc;
+    rc = xh_abcd_enqueue_spinup(ctx, ctx->stream, s, d_pars, d_pet, d_precip, d_tmin);
+    if (rc) return rc;
+    rc = xh_abcd_enqueue_sim(ctx, ctx->stream, s, 0, nmonths, d_pars, d_pet, d_precip, d_tmin, d_aet, d_q, d_sav);
+    if (rc) return rc;
+    if (d_sm0_out) XH_HIP(ctx, hipMemcpyAsync(d_sm0_out, s.d_sm0, sizeof(double) * n_groups, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_gw0_out) XH_HIP(ctx, hipMemcpyAsync(d_gw0_out, s.d_gw0, sizeof(double) * n_groups, hipMemcpyDeviceToDevice, ctx->stream));
     return XH_OK;
 }

@@ -51,6 +51,10 @@ struct xh_ctx {
     std::vector<xh_route_record> pending_routes;
     uint64_t work_seq = 0;         // bumped by every kernel-launching entry point (xh_span_begin)
     int64_t reroutes = 0;          // routing calls re-run after a device fault
+    // xh_run_fused: two side streams, their events and the device word that counts finished months of runoff
+    hipStream_t side_stream[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> side_events;
+    unsigned *d_months_ready = nullptr;
 };
 
 // Device fault word: kernels set it non-zero instead of hanging; the next synchronising call reports XH_ERR_DEVICE.
@@ -83,8 +87,10 @@ struct xh_span {
     xh_ctx *ctx;
     const char *name;
     hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t stream = nullptr;
 };
 xh_span xh_span_begin(xh_ctx *ctx, const char *name);
+xh_span xh_span_begin_on(xh_ctx *ctx, const char *name, hipStream_t stream);   // kernels of a pipelined call on a side stream
 void xh_span_end(xh_span &s);
 
 static inline int xh_is_leap_gregorian(int y) { return (y % 4 == 0 && y % 100 != 0) || (y % 400 == 0); }

@@ -93,8 +93,11 @@ int xh_fault_check(xh_ctx *ctx) {
     return XH_OK;
 }
 
-xh_span xh_span_begin(xh_ctx *ctx, const char *name) {
+xh_span xh_span_begin(xh_ctx *ctx, const char *name) { return xh_span_begin_on(ctx, name, ctx->stream); }
+
+xh_span xh_span_begin_on(xh_ctx *ctx, const char *name, hipStream_t stream) {
     xh_span s{ctx, name};
+    s.stream = stream;
     ctx->work_seq += 1;
     if (!ctx->timing) return s;
     auto take = [&](hipEvent_t &e) {
@@ -107,13 +110,13 @@ xh_span xh_span_begin(xh_ctx *ctx, const char *name) {
     };
     take(s.a);
     take(s.b);
-    if (s.a && s.b) (void)hipEventRecord(s.a, ctx->stream);
+    if (s.a && s.b) (void)hipEventRecord(s.a, stream);
     return s;
 }
 
 void xh_span_end(xh_span &s) {
     if (!s.ctx->timing || !s.a || !s.b) return;
-    (void)hipEventRecord(s.b, s.ctx->stream);
+    (void)hipEventRecord(s.b, s.stream);
     s.ctx->timers[s.name].pending.emplace_back(s.a, s.b);
 }
 
@@ -171,6 +174,13 @@ void xh_ctx_destroy(xh_ctx *ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 4; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->side_stream[i]) {
+            (void)hipStreamSynchronize(ctx->side_stream[i]);
+            (void)hipStreamDestroy(ctx->side_stream[i]);
+        }
+    for (auto e : ctx->side_events) (void)hipEventDestroy(e);
+    if (ctx->d_months_ready) (void)hipFree(ctx->d_months_ready);
     if (ctx->d_fault) (void)hipFree(ctx->d_fault);
     if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     (void)hipStreamDestroy(ctx->stream);

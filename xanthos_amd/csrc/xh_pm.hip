@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "xh_common.h"
+#include "xh_stage.h"
 
 namespace {
 
@@ -206,7 +207,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_i
 // Thread <-> (cell, pair of consecutive months). nmonths is a multiple of 12, hence even.
 __global__ void __launch_bounds__(256) k_pm_pet(const PmTablesDev *__restrict__ tab,
                                                 const int *__restrict__ lc_of_year, int64_t ncell, int nmonths,
-                                                const double *__restrict__ tas, const double *__restrict__ tmin,
+                                                int m_begin, int m_count, const double *__restrict__ tas, const double *__restrict__ tmin,
                                                 const double *__restrict__ rhs, const double *__restrict__ wind,
                                                 const double *__restrict__ rsds, const double *__restrict__ rlds,
                                                 const double *__restrict__ tairprev,
@@ -230,12 +231,12 @@ __global__ void __launch_bounds__(256) k_pm_pet(const PmTablesDev *__restrict__ 
     const int water_idx = tab->water_idx, snow_idx = tab->snow_idx, start_year = tab->start_year;
     const int n_lc_years = tab->n_lc_years;
     const double wind_pow = tab->wind_pow;
-    const int half = nmonths >> 1;
+    const int half = m_count >> 1;                  // pairs of months per cell in [m_begin, m_begin + m_count)
     const int64_t total = ncell * (int64_t)half;
     for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total;
          item += (int64_t)gridDim.x * blockDim.x) {
         const int64_t c = item / half;
-        const int m0 = (int)(item - c * half) * 2;
+        const int m0 = m_begin + (int)(item - c * half) * 2;
         const int64_t off = c * nmonths + m0;
         const double2 T = *reinterpret_cast<const double2 *>(tas + off);
         const double2 TN = *reinterpret_cast<const double2 *>(tmin + off);
@@ -280,14 +281,9 @@ int land_cover_index(int year, const std::vector<int> &sorted_years) {   // SetD
 
 }  // namespace
 
-extern "C" int xh_pm_pet(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int32_t nmonths, int32_t start_year,
-                         int32_t n_lc_years, const int32_t *h_lc_years, int32_t water_idx, int32_t snow_idx,
-                         const double *d_tas, const double *d_tmin, const double *d_rhs, const double *d_wind,
-                         const double *d_rsds, const double *d_rlds, const double *d_tairprev, const double *d_lct,
-                         const double *d_elev, double *d_pet) {
-    if (!ctx) return XH_ERR_ARG;
-    XH_REQUIRE(ctx, t && h_lc_years && d_tas && d_tmin && d_rhs && d_wind && d_rsds && d_rlds && d_lct && d_elev &&
-                        d_pet, "xh_pm_pet: NULL argument");
+int xh_pm_prepare(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int32_t nmonths, int32_t start_year,
+                  int32_t n_lc_years, const int32_t *h_lc_years, int32_t water_idx, int32_t snow_idx, xh_pm_setup *out) {
+    XH_REQUIRE(ctx, t && h_lc_years, "xh_pm_pet: NULL argument");
     XH_REQUIRE(ctx, ncell >= 0 && nmonths > 0 && nmonths % 12 == 0, "xh_pm_pet: nmonths must be a positive multiple of 12");
     XH_REQUIRE(ctx, n_lc_years >= 1, "xh_pm_pet: need at least one land-cover year");
     const int nlcs = t->nlcs;
@@ -296,8 +292,9 @@ extern "C" int xh_pm_pet(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int3
     XH_REQUIRE(ctx, nlcs >= 7, "xh_pm_pet: nlcs=%d; the reference indexes land classes 0 and 6, so nlcs >= 7", nlcs);
     XH_REQUIRE(ctx, water_idx >= 0 && water_idx < nlcs && snow_idx >= 0 && snow_idx < nlcs,
                "xh_pm_pet: water_idx/snow_idx out of range");
+    out->ncell = ncell;
+    out->nmonths = nmonths;
     if (ncell == 0) return XH_OK;
-
     const int nyears = nmonths / 12;
     PmTablesDev h;
     memset(&h, 0, sizeof(h));
@@ -353,15 +350,42 @@ extern "C" int xh_pm_pet(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int3
     XH_HIP(ctx, hipMemcpyAsync(d_lcy, lc_of_year.data(), sizeof(int) * nyears, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h / lc_of_year are stack/heap locals
 
-    const int64_t items = ncell * (int64_t)(nmonths / 2);
+    out->d_tab = d_tab;
+    out->d_lcy = d_lcy;
+    return XH_OK;
+}
+
+int xh_pm_enqueue(xh_ctx *ctx, hipStream_t st, const xh_pm_setup &s, int m_begin, int m_count, const double *d_tas,
+                  const double *d_tmin, const double *d_rhs, const double *d_wind, const double *d_rsds,
+                  const double *d_rlds, const double *d_tairprev, const double *d_lct, const double *d_elev,
+                  double *d_pet) {
+    if (s.ncell == 0 || m_count <= 0) return XH_OK;
+    XH_REQUIRE(ctx, m_begin >= 0 && m_begin % 2 == 0 && m_count % 2 == 0 && m_begin + m_count <= s.nmonths,
+               "xh_pm_pet: bad month block");
+    const int64_t items = s.ncell * (int64_t)(m_count / 2);
     int64_t blocks = (items + 255) / 256;
     const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 32;
     if (blocks > cap) blocks = cap;
-    xh_span sp = xh_span_begin(ctx, "pm_pet");
-    hipLaunchKernelGGL(k_pm_pet, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                       static_cast<const PmTablesDev *>(d_tab), d_lcy, ncell, (int)nmonths, d_tas, d_tmin, d_rhs,
-                       d_wind, d_rsds, d_rlds, d_tairprev, d_lct, d_elev, d_pet);
+    xh_span sp = xh_span_begin_on(ctx, "pm_pet", st);
+    hipLaunchKernelGGL(k_pm_pet, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const PmTablesDev *>(s.d_tab),
+                       s.d_lcy, s.ncell, s.nmonths, m_begin, m_count, d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds,
+                       d_tairprev, d_lct, d_elev, d_pet);
     xh_span_end(sp);
     XH_HIP(ctx, hipGetLastError());
     return XH_OK;
+}
+
+extern "C" int xh_pm_pet(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int32_t nmonths, int32_t start_year,
+                         int32_t n_lc_years, const int32_t *h_lc_years, int32_t water_idx, int32_t snow_idx,
+                         const double *d_tas, const double *d_tmin, const double *d_rhs, const double *d_wind,
+                         const double *d_rsds, const double *d_rlds, const double *d_tairprev, const double *d_lct,
+                         const double *d_elev, double *d_pet) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, d_tas && d_tmin && d_rhs && d_wind && d_rsds && d_rlds && d_lct && d_elev && d_pet,
+               "xh_pm_pet: NULL argument");
+    xh_pm_setup s;
+    int rc = xh_pm_prepare(ctx, t, ncell, nmonths, start_year, n_lc_years, h_lc_years, water_idx, snow_idx, &s);
+    if (rc || ncell == 0) return rc;
+    return xh_pm_enqueue(ctx, ctx->stream, s, 0, nmonths, d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds, d_tairprev, d_lct,
+                         d_elev, d_pet);
 }

@@ -5,6 +5,8 @@ on the context's stream; nothing crosses PCIe between stages.  ``components.Comp
 harness), ``bench.py`` and the multi-GPU sharding all drive this class; the per-stage plugin functions in
 ``pet/``, ``runoff/`` and ``routing/`` are the host-array entry points around the same C-ABI calls.
 """
+import os
+
 import numpy as np
 
 from . import _hip
@@ -92,7 +94,31 @@ class DevicePipeline:
                               self.d_velocity, self.d_area, self.out['q'] if runoff is None else runoff, self.d_S0,
                               self.out['chs'], self.out['avg'], flags=self.route_flags)
 
-    def run(self, stages=('pm', 'abcd', 'mrtm')):
+    def run_fused(self, with_routing=True, block_months=0):
+        """PM -> ABCD (-> MRTM) as one pipelined call (xh_run_fused): the stages overlap on the device."""
+        f = self.forcing
+        route = with_routing and self.plan is not None
+        self.ctx.run_fused(tables=self.pm_tables, ncell=self.ncell, nmonths=self.nmonths, start_year=self.start_year,
+                           lc_years=self.lc_years, water_idx=self.water_idx, snow_idx=self.snow_idx, tas=f['tas'],
+                           tmin=f['tmin'], rhs=f['rhs'], wind=f['wind'], rsds=f['rsds'], rlds=f['rlds'],
+                           tairprev=self.d_tairprev, lct=self.d_lct, elev=self.d_elev, abcd_spinup=self.abcd_spinup,
+                           n_groups=self.n_groups, basin_index=self.basin_index, par_index=self.par_index,
+                           npar_rows=self.npar_rows, pars=self.d_pars, precip=f['precip'],
+                           abcd_tmin=f['abcd_tmin'] if self.use_snow else None, pet=self.out['pet'], aet=self.out['aet'],
+                           q=self.out['q'], sav=self.out['sav'], plan=self.plan if route else None,
+                           routing_spinup=self.routing_spinup, ndays=self.ndays, dt=10800.0,
+                           flow_dist=self.d_flow_dist, velocity=self.d_velocity, area=self.d_area, S0=self.d_S0,
+                           chs=self.out['chs'] if route else None, avg=self.out['avg'] if route else None,
+                           route_flags=self.route_flags, block_months=block_months)
+
+    def run(self, stages=('pm', 'abcd', 'mrtm'), fused=None):
+        """Enqueue the stages.  PM + ABCD (+ MRTM) together go through the pipelined call unless ``fused=False`` (or
+        the series is shorter than the ABCD spin-up allows); the results are identical either way."""
+        if fused is None:
+            fused = os.environ.get('XH_NO_FUSED') != '1'
+        if fused and 'pm' in stages and 'abcd' in stages and self.nmonths % 12 == 0:
+            self.run_fused(with_routing='mrtm' in stages)
+            return
         if 'pm' in stages:
             self.run_pm()
         if 'abcd' in stages:
