@@ -179,9 +179,9 @@ int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t s
 /* ------------------------------------------------------------------ the whole path as one pipelined call
  * xh_run_fused replaces the stage-after-stage hand-over of components.py:simulation (:344-370: calculate_pet ->
  * calculate_runoff -> calculate_routing): Penman-Monteith, ABCD (spin-up, basin means, simulation) and MRTM are enqueued
- * together and overlap on the device -- PM runs in blocks of `block_months` months, the ABCD march follows one block
- * behind (PET still in cache; state carried from block to block), and routing starts on the first block of runoff and
- * polls a device word for the months it has not seen yet.  Results are bit-identical to xh_pm_pet + xh_abcd +
+ * together -- PM runs in blocks of `block_months` months and the ABCD march follows one block behind on a second stream
+ * (PET still in cache, the march on the issue slots PM leaves empty, its state carried from block to block); routing
+ * follows when the last block of runoff exists.  Results are bit-identical to xh_pm_pet + xh_abcd +
  * xh_route_series with the same arguments (same kernels, same arithmetic).  Arguments mean what they mean there.
  * d_pet and d_q must be given (they are the stages' hand-over and outputs of the model); d_aet, d_sav, d_chstorage,
  * d_avgchflow may be NULL; plan = NULL stops after the runoff.  block_months = 0 picks the default (96); it must be a

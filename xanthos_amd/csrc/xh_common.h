@@ -51,10 +51,9 @@ struct xh_ctx {
     std::vector<xh_route_record> pending_routes;
     uint64_t work_seq = 0;         // bumped by every kernel-launching entry point (xh_span_begin)
     int64_t reroutes = 0;          // routing calls re-run after a device fault
-    // xh_run_fused: two side streams, their events and the device word that counts finished months of runoff
+    // xh_run_fused: side stream and events of the block pipeline
     hipStream_t side_stream[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> side_events;
-    unsigned *d_months_ready = nullptr;
 };
 
 // Device fault word: kernels set it non-zero instead of hanging; the next synchronising call reports XH_ERR_DEVICE.

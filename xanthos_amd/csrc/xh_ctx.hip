@@ -180,7 +180,6 @@ void xh_ctx_destroy(xh_ctx *ctx) {
             (void)hipStreamDestroy(ctx->side_stream[i]);
         }
     for (auto e : ctx->side_events) (void)hipEventDestroy(e);
-    if (ctx->d_months_ready) (void)hipFree(ctx->d_months_ready);
     if (ctx->d_fault) (void)hipFree(ctx->d_fault);
     if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     (void)hipStreamDestroy(ctx->stream);

@@ -25,7 +25,6 @@
 
 #include "xh_common.h"
 #include "xh_mrtm_flow.h"
-#include "xh_stage.h"
 
 namespace {
 
@@ -703,27 +702,16 @@ extern "C" int xh_route_plan_stats(xh_route_plan *plan, int64_t max_words, uint6
 static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                              const int32_t *h_ndays, double dt, const double *d_flow_dist, const double *d_velocity,
                              const double *d_area, const double *d_runoff, const double *d_S0, double *d_chstorage,
-                             double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow,
-                             const xh_route_overlap *ov = nullptr);
+                             double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow);
 
 extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                                const int32_t *h_ndays, double dt, const double *d_flow_dist,
                                const double *d_velocity, const double *d_area, const double *d_runoff,
                                const double *d_S0, double *d_chstorage, double *d_avgchflow, double *d_S_end,
                                double *d_F_end, int32_t flags) {
-    return xh_route_enqueue(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff,
-                            d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end, flags, nullptr);
-}
-
-// With `ov` the kernels run on ov->stream (the caller joins it with the context's stream afterwards and then calls
-// xh_fault_collect itself); the call is remembered for a re-route all the same.
-int xh_route_enqueue(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months, const int32_t *h_ndays,
-                     double dt, const double *d_flow_dist, const double *d_velocity, const double *d_area,
-                     const double *d_runoff, const double *d_S0, double *d_chstorage, double *d_avgchflow,
-                     double *d_S_end, double *d_F_end, int32_t flags, const xh_route_overlap *ov) {
     bool used_flow = false;
     int rc = route_series_impl(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff,
-                               d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end, flags, &used_flow, ov);
+                               d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end, flags, &used_flow);
     if (rc || !used_flow) return rc;
     // remember the call until a synchronisation has confirmed that no bounded wait timed out (xh_fault_check)
     xh_route_record r;
@@ -744,7 +732,7 @@ int xh_route_enqueue(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t 
     r.F_end = d_F_end;
     r.seq_after = ctx->work_seq;
     ctx->pending_routes.push_back(std::move(r));
-    return ov ? XH_OK : xh_fault_collect(ctx);
+    return xh_fault_collect(ctx);
 }
 
 int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r) {
@@ -758,10 +746,8 @@ int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r) {
 static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                              const int32_t *h_ndays, double dt, const double *d_flow_dist, const double *d_velocity,
                              const double *d_area, const double *d_runoff, const double *d_S0, double *d_chstorage,
-                             double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow,
-                             const xh_route_overlap *ov) {
+                             double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow) {
     if (!ctx || !plan) return XH_ERR_ARG;
-    hipStream_t main_st = ov ? ov->stream : ctx->stream;
     XH_REQUIRE(ctx, plan->ctx == ctx, "xh_route_series: plan belongs to another context");
     XH_REQUIRE(ctx, h_ndays && d_flow_dist && d_velocity && d_area && d_runoff, "xh_route_series: NULL argument");
     XH_REQUIRE(ctx, nmonths > 0 && spinup_months >= 0 && spinup_months <= nmonths,
@@ -798,20 +784,19 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     int *d_nt = d_m + nit;
     int *d_g = d_nt + nit;
     unsigned char *d_wr = reinterpret_cast<unsigned char *>(d_g + nit + 1);
-    XH_HIP(ctx, hipMemcpyAsync(d_secs, ssecs.data(), sizeof(double) * nit, hipMemcpyHostToDevice, main_st));
-    XH_HIP(ctx, hipMemcpyAsync(d_m, sm.data(), sizeof(int) * nit, hipMemcpyHostToDevice, main_st));
-    XH_HIP(ctx, hipMemcpyAsync(d_nt, snt.data(), sizeof(int) * nit, hipMemcpyHostToDevice, main_st));
-    XH_HIP(ctx, hipMemcpyAsync(d_g, sg.data(), sizeof(int) * (nit + 1), hipMemcpyHostToDevice, main_st));
-    XH_HIP(ctx, hipMemcpyAsync(d_wr, swr.data(), (size_t)nit, hipMemcpyHostToDevice, main_st));
-    XH_HIP(ctx, hipStreamSynchronize(main_st));
+    XH_HIP(ctx, hipMemcpyAsync(d_secs, ssecs.data(), sizeof(double) * nit, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_m, sm.data(), sizeof(int) * nit, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_nt, snt.data(), sizeof(int) * nit, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_g, sg.data(), sizeof(int) * (nit + 1), hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipMemcpyAsync(d_wr, swr.data(), (size_t)nit, hipMemcpyHostToDevice, ctx->stream));
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
     const bool force_fb = (flags & XH_ROUTE_FORCE_FALLBACK) != 0;
     const bool atomic = (flags & XH_ROUTE_ATOMIC) != 0;
     bool use_flow = !force_fb && plan->flow != nullptr && (flags & XH_ROUTE_NO_DATAFLOW) == 0;
 
-    if (ov && ov->start) XH_HIP(ctx, hipStreamWaitEvent(main_st, ov->start, 0));   // after the uploads above: the host never waits for it
-    xh_span sp = xh_span_begin_on(ctx, "mrtm_route", main_st);
-    XH_HIP(ctx, hipEventRecord(plan->ev_fork, main_st));
+    xh_span sp = xh_span_begin(ctx, "mrtm_route");
+    XH_HIP(ctx, hipEventRecord(plan->ev_fork, ctx->stream));
     int njoin = 0;
     plan->last_tree_kernel = 0;
     if (use_flow) {     // tree-shaped networks: single-wave dataflow units on the context's own stream
@@ -821,17 +806,16 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
             ntmin = std::min(ntmin, v);
         }
         const FlowSched fs{nmonths, nit, ntmax, ntmin, sg[nit], d_m, d_nt, d_g, d_secs, d_wr, dt,
-                           (flags & XH_ROUTE_TEST_FAULT) != 0, ov ? ov->d_months_ready : nullptr};
+                           (flags & XH_ROUTE_TEST_FAULT) != 0};
         const FlowIO fio{d_flow_dist, d_velocity, d_area, d_runoff, d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end};
         // time-skewed units first; months shorter than the deepest lane lag (long dt) use the monthly-stream kernel
         static const bool skew_env = !(getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] == '0');
         rc = XH_ERR_LIMIT;
         plan->last_tree_kernel = 2;
-        if (skew_env && (flags & XH_ROUTE_NO_SKEW) == 0) rc = skew_launch(ctx, plan->flow, fs, fio, main_st);
+        if (skew_env && (flags & XH_ROUTE_NO_SKEW) == 0) rc = skew_launch(ctx, plan->flow, fs, fio, ctx->stream);
         if (rc == XH_ERR_LIMIT) {
             plan->last_tree_kernel = 1;
-            if (ov && ov->all_ready) XH_HIP(ctx, hipStreamWaitEvent(main_st, ov->all_ready, 0));   // no month flags there
-            rc = flow_launch(ctx, plan->flow, fs, fio, main_st);
+            rc = flow_launch(ctx, plan->flow, fs, fio, ctx->stream);
         }
         if (rc == XH_ERR_LIMIT) {
             use_flow = false;   // units cannot all be resident on this device: one workgroup per network instead
@@ -871,7 +855,6 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
             if ((use_flow ? plan->rest_units[cls] : plan->class_units[cls]).empty()) continue;
             hipStream_t st = plan->streams[cls];
             XH_HIP(ctx, hipStreamWaitEvent(st, plan->ev_fork, 0));
-            if (ov && ov->all_ready) XH_HIP(ctx, hipStreamWaitEvent(st, ov->all_ready, 0));   // these kernels read any month
             switch (cls) {
                 case 0: launch_units<1, 64>(plan, cls, a, st, use_flow); break;
                 case 1: launch_units<2, 64>(plan, cls, a, st, use_flow); break;
@@ -884,7 +867,7 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
             }
             XH_HIP(ctx, hipGetLastError());
             XH_HIP(ctx, hipEventRecord(plan->ev_join[njoin], st));
-            XH_HIP(ctx, hipStreamWaitEvent(main_st, plan->ev_join[njoin], 0));
+            XH_HIP(ctx, hipStreamWaitEvent(ctx->stream, plan->ev_join[njoin], 0));
             ++njoin;
         }
     }
@@ -932,7 +915,6 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         f.F_end = d_F_end;
         hipStream_t st = plan->fb_stream;
         XH_HIP(ctx, hipStreamWaitEvent(st, plan->ev_fork, 0));
-        if (ov && ov->all_ready) XH_HIP(ctx, hipStreamWaitEvent(st, ov->all_ready, 0));
         const dim3 grid((unsigned)((n_fb + 255) / 256)), block(256);
         hipLaunchKernelGGL(k_fb_init, grid, block, 0, st, f);
         for (int it = 0; it < nit; ++it) {
@@ -953,7 +935,7 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         hipLaunchKernelGGL(k_fb_finish, grid, block, 0, st, f);
         XH_HIP(ctx, hipGetLastError());
         XH_HIP(ctx, hipEventRecord(plan->ev_join[N_CLASS], st));
-        XH_HIP(ctx, hipStreamWaitEvent(main_st, plan->ev_join[N_CLASS], 0));
+        XH_HIP(ctx, hipStreamWaitEvent(ctx->stream, plan->ev_join[N_CLASS], 0));
     }
     xh_span_end(sp);
     *used_flow = use_flow;

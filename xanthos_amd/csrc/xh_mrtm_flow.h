@@ -31,7 +31,6 @@ struct FlowSched {
     const unsigned char *d_wr;        // [nit] 1 = simulation pass (store outputs)
     double dt;
     bool test_fault;                  // XH_ROUTE_TEST_FAULT: unit 0 raises the fault word and stops (tests of the re-route)
-    const unsigned *months_ready;     // pipelined call: month m of the runoff exists once *months_ready > m (else NULL)
 };
 
 struct FlowIO {

@@ -45,7 +45,7 @@ constexpr int GROUP = 16;                     // sub-steps per unrolled group (t
 constexpr int SK_R = 2;                       // block-transfer rounds: up to 8 * SK_R imports / outlets per unit
 constexpr int CH = 128;                       // iterations between flow-control checks (multiple of GROUP)
 constexpr int PUBLAG = 64;                    // a check publishes the stores older than this many iterations
-constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2, FAULT_RUNOFF_WAIT = 3;
+constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2;
 constexpr unsigned FAULT_TEST = 99;
 
 struct SkewArgs {
@@ -69,7 +69,6 @@ struct SkewArgs {
     unsigned *fault;
     unsigned long long spin_limit;    // bound of one wait, 100 MHz ticks (xh_spin_limit_ticks)
     int test_fault;
-    const unsigned *months_ready;     // pipelined call (xh_run_fused): runoff month m exists once *months_ready > m
     unsigned long long *stats;
 };
 
@@ -142,30 +141,6 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
     const int total = a.total, nit = a.nit;
 
-    // ---- runoff of one month.  In a pipelined call (xh_run_fused) the runoff kernel may still be writing later
-    //      months: wait until the month exists (one wave-uniform poll; `seen` remembers the last count, and once it
-    //      covers the series nothing is polled again), then load it past this XCD's L2 -- a line fetched for an earlier
-    //      month of the same row can hold stale values of this one.
-    unsigned months_seen = a.months_ready ? 0u : 0x7fffffffu;
-    auto runoff_of = [&](int m) -> double {
-        if (months_seen <= (unsigned)m) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            for (;;) {
-                months_seen = ld_relaxed(a.months_ready);
-                if (months_seen > (unsigned)m) break;
-                if (ld_relaxed(a.fault) != 0) return 0.0;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > a.spin_limit) {
-                    __hip_atomic_store(a.fault, FAULT_RUNOFF_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return 0.0;
-                }
-                __builtin_amdgcn_s_sleep(16);
-            }
-        }
-        if (!valid) return 0.0;
-        const double *p = a.runoff + (int64_t)gc * a.nmonths + m;
-        return a.months_ready ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-    };
-
     // ---- block-transfer roles: lane (k = lane / 8 + 8 r, i = lane % 8) moves sub-step i of outlet / import k
     if (has_x) xtab[__popcll(xmask & ((1ull << lane) - 1ull))] = make_uint2((unsigned)lane, (unsigned)xedge);
     const int sub = lane & 7, grp = lane >> 3;
@@ -202,9 +177,9 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
     int nx = a.lag[slot];                                  // iteration at which this lane enters its next month
     double erl_n = 0.0, qn = 0.0;                          // lateral inflow of the month to enter / runoff after that
     {
-        const double q0 = runoff_of(a.sched_m[0]);
+        const double q0 = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[0]] : 0.0;
         erl_n = (q0 * area) * 1000.0 / a.sched_secs[0];                        // mrtm.py:45
-        if (nit > 1) qn = runoff_of(a.sched_m[1]);
+        if (nit > 1) qn = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[1]] : 0.0;
     }
     double ob_s[8], ob_a[8];
 #pragma unroll
@@ -275,7 +250,7 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
             }
         }
         if (it + 1 < nit) erl_n = (qn * area) * 1000.0 / a.sched_secs[it + 1];
-        if (it + 2 < nit) qn = runoff_of(a.sched_m[it + 2]);
+        if (it + 2 < nit) qn = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[it + 2]] : 0.0;
     };
 
     // gathered pairs of the current sub-step (issued one iteration ago); import blocks in flight (two ahead)
@@ -543,7 +518,6 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.fault = fault;
     a.spin_limit = xh_spin_limit_ticks(s.total);
     a.test_fault = s.test_fault ? 1 : 0;
-    a.months_ready = s.months_ready;
     a.stats = nullptr;
     {
         const char *env = getenv("XH_FLOW_STATS");

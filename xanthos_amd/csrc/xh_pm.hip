@@ -363,9 +363,12 @@ int xh_pm_enqueue(xh_ctx *ctx, hipStream_t st, const xh_pm_setup &s, int m_begin
     XH_REQUIRE(ctx, m_begin >= 0 && m_begin % 2 == 0 && m_count % 2 == 0 && m_begin + m_count <= s.nmonths,
                "xh_pm_pet: bad month block");
     const int64_t items = s.ncell * (int64_t)(m_count / 2);
-    int64_t blocks = (items + 255) / 256;
+    // grid-stride loop with a whole number of passes per thread: a block of months (xh_run_fused) is only ~1.5 passes of
+    // the capped grid, and a ragged last pass would leave a quarter of the chip idle for it
     const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 32;
-    if (blocks > cap) blocks = cap;
+    const int64_t need = (items + 255) / 256;
+    const int64_t passes = (need + cap - 1) / cap;
+    int64_t blocks = (need + passes - 1) / passes;
     xh_span sp = xh_span_begin_on(ctx, "pm_pet", st);
     hipLaunchKernelGGL(k_pm_pet, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const PmTablesDev *>(s.d_tab),
                        s.d_lcy, s.ncell, s.nmonths, m_begin, m_count, d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds,

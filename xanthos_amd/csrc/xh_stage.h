@@ -35,16 +35,3 @@ int xh_abcd_enqueue_spinup(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, 
 int xh_abcd_enqueue_sim(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, int m_begin, int m_end,
                         const double *d_pars, const double *d_pet, const double *d_precip, const double *d_tmin,
                         double *d_aet, double *d_q, double *d_sav);
-
-// Routing that starts before all of its runoff exists: the time-skewed kernel reads month m of the runoff only once
-// *d_months_ready > m (agent-coherent loads); the other routing kernels wait for `all_ready` instead.
-struct xh_route_overlap {
-    hipStream_t stream = nullptr;          // stream the routing runs on
-    hipEvent_t start = nullptr;            // the stream waits for this before the first kernel (may be null)
-    hipEvent_t all_ready = nullptr;        // recorded when every month of the runoff has been written
-    const unsigned *d_months_ready = nullptr;
-};
-int xh_route_enqueue(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months, const int32_t *h_ndays,
-                     double dt, const double *d_flow_dist, const double *d_velocity, const double *d_area,
-                     const double *d_runoff, const double *d_S0, double *d_chstorage, double *d_avgchflow,
-                     double *d_S_end, double *d_F_end, int32_t flags, const xh_route_overlap *ov);

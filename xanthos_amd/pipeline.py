@@ -112,12 +112,13 @@ class DevicePipeline:
                            route_flags=self.route_flags, block_months=block_months)
 
     def run(self, stages=('pm', 'abcd', 'mrtm'), fused=None):
-        """Enqueue the stages.  PM + ABCD (+ MRTM) together go through the pipelined call unless ``fused=False`` (or
-        the series is shorter than the ABCD spin-up allows); the results are identical either way."""
+        """Enqueue the stages one after the other on the context's stream.  ``fused=True`` (or XH_FUSED=1) sends PM +
+        ABCD (+ MRTM) through the pipelined call xh_run_fused instead: identical results; on MI355X the stage-by-stage
+        order is the faster one at the full grid, so it is the default."""
         if fused is None:
-            fused = os.environ.get('XH_NO_FUSED') != '1'
+            fused = os.environ.get('XH_FUSED') == '1'
         if fused and 'pm' in stages and 'abcd' in stages and self.nmonths % 12 == 0:
-            self.run_fused(with_routing='mrtm' in stages)
+            self.run_fused(with_routing='mrtm' in stages, block_months=int(os.environ.get('XH_FUSED_BLOCK', '0')))
             return
         if 'pm' in stages:
             self.run_pm()
