@@ -7,7 +7,7 @@ otherwise.  WRITE_SIZE is exact for 16-B streaming stores (calibrated here on k_
 import collections, csv, glob, json, sys
 
 fetch_dir, write_dir, out = sys.argv[1:4]
-WIDE = {'k_pm_pet': 2.0, 'k_synth': 2.0}
+WIDE = {'k_pm_pet': 2.0, 'k_synth': 2.0, 'k_abcd_tile<false': 2.0, 'k_abcd_tile<true': 2.0}      # whole-line streams
 
 
 def read(d):
@@ -15,7 +15,8 @@ def read(d):
     for f in glob.glob(d + '/*/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             name = r['Kernel_Name']
-            key = next((k for k in ('k_pm_pet', 'k_abcd<true>', 'k_abcd<false>', 'k_abcd_basin_mean', 'k_mrtm_skew', 'k_mrtm_flow',
+            key = next((k for k in ('k_pm_pet', 'k_abcd_tile<false', 'k_abcd_tile<true', 'k_abcd<true>', 'k_abcd<false>', 'k_abcd_basin_mean',
+                                    'k_mrtm_skew', 'k_mrtm_flow',
                                     'k_mrtm_units', 'k_synth') if k in name), None)
             if key:
                 agg[key].append(float(r['Counter_Value']))

@@ -47,29 +47,35 @@ struct AbcdPre {
     int kind;                              // 1 = all rain (melt = pack*m), 2 = mixed (melt = pack*m*frac), 0 = no melt
 };
 
+// set_rain_and_snow (:141-169) for one (cell, month): NaN tmin matches no class => rain = snow = 0.
+// kind: 1 = all rain (melt = pack*m), 2 = mixed (melt = pack*m*frac), 0 = no melt.
+__device__ __forceinline__ void abcd_split(bool snow_on, double precip, double tmin, double &rain, double &snow,
+                                           double &frac, int &kind) {
+    rain = precip;
+    snow = 0.0;
+    frac = 0.0;
+    kind = 0;
+    if (snow_on) {
+        const bool allrain = tmin > TRAIN;
+        const bool mixed = (tmin <= TRAIN) && (tmin >= TSNOW);
+        const bool allsnow = tmin < TSNOW;
+        frac = (TRAIN - tmin) / (TRAIN - TSNOW);
+        rain = 0.0;
+        if (mixed) {
+            snow = precip * (TRAIN - tmin) / (TRAIN - TSNOW);
+            rain = precip - snow;
+        }
+        if (allrain) rain = precip;
+        if (allsnow) snow = precip;
+        kind = allrain ? 1 : (mixed ? 2 : 0);
+    }
+}
+
 __device__ __forceinline__ AbcdPre abcd_pre(const AbcdPar &P, bool snow_on, double pet, double precip, double tmin) {
     AbcdPre r;
     r.pet = pet;
     r.decay = exp(quot(-pet, P.b, P.inv_b));                          // :211
-    r.rain = precip;
-    r.snow = 0.0;
-    r.frac = 0.0;
-    r.kind = 0;
-    if (snow_on) {
-        // set_rain_and_snow (:141-169): NaN tmin matches no class => rain = snow = 0
-        const bool allrain = tmin > TRAIN;
-        const bool mixed = (tmin <= TRAIN) && (tmin >= TSNOW);
-        const bool allsnow = tmin < TSNOW;
-        r.frac = (TRAIN - tmin) / (TRAIN - TSNOW);
-        r.rain = 0.0;
-        if (mixed) {
-            r.snow = precip * (TRAIN - tmin) / (TRAIN - TSNOW);
-            r.rain = precip - r.snow;
-        }
-        if (allrain) r.rain = precip;
-        if (allsnow) r.snow = precip;
-        r.kind = allrain ? 1 : (mixed ? 2 : 0);
-    }
+    abcd_split(snow_on, precip, tmin, r.rain, r.snow, r.frac, r.kind);
     return r;
 }
 
@@ -80,7 +86,10 @@ __device__ __forceinline__ void abcd_step(const AbcdPar &P, AbcdState &s, bool s
     if (snow_on) {
         s.snowpack = s.snowpack + r.snow;                             // :180-183
         const double pm = s.snowpack * P.m;
-        snm = r.kind == 1 ? pm : (r.kind == 2 ? pm * r.frac : 0.0);   // :191-194
+        // :191-194: pack*m (all rain), pack*m*frac (mixed), 0 (all snow / no class); x * 1.0 is x, bit for bit
+        const double mf = r.kind == 2 ? r.frac : 1.0;
+        const double melt = pm * mf;
+        snm = r.kind == 0 ? 0.0 : melt;
         s.snowpack = s.snowpack - snm;                                // :197
     }
     const double w = first ? r.rain + s.sm : r.rain + s.sm + snm;     // :200-203

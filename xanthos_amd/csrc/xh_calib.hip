@@ -15,6 +15,7 @@
 //
 // All cross-lane / cross-wave sums run in a fixed order, so results are reproducible run to run.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "xh_abcd_dev.h"
@@ -235,18 +236,238 @@ __global__ void __launch_bounds__(256) k_calib_kge(const int *__restrict__ activ
     }
 }
 
+
+// =============================================================================== member-lane layout
+// lanes <-> members, CM cells per wave.  Everything that does not depend on the member -- PET, the rain / snow split,
+// the melt class, the cell area -- is the same for all 64 lanes: it arrives through the scalar unit (s_load) from the
+// split arrays k_calib_split filled once per problem, and the VALU only sees exp(-PET / b), the month update and three
+// instructions of accumulation: the sum over the wave's cells is a plain per-lane sum, no cross-lane reduction.
+// ~100 wave-instructions per member-cell-month against ~145 in the cell-lane kernel (whose DPP wave sum alone costs
+// 25 per member and month).  The price is a population that fills whole waves of 64 members.
+constexpr int CM = 16;   // cells per wave: 48 doubles of state per lane
+
+__global__ void __launch_bounds__(256) k_calib_split(const xh_calib_basin *__restrict__ basins, int nmonths) {
+    const xh_calib_basin B = basins[blockIdx.y];
+    const bool snow_on = B.tn != nullptr;
+    const int64_t n = (int64_t)B.ncell * nmonths;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double rain, snow, frac;
+        int kind;
+        abcd_split(snow_on, B.pr[i], snow_on ? B.tn[i] : 0.0, rain, snow, frac, kind);
+        B.rain[i] = rain;
+        B.snow[i] = snow;
+        B.frac[i] = frac;
+        B.kind[i] = kind;
+    }
+}
+
+// grid.x = CM-cell chunks of all basins, grid.y = blocks of 64 members; one wave per block
+template <bool SPINUP>
+__global__ void __launch_bounds__(64) k_calib_march_m(const xh_calib_basin *__restrict__ basins,
+                                                      const int *__restrict__ chunk_basin,
+                                                      const int *__restrict__ active, int nsteps, int nmembers, int npar,
+                                                      const double *__restrict__ pars, const double *__restrict__ sm0,
+                                                      const double *__restrict__ gw0,
+                                                      double *__restrict__ dec_sum,    // [chunk][6][member]
+                                                      int *__restrict__ dec_cnt,       // [chunk][6][member]
+                                                      double *__restrict__ part) {     // [chunk][nsteps][member]
+    const int chunk = blockIdx.x;
+    const int b = chunk_basin[chunk];
+    if (active && !active[b]) return;
+    const xh_calib_basin B = basins[b];
+    const int ncell = B.ncell;
+    const int base = (chunk - B.chunk0) * CM;
+    const int cnt = min(CM, ncell - base);
+    const int mem_raw = blockIdx.y * 64 + threadIdx.x;
+    const bool ok = mem_raw < nmembers;
+    const int mem = ok ? mem_raw : nmembers - 1;
+    const bool snow_on = B.tn != nullptr;
+    const AbcdPar P = member_par(pars, npar, b * nmembers + mem);
+    AbcdState s[CM];
+#pragma unroll
+    for (int j = 0; j < CM; ++j) {
+        s[j].snowpack = 0.0;
+        s[j].sm = SPINUP ? 100.0 : sm0[b * nmembers + mem];
+        s[j].gw = SPINUP ? 500.0 : gw0[b * nmembers + mem];
+    }
+    const double *__restrict__ pet_t = B.pet, *__restrict__ rain_t = B.rain, *__restrict__ snow_t = B.snow,
+                 *__restrict__ frac_t = B.frac, *__restrict__ area = B.area;
+    const int *__restrict__ kind_t = B.kind;
+    // Lane j (mod 16) fetches cell j's five values of a month with ordinary coalesced loads, one month ahead; each
+    // cell's values are then broadcast from that lane into scalar registers (v_readlane), so the march below has
+    // wave-uniform operands without a memory access on its path.  (Left to itself the compiler addresses the uniform
+    // values through vector registers and waits for every load: the split arrays are written by another kernel of this
+    // translation unit, so it will not use the scalar cache.)
+    const int lj = min((int)(threadIdx.x & (CM - 1)), cnt - 1);
+    const double area_l = area ? area[base + lj] : 1.0;
+    auto bcast = [](double v, int src) {
+        const long long bits = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), src);
+        const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    };
+    double n_pet = pet_t[base + lj], n_rain = rain_t[base + lj], n_snow = snow_t[base + lj], n_frac = frac_t[base + lj];
+    int n_kind = kind_t[base + lj];
+    for (int m = 0; m < nsteps; ++m) {
+        const int k = SPINUP ? ((m == nsteps - 1) ? 0 : ((m == nsteps - 13) ? 1 : ((m == nsteps - 25) ? 2 : -1))) : -1;
+        const double c_pet = n_pet, c_rain = n_rain, c_snow = n_snow, c_frac = n_frac;
+        const int c_kind = n_kind;
+        if (m + 1 < nsteps) {                                        // next month's values: in flight during this one
+            const int64_t o = (int64_t)(m + 1) * ncell + base + lj;
+            n_pet = pet_t[o];
+            n_rain = rain_t[o];
+            n_snow = snow_t[o];
+            n_frac = frac_t[o];
+            n_kind = kind_t[o];
+        }
+        double tot = 0.0, ssm = 0.0, sgw = 0.0;
+        int nsm = 0, ngw = 0;
+#pragma unroll
+        for (int j = 0; j < CM; ++j) {
+            if (j < cnt) {                                           // wave-uniform
+                AbcdPre pre;
+                pre.pet = bcast(c_pet, j);
+                pre.rain = bcast(c_rain, j);
+                pre.snow = bcast(c_snow, j);
+                pre.frac = bcast(c_frac, j);
+                pre.kind = __builtin_amdgcn_readlane(c_kind, j);
+                pre.decay = exp(quot(-pre.pet, P.b, P.inv_b));
+                double aet, q;
+                abcd_step(P, s[j], snow_on, m == 0, pre, aet, q);
+                if (SPINUP) {
+                    if (k >= 0) {
+                        const bool sm_ok = s[j].sm == s[j].sm, gw_ok = s[j].gw == s[j].gw;
+                        ssm += sm_ok ? s[j].sm : 0.0;
+                        sgw += gw_ok ? s[j].gw : 0.0;
+                        nsm += sm_ok ? 1 : 0;
+                        ngw += gw_ok ? 1 : 0;
+                    }
+                } else {
+                    const double v = area ? q * bcast(area_l, j) * 1e-6 : q;   // rsim * bsn_areas * 1e-6 (:159) or rsim (:162)
+                    tot += (v == v) ? v : 0.0;                                // nansum
+                }
+            }
+        }
+        if (SPINUP) {
+            if (k >= 0 && ok) {
+                const int64_t o = (int64_t)chunk * 6 * nmembers + mem;
+                dec_sum[o + (int64_t)k * nmembers] = ssm;
+                dec_sum[o + (int64_t)(3 + k) * nmembers] = sgw;
+                dec_cnt[o + (int64_t)k * nmembers] = nsm;
+                dec_cnt[o + (int64_t)(3 + k) * nmembers] = ngw;
+            }
+        } else if (ok) {
+            part[((int64_t)chunk * nsteps + m) * nmembers + mem] = tot;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_calib_init_m(const xh_calib_basin *__restrict__ basins,
+                                                     const int *__restrict__ active, int nbasins, int nmembers,
+                                                     const double *__restrict__ dec_sum, const int *__restrict__ dec_cnt,
+                                                     double *__restrict__ sm0, double *__restrict__ gw0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbasins * nmembers) return;
+    const int b = i / nmembers, mem = i - b * nmembers;
+    if (active && !active[b]) return;
+    const xh_calib_basin B = basins[b];
+    double sum[6] = {0, 0, 0, 0, 0, 0};
+    long long cnt[6] = {0, 0, 0, 0, 0, 0};
+    for (int ch = B.chunk0; ch < B.chunk0 + B.nchunks; ++ch) {
+        const int64_t o = (int64_t)ch * 6 * nmembers + mem;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            sum[k] += dec_sum[o + (int64_t)k * nmembers];
+            cnt[k] += dec_cnt[o + (int64_t)k * nmembers];
+        }
+    }
+    double mean[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) mean[k] = sum[k] / (double)cnt[k];
+    sm0[i] = ((mean[0] + mean[1]) + mean[2]) / 3.0;              // abcd.py:274-278
+    gw0[i] = ((mean[3] + mean[4]) + mean[5]) / 3.0;
+}
+
+// series_m[basin][month][member] = sum over the basin's chunks, in chunk order
+__global__ void __launch_bounds__(256) k_calib_series_m(const xh_calib_basin *__restrict__ basins,
+                                                        const int *__restrict__ active, int nbasins, int nmembers,
+                                                        int nmonths, const double *__restrict__ part,
+                                                        double *__restrict__ series_m) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_basin = (int64_t)nmembers * nmonths;
+    if (i >= per_basin * nbasins) return;
+    const int b = (int)(i / per_basin);
+    if (active && !active[b]) return;
+    const int64_t r = i - (int64_t)b * per_basin;                // month * nmembers + member
+    const xh_calib_basin B = basins[b];
+    double acc = 0.0;
+    for (int ch = B.chunk0; ch < B.chunk0 + B.nchunks; ++ch) acc += part[(int64_t)ch * per_basin + r];
+    series_m[i] = acc;
+}
+
+// one thread per (basin, member), lanes along the members: ED as in k_calib_kge, sums over the months in order
+__global__ void __launch_bounds__(64) k_calib_kge_m(const int *__restrict__ active, int nbasins, int nmonths, int nmembers,
+                                                    const double *__restrict__ series_m,
+                                                    const double *__restrict__ obs_all, double *__restrict__ ed) {
+    const int b = blockIdx.y;
+    const int mem = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mem >= nmembers || (active && !active[b])) return;
+    const double *x = series_m + (int64_t)b * nmonths * nmembers + mem;
+    const double *obs = obs_all + (int64_t)b * nmonths;
+    double sx = 0.0, so = 0.0;
+    for (int m = 0; m < nmonths; ++m) {
+        sx += x[(int64_t)m * nmembers];
+        so += obs[m];
+    }
+    const double n = (double)nmonths;
+    const double mx = sx / n, mo = so / n;
+    double vxx = 0.0, voo = 0.0, vxo = 0.0;
+    for (int m = 0; m < nmonths; ++m) {
+        const double dx = x[(int64_t)m * nmembers] - mx, d_o = obs[m] - mo;
+        vxx += dx * dx;
+        voo += d_o * d_o;
+        vxo += dx * d_o;
+    }
+    const double relvar = sqrt(vxx / n) / sqrt(voo / n);         // np.std, population
+    const double bias = mx / mo;
+    const double c00 = voo / (n - 1.0), c11 = vxx / (n - 1.0), c01 = vxo / (n - 1.0);   // np.corrcoef via np.cov
+    double r = c01 / sqrt(c11) / sqrt(c00);
+    r = r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);
+    ed[b * nmembers + mem] = sqrt((r - 1.0) * (r - 1.0) + (relvar - 1.0) * (relvar - 1.0) + (bias - 1.0) * (bias - 1.0));
+}
+
+// d_series [basin][member][month] from d_series_m [basin][month][member] (only when the caller asks for the series)
+__global__ void __launch_bounds__(256) k_calib_series_out(int nbasins, int nmembers, int nmonths,
+                                                          const double *__restrict__ series_m,
+                                                          double *__restrict__ series) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_basin = (int64_t)nmembers * nmonths;
+    if (i >= per_basin * nbasins) return;
+    const int b = (int)(i / per_basin);
+    const int64_t r = i - (int64_t)b * per_basin;
+    const int mem = (int)(r / nmonths), m = (int)(r - (int64_t)mem * nmonths);
+    series[i] = series_m[(int64_t)b * per_basin + (int64_t)m * nmembers + mem];
+}
+
 }  // namespace
 
 int xh_calib_problem_plan(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, int32_t nmonths, int32_t spinup,
                           int32_t nmembers, int32_t npar, const double *const *h_pet_t,
                           const double *const *h_precip_t, const double *const *h_tmin_t,
                           const double *const *h_area, std::vector<xh_calib_basin> &basins,
-                          std::vector<int> &chunk_basin, size_t *bytes) {
+                          std::vector<int> &chunk_basin, size_t *bytes, int *member_lanes) {
     XH_REQUIRE(ctx, nbasins > 0 && h_ncell && h_pet_t && h_precip_t, "xh_calib_objective: NULL argument");
     XH_REQUIRE(ctx, nmonths > 1 && nmembers > 0, "xh_calib_objective: bad size");
     XH_REQUIRE(ctx, npar == 4 || npar == 5, "xh_calib_objective: npar must be 4 (no snow) or 5");
     XH_REQUIRE(ctx, (npar == 5) == (h_tmin_t != nullptr), "xh_calib_objective: npar = 5 requires tmin and vice versa");
     XH_REQUIRE(ctx, spinup >= 25 && spinup <= nmonths, "xh_calib_objective: spin-up must be in [25, nmonths]");
+    // member-lane kernel when the population fills its waves of 64 members to at least 3/4 (XH_CALIB_LAYOUT = 0 / 1
+    // forces one: profiling and tests)
+    const int mblocks = (nmembers + 63) / 64;
+    int ml = (4 * nmembers >= 3 * 64 * mblocks) ? 1 : 0;
+    if (const char *e = getenv("XH_CALIB_LAYOUT")) ml = (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : ml);
+    *member_lanes = ml;
+    const int cs = ml ? CM : 64;                                 // cells per chunk
     basins.assign(nbasins, xh_calib_basin());
     chunk_basin.clear();
     for (int b = 0; b < nbasins; ++b) {
@@ -256,8 +477,10 @@ int xh_calib_problem_plan(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, 
         xh_calib_basin &B = basins[b];
         B.ncell = (int)h_ncell[b];
         B.chunk0 = (int)chunk_basin.size();
-        B.nchunks = (B.ncell + 63) / 64;
+        B.nchunks = (B.ncell + cs - 1) / cs;
         B.pad = 0;
+        B.rain = B.snow = B.frac = nullptr;
+        B.kind = nullptr;
         B.pet = h_pet_t[b];
         B.pr = h_precip_t[b];
         B.tn = npar == 5 ? h_tmin_t[b] : nullptr;
@@ -266,16 +489,19 @@ int xh_calib_problem_plan(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, 
     }
     XH_REQUIRE(ctx, (nmembers + MB - 1) / MB <= 65535, "xh_calib_objective: too many members");
     const size_t nchunks = chunk_basin.size(), nbm = (size_t)nbasins * nmembers;
+    size_t cells = 0;
+    for (int b = 0; b < nbasins; ++b) cells += (size_t)h_ncell[b];
     const size_t dbl = (size_t)nbasins * nmonths + 2 * nbm + nchunks * nmembers * 6 + nchunks * nmembers * (size_t)nmonths +
-                       nbm * nmonths;
+                       nbm * nmonths * (ml ? 2 : 1) + (ml ? 3 * cells * (size_t)nmonths : 0);
     const size_t tab_bytes = ((sizeof(xh_calib_basin) * nbasins + sizeof(int) * nchunks) + 255) & ~size_t(255);
-    *bytes = dbl * sizeof(double) + nchunks * nmembers * 6 * sizeof(int) + tab_bytes + 256;
+    *bytes = dbl * sizeof(double) + nchunks * nmembers * 6 * sizeof(int) + (ml ? cells * (size_t)nmonths * sizeof(int) : 0) +
+             tab_bytes + 512;
     return XH_OK;
 }
 
 int xh_calib_problem_place(xh_ctx *ctx, xh_calib_problem &P, int32_t nmonths, int32_t spinup, int32_t nmembers,
-                           int32_t npar, const std::vector<xh_calib_basin> &basins,
-                           const std::vector<int> &chunk_basin, const double *h_obs, void *buf) {
+                           int32_t npar, std::vector<xh_calib_basin> &basins, const std::vector<int> &chunk_basin,
+                           const double *h_obs, void *buf, int member_lanes) {
     XH_REQUIRE(ctx, h_obs != nullptr, "xh_calib_objective: obs is NULL");
     const int nbasins = (int)basins.size();
     const size_t nchunks = chunk_basin.size(), nbm = (size_t)nbasins * nmembers;
@@ -287,15 +513,37 @@ int xh_calib_problem_place(xh_ctx *ctx, xh_calib_problem &P, int32_t nmonths, in
     P.nmembers = nmembers;
     P.npar = npar;
     P.nchunks = nchunks;
+    P.member_lanes = member_lanes;
+    P.split_done = false;
     P.d_obs = static_cast<double *>(buf);
     P.d_sm0 = P.d_obs + (size_t)nbasins * nmonths;
     P.d_gw0 = P.d_sm0 + nbm;
     P.d_dec = P.d_gw0 + nbm;
     P.d_part = P.d_dec + n_dec;
     P.d_series = P.d_part + n_part;
-    P.d_basins = reinterpret_cast<xh_calib_basin *>(P.d_series + nbm * nmonths);
+    double *next = P.d_series + nbm * nmonths;
+    P.d_series_m = nullptr;
+    if (member_lanes) {
+        P.d_series_m = next;
+        next += nbm * nmonths;
+        for (xh_calib_basin &B : basins) {                       // rain / snow / frac of every (month, cell) of the basin
+            const size_t n = (size_t)B.ncell * nmonths;
+            B.rain = next;
+            B.snow = next + n;
+            B.frac = next + 2 * n;
+            next += 3 * n;
+        }
+    }
+    P.d_basins = reinterpret_cast<xh_calib_basin *>(next);
     P.d_chunk_basin = reinterpret_cast<int *>(P.d_basins + nbasins);
     P.d_cnt = reinterpret_cast<int *>(reinterpret_cast<char *>(P.d_basins) + tab_bytes);
+    if (member_lanes) {
+        int *kind = P.d_cnt + n_dec;
+        for (xh_calib_basin &B : basins) {
+            B.kind = kind;
+            kind += (size_t)B.ncell * nmonths;
+        }
+    }
     XH_HIP(ctx, hipMemcpyAsync(P.d_obs, h_obs, sizeof(double) * nbasins * nmonths, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipMemcpyAsync(P.d_basins, basins.data(), sizeof(xh_calib_basin) * nbasins, hipMemcpyHostToDevice,
                                ctx->stream));
@@ -305,7 +553,50 @@ int xh_calib_problem_place(xh_ctx *ctx, xh_calib_problem &P, int32_t nmonths, in
     return XH_OK;
 }
 
+static int calib_enqueue_m(xh_ctx *ctx, const xh_calib_problem &P, const double *d_pars, const int *d_active,
+                           double *d_ed) {
+    const size_t nbm = (size_t)P.nbasins * P.nmembers;
+    const dim3 grid((unsigned)P.nchunks, (unsigned)((P.nmembers + 63) / 64)), block(64);
+    {
+        xh_span sp = xh_span_begin(ctx, "calib_abcd");
+        if (!P.split_done) {
+            hipLaunchKernelGGL(k_calib_split, dim3(256, (unsigned)P.nbasins), dim3(256), 0, ctx->stream, P.d_basins, P.nmonths);
+            const_cast<xh_calib_problem &>(P).split_done = true;
+        }
+        hipLaunchKernelGGL(k_calib_march_m<true>, grid, block, 0, ctx->stream, P.d_basins, P.d_chunk_basin, d_active,
+                           P.spinup, P.nmembers, P.npar, d_pars, (const double *)nullptr, (const double *)nullptr,
+                           P.d_dec, P.d_cnt, (double *)nullptr);
+        hipLaunchKernelGGL(k_calib_init_m, dim3((unsigned)((nbm + 63) / 64)), dim3(64), 0, ctx->stream, P.d_basins,
+                           d_active, P.nbasins, P.nmembers, P.d_dec, P.d_cnt, P.d_sm0, P.d_gw0);
+        hipLaunchKernelGGL(k_calib_march_m<false>, grid, block, 0, ctx->stream, P.d_basins, P.d_chunk_basin, d_active,
+                           P.nmonths, P.nmembers, P.npar, d_pars, P.d_sm0, P.d_gw0, (double *)nullptr, (int *)nullptr,
+                           P.d_part);
+        xh_span_end(sp);
+    }
+    {
+        xh_span sp = xh_span_begin(ctx, "calib_kge");
+        const int64_t n = (int64_t)nbm * P.nmonths;
+        hipLaunchKernelGGL(k_calib_series_m, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P.d_basins,
+                           d_active, P.nbasins, P.nmembers, P.nmonths, P.d_part, P.d_series_m);
+        hipLaunchKernelGGL(k_calib_kge_m, dim3((unsigned)((P.nmembers + 63) / 64), (unsigned)P.nbasins), dim3(64), 0,
+                           ctx->stream, d_active, P.nbasins, P.nmonths, P.nmembers, P.d_series_m, P.d_obs, d_ed);
+        xh_span_end(sp);
+    }
+    XH_HIP(ctx, hipGetLastError());
+    return XH_OK;
+}
+
+int xh_calib_series_out(xh_ctx *ctx, const xh_calib_problem &P) {
+    if (!P.member_lanes) return XH_OK;
+    const int64_t n = (int64_t)P.nbasins * P.nmembers * P.nmonths;
+    hipLaunchKernelGGL(k_calib_series_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P.nbasins,
+                       P.nmembers, P.nmonths, P.d_series_m, P.d_series);
+    XH_HIP(ctx, hipGetLastError());
+    return XH_OK;
+}
+
 int xh_calib_enqueue(xh_ctx *ctx, const xh_calib_problem &P, const double *d_pars, const int *d_active, double *d_ed) {
+    if (P.member_lanes) return calib_enqueue_m(ctx, P, d_pars, d_active, d_ed);
     const int nmblocks = (P.nmembers + MB - 1) / MB;
     const size_t nbm = (size_t)P.nbasins * P.nmembers;
     const dim3 grid((unsigned)P.nchunks, (unsigned)nmblocks), block(64);
@@ -344,8 +635,9 @@ extern "C" int xh_calib_objective_multi(xh_ctx *ctx, int32_t nbasins, const int6
     std::vector<xh_calib_basin> basins;
     std::vector<int> chunk_basin;
     size_t bytes = 0;
+    int ml = 0;
     int rc = xh_calib_problem_plan(ctx, nbasins, h_ncell, nmonths, spinup, nmembers, npar, h_pet_t, h_precip_t, h_tmin_t,
-                                   h_area, basins, chunk_basin, &bytes);
+                                   h_area, basins, chunk_basin, &bytes, &ml);
     if (rc) return rc;
     const size_t nbm = (size_t)nbasins * nmembers;
     const size_t io_bytes = ((nbm * npar + nbm) * sizeof(double) + 255) & ~size_t(255);
@@ -357,10 +649,14 @@ extern "C" int xh_calib_objective_multi(xh_ctx *ctx, int32_t nbasins, const int6
     xh_calib_problem P;
     XH_HIP(ctx, hipMemcpyAsync(d_pars, h_pars, sizeof(double) * nbm * npar, hipMemcpyHostToDevice, ctx->stream));
     rc = xh_calib_problem_place(ctx, P, nmonths, spinup, nmembers, npar, basins, chunk_basin, h_obs,
-                                static_cast<char *>(buf) + io_bytes);
+                                static_cast<char *>(buf) + io_bytes, ml);
     if (rc) return rc;
     rc = xh_calib_enqueue(ctx, P, d_pars, nullptr, d_ed);
     if (rc) return rc;
+    if (h_series) {
+        rc = xh_calib_series_out(ctx, P);
+        if (rc) return rc;
+    }
     XH_HIP(ctx, hipMemcpyAsync(h_ed, d_ed, sizeof(double) * nbm, hipMemcpyDeviceToHost, ctx->stream));
     if (h_series)
         XH_HIP(ctx, hipMemcpyAsync(h_series, P.d_series, sizeof(double) * nbm * nmonths, hipMemcpyDeviceToHost, ctx->stream));

@@ -272,8 +272,9 @@ int xh_calib_de_create(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, con
     std::vector<xh_calib_basin> basins;
     std::vector<int> chunk_basin;
     size_t bytes = 0;
+    int ml = 0;
     int rc = xh_calib_problem_plan(ctx, nbasins, h_ncell, nmonths, spinup, nmembers, npar, h_pet_t, h_precip_t, h_tmin_t,
-                                   h_area, basins, chunk_basin, &bytes);
+                                   h_area, basins, chunk_basin, &bytes, &ml);
     if (rc) return rc;
     XH_HIP(ctx, hipSetDevice(ctx->device));
     xh_calib_de *de = new xh_calib_de();
@@ -291,7 +292,7 @@ int xh_calib_de_create(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, con
         }                                                                                               \
     } while (0)
     DE_TRY(hipMalloc(&de->d_problem, bytes));
-    rc = xh_calib_problem_place(ctx, de->P, nmonths, spinup, nmembers, npar, basins, chunk_basin, h_obs, de->d_problem);
+    rc = xh_calib_problem_place(ctx, de->P, nmonths, spinup, nmembers, npar, basins, chunk_basin, h_obs, de->d_problem, ml);
     if (rc) {
         xh_calib_de_destroy(de);
         return rc;

@@ -52,12 +52,13 @@ __device__ __forceinline__ int days_in_month(int year, int moy) {
 // infinity -- every denominator below is guarded or strictly positive) in 6 instructions instead of the ~13 of the
 // correctly rounded sequence.  The kernel is bound by its divisions (~145 per cell-month as written in the reference,
 // ~50 after the regroupings above): 4.9 ms -> 3.7 ms -> 3.1 ms per 67,420 x 600 launch.  PET still agrees with numpy to 5e-13 relative (exp / log dominate; tolerance 1e-6).
-__device__ __forceinline__ double fdiv(double a, double b) {
+__device__ __forceinline__ double frcp(double b) {
     double r = __builtin_amdgcn_rcp(b);
     r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
     r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
-    return a * r;
+    return r;
 }
+__device__ __forceinline__ double fdiv(double a, double b) { return a * frcp(b); }
 
 struct PmCell {          // per-cell quantities shared by the months a thread handles
     double p;            // air pressure (calc_p :185-188)
@@ -188,8 +189,9 @@ __device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_i
             const double inv_rasoil = inv_rtot + inv_rr;              // 1 / (rtot rr / (rtot + rr))
             const double soil_num = 86400.0 * dz * (sx * asoil + rho_cp * (1.0 - fc) * vpd * inv_rasoil);
             const double soil_den = (sx + GAMMA * rtot * inv_rasoil) * LAMBDA1;
-            const double ewet_soil = fdiv(soil_num * fwet, soil_den);      // :314-315
-            const double esoilpot = fdiv(soil_num * one_m_fwet, soil_den); // :316-317
+            const double inv_soil_den = frcp(soil_den);                    // both quotients share the divisor
+            const double ewet_soil = (soil_num * fwet) * inv_soil_den;      // :314-315
+            const double esoilpot = (soil_num * one_m_fwet) * inv_soil_den; // :316-317
             const double esoil = ewet_soil + esoilpot * exp(vpd * L.vec[V_INVBETA][l] * log_r100);   // pow(rh/100, vpd/beta) :323
 
             double trans = fdiv(dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_ra) * one_m_fwet,
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(256) k_pm_pet(const PmTablesDev *__restrict__ 
                                                 const double *__restrict__ rhs, const double *__restrict__ wind,
                                                 const double *__restrict__ rsds, const double *__restrict__ rlds,
                                                 const double *__restrict__ tairprev,
-                                                const double *__restrict__ lct, const double *__restrict__ elev,
+                                                const double *__restrict__ lct, const double *__restrict__ pressure,
                                                 double *__restrict__ pet) {
     __shared__ PmLds L;
     const int nlcs = tab->nlcs;
@@ -262,7 +264,7 @@ __global__ void __launch_bounds__(256) k_pm_pet(const PmTablesDev *__restrict__ 
             totpct = (l == 0) ? v : totpct + v;
         }
         totpct = totpct == 0.0 ? 0.01 : totpct;     // :47
-        const double p = 101325.0 * pow(1.0 - 0.0065 * elev[c] / 288.15, 5.2558);   // calc_p :185-188
+        const double p = pressure[c];               // calc_p (:185-188), once per cell by k_pm_pressure
         double2 out;
         out.x = pm_month(L, nlcs, water_idx, snow_idx, wind_pow, p, T.x, TN.x, RH.x, W.x, RS.x, RL.x, TP.x, moy,
                          (double)days_in_month(year, moy), lct_cell, n_lc_years, totpct);
@@ -270,6 +272,14 @@ __global__ void __launch_bounds__(256) k_pm_pet(const PmTablesDev *__restrict__ 
                          moy + 1, (double)days_in_month(year, moy + 1), lct_cell, n_lc_years, totpct);
         *reinterpret_cast<double2 *>(pet + off) = out;
     }
+}
+
+// calc_p (:185-188): air pressure from elevation, a per-cell constant (the pow() cost every (cell, month pair) ~5 % of
+// the kernel's instructions when it was evaluated in place)
+__global__ void __launch_bounds__(256) k_pm_pressure(int64_t ncell, const double *__restrict__ elev,
+                                                     double *__restrict__ pressure) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ncell) pressure[c] = 101325.0 * pow(1.0 - 0.0065 * elev[c] / 288.15, 5.2558);
 }
 
 int land_cover_index(int year, const std::vector<int> &sorted_years) {   // SetData :33-43
@@ -343,9 +353,12 @@ int xh_pm_prepare(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int32_t nmo
 
     void *d_tab = nullptr;
     const size_t tab_bytes = (sizeof(PmTablesDev) + 255) & ~size_t(255);
-    int rc = xh_scratch(ctx, 0, tab_bytes + sizeof(int) * nyears, &d_tab);
+    const size_t lcy_bytes = (sizeof(int) * nyears + 255) & ~size_t(255);
+    int rc = xh_scratch(ctx, 0, tab_bytes + lcy_bytes + sizeof(double) * ncell, &d_tab);
     if (rc) return rc;
     int *d_lcy = reinterpret_cast<int *>(static_cast<char *>(d_tab) + tab_bytes);
+    out->d_pressure = reinterpret_cast<double *>(static_cast<char *>(d_tab) + tab_bytes + lcy_bytes);
+    out->pressure_done = false;
     XH_HIP(ctx, hipMemcpyAsync(d_tab, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipMemcpyAsync(d_lcy, lc_of_year.data(), sizeof(int) * nyears, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h / lc_of_year are stack/heap locals
@@ -355,7 +368,7 @@ int xh_pm_prepare(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int32_t nmo
     return XH_OK;
 }
 
-int xh_pm_enqueue(xh_ctx *ctx, hipStream_t st, const xh_pm_setup &s, int m_begin, int m_count, const double *d_tas,
+int xh_pm_enqueue(xh_ctx *ctx, hipStream_t st, xh_pm_setup &s, int m_begin, int m_count, const double *d_tas,
                   const double *d_tmin, const double *d_rhs, const double *d_wind, const double *d_rsds,
                   const double *d_rlds, const double *d_tairprev, const double *d_lct, const double *d_elev,
                   double *d_pet) {
@@ -370,9 +383,14 @@ int xh_pm_enqueue(xh_ctx *ctx, hipStream_t st, const xh_pm_setup &s, int m_begin
     const int64_t passes = (need + cap - 1) / cap;
     int64_t blocks = (need + passes - 1) / passes;
     xh_span sp = xh_span_begin_on(ctx, "pm_pet", st);
+    if (!s.pressure_done) {
+        hipLaunchKernelGGL(k_pm_pressure, dim3((unsigned)((s.ncell + 255) / 256)), dim3(256), 0, st, s.ncell, d_elev,
+                           s.d_pressure);
+        s.pressure_done = true;
+    }
     hipLaunchKernelGGL(k_pm_pet, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const PmTablesDev *>(s.d_tab),
                        s.d_lcy, s.ncell, s.nmonths, m_begin, m_count, d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds,
-                       d_tairprev, d_lct, d_elev, d_pet);
+                       d_tairprev, d_lct, s.d_pressure, d_pet);
     xh_span_end(sp);
     XH_HIP(ctx, hipGetLastError());
     return XH_OK;

@@ -9,12 +9,14 @@ struct xh_pm_setup {
     const int *d_lcy = nullptr;       // land-cover column of each year
     int64_t ncell = 0;
     int nmonths = 0;
+    double *d_pressure = nullptr;     // [ncell] calc_p, filled by the first xh_pm_enqueue
+    bool pressure_done = false;
 };
 // Validates, builds the per-class tables and uploads them (waits for the context's stream once).
 int xh_pm_prepare(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int32_t nmonths, int32_t start_year,
                   int32_t n_lc_years, const int32_t *h_lc_years, int32_t water_idx, int32_t snow_idx, xh_pm_setup *out);
 // PET of months [m_begin, m_begin + m_count) (both multiples of 2) of every cell, on stream `st`.
-int xh_pm_enqueue(xh_ctx *ctx, hipStream_t st, const xh_pm_setup &s, int m_begin, int m_count, const double *d_tas,
+int xh_pm_enqueue(xh_ctx *ctx, hipStream_t st, xh_pm_setup &s, int m_begin, int m_count, const double *d_tas,
                   const double *d_tmin, const double *d_rhs, const double *d_wind, const double *d_rsds,
                   const double *d_rlds, const double *d_tairprev, const double *d_lct, const double *d_elev,
                   double *d_pet);
