@@ -158,12 +158,13 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
  *   d_S0 [ncell] or NULL (zeros); outputs d_chstorage / d_avgchflow [ncell, nmonths] (either may be NULL),
  *   d_S_end / d_F_end [ncell] optional.  streamrouting() itself is the nmonths = 1, spinup = 0 case.
  * flags: XH_ROUTE_ATOMIC routes with global fp64 atomic scatter-adds (non bit-reproducible variant).
- * The dataflow kernels (tree networks) keep every unit resident and let units wait for each other, bounded by a
- * timeout proportional to the run's length.  On a device shared with another routing call the units may not all fit:
- * the timeout then raises a sticky device fault, and the next synchronising call (xh_sync, xh_memcpy_d2h) re-routes
- * every call enqueued since the last synchronisation with one workgroup per network (no waits between workgroups)
- * before it returns -- XH_OK if nothing else was enqueued behind the routing, XH_ERR_DEVICE (routing outputs valid,
- * later results not) otherwise.  xh_route_plan_info[14] counts such re-runs.                                  */
+ * The dataflow kernels (tree networks) keep every unit resident and let units wait for each other, each wait bounded
+ * by a 5 s timeout (two orders of magnitude above the kernel's run time at the full grid).  On a device shared with
+ * another routing call the units may not all fit: the timeout then raises a sticky device fault, and the next
+ * synchronising call (xh_sync, xh_memcpy_d2h) re-routes every call enqueued since the last synchronisation with one
+ * workgroup per network (no waits between workgroups) before it returns -- XH_OK if nothing else was enqueued behind
+ * the routing, XH_ERR_DEVICE (routing outputs valid, later results not) otherwise.  xh_route_plan_info[14] counts such
+ * re-runs.                                                                                                       */
 #define XH_ROUTE_DEFAULT 0
 #define XH_ROUTE_FORCE_FALLBACK 1   /* route every network with the global-memory kernels (testing)        */
 #define XH_ROUTE_ATOMIC 2           /* with the fallback: scatter-add outflow with global_atomic_add_f64   */

@@ -58,7 +58,6 @@ struct xh_ctx {
 
 // Device fault word: kernels set it non-zero instead of hanging; the next synchronising call reports XH_ERR_DEVICE.
 int xh_fault_word(xh_ctx *ctx, unsigned **d_word);   // lazily allocated and zeroed ONCE: the word is sticky until a check clears it
-unsigned long long xh_spin_limit_ticks(int64_t total_substeps);   // bound of a wait between routing units, 100 MHz ticks
 int xh_fault_collect(xh_ctx *ctx);                   // enqueue device -> pinned host copy after the kernel
 int xh_fault_check(xh_ctx *ctx);                     // after a stream sync: XH_ERR_DEVICE if the word was set
 

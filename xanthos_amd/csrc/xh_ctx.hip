@@ -45,15 +45,6 @@ int xh_fault_word(xh_ctx *ctx, unsigned **d_word) {
     return XH_OK;
 }
 
-// A unit waits for another only while that one is behind, i.e. at most about the run time of the whole kernel
-// (~0.2 us per sub-step): allow 100x that, at least half a second, at most 20 s.
-unsigned long long xh_spin_limit_ticks(int64_t total_substeps) {
-    const double expected_s = (double)total_substeps * 0.25e-6;
-    double limit = 100.0 * expected_s;
-    limit = limit < 0.5 ? 0.5 : (limit > 20.0 ? 20.0 : limit);
-    return (unsigned long long)(limit * 1e8);
-}
-
 int xh_fault_collect(xh_ctx *ctx) {
     if (!ctx->d_fault) return XH_OK;
     XH_HIP(ctx, hipMemcpyAsync(ctx->h_fault, ctx->d_fault, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));

@@ -47,6 +47,7 @@ constexpr int RING = 4;           // months of stream kept in HBM per edge
 constexpr int PF = 8;             // sub-steps of ghost prefetch held in registers
 constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2;
 constexpr unsigned FAULT_TEST = 99;
+constexpr unsigned long long SPIN_LIMIT_TICKS = 500000000ull;   // 5 s of the 100 MHz real-time counter (see xh_mrtm_skew.hip)
 
 struct FlowArgs {
     const int *cell_of_slot;        // [units*64] global cell id or -1
@@ -67,8 +68,6 @@ struct FlowArgs {
     unsigned *ready;                // [edges] months published
     unsigned *done;                 // [units] months consumed
     unsigned *fault;
-    unsigned long long spin_limit;  // bound of one wait, 100 MHz ticks (xh_spin_limit_ticks)
-    int test_fault;
     unsigned long long *stats;      // [units][6] optional cycle accounting (XH_FLOW_STATS=1)
 };
 
@@ -78,14 +77,14 @@ __device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
 
 // All lanes with `need` wait until *p >= target.  Returns false (and raises the fault word) on timeout / fault.
 __device__ __forceinline__ bool wave_wait_ge(bool need, const unsigned *p, unsigned target, unsigned *fault,
-                                             unsigned code, unsigned long long limit) {
+                                             unsigned code) {
     bool ok = !need;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         if (!ok) ok = ld_relaxed(p) >= target;
         if (__all(ok)) return true;
         if (ld_relaxed(fault) != 0) return false;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > limit) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
             __hip_atomic_store(fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -133,10 +132,6 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
     const double dt = a.dt, dtinv = a.dtinv;
     double qn = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[0]] : 0.0;
     bool alive = true;
-    if (a.test_fault && unit == 0) {      // XH_ROUTE_TEST_FAULT: behave as if a wait had timed out
-        if (lane == 0) __hip_atomic_store(a.fault, FAULT_TEST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        alive = false;
-    }
     unsigned long long cyc_loop = 0, cyc_wait_data = 0, cyc_wait_ring = 0;
     double ob_s[8], ob_a[8];
 #pragma unroll
@@ -154,12 +149,12 @@ __device__ __forceinline__ void flow_unit(const FlowArgs &a, double2 *lds) {
         const int rs = it % RING;
         const unsigned long long w0 = __builtin_amdgcn_s_memtime();
         if (any_g) {      // the streams this unit imports must hold month `it`
-            alive = wave_wait_ge(has_g, ready_p, (unsigned)it + 1u, a.fault, FAULT_DATA_WAIT, a.spin_limit);
+            alive = wave_wait_ge(has_g, ready_p, (unsigned)it + 1u, a.fault, FAULT_DATA_WAIT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         const unsigned long long w1 = __builtin_amdgcn_s_memtime();
         if (any_x && it >= RING && alive)   // ring slot `rs` must have been consumed (month it - RING)
-            alive = wave_wait_ge(has_x, done_p, (unsigned)(it - RING) + 1u, a.fault, FAULT_RING_WAIT, a.spin_limit);
+            alive = wave_wait_ge(has_x, done_p, (unsigned)(it - RING) + 1u, a.fault, FAULT_RING_WAIT);
         cyc_wait_data += w1 - w0;
         cyc_wait_ring += __builtin_amdgcn_s_memtime() - w1;
         if (!alive) break;
@@ -792,8 +787,9 @@ int flow_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     int rc = xh_fault_word(ctx, &fault);
     if (rc) return rc;
     a.fault = fault;
-    a.spin_limit = xh_spin_limit_ticks(s.total);
-    a.test_fault = s.test_fault ? 1 : 0;
+    // XH_ROUTE_TEST_FAULT raises the fault word before the launch, as a timed-out wait of another unit would: every
+    // unit that has to wait gives up and the call is re-routed.
+    if (s.test_fault) XH_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fault), (int)FAULT_TEST, 1, st));
     a.stats = nullptr;
     {
         const char *env = getenv("XH_FLOW_STATS");

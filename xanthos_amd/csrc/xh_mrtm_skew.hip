@@ -67,8 +67,6 @@ struct SkewArgs {
     unsigned *ready;                  // [edges] sub-steps published
     unsigned *done;                   // [units] sub-steps consumed
     unsigned *fault;
-    unsigned long long spin_limit;    // bound of one wait, 100 MHz ticks (xh_spin_limit_ticks)
-    int test_fault;
     unsigned long long *stats;
 };
 
@@ -76,11 +74,19 @@ __device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Bound of one wait: 5 s of the 100 MHz real-time counter.  A unit waits for another only while that one is behind,
+// i.e. at most about the run time of the whole kernel (35 ms for 67,420 cells x 720 months), so this is two orders of
+// magnitude of slack; when it does expire (units of two dataflow kernels sharing the device) the call is re-routed
+// with one workgroup per network (xh_fault_check), so a wrong guess costs time, not results.  It is a literal on
+// purpose: passing the bound in (kernel argument, fault block, or derived from the sub-step count) kept one more
+// scalar live through the sub-step loop and cost 2-5 % of the kernel in spills (measured: 32.3 / 33.0 / 35.1 ms).
+constexpr unsigned long long SPIN_LIMIT_TICKS = 500000000ull;
+
 // Lanes with `need` wait until *p >= target (per lane); `seen` keeps the last value each lane read, so that the next
 // check can skip the poll (a counter only grows; one poll is an agent-coherent load, ~1-2 us).  False (and the fault
 // word raised) on timeout / fault.
 __device__ __forceinline__ bool wave_wait_ge(bool need, const unsigned *p, unsigned target, unsigned &seen,
-                                             unsigned *fault, unsigned code, unsigned long long limit) {
+                                             unsigned *fault, unsigned code) {
     bool ok = !need || seen >= target;
     if (__all(ok)) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -91,7 +97,7 @@ __device__ __forceinline__ bool wave_wait_ge(bool need, const unsigned *p, unsig
         }
         if (__all(ok)) return true;
         if (ld_relaxed(fault) != 0) return false;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > limit) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
             __hip_atomic_store(fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -201,8 +207,7 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
             if (has_x) __hip_atomic_store(a.ready + xedge, (unsigned)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int need = n + CH - lmax - a.rs;
             if (need > 0)
-                alive = wave_wait_ge(has_x, done_p, (unsigned)min(need, total), seen_done, a.fault, FAULT_RING_WAIT,
-                                     a.spin_limit);
+                alive = wave_wait_ge(has_x, done_p, (unsigned)min(need, total), seen_done, a.fault, FAULT_RING_WAIT);
         }
         const unsigned long long w1 = __builtin_amdgcn_s_memtime();
         if (any_g && alive) {   // the next CH iterations load up to sub-step n + CH + GROUP - 1 - lag_g
@@ -210,8 +215,7 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
                 __hip_atomic_store(a.done + unit, (unsigned)min(max(n - glmax, 0), total), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             const int need = min(total, n + CH + GROUP - lag_g);
-            alive = wave_wait_ge(has_g && need > 0, ready_p, (unsigned)max(need, 0), seen_ready, a.fault, FAULT_DATA_WAIT,
-                                 a.spin_limit);
+            alive = wave_wait_ge(has_g && need > 0, ready_p, (unsigned)max(need, 0), seen_ready, a.fault, FAULT_DATA_WAIT);
             asm volatile("" ::: "memory");      // the stream loads stay behind the poll
         }
         cyc_wait_ring += w1 - w0;
@@ -282,11 +286,7 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
             }
     };
 
-    if (a.test_fault && unit == 0) {      // XH_ROUTE_TEST_FAULT: behave as if a wait had timed out
-        if (lane == 0) __hip_atomic_store(a.fault, FAULT_TEST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        alive = false;
-    }
-    if (alive) check(0);
+    check(0);
 #pragma unroll
     for (int r = 0; r < SK_R; ++r) {
         gbuf[0][r] = HAS_G ? import_load(r, 0) : v2d{0.0, 0.0};
@@ -516,8 +516,9 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     int rc = xh_fault_word(ctx, &fault);
     if (rc) return rc;
     a.fault = fault;
-    a.spin_limit = xh_spin_limit_ticks(s.total);
-    a.test_fault = s.test_fault ? 1 : 0;
+    // XH_ROUTE_TEST_FAULT raises the fault word before the launch, as a timed-out wait of another unit would: every
+    // unit that has to wait gives up and the call is re-routed.
+    if (s.test_fault) XH_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fault), (int)FAULT_TEST, 1, st));
     a.stats = nullptr;
     {
         const char *env = getenv("XH_FLOW_STATS");

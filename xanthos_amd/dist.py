@@ -182,6 +182,7 @@ class OutputGather:
 
     def run(self):
         if self.kind == 'rccl':
+            self.ctx.sync()       # settles a routing fault (re-route) before the rows leave; ~10 us when there is none
             self.comm.gather_rows([self.pipe.out[k] for k in self.names], self.counts, self.pipe.nmonths,
                                   perm=self.d_perm, out=None if self.out is None else [self.out[k] for k in self.names],
                                   root=self.root)
