@@ -168,7 +168,8 @@ def test_config1_run_model_full_grid(tmp_path):
     assert rel(res.PET, pet) < 1e-9
     _, aet, q, sav = o_abcd.abcd_execute(w.n_basins, w.basin_ids, res.PET, f['precip'], np.nan_to_num(f['abcd_tmin']),
                                          w.abcd_pars, nm, 25, -1)
-    assert rel(res.AET, aet) < 1e-9 and rel(res.Q, q) < 1e-9 and rel(res.Sav, sav) < 1e-9
+    # chained run at full size: the ABCD cancellation (y = rpt - sqrt(...)) leaves up to ~5e-8; the gate is 1e-6
+    assert rel(res.AET, aet) < 2e-7 and rel(res.Q, q) < 2e-7 and rel(res.Sav, sav) < 2e-7
     assert np.nanmin(res.Q) >= 0 and np.isnan(res.Q).any()                  # NaN-precipitation cells stay NaN
     st = SimpleNamespace(ngridrow=w.nrow, ngridcol=w.ncol)
     um = o_mrtm.upstream_genmatrix(o_mrtm.upstream(w.coords, o_mrtm.downstream(w.coords, w.flow_dir, st), st))

@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) k_calib_kge(const int *__restrict__ activ
 // instructions of accumulation: the sum over the wave's cells is a plain per-lane sum, no cross-lane reduction.
 // ~100 wave-instructions per member-cell-month against ~145 in the cell-lane kernel (whose DPP wave sum alone costs
 // 25 per member and month).  The price is a population that fills whole waves of 64 members.
-constexpr int CM = 16;   // cells per wave: 48 doubles of state per lane
+constexpr int CM = 8;    // cells per wave: 24 doubles of state per lane
 
 __global__ void __launch_bounds__(256) k_calib_split(const xh_calib_basin *__restrict__ basins, int nmonths) {
     const xh_calib_basin B = basins[blockIdx.y];

@@ -36,8 +36,11 @@ struct PmTablesDev {
     double one_m_alpha[XH_MAX_LCS][12], lai[XH_MAX_LCS][12], fc[XH_MAX_LCS][12];
 };
 
+// The per-(class, month) tables are indexed by the thread's month and live in LDS; the per-class vectors are indexed by
+// the class loop counter alone, i.e. wave-uniform: they are read straight from the (read-only, restrict) table in global
+// memory, which the compiler turns into scalar loads -- as LDS reads they were 85 % of the kernel's 46 M LDS
+// wave-instructions, each ~16 cycles of a lone wave's issue.
 struct PmLds {
-    double vec[PM_NVEC][XH_MAX_LCS];
     double one_m_alpha[XH_MAX_LCS][12], lai[XH_MAX_LCS][12], fc[XH_MAX_LCS][12];
 };
 
@@ -65,7 +68,8 @@ struct PmCell {          // per-cell quantities shared by the months a thread ha
 };
 
 // One (cell, month): returns PET. lctw[l] = land-cover fraction of class l, totpct = their sum (0 -> 0.01).
-__device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_idx, int snow_idx, double wind_pow,
+__device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__restrict__ tab, int nlcs, int water_idx,
+                                           int snow_idx, double wind_pow,
                                            double p, double T, double TN, double RH, double W, double RS,
                                            double RL, double TP, int moy, double dz,
                                            const double *__restrict__ lct_cell, int lct_stride, double totpct) {
@@ -131,25 +135,25 @@ __device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_i
             et = et < 0.0 ? 0.0 : et;
         } else {
             // et_veg (:223-334)
-            const double topen = L.vec[V_TOPEN][l], tclose = L.vec[V_TCLOSE][l];
+            const double topen = tab->vec[V_TOPEN][l], tclose = tab->vec[V_TCLOSE][l];
             double mtmin = 0.0;                                       // calc_mtmin :102-114
             mtmin = TN >= topen ? 1.0 : mtmin;
             mtmin = TN <= tclose ? 0.1 : mtmin;
-            mtmin = (TN < topen && TN > tclose) ? (TN - tclose) * L.vec[V_INVTSPAN][l] : mtmin;
-            const double vclose = L.vec[V_VCLOSE][l], vopen = L.vec[V_VOPEN][l], inv_vspan = L.vec[V_INVVSPAN][l];
+            mtmin = (TN < topen && TN > tclose) ? (TN - tclose) * tab->vec[V_INVTSPAN][l] : mtmin;
+            const double vclose = tab->vec[V_VCLOSE][l], vopen = tab->vec[V_VOPEN][l], inv_vspan = tab->vec[V_INVVSPAN][l];
             const bool vmid = (vpd > vopen) && (vpd < vclose);
             double mvpd = vpd;                                        // calc_vpd :117-129
             mvpd = vpd <= vopen ? 1.0 : mvpd;
             mvpd = vpd >= vclose ? 0.1 : mvpd;
             mvpd = vmid ? (vclose - vpd) * inv_vspan : mvpd;
-            const double gs1 = L.vec[V_CL][l] * mtmin * mvpd * rcorr;    // :242
-            const double rblmin = L.vec[V_RBLMIN][l], rblmax = L.vec[V_RBLMAX][l];
+            const double gs1 = tab->vec[V_CL][l] * mtmin * mvpd * rcorr;    // :242
+            const double rblmin = tab->vec[V_RBLMIN][l], rblmax = tab->vec[V_RBLMAX][l];
             double rtotc = 0.0;                                       // calc_rtotc :132-145
             rtotc = vpd <= vopen ? rblmax : rtotc;
             rtotc = vpd >= vclose ? rblmin : rtotc;
-            rtotc = vmid ? rblmax - L.vec[V_RBLSPAN][l] * (vclose - vpd) * inv_vspan : rtotc;
+            rtotc = vmid ? rblmax - tab->vec[V_RBLSPAN][l] * (vclose - vpd) * inv_vspan : rtotc;
 
-            const double rnl = sig_t4 * L.vec[V_EMISS][l] * dz - rl_term;  // calc_a :148-162
+            const double rnl = sig_t4 * tab->vec[V_EMISS][l] * dz - rl_term;  // calc_a :148-162
             const double rn = oma * RS * 86400.0 * dz - rnl;
             const double a = rn * inv_secs;
 
@@ -158,7 +162,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_i
             const double asoil = (1.0 - fc) * a - g;
             double rtot = rtotc * rcorr;
             rtot = rtot > 80.0 ? 80.0 : rtot;
-            const double rc = L.vec[V_RC][l], inv_rc = L.vec[V_INVRC][l], rslimit = L.vec[V_RSLIMIT][l];
+            const double rc = tab->vec[V_RC][l], inv_rc = tab->vec[V_INVRC][l], rslimit = tab->vec[V_RSLIMIT][l];
             // Resistances in parallel / capped: only their reciprocals are used below, so they are formed directly:
             // 1 / (x rr / (x + rr)) = 1/x + 1/rr, and min(r, rtot) becomes max(1/r, 1/rtot) (same NaN selection).
             const double inv_rtot = fdiv(1.0, rtot);
@@ -174,7 +178,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_i
 
             const double lf = lai * fwet;                             // :296-301
             const double lai_fwet = lf == 0.0 ? 1.0 : lf;
-            const double inv_rslimit = L.vec[V_INVRSLIMIT][l];
+            const double inv_rslimit = tab->vec[V_INVRSLIMIT][l];
             double rhc = lai > 0.00001 ? fdiv(rc, lai_fwet) : rslimit;
             double inv_rhc = lai > 0.00001 ? lai_fwet * inv_rc : inv_rslimit;
             inv_rhc = rhc > rslimit ? inv_rslimit : inv_rhc;
@@ -192,7 +196,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_i
             const double inv_soil_den = frcp(soil_den);                    // both quotients share the divisor
             const double ewet_soil = (soil_num * fwet) * inv_soil_den;      // :314-315
             const double esoilpot = (soil_num * one_m_fwet) * inv_soil_den; // :316-317
-            const double esoil = ewet_soil + esoilpot * exp(vpd * L.vec[V_INVBETA][l] * log_r100);   // pow(rh/100, vpd/beta) :323
+            const double esoil = ewet_soil + esoilpot * exp(vpd * tab->vec[V_INVBETA][l] * log_r100);   // pow(rh/100, vpd/beta) :323
 
             double trans = fdiv(dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_ra) * one_m_fwet,
                                 (sx + GAMMA * (1.0 + rs * inv_ra)) * LAMBDA1);                   // :326-327
@@ -207,7 +211,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, int nlcs, int water_i
 }
 
 // Thread <-> (cell, pair of consecutive months). nmonths is a multiple of 12, hence even.
-__global__ void __launch_bounds__(256) k_pm_pet(const PmTablesDev *__restrict__ tab,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_pm_pet(const PmTablesDev *__restrict__ tab,
                                                 const int *__restrict__ lc_of_year, int64_t ncell, int nmonths,
                                                 int m_begin, int m_count, const double *__restrict__ tas, const double *__restrict__ tmin,
                                                 const double *__restrict__ rhs, const double *__restrict__ wind,
@@ -218,10 +222,6 @@ __global__ void __launch_bounds__(256) k_pm_pet(const PmTablesDev *__restrict__ 
     __shared__ PmLds L;
     const int nlcs = tab->nlcs;
     {
-        for (int i = threadIdx.x; i < PM_NVEC * XH_MAX_LCS; i += blockDim.x) {
-            const int v = i / XH_MAX_LCS, l = i % XH_MAX_LCS;
-            if (l < nlcs) L.vec[v][l] = tab->vec[v][l];
-        }
         for (int i = threadIdx.x; i < nlcs * 12; i += blockDim.x) {
             const int l = i / 12, m = i % 12;
             L.one_m_alpha[l][m] = tab->one_m_alpha[l][m];
@@ -266,9 +266,9 @@ __global__ void __launch_bounds__(256) k_pm_pet(const PmTablesDev *__restrict__ 
         totpct = totpct == 0.0 ? 0.01 : totpct;     // :47
         const double p = pressure[c];               // calc_p (:185-188), once per cell by k_pm_pressure
         double2 out;
-        out.x = pm_month(L, nlcs, water_idx, snow_idx, wind_pow, p, T.x, TN.x, RH.x, W.x, RS.x, RL.x, TP.x, moy,
+        out.x = pm_month(L, tab, nlcs, water_idx, snow_idx, wind_pow, p, T.x, TN.x, RH.x, W.x, RS.x, RL.x, TP.x, moy,
                          (double)days_in_month(year, moy), lct_cell, n_lc_years, totpct);
-        out.y = pm_month(L, nlcs, water_idx, snow_idx, wind_pow, p, T.y, TN.y, RH.y, W.y, RS.y, RL.y, TP.y,
+        out.y = pm_month(L, tab, nlcs, water_idx, snow_idx, wind_pow, p, T.y, TN.y, RH.y, W.y, RS.y, RL.y, TP.y,
                          moy + 1, (double)days_in_month(year, moy + 1), lct_cell, n_lc_years, totpct);
         *reinterpret_cast<double2 *>(pet + off) = out;
     }
