@@ -491,7 +491,19 @@ class Comm:
     def __init__(self, ctx, nranks, rank, unique_id):
         self.ctx, self.nranks, self.rank = ctx, int(nranks), int(rank)
         h = c_void_p()
-        ctx._check(lib().xh_comm_create(ctx.handle, self.nranks, self.rank, unique_id, len(unique_id), byref(h)))
+        # RCCL prints a version banner on stdout when a communicator is created; stdout belongs to the caller (bench.py
+        # prints ONE JSON line there), so the banner is sent to stderr
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            rc = lib().xh_comm_create(ctx.handle, self.nranks, self.rank, unique_id, len(unique_id), byref(h))
+            ctypes.CDLL(None).fflush(None)          # the banner sits in C stdio's buffer until flushed
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        ctx._check(rc)
         self.handle = h.value
 
     def gather_rows(self, local, counts, ncols, perm=None, out=None, root=0):
