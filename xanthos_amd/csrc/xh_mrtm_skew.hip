@@ -198,6 +198,15 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
     // ---- flow control, every CH iterations, at a group start.  Every block of 8 iterations issues at least one
     //      stream access, so "all but the 8 youngest memory operations have completed" covers every store older than
     //      PUBLAG iterations without draining the loads that are two blocks ahead.
+    //      MEMORY-ORDERING ASSUMPTION (outside the HIP memory model, stated here because everything rests on it): the
+    //      stream stores are write-through `sc1` buffer stores; vmcnt retires this wave's memory operations in issue
+    //      order and a write-through store retires only when the memory side has acknowledged it, so after
+    //      `s_waitcnt vmcnt(8)` every store older than PUBLAG iterations is visible at agent scope; only then is the
+    //      counter advanced (relaxed agent-scope store, itself ordered behind the waitcnt by the "memory" clobber).  A
+    //      consumer reads the counter with an agent-scope load and the data with `sc1` loads, which re-fetch past its
+    //      XCD's L2.  No release / acquire fences (an agent-scope release writes back the XCD's whole L2: -10 %).
+    //      Evidence: 25 full-size launches per suite run bit-identical to the oracle, two contexts routing concurrently,
+    //      the 800-case fuzzer; a violation would show as a wrong bit, and a lost wake-up as a bounded-wait fault.
     unsigned seen_ready = 0, seen_done = 0;
     auto check = [&](int n) {
         const unsigned long long w0 = __builtin_amdgcn_s_memtime();
