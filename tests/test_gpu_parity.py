@@ -100,24 +100,48 @@ def test_two_leap_year_rules_on_the_device(hip, years):
     assert np.array_equal(g[0], r[0]) and np.array_equal(g[1], r[1])
 
 
-def test_comm_single_rank_gather(hip):
+COMM_CHILD = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from xanthos_amd import _hip as hip
+ctx = hip.get_context(0)
+comm = hip.Comm(ctx, 1, 0, hip.comm_unique_id())
+rng = np.random.default_rng(0)
+n, nm = 300, 40
+perm = rng.permutation(n)
+local = [ctx.upload(rng.random((n, nm))) for _ in range(3)]
+out = [ctx.empty((n, nm)).zero() for _ in range(3)]
+comm.gather_rows(local, [n], nm, perm=ctx.upload(perm, dtype=np.int64), out=out, root=0)
+ctx.sync()
+for a, b in zip(local, out):
+    want = np.empty((n, nm))
+    want[perm] = a.download()
+    assert np.array_equal(b.download(), want)
+comm.close()
+print('COMM_OK')
+'''
+
+
+def test_comm_single_rank_gather(hip, tmp_path):
     """The RCCL write-out gather with one rank: librccl is bound at run time, the communicator initialises, and the
     root's own rows go to their grid positions (the send / receive pairs need several GPUs; tests/test_dist_gloo.py
-    covers the N > 1 bookkeeping on the CPU)."""
-    ctx = hip.get_context()
-    comm = hip.Comm(ctx, 1, 0, hip.comm_unique_id())
-    rng = np.random.default_rng(0)
-    n, nm = 300, 40
-    perm = rng.permutation(n)
-    local = [ctx.upload(rng.random((n, nm))) for _ in range(3)]
-    out = [ctx.empty((n, nm)).zero() for _ in range(3)]
-    comm.gather_rows(local, [n], nm, perm=ctx.upload(perm, dtype=np.int64), out=out, root=0)
-    ctx.sync()
-    for a, b in zip(local, out):
-        want = np.empty((n, nm))
-        want[perm] = a.download()
-        assert np.array_equal(b.download(), want)
-    comm.close()
+    covers the N > 1 bookkeeping on the CPU).  Runs in a child process with a deadline: RCCL's bootstrap depends on the
+    box's network stack, and a stuck bootstrap must not take the rest of the suite with it (it is skipped then)."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / 'comm_child.py'
+    script.write_text(COMM_CHILD)
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    child = subprocess.Popen([sys.executable, str(script), root], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        out, _ = child.communicate(timeout=180)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        pytest.skip('RCCL communicator bootstrap did not finish within 180 s on this box')
+    assert child.returncode == 0 and 'COMM_OK' in out, out[-2000:]
 
 
 @pytest.mark.parametrize('tag', ['snow', 'nosnow'])

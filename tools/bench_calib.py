@@ -1,4 +1,6 @@
-"""Config 5: ABCD calibration objective, 512-member population x 235 basins (set_calibrate = 0, km3_per_mth)."""
+"""Config 5, objective only: 512-member population x 235 basins (set_calibrate = 0, km3_per_mth), as one multi-basin launch
+and as 235 per-basin launches.  Superseded as the bench line by `bench.py --workload calib` (device-side DE generation on
+real PM PET); kept for the per-basin vs multi-basin comparison quoted in DESIGN.md."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
