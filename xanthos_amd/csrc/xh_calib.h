@@ -21,7 +21,7 @@ struct xh_calib_problem {
     // scalar loads, no cross-lane sums (populations that fill waves of 64 members: 100 instead of 145 wave-instructions
     // per member-cell-month).  Chosen by xh_calib_problem_plan; the work arrays below are laid out accordingly.
     int member_lanes = 0;
-    bool split_done = false;                  // member-lane layout: rain / snow split computed
+    mutable bool split_done = false;          // member-lane layout: rain / snow split computed (set by the first enqueue)
     xh_calib_basin *d_basins = nullptr;
     int *d_chunk_basin = nullptr;
     double *d_obs = nullptr;                  // [nbasins, nmonths]

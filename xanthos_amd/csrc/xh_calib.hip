@@ -561,7 +561,7 @@ static int calib_enqueue_m(xh_ctx *ctx, const xh_calib_problem &P, const double 
         xh_span sp = xh_span_begin(ctx, "calib_abcd");
         if (!P.split_done) {
             hipLaunchKernelGGL(k_calib_split, dim3(256, (unsigned)P.nbasins), dim3(256), 0, ctx->stream, P.d_basins, P.nmonths);
-            const_cast<xh_calib_problem &>(P).split_done = true;
+            P.split_done = true;
         }
         hipLaunchKernelGGL(k_calib_march_m<true>, grid, block, 0, ctx->stream, P.d_basins, P.d_chunk_basin, d_active,
                            P.spinup, P.nmembers, P.npar, d_pars, (const double *)nullptr, (const double *)nullptr,

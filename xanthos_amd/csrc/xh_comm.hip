@@ -15,6 +15,8 @@
 // RCCL is bound at run time (dlopen of librccl.so.1, the soname PyTorch-ROCm also loads, so a process that already
 // runs torch.distributed shares one RCCL): single-GPU users of libxanthos_hip.so do not need it at all.
 #include <dlfcn.h>
+
+#include <mutex>
 #include <rccl/rccl.h>
 
 #include "xh_common.h"
@@ -34,9 +36,16 @@ struct RcclApi {
     std::string error;
 };
 
+void rccl_load(RcclApi &api);
+
 RcclApi &rccl() {
     static RcclApi api;
-    if (api.handle || !api.error.empty()) return api;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_load(api); });
+    return api;
+}
+
+void rccl_load(RcclApi &api) {
     const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char *n : names) {
         api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -44,7 +53,7 @@ RcclApi &rccl() {
     }
     if (!api.handle) {
         api.error = std::string("cannot load librccl.so.1: ") + dlerror();
-        return api;
+        return;
     }
     auto sym = [&](const char *name) {
         void *p = dlsym(api.handle, name);
@@ -59,7 +68,6 @@ RcclApi &rccl() {
     api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
     api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
-    return api;
 }
 
 }  // namespace
