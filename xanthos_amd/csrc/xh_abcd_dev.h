@@ -7,6 +7,8 @@ namespace xh_abcd_dev {
 
 constexpr double TRAIN = 2.5;   // abcd.py:99
 constexpr double TSNOW = 0.6;   // abcd.py:100
+constexpr double TSPAN = TRAIN - TSNOW;        // the divisor of the mixed rain / snow class (:160, :192), as numpy forms it
+constexpr double INV_TSPAN = 1.0 / TSPAN;
 
 struct AbcdPar {
     double a2, b, b_over_a, c, d, d1, m;
@@ -31,6 +33,22 @@ __device__ __forceinline__ void finish_par(AbcdPar &P, double a) {
 __device__ __forceinline__ double quot(double x, double d, double inv_d) {
     const double q = x * inv_d;
     return __builtin_fma(__builtin_fma(-d, q, x), inv_d, q);
+}
+
+// sqrt for the month update.  The library's f64 sqrt is v_rsq_f64 + the Goldschmidt / Newton steps below, wrapped in a
+// rescaling for arguments below 2^-767 and a class test (22 instructions); its argument here, rpt^2 - w b / a, is zero
+// or of ordinary magnitude, so the same steps run bare (10 instructions + the zero / infinity select): identical
+// results, correctly rounded, 9 instructions fewer on the march's dependent chain.  Negative -> NaN like sqrt.
+__device__ __forceinline__ double xh_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y, h0 = 0.5 * y;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-g1, g1, x);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, x);
+    const double g3 = __builtin_fma(d1, h1, g2);
+    return (x == 0.0 || x == __builtin_inf()) ? x : g3;
 }
 
 struct AbcdState {
@@ -59,10 +77,12 @@ __device__ __forceinline__ void abcd_split(bool snow_on, double precip, double t
         const bool allrain = tmin > TRAIN;
         const bool mixed = (tmin <= TRAIN) && (tmin >= TSNOW);
         const bool allsnow = tmin < TSNOW;
-        frac = (TRAIN - tmin) / (TRAIN - TSNOW);
+        // both quotients have the constant divisor 1.9: reciprocal + one residual correction (quot) gives the correctly
+        // rounded quotient in 3 instructions instead of the 12 of a general division
+        frac = quot(TRAIN - tmin, TSPAN, INV_TSPAN);
         rain = 0.0;
         if (mixed) {
-            snow = precip * (TRAIN - tmin) / (TRAIN - TSNOW);
+            snow = quot(precip * (TRAIN - tmin), TSPAN, INV_TSPAN);
             rain = precip - snow;
         }
         if (allrain) rain = precip;
@@ -94,7 +114,7 @@ __device__ __forceinline__ void abcd_step(const AbcdPar &P, AbcdState &s, bool s
     }
     const double w = first ? r.rain + s.sm : r.rain + s.sm + snm;     // :200-203
     const double rpt = quot(w + P.b, P.a2, P.inv_a2);                 // :206-207
-    const double y = rpt - sqrt(rpt * rpt - (w * P.b_over_a));        // :208
+    const double y = rpt - xh_sqrt(rpt * rpt - (w * P.b_over_a));     // :208
     const double sm1 = y * r.decay;                                   // :211
     const double awet = w - y;
     const double c_awet = P.c * awet;
