@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(64) k_abcd(int64_t ncell, int nmonths, int nst
     if (c >= ncell) return;
     const bool snow_on = tmin != nullptr;
     const AbcdPar P = load_par(pars, par_index[c], snow_on);
+    const XhExpConsts K = xh_exp_consts();
     AbcdState s;
     s.snowpack = 0.0;                                                 // SN0 (:98); also reset before simulate()
     if (SPINUP) {
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(64) k_abcd(int64_t ncell, int nmonths, int nst
         double oa[TM], oq[TM], os[TM];
         AbcdPre pre[TM];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) pre[j] = abcd_pre(P, snow_on, tl.pet[j], tl.pr[j], tl.tn[j]);   // independent: ILP
+        for (int j = 0; j < TM; ++j) pre[j] = abcd_pre(P, K, snow_on, tl.pet[j], tl.pr[j], tl.tn[j]);   // independent: ILP
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             abcd_step(P, s, snow_on, (m0 + j) == 0, pre[j], oa[j], oq[j]);
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(64) k_abcd(int64_t ncell, int nmonths, int nst
     }
     for (int m = ntiles * TM; m < nsteps; ++m) {                      // tail months (spin-up length is arbitrary)
         double oa, oq;
-        abcd_month(P, s, snow_on, m == 0, pet[row + m], precip[row + m], tmin ? tmin[row + m] : 0.0, oa, oq);
+        abcd_month(P, K, s, snow_on, m == 0, pet[row + m], precip[row + m], tmin ? tmin[row + m] : 0.0, oa, oq);
         if (SPINUP) {
             const int k = (m == nsteps - 1) ? 0 : ((m == nsteps - 13) ? 1 : ((m == nsteps - 25) ? 2 : -1));
             if (k >= 0) {
@@ -190,6 +191,7 @@ __global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, in
     const bool mine = lane < CPW && c < ncell;
     const int64_t cc = mine ? c : (ncell - 1);
     const AbcdPar P = load_par(pars, par_index[cc], snow_on);
+    const XhExpConsts K = xh_exp_consts();
     const int shift = (int)((cc * (int64_t)nmonths) & (TMS - 1));
     AbcdState s;
     s.snowpack = 0.0;
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, in
                 if (mbase + h >= m_begin && mbase + h + 8 <= m_end) {             // all eight months belong to this block
                     AbcdPre pre[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pre[j] = abcd_pre(P, snow_on, ipet[j], ipr[j], itn[j]);
+                    for (int j = 0; j < 8; ++j) pre[j] = abcd_pre(P, K, snow_on, ipet[j], ipr[j], itn[j]);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int m = mbase + h + j;
@@ -260,7 +262,7 @@ __global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, in
                         const int m = mbase + h + j;
                         if (m >= m_begin && m < m_end) {
                             double oa, oq;
-                            abcd_month(P, s, snow_on, m == 0, ipet[j], ipr[j], itn[j], oa, oq);
+                            abcd_month(P, K, s, snow_on, m == 0, ipet[j], ipr[j], itn[j], oa, oq);
                             if (SPINUP) {
                                 const int k = (m == nsteps - 1) ? 0 : ((m == nsteps - 13) ? 1 : ((m == nsteps - 25) ? 2 : -1));
                                 if (k >= 0) {

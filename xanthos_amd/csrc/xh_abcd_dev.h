@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "xh_math.h"
+
 namespace xh_abcd_dev {
 
 constexpr double TRAIN = 2.5;   // abcd.py:99
@@ -91,10 +93,11 @@ __device__ __forceinline__ void abcd_split(bool snow_on, double precip, double t
     }
 }
 
-__device__ __forceinline__ AbcdPre abcd_pre(const AbcdPar &P, bool snow_on, double pet, double precip, double tmin) {
+__device__ __forceinline__ AbcdPre abcd_pre(const AbcdPar &P, const XhExpConsts &K, bool snow_on, double pet, double precip,
+                                            double tmin) {
     AbcdPre r;
     r.pet = pet;
-    r.decay = exp(quot(-pet, P.b, P.inv_b));                          // :211
+    r.decay = xh_exp(quot(-pet, P.b, P.inv_b), K);                    // :211
     abcd_split(snow_on, precip, tmin, r.rain, r.snow, r.frac, r.kind);
     return r;
 }
@@ -127,9 +130,9 @@ __device__ __forceinline__ void abcd_step(const AbcdPar &P, AbcdState &s, bool s
     q = (awet - c_awet) + P.d * s.gw;                                 // :228
 }
 
-__device__ __forceinline__ void abcd_month(const AbcdPar &P, AbcdState &s, bool snow_on, bool first, double pet,
-                                           double precip, double tmin, double &aet, double &q) {
-    const AbcdPre r = abcd_pre(P, snow_on, pet, precip, tmin);
+__device__ __forceinline__ void abcd_month(const AbcdPar &P, const XhExpConsts &K, AbcdState &s, bool snow_on, bool first,
+                                           double pet, double precip, double tmin, double &aet, double &q) {
+    const AbcdPre r = abcd_pre(P, K, snow_on, pet, precip, tmin);
     abcd_step(P, s, snow_on, first, r, aet, q);
 }
 

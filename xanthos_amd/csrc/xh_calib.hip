@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(64) k_calib_march(const CalibBasin *__restrict
 
     AbcdPar P[MB];
     AbcdState s[MB];
+    const XhExpConsts K = xh_exp_consts();
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
         const int mem = min(mb0 + j, nmembers - 1);
@@ -114,11 +115,11 @@ __global__ void __launch_bounds__(64) k_calib_march(const CalibBasin *__restrict
         }
         const int k = SPINUP ? ((m == nsteps - 1) ? 0 : ((m == nsteps - 13) ? 1 : ((m == nsteps - 25) ? 2 : -1))) : -1;
         // the rain / snow split does not depend on the member: evaluate it once, then only exp(-PET/b) per member
-        AbcdPre pre = abcd_pre(P[0], snow_on, pet_c, pr_c, tn_c);
+        AbcdPre pre = abcd_pre(P[0], K, snow_on, pet_c, pr_c, tn_c);
 #pragma unroll
         for (int j = 0; j < MB; ++j) {
             double aet, q;
-            if (j > 0) pre.decay = exp(quot(-pet_c, P[j].b, P[j].inv_b));
+            if (j > 0) pre.decay = xh_exp(quot(-pet_c, P[j].b, P[j].inv_b), K);
             abcd_step(P[j], s[j], snow_on, m == 0, pre, aet, q);
             if (SPINUP) {
                 if (k >= 0) {                                    // wave-uniform
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(256) k_calib_split(const xh_calib_basin *__res
 
 // grid.x = CM-cell chunks of all basins, grid.y = blocks of 64 members; one wave per block
 template <bool SPINUP>
-__global__ void __launch_bounds__(64) k_calib_march_m(const xh_calib_basin *__restrict__ basins,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) k_calib_march_m(const xh_calib_basin *__restrict__ basins,
                                                       const int *__restrict__ chunk_basin,
                                                       const int *__restrict__ active, int nsteps, int nmembers, int npar,
                                                       const double *__restrict__ pars, const double *__restrict__ sm0,
@@ -283,6 +284,7 @@ __global__ void __launch_bounds__(64) k_calib_march_m(const xh_calib_basin *__re
     const int mem = ok ? mem_raw : nmembers - 1;
     const bool snow_on = B.tn != nullptr;
     const AbcdPar P = member_par(pars, npar, b * nmembers + mem);
+    const XhExpConsts K = xh_exp_consts();
     AbcdState s[CM];
 #pragma unroll
     for (int j = 0; j < CM; ++j) {
@@ -293,45 +295,54 @@ __global__ void __launch_bounds__(64) k_calib_march_m(const xh_calib_basin *__re
     const double *__restrict__ pet_t = B.pet, *__restrict__ rain_t = B.rain, *__restrict__ snow_t = B.snow,
                  *__restrict__ frac_t = B.frac, *__restrict__ area = B.area;
     const int *__restrict__ kind_t = B.kind;
-    // Lane j (mod 16) fetches cell j's five values of a month with ordinary coalesced loads, one month ahead; each
-    // cell's values are then broadcast from that lane into scalar registers (v_readlane), so the march below has
-    // wave-uniform operands without a memory access on its path.  (Left to itself the compiler addresses the uniform
-    // values through vector registers and waits for every load: the split arrays are written by another kernel of this
-    // translation unit, so it will not use the scalar cache.)
-    const int lj = min((int)(threadIdx.x & (CM - 1)), cnt - 1);
-    const double area_l = area ? area[base + lj] : 1.0;
-    auto bcast = [](double v, int src) {
-        const long long bits = __double_as_longlong(v);
-        const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), src);
-        const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
-        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    // Lane j (< CM) fetches cell j's five values of a month with ordinary coalesced loads, two months ahead, and drops
+    // them into a small LDS slot one month ahead; the march reads each cell's values from ONE LDS address (a broadcast
+    // read, conflict-free), i.e. with wave-uniform values in vector registers and no memory access on its path.
+    // (Left to itself the compiler addresses the uniform values through global loads and waits for every one: the split
+    // arrays are written by another kernel of this translation unit, so it will not use the scalar cache.  Broadcasting
+    // through v_readlane instead costs 11 readlanes + ~13 register moves per cell and month: 57.2 ms -> see DESIGN.)
+    struct Slot {
+        double pet, rain, snow, frac;
+        int kind, pad;
     };
-    double n_pet = pet_t[base + lj], n_rain = rain_t[base + lj], n_snow = snow_t[base + lj], n_frac = frac_t[base + lj];
-    int n_kind = kind_t[base + lj];
+    __shared__ Slot slot[2][CM];
+    const int lane = threadIdx.x;
+    const int lj = min(lane & (CM - 1), cnt - 1);
+    const double area_l = area ? area[base + lj] : 1.0;
+    __shared__ double area_sh[CM];
+    if (lane < CM) area_sh[lane] = area_l;
+    auto fetch = [&](int m, Slot &v) {
+        const int64_t o = (int64_t)m * ncell + base + lj;
+        v.pet = pet_t[o];
+        v.rain = rain_t[o];
+        v.snow = snow_t[o];
+        v.frac = frac_t[o];
+        v.kind = kind_t[o];
+        v.pad = 0;
+    };
+    Slot nxt;
+    fetch(0, nxt);
+    if (lane < CM) slot[0][lane] = nxt;
+    if (nsteps > 1) fetch(1, nxt);
+    __syncthreads();
     for (int m = 0; m < nsteps; ++m) {
         const int k = SPINUP ? ((m == nsteps - 1) ? 0 : ((m == nsteps - 13) ? 1 : ((m == nsteps - 25) ? 2 : -1))) : -1;
-        const double c_pet = n_pet, c_rain = n_rain, c_snow = n_snow, c_frac = n_frac;
-        const int c_kind = n_kind;
-        if (m + 1 < nsteps) {                                        // next month's values: in flight during this one
-            const int64_t o = (int64_t)(m + 1) * ncell + base + lj;
-            n_pet = pet_t[o];
-            n_rain = rain_t[o];
-            n_snow = snow_t[o];
-            n_frac = frac_t[o];
-            n_kind = kind_t[o];
-        }
+        // month m + 1 into the other slot (its loads were issued a month ago), month m + 2 into flight
+        if (m + 1 < nsteps && lane < CM) slot[(m + 1) & 1][lane] = nxt;
+        if (m + 2 < nsteps) fetch(m + 2, nxt);
+        const Slot *cur = slot[m & 1];
         double tot = 0.0, ssm = 0.0, sgw = 0.0;
         int nsm = 0, ngw = 0;
 #pragma unroll
         for (int j = 0; j < CM; ++j) {
             if (j < cnt) {                                           // wave-uniform
                 AbcdPre pre;
-                pre.pet = bcast(c_pet, j);
-                pre.rain = bcast(c_rain, j);
-                pre.snow = bcast(c_snow, j);
-                pre.frac = bcast(c_frac, j);
-                pre.kind = __builtin_amdgcn_readlane(c_kind, j);
-                pre.decay = exp(quot(-pre.pet, P.b, P.inv_b));
+                pre.pet = cur[j].pet;
+                pre.rain = cur[j].rain;
+                pre.snow = cur[j].snow;
+                pre.frac = cur[j].frac;
+                pre.kind = cur[j].kind;
+                pre.decay = xh_exp(quot(-pre.pet, P.b, P.inv_b), K);
                 double aet, q;
                 abcd_step(P, s[j], snow_on, m == 0, pre, aet, q);
                 if (SPINUP) {
@@ -343,7 +354,7 @@ __global__ void __launch_bounds__(64) k_calib_march_m(const xh_calib_basin *__re
                         ngw += gw_ok ? 1 : 0;
                     }
                 } else {
-                    const double v = area ? q * bcast(area_l, j) * 1e-6 : q;   // rsim * bsn_areas * 1e-6 (:159) or rsim (:162)
+                    const double v = area ? q * area_sh[j] * 1e-6 : q;         // rsim * bsn_areas * 1e-6 (:159) or rsim (:162)
                     tot += (v == v) ? v : 0.0;                                // nansum
                 }
             }
@@ -359,6 +370,7 @@ __global__ void __launch_bounds__(64) k_calib_march_m(const xh_calib_basin *__re
         } else if (ok) {
             part[((int64_t)chunk * nsteps + m) * nmembers + mem] = tot;
         }
+        __syncthreads();      // one wave: orders this month's slot reads before the next month's slot writes
     }
 }
 

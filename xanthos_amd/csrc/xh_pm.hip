@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "xh_common.h"
+#include "xh_math.h"
 #include "xh_stage.h"
 
 namespace {
@@ -68,13 +69,13 @@ struct PmCell {          // per-cell quantities shared by the months a thread ha
 };
 
 // One (cell, month): returns PET. lctw[l] = land-cover fraction of class l, totpct = their sum (0 -> 0.01).
-__device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__restrict__ tab, int nlcs, int water_idx,
-                                           int snow_idx, double wind_pow,
+__device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__restrict__ tab, const XhExpConsts &K,
+                                           int nlcs, int water_idx, int snow_idx, double wind_pow,
                                            double p, double T, double TN, double RH, double W, double RS,
                                            double RL, double TP, int moy, double dz,
                                            const double *__restrict__ lct_cell, int lct_stride, double totpct) {
     // ---- terms shared by every land class (SetData :83-99, et_veg :226-282)
-    const double esx = 6.10588 * exp(fdiv(17.32491 * T, T + 238.102));
+    const double esx = 6.10588 * xh_exp(fdiv(17.32491 * T, T + 238.102), K);
     const double vap = esx * fdiv(RH, 100.0);
     const double tk1 = T + 238.1;
     const double sx = fdiv(238.1 * 17.325 * esx, tk1 * tk1);
@@ -196,7 +197,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             const double inv_soil_den = frcp(soil_den);                    // both quotients share the divisor
             const double ewet_soil = (soil_num * fwet) * inv_soil_den;      // :314-315
             const double esoilpot = (soil_num * one_m_fwet) * inv_soil_den; // :316-317
-            const double esoil = ewet_soil + esoilpot * exp(vpd * tab->vec[V_INVBETA][l] * log_r100);   // pow(rh/100, vpd/beta) :323
+            const double esoil = ewet_soil + esoilpot * xh_exp(vpd * tab->vec[V_INVBETA][l] * log_r100, K);   // pow(rh/100, vpd/beta) :323
 
             double trans = fdiv(dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_ra) * one_m_fwet,
                                 (sx + GAMMA * (1.0 + rs * inv_ra)) * LAMBDA1);                   // :326-327
@@ -233,6 +234,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int water_idx = tab->water_idx, snow_idx = tab->snow_idx, start_year = tab->start_year;
     const int n_lc_years = tab->n_lc_years;
     const double wind_pow = tab->wind_pow;
+    const XhExpConsts K = xh_exp_consts();
     const int half = m_count >> 1;                  // pairs of months per cell in [m_begin, m_begin + m_count)
     const int64_t total = ncell * (int64_t)half;
     for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total;
@@ -266,9 +268,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         totpct = totpct == 0.0 ? 0.01 : totpct;     // :47
         const double p = pressure[c];               // calc_p (:185-188), once per cell by k_pm_pressure
         double2 out;
-        out.x = pm_month(L, tab, nlcs, water_idx, snow_idx, wind_pow, p, T.x, TN.x, RH.x, W.x, RS.x, RL.x, TP.x, moy,
+        out.x = pm_month(L, tab, K, nlcs, water_idx, snow_idx, wind_pow, p, T.x, TN.x, RH.x, W.x, RS.x, RL.x, TP.x, moy,
                          (double)days_in_month(year, moy), lct_cell, n_lc_years, totpct);
-        out.y = pm_month(L, tab, nlcs, water_idx, snow_idx, wind_pow, p, T.y, TN.y, RH.y, W.y, RS.y, RL.y, TP.y,
+        out.y = pm_month(L, tab, K, nlcs, water_idx, snow_idx, wind_pow, p, T.y, TN.y, RH.y, W.y, RS.y, RL.y, TP.y,
                          moy + 1, (double)days_in_month(year, moy + 1), lct_cell, n_lc_years, totpct);
         *reinterpret_cast<double2 *>(pet + off) = out;
     }
