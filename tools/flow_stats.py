@@ -22,6 +22,8 @@ st = pipe.plan.stats().astype(np.float64)
 nsub = sum(int(d) * 8 for d in pipe.ndays)
 print('route ms', ms / n, 'substeps', nsub, 'us/substep', ms / n * 1e3 / nsub)
 raw3 = pipe.plan.stats()[:, 3]
+if os.environ.get('XH_STATS_SAVE'):
+    np.save(os.environ['XH_STATS_SAVE'], pipe.plan.stats())
 loop, total, ticks, shape = st[:, 0], st[:, 1], st[:, 2], (raw3 & np.uint64(255)).astype(int)
 clock = total / (ticks / 100e6) / 1e9
 print('units', len(st), 'clock GHz median', np.median(clock))

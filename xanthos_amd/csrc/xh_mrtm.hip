@@ -801,12 +801,14 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     plan->last_tree_kernel = 0;
     if (use_flow) {     // tree-shaped networks: single-wave dataflow units on the context's own stream
         int ntmax = 0, ntmin = INT_MAX;
+        bool nt_even = true;
         for (int v : snt) {
             ntmax = std::max(ntmax, v);
             ntmin = std::min(ntmin, v);
+            nt_even = nt_even && (v & 1) == 0;
         }
         const FlowSched fs{nmonths, nit, ntmax, ntmin, sg[nit], d_m, d_nt, d_g, d_secs, d_wr, dt,
-                           (flags & XH_ROUTE_TEST_FAULT) != 0};
+                           (flags & XH_ROUTE_TEST_FAULT) != 0, nt_even};
         const FlowIO fio{d_flow_dist, d_velocity, d_area, d_runoff, d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end};
         // time-skewed units first; months shorter than the deepest lane lag (long dt) use the monthly-stream kernel
         static const bool skew_env = !(getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] == '0');

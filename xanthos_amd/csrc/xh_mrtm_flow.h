@@ -21,6 +21,7 @@ struct FlowPlan {
     void *d_x = nullptr;
     size_t x_bytes = 0;
     unsigned long long *d_stats = nullptr;
+    void *d_skew_args = nullptr;         // argument block of k_mrtm_skew (rewritten, stream-ordered, by every launch)
 };
 
 struct FlowSched {
@@ -31,6 +32,7 @@ struct FlowSched {
     const unsigned char *d_wr;        // [nit] 1 = simulation pass (store outputs)
     double dt;
     bool test_fault;                  // XH_ROUTE_TEST_FAULT: unit 0 raises the fault word and stops (tests of the re-route)
+    bool nt_even;                     // every month has an even number of sub-steps (dt = 3 h: 8 per day)
 };
 
 struct FlowIO {

@@ -301,6 +301,7 @@ void flow_plan_destroy(FlowPlan *fp) {
     for (FlowBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (fp->d_x) (void)hipFree(fp->d_x);
+    if (fp->d_skew_args) (void)hipFree(fp->d_skew_args);
     if (fp->d_stats) (void)hipFree(fp->d_stats);
     delete fp;
 }
@@ -675,6 +676,19 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
         fprintf(stderr, "\n  units by lmax/16 (0..9+):");
         for (int k = 0; k < 10; ++k) fprintf(stderr, " %d", hl[k]);
         fprintf(stderr, "\n");
+    }
+
+    if (const char *dump = getenv("XH_FLOW_DUMP")) {      // partition as int32 rows [n]: downstream cell, piece, unit, height
+        if (FILE *f = fopen(dump, "wb")) {
+            std::vector<int> row(n);
+            fwrite(&n, sizeof(int), 1, f);
+            fwrite(ds.data(), sizeof(int), n, f);
+            fwrite(piece.data(), sizeof(int), n, f);
+            for (int c = 0; c < n; ++c) row[c] = piece[c] >= 0 ? unit_of_piece[piece[c]] : -1;
+            fwrite(row.data(), sizeof(int), n, f);
+            fwrite(hgt.data(), sizeof(int), n, f);
+            fclose(f);
+        }
     }
 
     FlowPlan *fp = new FlowPlan();

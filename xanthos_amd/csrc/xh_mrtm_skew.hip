@@ -54,6 +54,7 @@ struct SkewArgs {
     const int *unit_p, *unit_lmax, *unit_glmax;
     int64_t total_slots;
     int nmonths, nit, total;
+    int odd_ok;                       // 0: months have an even number of sub-steps, so lanes only cross a month start at even iterations
     const int *sched_m, *sched_nt, *sched_g;
     const double *sched_secs;
     const unsigned char *sched_write;
@@ -112,40 +113,52 @@ typedef __attribute__((address_space(3))) const char lds_cchar;
 typedef __attribute__((address_space(3))) const v2d lds_cd2;
 typedef __attribute__((address_space(3))) v2d lds_d2;
 
+// The arguments live in device memory and every use re-reads the field it needs (scalar loads of a laundered pointer): held
+// as kernel arguments, the ~70 scalar registers of pointers and sizes stayed live across the sub-step loop and were spilled
+// to vector lanes and restored around every group of 16 sub-steps.
+typedef __attribute__((address_space(4))) const SkewArgs SkewArgsK;      // constant address space: always scalar loads
+template <class T>
+__device__ __forceinline__ T xh_ldarg(__attribute__((address_space(4))) const T *p) {
+    asm volatile("" : "+s"(p));
+    return *p;
+}
+#define A(f) xh_ldarg(&ap->f)
+
 template <int PRE, int POST, bool HAS_G>
-__device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xtab) {
+__device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) {
     lds_cchar *lds0 = (lds_cchar *)lds;
     const int lane = threadIdx.x, unit = blockIdx.x;
     const int64_t slot = (int64_t)unit * LANES + lane;
 
-    const int gc = a.cell_of_slot[slot];
+    const int gc = A(cell_of_slot)[slot];
     const bool valid = gc >= 0;
-    const double tauinv = valid ? a.velocity[gc] / a.flow_dist[gc] : 0.0;      // mrtm.py:40
-    const double area = valid ? a.area[gc] : 0.0;
-    const double S0v = (valid && a.S0) ? a.S0[gc] : 0.0;
+    const double tauinv = valid ? A(velocity)[gc] / A(flow_dist)[gc] : 0.0;      // mrtm.py:40
+    const double area = valid ? A(area)[gc] : 0.0;
+    const double S0v = (valid && A(S0)) ? A(S0)[gc] : 0.0;
     lds_cchar *epre[PRE], *epost[POST];
 #pragma unroll
-    for (int w = 0; w < PRE; ++w) epre[w] = lds0 + a.ent2[(int64_t)w * a.total_slots + slot];
+    for (int w = 0; w < PRE; ++w) epre[w] = lds0 + A(ent2)[(int64_t)w * A(total_slots) + slot];
 #pragma unroll
-    for (int w = 0; w < POST; ++w) epost[w] = lds0 + a.ent2[(int64_t)(SK_P + w) * a.total_slots + slot];
+    for (int w = 0; w < POST; ++w) epost[w] = lds0 + A(ent2)[(int64_t)(SK_P + w) * A(total_slots) + slot];
     lds_d2 *own = (lds_d2 *)lds + lane;
-    const int xedge = a.export_edge[slot];
-    const int gedge = a.ghost_edge[slot];
+    const int xedge = A(export_edge)[slot];
+    const int gedge = A(ghost_edge)[slot];
     const bool has_x = xedge >= 0, has_g = gedge >= 0;
     const unsigned long long xmask = __ballot(has_x), gmask = __ballot(has_g);
     const bool any_x = xmask != 0, any_g = HAS_G;
     const int nx_out = __popcll(xmask), ng = __popcll(gmask);       // outlets / imports of this unit
-    const int lmax = a.unit_lmax[unit], glmax = a.unit_glmax[unit];
-    const int lag_g = has_g ? a.ghost_lag[slot] : 0;
-    const unsigned *ready_p = a.ready + (has_g ? gedge : 0);
-    const unsigned *done_p = a.done + (has_x ? a.edge_cons_unit[xedge] : 0);
-    const unsigned maskb = a.ring_mask_b;
+    const int lmax = A(unit_lmax)[unit], glmax = A(unit_glmax)[unit];
+    const int lag_g = has_g ? A(ghost_lag)[slot] : 0;
+    const unsigned *ready_p = A(ready) + (has_g ? gedge : 0);
+    const unsigned *done_p = A(done) + (has_x ? A(edge_cons_unit)[xedge] : 0);
+    const unsigned maskb = A(ring_mask_b);
     // The streams are read and written through a buffer resource with the agent-coherent cache policy: stores write
     // through to memory (whole 128-byte lines per outlet and block), loads re-fetch.  No release / acquire fence is
     // needed around the counters -- an agent-scope release writes back the whole L2 of the XCD and was measured to slow
     // every unit on it, importing or not, by ~10 %.
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, (int)a.xbytes, 0x00020000);
-    const int total = a.total, nit = a.nit;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(A(xbuf), 0, (int)A(xbytes), 0x00020000);
+    const int total = A(total), nit = A(nit);
+    const bool odd_ok = A(odd_ok) != 0;
 
     // ---- block-transfer roles: lane (k = lane / 8 + 8 r, i = lane % 8) moves sub-step i of outlet / import k
     if (has_x) xtab[__popcll(xmask & ((1ull << lane) - 1ull))] = make_uint2((unsigned)lane, (unsigned)xedge);
@@ -160,8 +173,8 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
     for (int r = 0; r < SK_R; ++r) {
         const int k = r * 8 + grp;
         gon[r] = k < ng;
-        const int ge = gon[r] ? a.ghost_edge[(int64_t)unit * LANES + k] : 0;
-        glag[r] = gon[r] ? a.ghost_lag[(int64_t)unit * LANES + k] : 0;
+        const int ge = gon[r] ? A(ghost_edge)[(int64_t)unit * LANES + k] : 0;
+        glag[r] = gon[r] ? A(ghost_lag)[(int64_t)unit * LANES + k] : 0;
         gbyte[r] = (unsigned)ge * (maskb + 1u);
         gdst[r] = (lds_d2 *)lds + sub * NSLOT + LANES + (k & 63);
         xon[r] = k < nx_out;
@@ -177,15 +190,15 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
         if (lane == 0) own[k * NSLOT + 2 * LANES] = v2d{0.0, 0.0};
     }
 
-    const double dt = a.dt, dtinv = a.dtinv;
+    const double dt = A(dt), dtinv = A(dtinv);
     double S = 0.0, F = 0.0, favg = 0.0, erl = 0.0;
     double snapS = 0.0, snapA = 0.0, snapF = 0.0;
-    int nx = a.lag[slot];                                  // iteration at which this lane enters its next month
+    int nx = A(lag)[slot];                                  // iteration at which this lane enters its next month
     double erl_n = 0.0, qn = 0.0;                          // lateral inflow of the month to enter / runoff after that
     {
-        const double q0 = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[0]] : 0.0;
-        erl_n = (q0 * area) * 1000.0 / a.sched_secs[0];                        // mrtm.py:45
-        if (nit > 1) qn = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[1]] : 0.0;
+        const double q0 = valid ? A(runoff)[(int64_t)gc * A(nmonths) + A(sched_m)[0]] : 0.0;
+        erl_n = (q0 * area) * 1000.0 / A(sched_secs)[0];                        // mrtm.py:45
+        if (nit > 1) qn = valid ? A(runoff)[(int64_t)gc * A(nmonths) + A(sched_m)[1]] : 0.0;
     }
     double ob_s[8], ob_a[8];
 #pragma unroll
@@ -213,18 +226,18 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
         if (any_x) {      // publish what has certainly been stored, then make sure the next CH iterations have ring space
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // write-through stores of older blocks acknowledged
             const int pub = min(max(n - PUBLAG - RING - lmax, 0), total);
-            if (has_x) __hip_atomic_store(a.ready + xedge, (unsigned)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int need = n + CH - lmax - a.rs;
+            if (has_x) __hip_atomic_store(A(ready) + xedge, (unsigned)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int need = n + CH - lmax - A(rs);
             if (need > 0)
-                alive = wave_wait_ge(has_x, done_p, (unsigned)min(need, total), seen_done, a.fault, FAULT_RING_WAIT);
+                alive = wave_wait_ge(has_x, done_p, (unsigned)min(need, total), seen_done, A(fault), FAULT_RING_WAIT);
         }
         const unsigned long long w1 = __builtin_amdgcn_s_memtime();
         if (any_g && alive) {   // the next CH iterations load up to sub-step n + CH + GROUP - 1 - lag_g
             if (lane == 0)    // every import has been consumed up to n - glmax
-                __hip_atomic_store(a.done + unit, (unsigned)min(max(n - glmax, 0), total), __ATOMIC_RELAXED,
+                __hip_atomic_store(A(done) + unit, (unsigned)min(max(n - glmax, 0), total), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             const int need = min(total, n + CH + GROUP - lag_g);
-            alive = wave_wait_ge(has_g && need > 0, ready_p, (unsigned)max(need, 0), seen_ready, a.fault, FAULT_DATA_WAIT);
+            alive = wave_wait_ge(has_g && need > 0, ready_p, (unsigned)max(need, 0), seen_ready, A(fault), FAULT_DATA_WAIT);
             asm volatile("" ::: "memory");      // the stream loads stay behind the poll
         }
         cyc_wait_ring += w1 - w0;
@@ -234,7 +247,7 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
     // ---- month bookkeeping for all lanes at once: outputs of iteration it - 1, lateral inflow of iteration it + 1
     auto finalize = [&](int it) {
         if (it >= 1) {
-            const int m = a.sched_m[it - 1], ntp = a.sched_nt[it - 1];
+            const int m = A(sched_m)[it - 1], ntp = A(sched_nt)[it - 1];
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 ob_s[j] = ob_s[j + 1];
@@ -242,28 +255,28 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
             }
             ob_s[7] = snapS;
             ob_a[7] = snapA / (double)ntp;                                     // mrtm.py:80
-            if (a.sched_write[it - 1] && valid) {     // whole 64-byte groups of 8 months per cell
+            if (A(sched_write)[it - 1] && valid) {     // whole 64-byte groups of 8 months per cell
                 if ((m & 7) == 7) {
-                    const int64_t o = (int64_t)gc * a.nmonths + (m - 7);
+                    const int64_t o = (int64_t)gc * A(nmonths) + (m - 7);
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) {
-                        if (a.chs) *reinterpret_cast<v2d *>(a.chs + o + j) = v2d{ob_s[j], ob_s[j + 1]};
-                        if (a.avg) *reinterpret_cast<v2d *>(a.avg + o + j) = v2d{ob_a[j], ob_a[j + 1]};
+                        if (A(chs)) *reinterpret_cast<v2d *>(A(chs) + o + j) = v2d{ob_s[j], ob_s[j + 1]};
+                        if (A(avg)) *reinterpret_cast<v2d *>(A(avg) + o + j) = v2d{ob_a[j], ob_a[j + 1]};
                     }
-                } else if (m == a.nmonths - 1) {                                // last, partial group
+                } else if (m == A(nmonths) - 1) {                                // last, partial group
                     const int r = (m & 7) + 1;
-                    const int64_t o = (int64_t)gc * a.nmonths + (m + 1 - r);
+                    const int64_t o = (int64_t)gc * A(nmonths) + (m + 1 - r);
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
                         if (j >= 8 - r) {
-                            if (a.chs) a.chs[o + j - (8 - r)] = ob_s[j];
-                            if (a.avg) a.avg[o + j - (8 - r)] = ob_a[j];
+                            if (A(chs)) A(chs)[o + j - (8 - r)] = ob_s[j];
+                            if (A(avg)) A(avg)[o + j - (8 - r)] = ob_a[j];
                         }
                 }
             }
         }
-        if (it + 1 < nit) erl_n = (qn * area) * 1000.0 / a.sched_secs[it + 1];
-        if (it + 2 < nit) qn = valid ? a.runoff[(int64_t)gc * a.nmonths + a.sched_m[it + 2]] : 0.0;
+        if (it + 1 < nit) erl_n = (qn * area) * 1000.0 / A(sched_secs)[it + 1];
+        if (it + 2 < nit) qn = valid ? A(runoff)[(int64_t)gc * A(nmonths) + A(sched_m)[it + 2]] : 0.0;
     };
 
     // gathered pairs of the current sub-step (issued one iteration ago); import blocks in flight (two ahead)
@@ -305,7 +318,7 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
     const int N = (total + lmax + 1 + GROUP - 1) & ~(GROUP - 1);
     int itz = 0, gz = 0;                 // month whose start zone [gz, gz + lmax] is next (itz == nit: the end zone)
     int itf = 0, nf = (lmax + 1 + GROUP - 1) & ~(GROUP - 1);     // next month bookkeeping and its iteration
-    int ntz = nit > 0 ? a.sched_nt[0] : 0;
+    int ntz = nit > 0 ? A(sched_nt)[0] : 0;
 
     for (int n = 0; n < N && alive; n += GROUP) {
         if (n > 0 && (n & (CH - 1)) == 0) {
@@ -315,12 +328,14 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
         if (n == nf) {
             finalize(itf);
             ++itf;
-            nf = itf <= nit ? ((a.sched_g[itf] + lmax + 1 + GROUP - 1) & ~(GROUP - 1)) : INT_MAX;
+            nf = itf <= nit ? ((A(sched_g)[itf] + lmax + 1 + GROUP - 1) & ~(GROUP - 1)) : INT_MAX;
         }
         const bool zone = itz <= nit && n + GROUP > gz && n <= gz + lmax;
 
         auto substep = [&](const int j, const bool in_zone) {
-            if (in_zone) {    // lanes crossing a month start (or starting / finishing the series) at this iteration
+            // lanes crossing a month start (or starting / finishing the series) at this iteration.  Lane lags are even and
+            // so are the month lengths of any dt that divides 12 h: the odd sub-steps of a group then have no lane to look for
+            if (in_zone && ((j & 1) == 0 || odd_ok)) {
                 if (nx == n + j) {
                     snapS = S;
                     snapA = favg;
@@ -340,6 +355,12 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
             for (int w = 0; w < PRE; ++w) an[w] = *(lds_cd2 *)(epre[w] + ((j + RING - 1) & (RING - 1)) * SLOTB);
 #pragma unroll
             for (int w = 0; w < POST; ++w) bn[w] = *(lds_cd2 *)(epost[w] + ((j + RING - 1) & (RING - 1)) * SLOTB);
+            __builtin_amdgcn_sched_barrier(0);
+            // everything older than the PRE + POST reads just issued and the pair stored at the end of the previous
+            // sub-step has returned (LDS answers in order; the loop holds no scalar loads): one counted wait here instead
+            // of one in front of every add that consumes a pair.  The store is left out: a unit with few terms would wait
+            // for it (measured: 220 -> 254 cycles per sub-step at 2 terms).
+            __builtin_amdgcn_s_waitcnt(0xC07F | ((PRE + POST + 1) << 8));
             __builtin_amdgcn_sched_barrier(0);
             if ((j & (RING - 1)) == 0) block_io(n + j, j / RING);
             const double F0 = S * tauinv;                                      // mrtm.py:50
@@ -362,7 +383,9 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
 #pragma unroll
             for (int w = 0; w < POST; ++w) s2 += bc[w].y;
             const double dsdt2 = s2 + erl;
-            S = sx ? 0.0 : S + dsdt2 * dt;                                     // mrtm.py:63, 69
+            double Sn = S + dsdt2 * dt;
+            asm volatile("" : "+v"(Sn));            // keeps the second sum out of an exec-masked region (4 more instructions)
+            S = sx ? 0.0 : Sn;                                                 // mrtm.py:63, 69
             F = f2;
             favg += f2;                                                        // mrtm.py:78
 #pragma unroll
@@ -377,8 +400,8 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
             for (int j = 0; j < GROUP; ++j) substep(j, true);
             if (n + GROUP > gz + lmax) {      // every lane has crossed: next boundary
                 ++itz;
-                gz = itz <= nit ? a.sched_g[itz] : INT_MAX;
-                ntz = itz < nit ? a.sched_nt[itz] : 0;
+                gz = itz <= nit ? A(sched_g)[itz] : INT_MAX;
+                ntz = itz < nit ? A(sched_nt)[itz] : 0;
             }
         } else {
 #pragma unroll
@@ -396,17 +419,17 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, *xsrc[r]), xr, xbyte[r], xpos, AUX_SC1);
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // write-through stores acknowledged
-            if (has_x) __hip_atomic_store(a.ready + xedge, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (has_x) __hip_atomic_store(A(ready) + xedge, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (any_g && lane == 0)
-            __hip_atomic_store(a.done + unit, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(A(done) + unit, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (valid) {
-            if (a.S_end) a.S_end[gc] = snapS;
-            if (a.F_end) a.F_end[gc] = snapF;
+            if (A(S_end)) A(S_end)[gc] = snapS;
+            if (A(F_end)) A(F_end)[gc] = snapF;
         }
     }
-    if (a.stats && lane == 0) {
-        unsigned long long *st = a.stats + (int64_t)unit * 6;
+    if (A(stats) && lane == 0) {
+        unsigned long long *st = A(stats) + (int64_t)unit * 6;
         const unsigned long long cyc = __builtin_amdgcn_s_memtime() - cyc_begin;
         st[0] = cyc - cyc_wait_data - cyc_wait_ring;
         st[1] = cyc;
@@ -421,26 +444,32 @@ __device__ __forceinline__ void skew_unit(const SkewArgs &a, v2d *lds, uint2 *xt
 }
 
 // Two waves per SIMD must fit (1,121 units of the 67,420-cell grid on 1,024 SIMDs): at most 256 registers.
-__global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mrtm_skew(SkewArgs a) {
+__global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mrtm_skew(const SkewArgs *ap_) {
+    SkewArgsK *ap = (SkewArgsK *)ap_;
     __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
     __shared__ uint2 xtab[LANES];
-    const int p = a.unit_p[blockIdx.x];             // uniform per workgroup: terms before | after the diagonal << 4
-    const bool g = __any(a.ghost_edge[(int64_t)blockIdx.x * LANES + threadIdx.x] >= 0);
+    const int p = A(unit_p)[blockIdx.x];             // uniform per workgroup: terms before | after the diagonal << 4
+    const bool g = __any(A(ghost_edge)[(int64_t)blockIdx.x * LANES + threadIdx.x] >= 0);
     // one specialisation per (terms before, terms after, imports?): an LDS read costs a lone wave ~17 cycles of issue
     // whatever its width (tools/micro/substep_cost.hip), so no unit should read padding it does not need
 #define SKEW_CASE(PRE, POST)                                  \
     case (PRE) | ((POST) << 4):                               \
-        if (g) skew_unit<PRE, POST, true>(a, lds, xtab);      \
-        else skew_unit<PRE, POST, false>(a, lds, xtab);       \
+        if (g) skew_unit<PRE, POST, true>(ap, lds, xtab);      \
+        else skew_unit<PRE, POST, false>(ap, lds, xtab);       \
         break;
     switch (p) {
         SKEW_CASE(1, 1) SKEW_CASE(1, 2) SKEW_CASE(1, 3) SKEW_CASE(1, 4)
         SKEW_CASE(2, 1) SKEW_CASE(2, 2) SKEW_CASE(2, 3) SKEW_CASE(2, 4)
         SKEW_CASE(3, 1) SKEW_CASE(3, 2) SKEW_CASE(3, 3) SKEW_CASE(3, 4)
         SKEW_CASE(4, 1) SKEW_CASE(4, 2) SKEW_CASE(4, 3)
-        default: if (g) skew_unit<4, 4, true>(a, lds, xtab); else skew_unit<4, 4, false>(a, lds, xtab);
+        default: if (g) skew_unit<4, 4, true>(ap, lds, xtab); else skew_unit<4, 4, false>(ap, lds, xtab);
     }
 #undef SKEW_CASE
+}
+#undef A
+
+__global__ void k_mrtm_skew_args(SkewArgs a, SkewArgs *dst) {
+    if (threadIdx.x == 0) *dst = a;
 }
 
 }  // namespace
@@ -499,6 +528,7 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.nmonths = s.nmonths;
     a.nit = s.nit;
     a.total = s.total;
+    a.odd_ok = s.nt_even ? 0 : 1;
     a.sched_m = s.d_m;
     a.sched_nt = s.d_nt;
     a.sched_g = s.d_g;
@@ -536,7 +566,11 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
             a.stats = fp->d_stats;
         }
     }
-    hipLaunchKernelGGL(k_mrtm_skew, dim3((unsigned)fp->n_units), dim3(LANES), lds, st, a);
+    if (!fp->d_skew_args) XH_HIP(ctx, hipMalloc(&fp->d_skew_args, sizeof(SkewArgs)));
+    // stream-ordered: the previous launch has finished reading the block before this one rewrites it
+    hipLaunchKernelGGL(k_mrtm_skew_args, dim3(1), dim3(64), 0, st, a, static_cast<SkewArgs *>(fp->d_skew_args));
+    hipLaunchKernelGGL(k_mrtm_skew, dim3((unsigned)fp->n_units), dim3(LANES), lds, st,
+                       static_cast<const SkewArgs *>(fp->d_skew_args));
     XH_HIP(ctx, hipGetLastError());
     return XH_OK;
 }
