@@ -21,6 +21,8 @@ struct FlowPlan {
     void *d_x = nullptr;
     size_t x_bytes = 0;
     unsigned long long *d_stats = nullptr;
+    unsigned *d_trace = nullptr;         // XH_FLOW_TRACE=<file>: month-end times of every unit, dumped by flow_stats_fetch
+    size_t trace_words = 0;
     void *d_skew_args = nullptr;         // argument block of k_mrtm_skew (rewritten, stream-ordered, by every launch)
 };
 

@@ -303,6 +303,7 @@ void flow_plan_destroy(FlowPlan *fp) {
     if (fp->d_x) (void)hipFree(fp->d_x);
     if (fp->d_skew_args) (void)hipFree(fp->d_skew_args);
     if (fp->d_stats) (void)hipFree(fp->d_stats);
+    if (fp->d_trace) (void)hipFree(fp->d_trace);
     delete fp;
 }
 
@@ -368,123 +369,247 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
         for (int c = 0; c < n; ++c)
             if (ds[c] >= 0) child[fill[ds[c]]++] = c;
     }
-    std::vector<int> queue;
-    queue.reserve(n);
-    std::vector<int> left(nchild);
-    for (int c = 0; c < n; ++c)
-        if (comp_ok[comp[c]] && nchild[c] == 0) queue.push_back(c);
-    std::vector<int> dsu(n);
-    std::iota(dsu.begin(), dsu.end(), 0);
-    auto find = [&](int x) {
-        while (dsu[x] != x) {
-            dsu[x] = dsu[dsu[x]];
-            x = dsu[x];
+    // longest side of every row either side of its diagonal (the time-skewed kernel reads that many pairs per sub-step)
+    std::vector<int> cell_pre(n, 0), cell_post(n, 0);
+    for (int c = 0; c < n; ++c) {
+        bool past = false;
+        for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {
+            if (indices[j] == c) past = true;
+            else ++(past ? cell_post[c] : cell_pre[c]);
         }
-        return x;
+    }
+    const int simds = 4 * (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 0);
+
+    // ---- partition for one piece capacity `cap`: bottom-up cut into connected pieces of <= cap cells with <= G_MAX
+    //      imported streams, then pieces packed into units of LANES cells.
+    //      A smaller capacity than LANES costs streams (every cut is one) and buys units: pieces of 33..64 cells cannot
+    //      share a unit, so the largest capacity leaves every other unit ~10 lanes short of full (67,420 cells: 1,121
+    //      units at 64; 1,054 = every lane used at 40, with 1,490 streams instead of 826).  Units beyond the SIMD count
+    //      share a SIMD with another unit and the slowest unit paces the run, so units are what counts.
+    struct Partition {
+        std::vector<int> queue, piece, closed_roots, piece_of_root, piece_size, piece_imp, piece_depth;
+        std::vector<int> edge_prod_cell, edge_cons_cell, edge_of_prod;
+        std::vector<int> unit_of_piece, unit_cells_n, unit_imp_n, unit_depth;
+        std::vector<char> reached;
+        int nunit = 0, nedge = 0, maxdepth = 0;
     };
-    std::vector<int> open_cnt(n, 0), open_imp(n, 0);
-    std::vector<int> closed_roots;                 // piece roots in closing order (upstream pieces first)
-    std::vector<int> kids;
-    for (size_t qi = 0; qi < queue.size(); ++qi) {
-        const int v = queue[qi];
-        kids.assign(child.begin() + child_ptr[v], child.begin() + child_ptr[v + 1]);
-        std::sort(kids.begin(), kids.end(), [&](int x, int y) {
-            return open_cnt[x] != open_cnt[y] ? open_cnt[x] < open_cnt[y] : x < y;
-        });
-        int total = 1, imp = (int)kids.size();
-        for (int c : kids) {
-            if (total + open_cnt[c] <= LANES && imp - 1 + open_imp[c] <= G_MAX) {
-                dsu[find(c)] = v;                   // c's open piece joins v's
-                total += open_cnt[c];
-                imp += open_imp[c] - 1;
-            } else {
-                closed_roots.push_back(c);          // c's piece is final; its outlet streams into v
+    auto make_partition = [&](int cap, Partition &P) {
+        P = Partition();
+        std::vector<int> &queue = P.queue;
+        queue.reserve(n);
+        std::vector<int> left(nchild);
+        for (int c = 0; c < n; ++c)
+            if (comp_ok[comp[c]] && nchild[c] == 0) queue.push_back(c);
+        std::vector<int> dsu(n);
+        std::iota(dsu.begin(), dsu.end(), 0);
+        auto find = [&](int x) {
+            while (dsu[x] != x) {
+                dsu[x] = dsu[dsu[x]];
+                x = dsu[x];
             }
-        }
-        open_cnt[v] = total;
-        open_imp[v] = imp;
-        if (ds[v] < 0) {
-            closed_roots.push_back(v);
-        } else if (--left[ds[v]] == 0) {
-            queue.push_back(ds[v]);
-        }
-    }
-    // cells of ok networks that were never reached (cannot happen for trees) stay unhandled
-    std::vector<char> reached(n, 0);
-    for (int v : queue) reached[v] = 1;
-
-    // ---- pieces, their stream edges and pipeline depth
-    const int npiece = (int)closed_roots.size();
-    std::vector<int> piece_of_root(n, -1);
-    for (int p = 0; p < npiece; ++p) piece_of_root[closed_roots[p]] = p;
-    std::vector<int> piece(n, -1);
-    std::vector<int> piece_size(npiece, 0), piece_imp(npiece, 0), piece_depth(npiece, 0);
-    for (int c = 0; c < n; ++c)
-        if (reached[c]) {
-            piece[c] = piece_of_root[find(c)];
-            piece_size[piece[c]]++;
-        }
-    std::vector<int> edge_prod_cell, edge_cons_cell;     // one stream per closed piece that has a downstream cell
-    std::vector<int> edge_of_prod(n, -1);
-    for (int p = 0; p < npiece; ++p) {                   // closing order: upstream pieces come first
-        const int r = closed_roots[p];
-        if (ds[r] >= 0) {
-            const int cp = piece[ds[r]];
-            edge_of_prod[r] = (int)edge_prod_cell.size();
-            edge_prod_cell.push_back(r);
-            edge_cons_cell.push_back(ds[r]);
-            piece_imp[cp]++;
-            piece_depth[cp] = std::max(piece_depth[cp], piece_depth[p] + 1);
-        }
-    }
-    const int nedge = (int)edge_prod_cell.size();
-
-    // ---- pack pieces of equal depth into units (first-fit decreasing on cells, bounded imports)
-    const int maxdepth = npiece ? *std::max_element(piece_depth.begin(), piece_depth.end()) : 0;
-    std::vector<int> order(npiece);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-        return piece_depth[x] != piece_depth[y] ? piece_depth[x] < piece_depth[y] : piece_size[x] > piece_size[y];
-    });
-    std::vector<int> unit_of_piece(npiece, -1), unit_cells_n, unit_imp_n, unit_depth, unit_out_n;   // outlets: <= G_MAX too
-    {
-        size_t first_open = 0;
-        int cur_depth = -1;
-        for (int p : order) {
-            if (piece_depth[p] != cur_depth) {
-                cur_depth = piece_depth[p];
-                first_open = unit_cells_n.size();
-            }
-            int u = -1;
-            for (size_t b = first_open; b < unit_cells_n.size(); ++b)
-                if (unit_cells_n[b] + piece_size[p] <= LANES && unit_imp_n[b] + piece_imp[p] <= G_MAX &&
-                    unit_out_n[b] + (ds[closed_roots[p]] >= 0 ? 1 : 0) <= G_MAX) {
-                    u = (int)b;
-                    break;
+            return x;
+        };
+        std::vector<int> open_cnt(n, 0), open_imp(n, 0);
+        std::vector<int> &closed_roots = P.closed_roots;            // piece roots in closing order (upstream pieces first)
+        std::vector<int> kids;
+        for (size_t qi = 0; qi < queue.size(); ++qi) {
+            const int v = queue[qi];
+            kids.assign(child.begin() + child_ptr[v], child.begin() + child_ptr[v + 1]);
+            std::sort(kids.begin(), kids.end(), [&](int x, int y) {
+                return open_cnt[x] != open_cnt[y] ? open_cnt[x] < open_cnt[y] : x < y;
+            });
+            int total = 1, imp = (int)kids.size();
+            for (int c : kids) {
+                if (total + open_cnt[c] <= cap && imp - 1 + open_imp[c] <= G_MAX) {
+                    dsu[find(c)] = v;                   // c's open piece joins v's
+                    total += open_cnt[c];
+                    imp += open_imp[c] - 1;
+                } else {
+                    closed_roots.push_back(c);          // c's piece is final; its outlet streams into v
                 }
-            if (u < 0) {
-                u = (int)unit_cells_n.size();
-                unit_cells_n.push_back(0);
-                unit_imp_n.push_back(0);
-                unit_out_n.push_back(0);
-                unit_depth.push_back(cur_depth);
             }
-            unit_of_piece[p] = u;
-            unit_cells_n[u] += piece_size[p];
-            unit_imp_n[u] += piece_imp[p];
-            unit_out_n[u] += ds[closed_roots[p]] >= 0 ? 1 : 0;
-            while (first_open < unit_cells_n.size() && unit_cells_n[first_open] >= LANES) ++first_open;
+            open_cnt[v] = total;
+            open_imp[v] = imp;
+            if (ds[v] < 0) {
+                closed_roots.push_back(v);
+            } else if (--left[ds[v]] == 0) {
+                queue.push_back(ds[v]);
+            }
+        }
+        // cells of ok networks that were never reached (cannot happen for trees) stay unhandled
+        P.reached.assign(n, 0);
+        for (int v : queue) P.reached[v] = 1;
+
+        // ---- pieces, their stream edges and pipeline depth
+        const int npiece = (int)closed_roots.size();
+        P.piece_of_root.assign(n, -1);
+        for (int p = 0; p < npiece; ++p) P.piece_of_root[closed_roots[p]] = p;
+        P.piece.assign(n, -1);
+        P.piece_size.assign(npiece, 0);
+        P.piece_imp.assign(npiece, 0);
+        P.piece_depth.assign(npiece, 0);
+        std::vector<int> ppre(npiece, 0), ppost(npiece, 0);
+        for (int c = 0; c < n; ++c)
+            if (P.reached[c]) {
+                const int q = P.piece_of_root[find(c)];
+                P.piece[c] = q;
+                P.piece_size[q]++;
+                ppre[q] = std::max(ppre[q], cell_pre[c]);
+                ppost[q] = std::max(ppost[q], cell_post[c]);
+            }
+        P.edge_of_prod.assign(n, -1);                        // one stream per closed piece that has a downstream cell
+        for (int p = 0; p < npiece; ++p) {                   // closing order: upstream pieces come first
+            const int r = closed_roots[p];
+            if (ds[r] >= 0) {
+                const int cp = P.piece[ds[r]];
+                P.edge_of_prod[r] = (int)P.edge_prod_cell.size();
+                P.edge_prod_cell.push_back(r);
+                P.edge_cons_cell.push_back(ds[r]);
+                P.piece_imp[cp]++;
+                P.piece_depth[cp] = std::max(P.piece_depth[cp], P.piece_depth[p] + 1);
+            }
+        }
+        P.nedge = (int)P.edge_prod_cell.size();
+        P.maxdepth = npiece ? *std::max_element(P.piece_depth.begin(), P.piece_depth.end()) : 0;
+
+        // ---- packing.  Pieces with a stream in or out: equal depth per unit (a unit then only ever waits for units
+        //      strictly upstream or downstream of it), first-fit decreasing.  Pieces without streams -- whole small
+        //      networks -- wait for nobody and go wherever lanes are free; the `cheap_units` cheapest of them (fewest row
+        //      terms) are kept together instead: units for the SIMDs that must hold two waves (see the numbering below).
+        auto has_out = [&](int p) { return ds[closed_roots[p]] >= 0; };
+        auto terms_of = [&](int p) { return std::max(ppre[p], 1) + std::max(ppost[p], 1); };
+        std::vector<int> dep, fre;
+        for (int p = 0; p < npiece; ++p) (P.piece_imp[p] > 0 || has_out(p) ? dep : fre).push_back(p);
+        std::stable_sort(dep.begin(), dep.end(), [&](int x, int y) {
+            return P.piece_depth[x] != P.piece_depth[y] ? P.piece_depth[x] < P.piece_depth[y]
+                                                        : P.piece_size[x] > P.piece_size[y];
+        });
+        int cheap_units = 0;
+        for (int round = 0; round < 4; ++round) {
+            P.unit_of_piece.assign(npiece, -1);
+            P.unit_cells_n.clear();
+            P.unit_imp_n.clear();
+            P.unit_depth.clear();
+            std::vector<int> unit_out_n;                                   // outlets: <= G_MAX too
+            auto new_unit = [&](int depth) {
+                P.unit_cells_n.push_back(0);
+                P.unit_imp_n.push_back(0);
+                unit_out_n.push_back(0);
+                P.unit_depth.push_back(depth);
+                return (int)P.unit_cells_n.size() - 1;
+            };
+            auto put_piece = [&](int p, int u) {
+                P.unit_of_piece[p] = u;
+                P.unit_cells_n[u] += P.piece_size[p];
+                P.unit_imp_n[u] += P.piece_imp[p];
+                unit_out_n[u] += has_out(p) ? 1 : 0;
+            };
+            {
+                size_t first_open = 0;
+                int cur_depth = -1;
+                for (int p : dep) {
+                    if (P.piece_depth[p] != cur_depth) {
+                        cur_depth = P.piece_depth[p];
+                        first_open = P.unit_cells_n.size();
+                    }
+                    int u = -1;
+                    for (size_t b = first_open; b < P.unit_cells_n.size(); ++b)
+                        if (P.unit_cells_n[b] + P.piece_size[p] <= LANES && P.unit_imp_n[b] + P.piece_imp[p] <= G_MAX &&
+                            unit_out_n[b] + (has_out(p) ? 1 : 0) <= G_MAX) {
+                            u = (int)b;
+                            break;
+                        }
+                    if (u < 0) u = new_unit(cur_depth);
+                    put_piece(p, u);
+                    while (first_open < P.unit_cells_n.size() && P.unit_cells_n[first_open] >= LANES) ++first_open;
+                }
+            }
+            // the cheap units: free pieces by (row terms, size), filled one unit after the other
+            std::vector<int> by_terms(fre);
+            std::stable_sort(by_terms.begin(), by_terms.end(), [&](int x, int y) {
+                return terms_of(x) != terms_of(y) ? terms_of(x) < terms_of(y) : P.piece_size[x] < P.piece_size[y];
+            });
+            std::vector<char> taken(npiece, 0);
+            {
+                int made = 0, u = -1;
+                for (int p : by_terms) {
+                    if (terms_of(p) > 3) break;
+                    if (u < 0 || P.unit_cells_n[u] + P.piece_size[p] > LANES) {
+                        if (made == cheap_units) break;
+                        u = new_unit(0);
+                        ++made;
+                    }
+                    put_piece(p, u);
+                    taken[p] = 1;
+                }
+            }
+            // the other free pieces: largest first, each into the fullest unit that still takes it
+            std::vector<int> by_size;
+            for (int p : fre)
+                if (!taken[p]) by_size.push_back(p);
+            std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) { return P.piece_size[x] > P.piece_size[y]; });
+            {
+                // units by free lanes: bucket[f] = units with f free lanes
+                std::vector<std::vector<int>> bucket(LANES + 1);
+                for (int u = 0; u < (int)P.unit_cells_n.size(); ++u) bucket[LANES - P.unit_cells_n[u]].push_back(u);
+                for (int p : by_size) {
+                    const int sz = P.piece_size[p];
+                    int u = -1;
+                    for (int f = sz; f <= LANES && u < 0; ++f)
+                        if (!bucket[f].empty()) {
+                            u = bucket[f].back();
+                            bucket[f].pop_back();
+                        }
+                    if (u < 0) u = new_unit(0);
+                    put_piece(p, u);
+                    bucket[LANES - P.unit_cells_n[u]].push_back(u);
+                }
+            }
+            P.nunit = (int)P.unit_cells_n.size();
+            const int need = simds > 0 ? std::max(P.nunit - simds, 0) : 0;
+            if (need <= cheap_units) break;
+            cheap_units = need + (round > 0 ? 2 : 0);      // the cheap units themselves may add a unit or two
+        }
+    };
+    Partition P;
+    {
+        // the capacity with the fewest units wins (ties: the larger capacity = fewer streams)
+        static const int caps[] = {LANES, 56, 48, 40, 32};
+        int forced = 0;
+        if (const char *env = getenv("XH_FLOW_PIECE_CAP")) forced = std::min(std::max(atoi(env), 1), LANES);      // experiments
+        Partition Q;
+        bool have = false;
+        for (int cap : caps) {
+            if (forced) cap = forced;
+            make_partition(cap, Q);
+            if (!have || Q.nunit < P.nunit) {
+                std::swap(P, Q);
+                have = true;
+            }
+            if (forced || (simds > 0 && P.nunit <= simds)) break;       // every unit has a SIMD of its own: good enough
         }
     }
-    const int nunit = (int)unit_cells_n.size();
+    std::vector<int> &queue = P.queue, &piece = P.piece, &closed_roots = P.closed_roots, &piece_of_root = P.piece_of_root;
+    std::vector<int> &piece_size = P.piece_size, &piece_imp = P.piece_imp, &piece_depth = P.piece_depth;
+    std::vector<int> &edge_prod_cell = P.edge_prod_cell, &edge_cons_cell = P.edge_cons_cell, &edge_of_prod = P.edge_of_prod;
+    std::vector<int> &unit_of_piece = P.unit_of_piece, &unit_cells_n = P.unit_cells_n, &unit_imp_n = P.unit_imp_n;
+    std::vector<int> &unit_depth = P.unit_depth;
+    std::vector<char> &reached = P.reached;
+    (void)reached;
+    (void)piece_size;
+    (void)piece_imp;
+    (void)piece_depth;
+    const int npiece = (int)closed_roots.size();
+    const int nedge = P.nedge, maxdepth = P.maxdepth;
+    const int nunit = P.nunit;
     if (nunit == 0) return XH_OK;
 
-    // ---- unit numbering = workgroup id.  With more units than SIMDs some SIMDs hold two waves, and both then run
-    //      ~15 % slower; the slowest unit paces the run.  On MI355X workgroup k and workgroup (SIMDs + k) were
-    //      observed to land on the same SIMD (HW_ID of every unit, tools/flow_stats.py), so the cheapest units take
-    //      the first and the last (units - SIMDs) numbers and the expensive ones get a SIMD of their own.
+    // ---- unit numbering = workgroup id.  With more units than SIMDs some SIMDs hold two waves; the slowest unit paces
+    //      the run.  On MI355X workgroup k and workgroup (SIMDs + k) were observed to land on the same SIMD (HW_ID of
+    //      every unit, tools/flow_stats.py).  Two waves on a SIMD take about as long as their instruction streams put
+    //      together (two 4-term units: 380 cycles per sub-step each against 290 alone), so the k-th cheapest unit shares
+    //      with the k-th dearest of the 2 * extra cheapest: the 2-term units built above next to ordinary ones.
     {
-        const int simds = 4 * (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 0);
         const int extra = nunit - simds;
         if (simds > 0 && extra > 0 && 2 * extra <= nunit) {
             std::vector<int> cost(nunit, 0), uexp(nunit, 0);
@@ -492,24 +617,28 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                 if (ds[closed_roots[p]] >= 0) uexp[unit_of_piece[p]] = 1;
             for (int c = 0; c < n; ++c) {
                 if (piece[c] < 0) continue;
-                int npre = 0, npost = 0;
-                bool past = false;
-                for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {
-                    if (indices[j] == c) past = true;
-                    else ++(past ? npost : npre);
-                }
                 int &k = cost[unit_of_piece[piece[c]]];             // longest pre side | longest post side << 8
-                k = std::max(k & 255, npre) | (std::max(k >> 8, npost) << 8);
+                k = std::max(k & 255, cell_pre[c]) | (std::max(k >> 8, cell_post[c]) << 8);
             }
-            for (int u = 0; u < nunit; ++u)     // measured (tools/flow_stats.py): ~25 cycles per gathered term, ~30 for
-                cost[u] = 25 * ((cost[u] & 255) + (cost[u] >> 8)) + (unit_imp_n[u] > 0 ? 30 : 0) + 20 * uexp[u];   // imports, ~20 for outlets
+            for (int u = 0; u < nunit; ++u)     // measured (tools/flow_stats.py): ~25 cycles per gathered term, ~15 for
+                cost[u] = 25 * (std::max(cost[u] & 255, 1) + std::max(cost[u] >> 8, 1)) + (unit_imp_n[u] > 0 ? 15 : 0) +
+                          15 * uexp[u];                                                                 // imports, outlets
+            // candidates: units without streams first (nobody waits for them: sharing a SIMD only delays themselves,
+            // measured +50 % for a 5-term unit next to a 2-term one, and a unit with streams passes its delay on to every
+            // unit downstream and, through the ring limits, upstream of it), then the others, each group by cost
             std::vector<int> by_cost(nunit);
             std::iota(by_cost.begin(), by_cost.end(), 0);
-            std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) { return cost[x] < cost[y]; });
+            auto coupled = [&](int u) { return unit_imp_n[u] > 0 || uexp[u] != 0; };
+            std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) {
+                return coupled(x) != coupled(y) ? !coupled(x) : cost[x] < cost[y];
+            });
+            // the 2 * extra first candidates, cheapest next to dearest
+            std::vector<int> cand(by_cost.begin(), by_cost.begin() + 2 * extra);
+            std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) { return cost[x] < cost[y]; });
             std::vector<int> newid(nunit, -1);
             for (int k = 0; k < extra; ++k) {
-                newid[by_cost[2 * k]] = k;                          // cheapest 2 * extra units pair up
-                newid[by_cost[2 * k + 1]] = simds + k;
+                newid[cand[k]] = k;
+                newid[cand[2 * extra - 1 - k]] = simds + k;
             }
             int next = extra;
             for (int u = 0; u < nunit; ++u)                         // the rest keep their (depth) order
@@ -726,6 +855,18 @@ int flow_stats_fetch(xh_ctx *ctx, FlowPlan *fp, std::vector<unsigned long long> 
     out.resize((size_t)fp->n_units * 6);
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     XH_HIP(ctx, hipMemcpy(out.data(), fp->d_stats, out.size() * 8, hipMemcpyDeviceToHost));
+    if (const char *path = getenv("XH_FLOW_TRACE")) {
+        if (fp->d_trace && fp->trace_words) {
+            std::vector<unsigned> tr(fp->trace_words);
+            XH_HIP(ctx, hipMemcpy(tr.data(), fp->d_trace, tr.size() * 4, hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(path, "wb")) {
+                const int nu = fp->n_units;
+                fwrite(&nu, 4, 1, f);
+                fwrite(tr.data(), 4, tr.size(), f);
+                fclose(f);
+            }
+        }
+    }
     return XH_OK;
 }
 

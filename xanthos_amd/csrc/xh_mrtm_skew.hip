@@ -69,6 +69,7 @@ struct SkewArgs {
     unsigned *done;                   // [units] sub-steps consumed
     unsigned *fault;
     unsigned long long *stats;
+    unsigned *trace;                  // [units][nit + 1] 100 MHz ticks at which each unit finished each month (XH_FLOW_TRACE, with stats)
 };
 
 __device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
@@ -200,9 +201,12 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
         erl_n = (q0 * area) * 1000.0 / A(sched_secs)[0];                        // mrtm.py:45
         if (nit > 1) qn = valid ? A(runoff)[(int64_t)gc * A(nmonths) + A(sched_m)[1]] : 0.0;
     }
-    double ob_s[8], ob_a[8];
+    // month outputs leave as groups of OB months per cell (32 bytes = one memory sector); 8 months per group held 16
+    // more vector registers per lane across the whole sub-step loop
+    constexpr int OB = 4;
+    double ob_s[OB], ob_a[OB];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ob_s[j] = ob_a[j] = 0.0;
+    for (int j = 0; j < OB; ++j) ob_s[j] = ob_a[j] = 0.0;
     bool alive = true;
     unsigned long long cyc_wait_data = 0, cyc_wait_ring = 0, zone_groups = 0;
     const unsigned long long cyc_begin = __builtin_amdgcn_s_memtime();
@@ -220,14 +224,27 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
     //      XCD's L2.  No release / acquire fences (an agent-scope release writes back the XCD's whole L2: -10 %).
     //      Evidence: 25 full-size launches per suite run bit-identical to the oracle, two contexts routing concurrently,
     //      the 800-case fuzzer; a violation would show as a wrong bit, and a lost wake-up as a bounded-wait fault.
-    unsigned seen_ready = 0, seen_done = 0;
+    //      A poll is an agent-coherent load: 1-2 us during which a lone wave does nothing, i.e. ~30 cycles per sub-step
+    //      when every check needs one -- and a unit whose neighbour is only just ahead of it does (measured: every unit
+    //      with streams ran at 381-395 cycles per sub-step with no unit's own loop above 364).  So each check asks for
+    //      the counters the NEXT check will look at (pend_*, loaded by inline asm so that no wait is attached to them) and
+    //      first looks at the values asked for 128 iterations ago; only if those do not cover its needs does it poll and
+    //      wait.  Counters only grow, so a stale value is merely conservative.  The `s_waitcnt vmcnt(8)` at the top also
+    //      covers the pending counter loads: a unit with streams issues at least 16 memory operations between checks.
+    unsigned seen_ready = 0, seen_done = 0, pend_ready = 0, pend_done = 0;
+    auto load_async = [&](const unsigned *q) {
+        unsigned v;
+        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(q) : "memory");
+        return v;
+    };
     auto check = [&](int n) {
         const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(pend_ready), "+v"(pend_done) : : "memory");   // older stores acknowledged, pend_* in
         if (any_x) {      // publish what has certainly been stored, then make sure the next CH iterations have ring space
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // write-through stores of older blocks acknowledged
             const int pub = min(max(n - PUBLAG - RING - lmax, 0), total);
             if (has_x) __hip_atomic_store(A(ready) + xedge, (unsigned)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int need = n + CH - lmax - A(rs);
+            seen_done = max(seen_done, pend_done);
             if (need > 0)
                 alive = wave_wait_ge(has_x, done_p, (unsigned)min(need, total), seen_done, A(fault), FAULT_RING_WAIT);
         }
@@ -237,40 +254,45 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
                 __hip_atomic_store(A(done) + unit, (unsigned)min(max(n - glmax, 0), total), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             const int need = min(total, n + CH + GROUP - lag_g);
+            seen_ready = max(seen_ready, pend_ready);
             alive = wave_wait_ge(has_g && need > 0, ready_p, (unsigned)max(need, 0), seen_ready, A(fault), FAULT_DATA_WAIT);
             asm volatile("" ::: "memory");      // the stream loads stay behind the poll
         }
+        if (any_x) pend_done = load_async(done_p);
+        if (any_g) pend_ready = load_async(ready_p);
         cyc_wait_ring += w1 - w0;
         cyc_wait_data += __builtin_amdgcn_s_memtime() - w1;
     };
 
     // ---- month bookkeeping for all lanes at once: outputs of iteration it - 1, lateral inflow of iteration it + 1
     auto finalize = [&](int it) {
+        if (A(trace) && lane == 0) A(trace)[(int64_t)unit * (nit + 1) + it] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt_begin);
         if (it >= 1) {
             const int m = A(sched_m)[it - 1], ntp = A(sched_nt)[it - 1];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
+            for (int j = 0; j < OB - 1; ++j) {
                 ob_s[j] = ob_s[j + 1];
                 ob_a[j] = ob_a[j + 1];
             }
-            ob_s[7] = snapS;
-            ob_a[7] = snapA / (double)ntp;                                     // mrtm.py:80
-            if (A(sched_write)[it - 1] && valid) {     // whole 64-byte groups of 8 months per cell
-                if ((m & 7) == 7) {
-                    const int64_t o = (int64_t)gc * A(nmonths) + (m - 7);
+            ob_s[OB - 1] = snapS;
+            ob_a[OB - 1] = snapA / (double)ntp;                                // mrtm.py:80
+            if (A(sched_write)[it - 1] && valid) {     // whole groups of OB months per cell
+                const int nmo = A(nmonths);
+                if ((m & (OB - 1)) == OB - 1) {
+                    const int64_t o = (int64_t)gc * nmo + (m - (OB - 1));
 #pragma unroll
-                    for (int j = 0; j < 8; j += 2) {
+                    for (int j = 0; j < OB; j += 2) {
                         if (A(chs)) *reinterpret_cast<v2d *>(A(chs) + o + j) = v2d{ob_s[j], ob_s[j + 1]};
                         if (A(avg)) *reinterpret_cast<v2d *>(A(avg) + o + j) = v2d{ob_a[j], ob_a[j + 1]};
                     }
-                } else if (m == A(nmonths) - 1) {                                // last, partial group
-                    const int r = (m & 7) + 1;
-                    const int64_t o = (int64_t)gc * A(nmonths) + (m + 1 - r);
+                } else if (m == nmo - 1) {                                      // last, partial group
+                    const int r = (m & (OB - 1)) + 1;
+                    const int64_t o = (int64_t)gc * nmo + (m + 1 - r);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (j >= 8 - r) {
-                            if (A(chs)) A(chs)[o + j - (8 - r)] = ob_s[j];
-                            if (A(avg)) A(avg)[o + j - (8 - r)] = ob_a[j];
+                    for (int j = 0; j < OB; ++j)
+                        if (j >= OB - r) {
+                            if (A(chs)) A(chs)[o + j - (OB - r)] = ob_s[j];
+                            if (A(avg)) A(avg)[o + j - (OB - r)] = ob_a[j];
                         }
                 }
             }
@@ -290,7 +312,13 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
         return __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(xr, gbyte[r] | pos, 0, AUX_SC1));
     };
     // Block work of the sub-steps m0 = 0 (mod 8), after their gather reads: drop the import block of iterations
-    // m0 .. m0 + 7 into the ghost entries, load the block two ahead, store the outlets' block of m0 - 8 .. m0 - 1.
+    // m0 .. m0 + 7 into the ghost entries, load the block two ahead, read the outlets' block of m0 - 8 .. m0 - 1 out of
+    // the LDS ring (before the end of this sub-step overwrites slot 0).  The block is stored one sub-step later
+    // (block_store), behind that sub-step's counted wait: stored here, the wave sat out the whole LDS latency of the read
+    // it had just issued, once per block (measured: a unit with outlets ran ~35 cycles per sub-step behind one without).
+    v4u xb[SK_R];
+#pragma unroll
+    for (int r = 0; r < SK_R; ++r) xb[r] = v4u{0u, 0u, 0u, 0u};
     auto block_io = [&](int m0, const int b) {
         if (HAS_G) {     // both rounds, unconditionally: lanes past the last import read (and ignore) ring 0
 #pragma unroll
@@ -299,12 +327,18 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
                 gbuf[b][r] = import_load(r, m0 + GROUP);
             }
         }
+#pragma unroll
+        for (int r = 0; r < SK_R; ++r)
+            if (r < nxr) {
+                if (xon[r]) xb[r] = __builtin_bit_cast(v4u, *xsrc[r]);
+            }
+    };
+    auto block_store = [&](int m0) {
         const unsigned xpos = ((unsigned)(m0 - RING - lmax) * 16u) & maskb;   // 8 sub-steps, never wrapping
 #pragma unroll
         for (int r = 0; r < SK_R; ++r)
             if (r < nxr) {
-                if (xon[r])
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, *xsrc[r]), xr, xbyte[r], xpos, AUX_SC1);
+                if (xon[r]) __builtin_amdgcn_raw_buffer_store_b128(xb[r], xr, xbyte[r], xpos, AUX_SC1);
             }
     };
 
@@ -363,6 +397,7 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
             __builtin_amdgcn_s_waitcnt(0xC07F | ((PRE + POST + 1) << 8));
             __builtin_amdgcn_sched_barrier(0);
             if ((j & (RING - 1)) == 0) block_io(n + j, j / RING);
+            if ((j & (RING - 1)) == 1) block_store(n + j - 1);
             const double F0 = S * tauinv;                                      // mrtm.py:50
             double s1 = 0.0, s2 = 0.0;                                         // UM.dot(F), stored order (mrtm.py:51)
 #pragma unroll
@@ -564,8 +599,15 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         if (env && env[0] == '1') {
             if (!fp->d_stats) XH_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&fp->d_stats), (size_t)fp->n_units * 48));
             a.stats = fp->d_stats;
+            if (getenv("XH_FLOW_TRACE")) {
+                if (fp->d_trace) (void)hipFree(fp->d_trace);
+                fp->trace_words = (size_t)fp->n_units * (size_t)(s.nit + 1);
+                XH_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&fp->d_trace), fp->trace_words * 4));
+                XH_HIP(ctx, hipMemsetAsync(fp->d_trace, 0, fp->trace_words * 4, st));
+            }
         }
     }
+    a.trace = fp->d_trace;
     if (!fp->d_skew_args) XH_HIP(ctx, hipMalloc(&fp->d_skew_args, sizeof(SkewArgs)));
     // stream-ordered: the previous launch has finished reading the block before this one rewrites it
     hipLaunchKernelGGL(k_mrtm_skew_args, dim3(1), dim3(64), 0, st, a, static_cast<SkewArgs *>(fp->d_skew_args));
