@@ -10,14 +10,23 @@ months = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 ctx = _hip.get_context(0)
 ncell_env = int(os.environ.get('XH_STATS_NCELL', '67420'))
 w = synth.make_world(ncell=ncell_env, n_basins=max(1, 235 * ncell_env // 67420))
-pipe = pipeline_from_world(ctx, w, months, 1961, 60, 0)
+pipe = pipeline_from_world(ctx, w, months, 1961, int(os.environ.get('XH_STATS_ABCD_SPIN', '60')), int(os.environ.get('XH_STATS_ROUTE_SPIN', '0')))
 f = pipe.alloc_forcing()
 ctx.synth_forcing(1, pipe.ncell, pipe.nmonths, ctx.upload(w.latitude), f, nan_frac=0.0)
 pipe.run(('pm', 'abcd'))
 for rep in range(2):
+    if os.environ.get('XH_STATS_WITH_PM'):
+        pipe.run(('pm', 'abcd'))
     ctx.timing_reset()
     pipe.run_mrtm()
     ms, n = ctx.timing('mrtm_route')
+if os.environ.get('XH_STATS_LOOP'):
+    ctx.sync(); ctx.timing_reset()
+    for rep in range(int(os.environ['XH_STATS_LOOP'])):
+        pipe.run(('pm', 'abcd', 'mrtm'))
+    ctx.sync()
+    ms, n = ctx.timing('mrtm_route')
+    print('back-to-back steps: mrtm_route avg ms', ms / n)
 st = pipe.plan.stats().astype(np.float64)
 nsub = sum(int(d) * 8 for d in pipe.ndays)
 print('route ms', ms / n, 'substeps', nsub, 'us/substep', ms / n * 1e3 / nsub)
