@@ -297,7 +297,7 @@ void flow_plan_destroy(FlowPlan *fp) {
     if (!fp) return;
     FlowBuf *bufs[] = {&fp->d_cell_of_slot, &fp->d_ent,      &fp->d_export_edge, &fp->d_ghost_edge,
                        &fp->d_edge_cons_unit, &fp->d_unit_terms, &fp->d_lag,        &fp->d_ghost_lag,
-                       &fp->d_ent2,         &fp->d_unit_p,     &fp->d_unit_lmax,   &fp->d_unit_glmax};
+                       &fp->d_ent2,         &fp->d_eprev,       &fp->d_unit_p,     &fp->d_unit_lmax,   &fp->d_unit_glmax};
     for (FlowBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (fp->d_x) (void)hipFree(fp->d_x);
@@ -419,14 +419,64 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                 return open_cnt[x] != open_cnt[y] ? open_cnt[x] < open_cnt[y] : x < y;
             });
             int total = 1, imp = (int)kids.size();
-            for (int c : kids) {
+            unsigned keep = 0;                          // bit i: kids[i]'s open piece joins v's
+            for (size_t i = 0; i < kids.size(); ++i) {
+                const int c = kids[i];
                 if (total + open_cnt[c] <= cap && imp - 1 + open_imp[c] <= G_MAX) {
-                    dsu[find(c)] = v;                   // c's open piece joins v's
+                    keep |= 1u << i;
                     total += open_cnt[c];
                     imp += open_imp[c] - 1;
-                } else {
-                    closed_roots.push_back(c);          // c's piece is final; its outlet streams into v
                 }
+            }
+            static const bool cut_rule = !(getenv("XH_FLOW_CUTRULE") && getenv("XH_FLOW_CUTRULE")[0] == '0');
+            if (cut_rule && keep + 1 != (1u << kids.size()) && cell_pre[v] >= 3 && kids.size() <= 8) {
+                // Not every child fits, and v's row has a long front side: which children become streams decides how many
+                // pairs v reads per sub-step (a stream may only open the chain that sums the front side on the way, see
+                // the time-skewed layout below).  Among the choices that fit: fewest reads for v, then most cells kept.
+                auto v_reads = [&](unsigned kp) {
+                    int j = 0, k = 0;
+                    bool in_prefix = true;
+                    for (int64_t e = indptr[v]; e < indptr[v + 1]; ++e) {
+                        const int src = indices[e];
+                        if (src == v) break;
+                        bool kept = false;
+                        for (size_t i = 0; i < kids.size(); ++i)
+                            if (kids[i] == src) kept = (kp >> i) & 1u;
+                        if (in_prefix && (kept || k == 0)) ++j;
+                        else in_prefix = false;
+                        ++k;
+                    }
+                    const int dir = j >= 2 ? 1 + k - j : k;
+                    return (k - dir >= 2 ? dir + 1 : k) + cell_post[v];
+                };
+                int best_reads = v_reads(keep), best_total = total;
+                for (unsigned kp = 0; kp < (1u << kids.size()); ++kp) {
+                    int t = 1, im = (int)kids.size();
+                    for (size_t i = 0; i < kids.size(); ++i)
+                        if ((kp >> i) & 1u) {
+                            t += open_cnt[kids[i]];
+                            im += open_imp[kids[i]] - 1;
+                        }
+                    if (t > cap || im > G_MAX) continue;
+                    const int r = v_reads(kp);
+                    if (r < best_reads || (r == best_reads && t > best_total)) {
+                        best_reads = r;
+                        best_total = t;
+                        keep = kp;
+                    }
+                }
+                total = 1;
+                imp = (int)kids.size();
+                for (size_t i = 0; i < kids.size(); ++i)
+                    if ((keep >> i) & 1u) {
+                        total += open_cnt[kids[i]];
+                        imp += open_imp[kids[i]] - 1;
+                    }
+            }
+            for (size_t i = 0; i < kids.size(); ++i) {
+                const int c = kids[i];
+                if ((keep >> i) & 1u) dsu[find(c)] = v;      // c's open piece joins v's
+                else closed_roots.push_back(c);             // c's piece is final; its outlet streams into v
             }
             open_cnt[v] = total;
             open_imp[v] = imp;
@@ -448,7 +498,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
         P.piece_size.assign(npiece, 0);
         P.piece_imp.assign(npiece, 0);
         P.piece_depth.assign(npiece, 0);
-        std::vector<int> ppre(npiece, 0), ppost(npiece, 0);
+        std::vector<int> ppre(npiece, 0), ppost(npiece, 0), pdir(npiece, 0);
         for (int c = 0; c < n; ++c)
             if (P.reached[c]) {
                 const int q = P.piece_of_root[find(c)];
@@ -456,6 +506,22 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                 P.piece_size[q]++;
                 ppre[q] = std::max(ppre[q], cell_pre[c]);
                 ppost[q] = std::max(ppost[q], cell_post[c]);
+            }
+        // front-side terms a cell still reads one by one when its unit is chained (see the time-skewed layout below): the
+        // prefix of cells of its own piece (the first may be an imported stream) counts as one
+        for (int c = 0; c < n; ++c)
+            if (P.reached[c]) {
+                const int q = P.piece[c];
+                int j = 0, k = 0;
+                bool in_prefix = true;
+                for (int64_t e = indptr[c]; e < indptr[c + 1]; ++e) {
+                    const int src = indices[e];
+                    if (src == c) break;
+                    if (in_prefix && (P.piece[src] == q || k == 0)) ++j;
+                    else in_prefix = false;
+                    ++k;
+                }
+                pdir[q] = std::max(pdir[q], j >= 2 ? 1 + k - j : k);
             }
         P.edge_of_prod.assign(n, -1);                        // one stream per closed piece that has a downstream cell
         for (int p = 0; p < npiece; ++p) {                   // closing order: upstream pieces come first
@@ -477,7 +543,12 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
         //      networks -- wait for nobody and go wherever lanes are free; the `cheap_units` cheapest of them (fewest row
         //      terms) are kept together instead: units for the SIMDs that must hold two waves (see the numbering below).
         auto has_out = [&](int p) { return ds[closed_roots[p]] >= 0; };
-        auto terms_of = [&](int p) { return std::max(ppre[p], 1) + std::max(ppost[p], 1); };
+        // pairs a unit reads per sub-step: chained when that saves a read (front side - one-by-one terms >= 2)
+        auto reads = [](int pre, int dir, int post) {
+            return std::max(pre - dir >= 2 ? dir + 1 : pre, 1) + std::max(post, 1);
+        };
+        auto terms_of = [&](int p) { return reads(ppre[p], pdir[p], ppost[p]); };
+        static const int tlimit = getenv("XH_FLOW_TLIMIT") ? atoi(getenv("XH_FLOW_TLIMIT")) : 5;
         std::vector<int> dep, fre;
         for (int p = 0; p < npiece; ++p) (P.piece_imp[p] > 0 || has_out(p) ? dep : fre).push_back(p);
         std::stable_sort(dep.begin(), dep.end(), [&](int x, int y) {
@@ -491,10 +562,14 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
             P.unit_imp_n.clear();
             P.unit_depth.clear();
             std::vector<int> unit_out_n;                                   // outlets: <= G_MAX too
+            std::vector<int> upre, udir, upost;                            // longest sides of the unit's rows
             auto new_unit = [&](int depth) {
                 P.unit_cells_n.push_back(0);
                 P.unit_imp_n.push_back(0);
                 unit_out_n.push_back(0);
+                upre.push_back(0);
+                udir.push_back(0);
+                upost.push_back(0);
                 P.unit_depth.push_back(depth);
                 return (int)P.unit_cells_n.size() - 1;
             };
@@ -503,6 +578,16 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                 P.unit_cells_n[u] += P.piece_size[p];
                 P.unit_imp_n[u] += P.piece_imp[p];
                 unit_out_n[u] += has_out(p) ? 1 : 0;
+                upre[u] = std::max(upre[u], ppre[p]);
+                udir[u] = std::max(udir[u], pdir[p]);
+                upost[u] = std::max(upost[u], ppost[p]);
+            };
+            // a piece joins a unit only if the unit then reads no more pairs per sub-step than `tlimit`, or than the piece
+            // or the unit need on their own: the slowest unit paces the run, and it is the one with the longest rows
+            auto class_ok = [&](int p, int u) {
+                const int t = reads(std::max(upre[u], ppre[p]), std::max(udir[u], pdir[p]), std::max(upost[u], ppost[p]));
+                return P.unit_cells_n[u] == 0 ||
+                       t <= std::max(tlimit, std::max(terms_of(p), reads(upre[u], udir[u], upost[u])));
             };
             {
                 size_t first_open = 0;
@@ -515,7 +600,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                     int u = -1;
                     for (size_t b = first_open; b < P.unit_cells_n.size(); ++b)
                         if (P.unit_cells_n[b] + P.piece_size[p] <= LANES && P.unit_imp_n[b] + P.piece_imp[p] <= G_MAX &&
-                            unit_out_n[b] + (has_out(p) ? 1 : 0) <= G_MAX) {
+                            unit_out_n[b] + (has_out(p) ? 1 : 0) <= G_MAX && class_ok(p, (int)b)) {
                             u = (int)b;
                             break;
                         }
@@ -555,11 +640,14 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                 for (int p : by_size) {
                     const int sz = P.piece_size[p];
                     int u = -1;
-                    for (int f = sz; f <= LANES && u < 0; ++f)
-                        if (!bucket[f].empty()) {
-                            u = bucket[f].back();
-                            bucket[f].pop_back();
-                        }
+                    for (int pass = 0; pass < 2 && u < 0; ++pass)          // second pass: any unit with room
+                        for (int f = sz; f <= LANES && u < 0; ++f)
+                            for (size_t i = bucket[f].size(); i-- > 0;)
+                                if (pass == 1 || class_ok(p, bucket[f][i])) {
+                                    u = bucket[f][i];
+                                    bucket[f].erase(bucket[f].begin() + (long)i);
+                                    break;
+                                }
                     if (u < 0) u = new_unit(0);
                     put_piece(p, u);
                     bucket[LANES - P.unit_cells_n[u]].push_back(u);
@@ -574,16 +662,32 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     Partition P;
     {
         // the capacity with the fewest units wins (ties: the larger capacity = fewer streams)
-        static const int caps[] = {LANES, 56, 48, 40, 32};
+        static const int caps[] = {LANES, 56, 48, 44, 40, 36, 32};
         int forced = 0;
         if (const char *env = getenv("XH_FLOW_PIECE_CAP")) forced = std::min(std::max(atoi(env), 1), LANES);      // experiments
         Partition Q;
         bool have = false;
+        long best_score = 0;
         for (int cap : caps) {
             if (forced) cap = forced;
             make_partition(cap, Q);
-            if (!have || Q.nunit < P.nunit) {
+            // units beyond the SIMD count share a SIMD; only units without streams may (see the numbering below): a unit
+            // with streams that has to share one slows every unit it is linked to, which costs far more than a few units
+            int indep = 0;
+            {
+                std::vector<char> coupled(Q.nunit, 0);
+                for (size_t p = 0; p < Q.closed_roots.size(); ++p)
+                    if (Q.piece_imp[p] > 0 || ds[Q.closed_roots[p]] >= 0) coupled[Q.unit_of_piece[p]] = 1;
+                for (int u = 0; u < Q.nunit; ++u) indep += coupled[u] ? 0 : 1;
+            }
+            const int extra = simds > 0 ? std::max(Q.nunit - simds, 0) : 0;
+            const long score = 1000000L * std::max(2 * extra - indep, 0) + 1000L * Q.nunit + Q.nedge / 8;
+            if (getenv("XH_FLOW_DEBUG"))
+                fprintf(stderr, "flow plan: piece capacity %d -> %d units, %d streams, %d units without streams\n", cap,
+                        Q.nunit, Q.nedge, indep);
+            if (!have || score < best_score) {
                 std::swap(P, Q);
+                best_score = score;
                 have = true;
             }
             if (forced || (simds > 0 && P.nunit <= simds)) break;       // every unit has a SIMD of its own: good enough
@@ -730,27 +834,86 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     constexpr int SK_P = 4;
     constexpr unsigned SK_ZERO = 2u * LANES * 16u;
     bool skew_ok = true;
+    // Chained units (xh_mrtm_skew.hip, CHAIN): the cells that feed a cell from in front of its diagonal, as far as they
+    // are lanes of the unit from the first one on (an imported stream ends the chain: its pair is dropped into LDS by the
+    // block transfers, not computed by a lane), pass a running sum along their stored order; the fed cell reads the last
+    // one's pair as one term and the rest of its front side term by term.  A unit is chained when that saves at least
+    // one read per sub-step: longest front side (reads saved + 1 for the running pair) at least 2 shorter.
+    std::vector<char> unit_chain(nunit, 0);
+    std::vector<int> chain_extra(n, 0), chain_prev(n, -1), chain_len(n, 0);   // levels below the last of the chain; cell before
+    std::vector<int> edge_reader(edge_cons_cell);      // the cell whose lane reads an imported pair out of LDS
+    {
+        static const bool chain_env = !(getenv("XH_FLOW_CHAIN") && getenv("XH_FLOW_CHAIN")[0] == '0');
+        std::vector<int> upre(nunit, 0), udir(nunit, 0);
+        auto front = [&](int c, int u, int &k) {       // k = terms in front of the diagonal, returns the chainable prefix:
+            int j = 0;                                 // lanes of the unit, the first one possibly an imported stream
+            bool in_prefix = true;
+            k = 0;
+            for (int64_t e = indptr[c]; e < indptr[c + 1]; ++e) {
+                const int src = indices[e];
+                if (src == c) break;
+                const bool inu = piece[src] >= 0 && unit_of_piece[piece[src]] == u;
+                if (in_prefix && (inu || k == 0)) ++j;
+                else in_prefix = false;
+                ++k;
+            }
+            return j;
+        };
+        for (int c = 0; c < n; ++c) {
+            if (piece[c] < 0) continue;
+            const int u = unit_of_piece[piece[c]];
+            int k;
+            const int j = front(c, u, k);
+            upre[u] = std::max(upre[u], k);
+            udir[u] = std::max(udir[u], j >= 2 ? 1 + k - j : k);
+        }
+        for (int u = 0; u < nunit; ++u) unit_chain[u] = chain_env && upre[u] - udir[u] >= 2 && udir[u] <= 2;
+        for (int c = 0; c < n; ++c) {
+            if (piece[c] < 0) continue;
+            const int u = unit_of_piece[piece[c]];
+            if (!unit_chain[u]) continue;
+            int k;
+            const int j = front(c, u, k);
+            if (j < 2) continue;
+            chain_len[c] = j;
+            int prev = -1;
+            for (int i = 0; i < j; ++i) {
+                const int t = indices[indptr[c] + i];
+                const bool inu = piece[t] >= 0 && unit_of_piece[piece[t]] == u;
+                if (!inu) {             // an imported stream opens the chain: the next cell adds its flows to the ghost pair
+                    edge_reader[edge_of_prod[t]] = indices[indptr[c] + 1];
+                    prev = -2 - edge_of_prod[t];
+                    continue;
+                }
+                chain_extra[t] = j - 1 - i;
+                chain_prev[t] = prev;
+                prev = t;
+            }
+        }
+    }
     std::vector<int> hgt(n, 0), unit_h(nunit, 0);
     for (size_t qi = queue.size(); qi-- > 0;) {          // reverse bottom-up order: downstream cells first
         const int c = queue[qi];
         if (piece[c] < 0) continue;
-        hgt[c] = (piece_of_root[c] == piece[c]) ? 0 : hgt[ds[c]] + 1;
+        hgt[c] = (piece_of_root[c] == piece[c]) ? 0 : hgt[ds[c]] + 1 + chain_extra[c];
         int &uh = unit_h[unit_of_piece[piece[c]]];
         uh = std::max(uh, hgt[c]);
     }
     for (int ed = 0; ed < nedge; ++ed) {
         int &uh = unit_h[edge_cons_unit[ed]];
-        uh = std::max(uh, hgt[edge_cons_cell[ed]] + 1);
+        uh = std::max(uh, hgt[edge_reader[ed]] + 1);
     }
     std::vector<int> lag(ts, 0), ghost_lag(ts, 0), unit_p(nunit, 0x11), unit_lmax(nunit, 0), unit_glmax(nunit, 0);
-    std::vector<unsigned> ent2((size_t)2 * SK_P * ts, SK_ZERO);
+    std::vector<unsigned> ent2((size_t)2 * SK_P * ts, SK_ZERO), eprev(ts, SK_ZERO);
     for (int u = 0; u < nunit; ++u) unit_lmax[u] = (2 * unit_h[u] + 15) & ~15;
     for (int c = 0; c < n; ++c) {
         if (piece[c] < 0) continue;
         const int u = unit_of_piece[piece[c]];
         const int64_t slot = (int64_t)u * LANES + slot_of_cell[c];
         lag[slot] = unit_lmax[u] - 2 * hgt[c];
-        int npre = 0, npost = 0;
+        if (chain_prev[c] >= 0) eprev[slot] = (unsigned)slot_of_cell[chain_prev[c]] * 16u;
+        else if (chain_prev[c] <= -2) eprev[slot] = (unsigned)(LANES + edge_ghost[-2 - chain_prev[c]]) * 16u;
+        int npre = 0, npost = 0, seen = 0;
         bool past = false;
         for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {
             const int src = indices[j];
@@ -758,6 +921,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                 past = true;
                 continue;
             }
+            if (!past && ++seen < chain_len[c]) continue;      // summed on the way: only the last of the chain is read
             unsigned off;
             if (piece[src] >= 0 && unit_of_piece[piece[src]] == u) off = (unsigned)slot_of_cell[src] * 16u;
             else off = (unsigned)(LANES + edge_ghost[edge_of_prod[src]]) * 16u;
@@ -769,11 +933,11 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
             ent2[(size_t)((past ? SK_P : 0) + k) * ts + slot] = off;
             ++k;
         }
-        unit_p[u] = std::max(unit_p[u] & 15, npre) | (std::max(unit_p[u] >> 4, npost) << 4);
+        unit_p[u] = std::max(unit_p[u] & 15, npre) | (std::max((unit_p[u] >> 4) & 15, npost) << 4) | (unit_chain[u] ? 0x100 : 0);
     }
     for (int ed = 0; ed < nedge; ++ed) {
         const int u = edge_cons_unit[ed];
-        const int gl = unit_lmax[u] - 2 * (hgt[edge_cons_cell[ed]] + 1);
+        const int gl = unit_lmax[u] - 2 * (hgt[edge_reader[ed]] + 1);
         ghost_lag[(int64_t)u * LANES + edge_ghost[ed]] = gl;
         unit_glmax[u] = std::max(unit_glmax[u], gl);
     }
@@ -782,10 +946,12 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     for (int ed = 0; ed < nedge; ++ed) unit_exp[unit_of_piece[piece[edge_prod_cell[ed]]]]++;
     if (getenv("XH_FLOW_DEBUG")) {      // partition statistics on stderr
         std::vector<int> hp(8, 0), hi(9, 0), hx(9, 0), hl(10, 0), hpp(25, 0);
+        int n_chain = 0;
         auto bucket = [](int v) { return v == 0 ? 0 : v <= 1 ? 1 : v <= 2 ? 2 : v <= 4 ? 3 : v <= 8 ? 4 : v <= 16 ? 5 : v <= 32 ? 6 : 7; };
         for (int u = 0; u < nunit; ++u) {
-            hp[std::max(unit_p[u] & 15, unit_p[u] >> 4)]++;
-            hpp[(unit_p[u] & 15) * 5 + (unit_p[u] >> 4)]++;
+            hp[std::max(unit_p[u] & 15, (unit_p[u] >> 4) & 15)]++;
+            hpp[(unit_p[u] & 15) * 5 + ((unit_p[u] >> 4) & 15)]++;
+            if (unit_p[u] & 0x100) ++n_chain;
             hi[bucket(unit_imp_n[u])]++;
             hx[bucket(unit_exp[u])]++;
             hl[std::min(unit_lmax[u] / 16, 9)]++;
@@ -815,6 +981,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                     if (hpc[a * 5 + b]) fprintf(stderr, " (%d,%d) %d (%d)", a, b, hpc[a * 5 + b], hcells[a * 5 + b]);
             fprintf(stderr, "\n");
         }
+        fprintf(stderr, "  chained units: %d\n", n_chain);
         fprintf(stderr, "  units by P (1..4):");
         for (int k = 1; k <= 4; ++k) fprintf(stderr, " %d", hp[k]);
         fprintf(stderr, "\n  units by (pre, post) terms:");
@@ -860,6 +1027,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     rc |= put(ctx, fp->d_lag, lag);
     rc |= put(ctx, fp->d_ghost_lag, ghost_lag);
     rc |= put(ctx, fp->d_ent2, ent2);
+    rc |= put(ctx, fp->d_eprev, eprev);
     rc |= put(ctx, fp->d_unit_p, unit_p);
     rc |= put(ctx, fp->d_unit_lmax, unit_lmax);
     rc |= put(ctx, fp->d_unit_glmax, unit_glmax);

@@ -51,9 +51,11 @@ constexpr unsigned FAULT_TEST = 99;
 struct SkewArgs {
     const int *cell_of_slot, *lag, *ghost_lag, *export_edge, *ghost_edge, *edge_cons_unit;
     const unsigned *ent2;             // [2][SK_P][units*64] LDS byte offsets inside a slot (before / after the diagonal)
+    const unsigned *eprev;            // [units*64] chained units: offset of the pair this lane's own flows are added to
     const int *unit_p, *unit_lmax, *unit_glmax;
     int64_t total_slots;
     int nmonths, nit, total;
+    int prio_from;                    // units numbered from here on share their SIMD with a cheaper unit and get issue priority
     int odd_ok;                       // 0: months have an even number of sub-steps, so lanes only cross a month start at even iterations
     const int *sched_m, *sched_nt, *sched_g;
     const double *sched_secs;
@@ -125,7 +127,7 @@ __device__ __forceinline__ T xh_ldarg(__attribute__((address_space(4))) const T 
 }
 #define A(f) xh_ldarg(&ap->f)
 
-template <int PRE, int POST, bool HAS_G>
+template <int PRE, int POST, bool HAS_G, bool CHAIN>
 __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) {
     lds_cchar *lds0 = (lds_cchar *)lds;
     const int lane = threadIdx.x, unit = blockIdx.x;
@@ -141,6 +143,13 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
     for (int w = 0; w < PRE; ++w) epre[w] = lds0 + A(ent2)[(int64_t)w * A(total_slots) + slot];
 #pragma unroll
     for (int w = 0; w < POST; ++w) epost[w] = lds0 + A(ent2)[(int64_t)(SK_P + w) * A(total_slots) + slot];
+    // CHAIN: the terms in front of a row's diagonal are summed on the way.  The cells that feed one cell from in front of
+    // its diagonal form a chain in their stored order; each runs one level (two iterations) behind the one before it and
+    // stores {running sum + F, running sum + F2} instead of {F, F2}: the running pair of the cell before it (eprv; the
+    // constant zero for the first) plus its own flows.  The cell they feed reads the last one's pair as ONE term.  The
+    // additions and their order are those of the row sum ((0 + F_1) + F_2) + ...: same bits, PRE - 1 reads and
+    // 2 (PRE - 2) adds fewer per sub-step for a unit whose longest front side is PRE >= 3.
+    lds_cchar *eprv = lds0 + (CHAIN ? A(eprev)[slot] : 0u);
     lds_d2 *own = (lds_d2 *)lds + lane;
     const int xedge = A(export_edge)[slot];
     const int gedge = A(ghost_edge)[slot];
@@ -303,6 +312,7 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
 
     // gathered pairs of the current sub-step (issued one iteration ago); import blocks in flight (two ahead)
     v2d ac[PRE], bc[POST], gbuf[2][SK_R];
+    v2d rc = v2d{0.0, 0.0};              // CHAIN: running pair of the cell before this one, current sub-step
 #pragma unroll
     for (int w = 0; w < PRE; ++w) ac[w] = v2d{0.0, 0.0};
 #pragma unroll
@@ -384,7 +394,8 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
             // reads here, a whole sub-step ahead of the sums that consume them (left alone, the scheduler pulls the next
             // sub-step's first adds up to ~15 instructions behind the reads and the wave waits out the LDS latency).
             __builtin_amdgcn_sched_barrier(0);
-            v2d an[PRE], bn[POST];
+            v2d an[PRE], bn[POST], rn = v2d{0.0, 0.0};
+            if (CHAIN) rn = *(lds_cd2 *)(eprv + ((j + RING - 1) & (RING - 1)) * SLOTB);
 #pragma unroll
             for (int w = 0; w < PRE; ++w) an[w] = *(lds_cd2 *)(epre[w] + ((j + RING - 1) & (RING - 1)) * SLOTB);
 #pragma unroll
@@ -394,7 +405,7 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
             // sub-step has returned (LDS answers in order; the loop holds no scalar loads): one counted wait here instead
             // of one in front of every add that consumes a pair.  The store is left out: a unit with few terms would wait
             // for it (measured: 220 -> 254 cycles per sub-step at 2 terms).
-            __builtin_amdgcn_s_waitcnt(0xC07F | ((PRE + POST + 1) << 8));
+            __builtin_amdgcn_s_waitcnt(0xC07F | ((PRE + POST + (CHAIN ? 1 : 0) + 1) << 8));
             __builtin_amdgcn_sched_barrier(0);
             if ((j & (RING - 1)) == 0) block_io(n + j, j / RING);
             if ((j & (RING - 1)) == 1) block_store(n + j - 1);
@@ -411,7 +422,7 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
             const double dsdt = s1 + erl;
             const bool sx = (dsdt * dt) < (-S);                                // mrtm.py:54
             const double f2 = sx ? (dsdt + F0) + S * dtinv : F0;               // mrtm.py:60
-            own[(j & (RING - 1)) * NSLOT] = v2d{F0, f2};
+            own[(j & (RING - 1)) * NSLOT] = CHAIN ? v2d{rc.x + F0, rc.y + f2} : v2d{F0, f2};
             // second sum with the adjusted flows (mrtm.py:66-69); equal to the first, bit for bit, when nothing it
             // gathers was adjusted, which is the reference's "no cell fired" branch (mrtm.py:76)
             s2 -= f2;
@@ -423,6 +434,7 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
             S = sx ? 0.0 : Sn;                                                 // mrtm.py:63, 69
             F = f2;
             favg += f2;                                                        // mrtm.py:78
+            if (CHAIN) rc = rn;
 #pragma unroll
             for (int w = 0; w < PRE; ++w) ac[w] = an[w];
 #pragma unroll
@@ -471,7 +483,7 @@ __device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) 
         st[2] = __builtin_amdgcn_s_memrealtime() - rt_begin;
         const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
-        st[3] = (unsigned long long)(PRE + POST + 1) | (any_g ? 16u : 0u) | (any_x ? 32u : 0u) |
+        st[3] = (unsigned long long)(PRE + POST + (CHAIN ? 1 : 0) + 1) | (any_g ? 16u : 0u) | (any_x ? 32u : 0u) |
                 ((unsigned long long)hw << 8) | ((unsigned long long)(xcc & 15u) << 40) | (zone_groups << 44);
         st[4] = cyc_wait_data;
         st[5] = cyc_wait_ring;
@@ -484,21 +496,33 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
     __shared__ uint2 xtab[LANES];
     const int p = A(unit_p)[blockIdx.x];             // uniform per workgroup: terms before | after the diagonal << 4
+    // two units on one SIMD: the dearer one (xh_mrtm_flow.hip numbers it SIMDs + k) goes first whenever it can issue, the
+    // cheap one, which would otherwise finish at 60 % of the run, fills the gaps
+    if ((int)blockIdx.x >= A(prio_from)) __builtin_amdgcn_s_setprio(3);
     const bool g = __any(A(ghost_edge)[(int64_t)blockIdx.x * LANES + threadIdx.x] >= 0);
     // one specialisation per (terms before, terms after, imports?): an LDS read costs a lone wave ~17 cycles of issue
     // whatever its width (tools/micro/substep_cost.hip), so no unit should read padding it does not need
-#define SKEW_CASE(PRE, POST)                                  \
-    case (PRE) | ((POST) << 4):                               \
-        if (g) skew_unit<PRE, POST, true>(ap, lds, xtab);      \
-        else skew_unit<PRE, POST, false>(ap, lds, xtab);       \
+#define SKEW_CASE(PRE, POST)                                         \
+    case (PRE) | ((POST) << 4):                                      \
+        if (g) skew_unit<PRE, POST, true, false>(ap, lds, xtab);     \
+        else skew_unit<PRE, POST, false, false>(ap, lds, xtab);      \
+        break;
+#define SKEW_CHAIN(PRE, POST)                                        \
+    case (PRE) | ((POST) << 4) | 0x100:                              \
+        if (g) skew_unit<PRE, POST, true, true>(ap, lds, xtab);      \
+        else skew_unit<PRE, POST, false, true>(ap, lds, xtab);       \
         break;
     switch (p) {
         SKEW_CASE(1, 1) SKEW_CASE(1, 2) SKEW_CASE(1, 3) SKEW_CASE(1, 4)
         SKEW_CASE(2, 1) SKEW_CASE(2, 2) SKEW_CASE(2, 3) SKEW_CASE(2, 4)
         SKEW_CASE(3, 1) SKEW_CASE(3, 2) SKEW_CASE(3, 3) SKEW_CASE(3, 4)
         SKEW_CASE(4, 1) SKEW_CASE(4, 2) SKEW_CASE(4, 3)
-        default: if (g) skew_unit<4, 4, true>(ap, lds, xtab); else skew_unit<4, 4, false>(ap, lds, xtab);
+        // chained units: front side 3 or 4 summed on the way, 1 or 2 terms left to read (xh_mrtm_flow.hip)
+        SKEW_CHAIN(1, 1) SKEW_CHAIN(1, 2) SKEW_CHAIN(1, 3) SKEW_CHAIN(1, 4)
+        SKEW_CHAIN(2, 1) SKEW_CHAIN(2, 2) SKEW_CHAIN(2, 3) SKEW_CHAIN(2, 4)
+        default: if (g) skew_unit<4, 4, true, false>(ap, lds, xtab); else skew_unit<4, 4, false, false>(ap, lds, xtab);
     }
+#undef SKEW_CHAIN
 #undef SKEW_CASE
 }
 #undef A
@@ -556,6 +580,7 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.ghost_edge = static_cast<const int *>(fp->d_ghost_edge.p);
     a.edge_cons_unit = static_cast<const int *>(fp->d_edge_cons_unit.p);
     a.ent2 = static_cast<const unsigned *>(fp->d_ent2.p);
+    a.eprev = static_cast<const unsigned *>(fp->d_eprev.p);
     a.unit_p = static_cast<const int *>(fp->d_unit_p.p);
     a.unit_lmax = static_cast<const int *>(fp->d_unit_lmax.p);
     a.unit_glmax = static_cast<const int *>(fp->d_unit_glmax.p);
@@ -564,6 +589,7 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.nit = s.nit;
     a.total = s.total;
     a.odd_ok = s.nt_even ? 0 : 1;
+    a.prio_from = 4 * (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : (1 << 28));
     a.sched_m = s.d_m;
     a.sched_nt = s.d_nt;
     a.sched_g = s.d_g;
