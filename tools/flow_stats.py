@@ -23,7 +23,9 @@ for rep in range(2):
 if os.environ.get('XH_STATS_LOOP'):
     ctx.sync(); ctx.timing_reset()
     for rep in range(int(os.environ['XH_STATS_LOOP'])):
-        pipe.run(('pm', 'abcd', 'mrtm'))
+        pipe.run(tuple(os.environ.get('XH_STATS_STAGES', 'pm,abcd,mrtm').split(',')))
+        if os.environ.get('XH_STATS_SYNC'):
+            ctx.sync()
     ctx.sync()
     ms, n = ctx.timing('mrtm_route')
     print('back-to-back steps: mrtm_route avg ms', ms / n)

@@ -297,7 +297,7 @@ void flow_plan_destroy(FlowPlan *fp) {
     if (!fp) return;
     FlowBuf *bufs[] = {&fp->d_cell_of_slot, &fp->d_ent,      &fp->d_export_edge, &fp->d_ghost_edge,
                        &fp->d_edge_cons_unit, &fp->d_unit_terms, &fp->d_lag,        &fp->d_ghost_lag,
-                       &fp->d_ent2,         &fp->d_eprev,       &fp->d_unit_p,     &fp->d_unit_lmax,   &fp->d_unit_glmax};
+                       &fp->d_ent2,         &fp->d_eprev,       &fp->d_unit_order,  &fp->d_unit_p,     &fp->d_unit_lmax,   &fp->d_unit_glmax};
     for (FlowBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (fp->d_x) (void)hipFree(fp->d_x);
@@ -708,79 +708,37 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     const int nunit = P.nunit;
     if (nunit == 0) return XH_OK;
 
-    // ---- unit numbering = workgroup id.  With more units than SIMDs some SIMDs hold two waves; the slowest unit paces
-    //      the run.  On MI355X workgroup k and workgroup (SIMDs + k) were observed to land on the same SIMD (HW_ID of
-    //      every unit, tools/flow_stats.py).  Two waves on a SIMD take about as long as their instruction streams put
-    //      together (two 4-term units: 380 cycles per sub-step each against 290 alone), so the k-th cheapest unit shares
-    //      with the k-th dearest of the 2 * extra cheapest: the 2-term units built above next to ordinary ones.
-    //      The other units are numbered so that the 4 units of a CU (ids k, k + CUs, k + 2 CUs, ...; XCD = id mod 8), and
-    //      as far as possible the CUs next to it in its XCD, run the same specialisation of the kernel (same row terms,
-    //      imports or not): a specialisation's two loop bodies are ~10 KB of code, the instruction cache is shared
-    //      between CUs, and 9-10 units with different code do not fit in it (SQC_ICACHE_MISSES: 0.05 per unit and
-    //      sub-step before).
+    // ---- which unit runs where.  With more units than SIMDs some SIMDs hold two waves; the slowest unit paces the run,
+    //      and two waves on a SIMD take about as long as their instruction streams put together (+50 % for a 5-term unit
+    //      next to a 2-term one).  A unit with streams passes its delay on to every unit downstream and, through the ring
+    //      limits, upstream of it; a unit without streams only delays itself.  So the SIMDs with two waves should hold
+    //      units without streams, a cheap one next to a dearer one that gets issue priority.  Which workgroup lands on
+    //      which SIMD cannot be planned: it follows the workgroup id only on an idle device (measured: with the ABCD
+    //      kernel's last waves still draining, 38 SIMDs instead of 34 got two workgroups, ids unrelated, and the call
+    //      took 31 ms instead of 25.6).  The kernel therefore lets every workgroup find out where it runs and claim its
+    //      unit from this list (xh_mrtm_skew.hip, claim_unit): units without streams by rising cost, then the others.
+    std::vector<int> unit_order(nunit);
+    int n_indep = 0;
     {
-        const int extra = simds > 0 ? std::max(nunit - simds, 0) : 0;
-        const int cus = simds / 4;
-        if (simds > 0 && 2 * extra <= nunit && nunit > cus) {
-            std::vector<int> cost(nunit, 0), uexp(nunit, 0), kls(nunit, 0);
-            for (int p = 0; p < npiece; ++p)
-                if (ds[closed_roots[p]] >= 0) uexp[unit_of_piece[p]] = 1;
-            for (int c = 0; c < n; ++c) {
-                if (piece[c] < 0) continue;
-                int &k = cost[unit_of_piece[piece[c]]];             // longest pre side | longest post side << 8
-                k = std::max(k & 255, cell_pre[c]) | (std::max(k >> 8, cell_post[c]) << 8);
-            }
-            for (int u = 0; u < nunit; ++u) {   // measured (tools/flow_stats.py): ~25 cycles per gathered term, ~15 for
-                const int pre = std::max(cost[u] & 255, 1), post = std::max(cost[u] >> 8, 1);
-                kls[u] = ((pre + post) << 12) | (pre << 8) | (post << 4) | (unit_imp_n[u] > 0 ? 1 : 0);
-                cost[u] = 25 * (pre + post) + (unit_imp_n[u] > 0 ? 15 : 0) + 15 * uexp[u];            // imports, outlets
-            }
-            std::vector<int> newid(nunit, -1);
-            if (extra > 0) {
-                // candidates: units without streams first (nobody waits for them: sharing a SIMD only delays themselves,
-                // measured +50 % for a 5-term unit next to a 2-term one, and a unit with streams passes its delay on to
-                // every unit downstream and, through the ring limits, upstream of it), then the others, each group by cost
-                std::vector<int> by_cost(nunit);
-                std::iota(by_cost.begin(), by_cost.end(), 0);
-                auto coupled = [&](int u) { return unit_imp_n[u] > 0 || uexp[u] != 0; };
-                std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) {
-                    return coupled(x) != coupled(y) ? !coupled(x) : cost[x] < cost[y];
-                });
-                // the 2 * extra first candidates, cheapest next to dearest
-                std::vector<int> cand(by_cost.begin(), by_cost.begin() + 2 * extra);
-                std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) { return cost[x] < cost[y]; });
-                for (int k = 0; k < extra; ++k) {
-                    newid[cand[k]] = k;
-                    newid[cand[2 * extra - 1 - k]] = simds + k;
-                }
-            }
-            std::vector<int> rest;
-            for (int u = 0; u < nunit; ++u)
-                if (newid[u] < 0) rest.push_back(u);
-            std::stable_sort(rest.begin(), rest.end(), [&](int x, int y) { return kls[x] < kls[y]; });
-            const int top = std::min(nunit, simds);                 // ids extra .. top - 1 are free
-            size_t next = 0;
-            for (int x = 0; x < 8 && next < rest.size(); ++x)       // CUs XCD by XCD
-                for (int c = x; c < cus && next < rest.size(); c += 8)
-                    for (int id = c; id < top && next < rest.size(); id += cus)
-                        if (id >= extra) newid[rest[next++]] = id;
-            for (int id = extra; next < rest.size(); ++id) {        // cannot happen: every id in [extra, top) was visited
-                bool used = false;
-                for (int u = 0; u < nunit && !used; ++u) used = newid[u] == id;
-                if (!used) newid[rest[next++]] = id;
-            }
-            for (int p = 0; p < npiece; ++p) unit_of_piece[p] = newid[unit_of_piece[p]];
-            std::vector<int> cn(nunit), in(nunit), dp(nunit);
-            for (int u = 0; u < nunit; ++u) {
-                cn[newid[u]] = unit_cells_n[u];
-                in[newid[u]] = unit_imp_n[u];
-                dp[newid[u]] = unit_depth[u];
-            }
-            unit_cells_n.swap(cn);
-            unit_imp_n.swap(in);
-            unit_depth.swap(dp);
+        std::vector<int> cost(nunit, 0), uexp(nunit, 0);
+        for (int p = 0; p < npiece; ++p)
+            if (ds[closed_roots[p]] >= 0) uexp[unit_of_piece[p]] = 1;
+        for (int c = 0; c < n; ++c) {
+            if (piece[c] < 0) continue;
+            int &k = cost[unit_of_piece[piece[c]]];             // longest pre side | longest post side << 8
+            k = std::max(k & 255, cell_pre[c]) | (std::max(k >> 8, cell_post[c]) << 8);
         }
+        for (int u = 0; u < nunit; ++u)       // measured (tools/flow_stats.py): ~25 cycles per gathered term, ~15 for
+            cost[u] = 25 * (std::max(cost[u] & 255, 1) + std::max(cost[u] >> 8, 1)) + (unit_imp_n[u] > 0 ? 15 : 0) +
+                      15 * uexp[u];                                                                   // imports, outlets
+        auto coupled = [&](int u) { return unit_imp_n[u] > 0 || uexp[u] != 0; };
+        std::iota(unit_order.begin(), unit_order.end(), 0);
+        std::stable_sort(unit_order.begin(), unit_order.end(), [&](int x, int y) {
+            return coupled(x) != coupled(y) ? !coupled(x) : cost[x] < cost[y];
+        });
+        for (int u = 0; u < nunit; ++u) n_indep += coupled(u) ? 0 : 1;
     }
+    (void)n_indep;
 
     // ---- slots, ghosts, gather offsets
     const int64_t ts = (int64_t)nunit * LANES;
@@ -1029,6 +987,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     rc |= put(ctx, fp->d_ent2, ent2);
     rc |= put(ctx, fp->d_eprev, eprev);
     rc |= put(ctx, fp->d_unit_p, unit_p);
+    rc |= put(ctx, fp->d_unit_order, unit_order);
     rc |= put(ctx, fp->d_unit_lmax, unit_lmax);
     rc |= put(ctx, fp->d_unit_glmax, unit_glmax);
     if (rc) {

@@ -47,6 +47,9 @@ constexpr int CH = 128;                       // iterations between flow-control
 constexpr int PUBLAG = 64;                    // a check publishes the stores older than this many iterations
 constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2;
 constexpr unsigned FAULT_TEST = 99;
+constexpr unsigned FAULT_PLACE_WAIT = 3;
+constexpr int PLACE_KEYS = 16 * 8 * 2 * 16 * 4;      // (xcc, se, sh, cu, simd) of HW_ID / XCC_ID
+constexpr int PLACE_WORDS = 16 + PLACE_KEYS;
 
 struct SkewArgs {
     const int *cell_of_slot, *lag, *ghost_lag, *export_edge, *ghost_edge, *edge_cons_unit;
@@ -55,7 +58,9 @@ struct SkewArgs {
     const int *unit_p, *unit_lmax, *unit_glmax;
     int64_t total_slots;
     int nmonths, nit, total;
-    int prio_from;                    // units numbered from here on share their SIMD with a cheaper unit and get issue priority
+    const int *unit_order;            // [units] claim list: units without streams by rising cost, then the others
+    unsigned *place;                  // [PLACE_WORDS] counters of claim_unit, zeroed before every launch
+    int n_units;
     int odd_ok;                       // 0: months have an even number of sub-steps, so lanes only cross a month start at even iterations
     const int *sched_m, *sched_nt, *sched_g;
     const double *sched_secs;
@@ -128,9 +133,9 @@ __device__ __forceinline__ T xh_ldarg(__attribute__((address_space(4))) const T 
 #define A(f) xh_ldarg(&ap->f)
 
 template <int PRE, int POST, bool HAS_G, bool CHAIN>
-__device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab) {
+__device__ __forceinline__ void skew_unit(SkewArgsK *ap, v2d *lds, uint2 *xtab, const int unit) {
     lds_cchar *lds0 = (lds_cchar *)lds;
-    const int lane = threadIdx.x, unit = blockIdx.x;
+    const int lane = threadIdx.x;
     const int64_t slot = (int64_t)unit * LANES + lane;
 
     const int gc = A(cell_of_slot)[slot];
@@ -495,22 +500,64 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     SkewArgsK *ap = (SkewArgsK *)ap_;
     __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
     __shared__ uint2 xtab[LANES];
-    const int p = A(unit_p)[blockIdx.x];             // uniform per workgroup: terms before | after the diagonal << 4
-    // two units on one SIMD: the dearer one (xh_mrtm_flow.hip numbers it SIMDs + k) goes first whenever it can issue, the
-    // cheap one, which would otherwise finish at 60 % of the run, fills the gaps
-    if ((int)blockIdx.x >= A(prio_from)) __builtin_amdgcn_s_setprio(3);
-    const bool g = __any(A(ghost_edge)[(int64_t)blockIdx.x * LANES + threadIdx.x] >= 0);
+    // ---- which unit this workgroup runs (see xh_mrtm_flow.hip, "which unit runs where"): every workgroup registers on
+    //      its SIMD, waits until all have (they are all resident: the launch made sure), and then knows whether it has
+    //      the SIMD to itself.  Second arrivals on a SIMD take the cheapest units of the list, the first arrivals on
+    //      those SIMDs the next ones, with issue priority; everybody else takes the rest in list order.
+    __shared__ int unit_sh;
+    if (threadIdx.x == 0) {
+        unsigned *pl = A(place);
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 15u;
+        const unsigned key = ((((xcc * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u)) * 4u) +
+                             ((hw >> 4) & 3u);
+        const int n_units = A(n_units);
+        const unsigned rank = __hip_atomic_fetch_add(pl + 16 + key, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (rank >= 1) __hip_atomic_fetch_add(pl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // second waves
+        if (rank == 1) __hip_atomic_fetch_add(pl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // shared SIMDs
+        __hip_atomic_fetch_add(pl + 0, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool ok = true;
+        while (__hip_atomic_load(pl + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_units) {
+            if (ld_relaxed(A(fault)) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
+                __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        int idx = -1;
+        if (ok) {
+            const unsigned seconds = ld_relaxed(pl + 1), shared = ld_relaxed(pl + 2);
+            const unsigned here = ld_relaxed(pl + 16 + key);
+            if (here >= 2 && rank >= 1) {
+                idx = (int)__hip_atomic_fetch_add(pl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (here >= 2) {
+                idx = (int)(seconds + __hip_atomic_fetch_add(pl + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                __builtin_amdgcn_s_setprio(3);
+            } else {
+                idx = (int)(seconds + shared + __hip_atomic_fetch_add(pl + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            if (idx >= n_units) idx = -1;      // cannot happen: the three ranges add up to the units
+        }
+        unit_sh = idx >= 0 ? A(unit_order)[idx] : -1;
+    }
+    __syncthreads();
+    const int unit = unit_sh;
+    if (unit < 0) return;
+    const int p = A(unit_p)[unit];                   // uniform per workgroup: terms before | after the diagonal << 4
+    const bool g = __any(A(ghost_edge)[(int64_t)unit * LANES + threadIdx.x] >= 0);
     // one specialisation per (terms before, terms after, imports?): an LDS read costs a lone wave ~17 cycles of issue
     // whatever its width (tools/micro/substep_cost.hip), so no unit should read padding it does not need
 #define SKEW_CASE(PRE, POST)                                         \
     case (PRE) | ((POST) << 4):                                      \
-        if (g) skew_unit<PRE, POST, true, false>(ap, lds, xtab);     \
-        else skew_unit<PRE, POST, false, false>(ap, lds, xtab);      \
+        if (g) skew_unit<PRE, POST, true, false>(ap, lds, xtab, unit);     \
+        else skew_unit<PRE, POST, false, false>(ap, lds, xtab, unit);      \
         break;
 #define SKEW_CHAIN(PRE, POST)                                        \
     case (PRE) | ((POST) << 4) | 0x100:                              \
-        if (g) skew_unit<PRE, POST, true, true>(ap, lds, xtab);      \
-        else skew_unit<PRE, POST, false, true>(ap, lds, xtab);       \
+        if (g) skew_unit<PRE, POST, true, true>(ap, lds, xtab, unit);      \
+        else skew_unit<PRE, POST, false, true>(ap, lds, xtab, unit);       \
         break;
     switch (p) {
         SKEW_CASE(1, 1) SKEW_CASE(1, 2) SKEW_CASE(1, 3) SKEW_CASE(1, 4)
@@ -520,7 +567,7 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
         // chained units: front side 3 or 4 summed on the way, 1 or 2 terms left to read (xh_mrtm_flow.hip)
         SKEW_CHAIN(1, 1) SKEW_CHAIN(1, 2) SKEW_CHAIN(1, 3) SKEW_CHAIN(1, 4)
         SKEW_CHAIN(2, 1) SKEW_CHAIN(2, 2) SKEW_CHAIN(2, 3) SKEW_CHAIN(2, 4)
-        default: if (g) skew_unit<4, 4, true, false>(ap, lds, xtab); else skew_unit<4, 4, false, false>(ap, lds, xtab);
+        default: if (g) skew_unit<4, 4, true, false>(ap, lds, xtab, unit); else skew_unit<4, 4, false, false>(ap, lds, xtab, unit);
     }
 #undef SKEW_CHAIN
 #undef SKEW_CASE
@@ -536,14 +583,18 @@ __global__ void k_mrtm_skew_args(SkewArgs a, SkewArgs *dst) {
 int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st) {
     if (!fp || fp->n_units == 0) return XH_OK;
     // a lane must have left month it - 1 before the unit's clock reaches month it + 1 (one pending snapshot per lane)
-    if (!fp->skew_ok || fp->max_imports > 8 * SK_R || fp->max_exports > 8 * SK_R || s.ntmin < fp->skew_lmax + 2 * GROUP)
+    if (!fp->skew_ok || fp->max_imports > 8 * SK_R || fp->max_exports > 8 * SK_R || s.ntmin < fp->skew_lmax + 2 * GROUP) {
+        if (getenv("XH_FLOW_DEBUG"))
+            fprintf(stderr, "skew kernel not used: skew_ok %d, imports %d, outlets %d, shortest month %d sub-steps, largest lag %d\n",
+                    (int)fp->skew_ok, fp->max_imports, fp->max_exports, s.ntmin, fp->skew_lmax);
         return XH_ERR_LIMIT;
+    }
     // ring: a consumer asks for ~2 CH + lag sub-steps ahead of its clock, a producer may run RS - CH - lag ahead
     int rs = 2048;
     while (rs < 8 * CH + 4 * fp->skew_lmax) rs *= 2;
     const size_t x_streams = (size_t)std::max(fp->n_edges, 1) * (size_t)rs * sizeof(v2d);
     if (x_streams >= ((size_t)1 << 32)) return XH_ERR_LIMIT;      // 32-bit ring offsets
-    const size_t x_cnt = ((size_t)(fp->n_edges + fp->n_units) * sizeof(unsigned) + 255) & ~size_t(255);
+    const size_t x_cnt = ((size_t)(fp->n_edges + fp->n_units + PLACE_WORDS) * sizeof(unsigned) + 255) & ~size_t(255);
     if (x_streams + x_cnt > fp->x_bytes) {
         if (fp->d_x) {
             XH_HIP(ctx, hipStreamSynchronize(st));
@@ -563,7 +614,7 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         const char *env = getenv("XH_FLOW_PER_CU_EXTRA");     // experiments only
         if (env) per_cu += atoi(env);
     }
-    const size_t lds_static = (size_t)RING * NSLOT * sizeof(v2d) + LANES * sizeof(uint2);
+    const size_t lds_static = (size_t)RING * NSLOT * sizeof(v2d) + LANES * sizeof(uint2) + 64;      // + unit_sh, padded
     const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
     size_t lds = share > lds_static + 1024 ? share - lds_static : 0;
     XH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mrtm_skew), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -582,6 +633,8 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.ent2 = static_cast<const unsigned *>(fp->d_ent2.p);
     a.eprev = static_cast<const unsigned *>(fp->d_eprev.p);
     a.unit_p = static_cast<const int *>(fp->d_unit_p.p);
+    a.unit_order = static_cast<const int *>(fp->d_unit_order.p);
+    a.n_units = fp->n_units;
     a.unit_lmax = static_cast<const int *>(fp->d_unit_lmax.p);
     a.unit_glmax = static_cast<const int *>(fp->d_unit_glmax.p);
     a.total_slots = (int64_t)fp->n_units * LANES;
@@ -589,7 +642,6 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.nit = s.nit;
     a.total = s.total;
     a.odd_ok = s.nt_even ? 0 : 1;
-    a.prio_from = 4 * (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : (1 << 28));
     a.sched_m = s.d_m;
     a.sched_nt = s.d_nt;
     a.sched_g = s.d_g;
@@ -612,6 +664,7 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.rs = rs;
     a.ready = cnt;
     a.done = cnt + fp->n_edges;
+    a.place = cnt + fp->n_edges + fp->n_units;
     unsigned *fault = nullptr;
     int rc = xh_fault_word(ctx, &fault);
     if (rc) return rc;
