@@ -20,5 +20,6 @@ timeout 300 python3 bench.py --workload pm_abcd --steps 10 --warmup 2 > gpurun_o
 timeout 600 python3 bench.py --workload calib --steps 5 --warmup 1 > gpurun_out/bench_calib.json 2> gpurun_out/bench_calib.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace_calib -- python3 bench.py --workload calib --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 cp gpurun_out/prof_trace_calib/*/*kernel_stats.csv gpurun_out/kernel_stats_calib.csv
-XH_FLOW_STATS=1 timeout 300 python3 tools/flow_stats.py 120 > gpurun_out/flow_unit_cycles.txt 2>&1
+XH_FLOW_DEBUG=1 XH_FLOW_STATS=1 timeout 300 python3 tools/flow_stats.py 720 > gpurun_out/flow_unit_cycles.txt 2>&1
+XH_STATS_ROUTE_SPIN=120 XH_STATS_ABCD_SPIN=120 XH_STATS_LOOP=5 timeout 300 python3 tools/flow_stats.py 600 2>&1 | grep -E "back-to-back|histogram|wave\(s\)" > gpurun_out/flow_pipelined.txt
 head -c 600 gpurun_out/bench.json; echo; head -8 gpurun_out/kernel_stats.csv | cut -c1-160; cat gpurun_out/pmc_traffic.json | head -50

@@ -16,6 +16,7 @@ struct FlowPlan {
     // time-skewed layout (xh_mrtm_skew.hip); skew_ok = every row has <= 4 terms either side of its diagonal
     bool skew_ok = false;
     int skew_lmax = 0;                   // largest lane lag of any unit (sub-steps)
+    int skew_span = 1;                   // most pipeline levels a stream jumps over (consumer depth - producer depth)
     FlowBuf d_lag, d_ghost_lag, d_ent2, d_eprev, d_unit_p, d_unit_lmax, d_unit_glmax, d_unit_order;
     // per-call exchange buffers (grow-only)
     void *d_x = nullptr;

@@ -449,6 +449,8 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                     const int dir = j >= 2 ? 1 + k - j : k;
                     return (k - dir >= 2 ? dir + 1 : k) + cell_post[v];
                 };
+                // (the capacity is there for the packing; a piece around such a cell may grow up to a whole unit if that is
+                // what it takes to keep its chain)
                 int best_reads = v_reads(keep), best_total = total;
                 for (unsigned kp = 0; kp < (1u << kids.size()); ++kp) {
                     int t = 1, im = (int)kids.size();
@@ -457,9 +459,10 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                             t += open_cnt[kids[i]];
                             im += open_imp[kids[i]] - 1;
                         }
-                    if (t > cap || im > G_MAX) continue;
+                    if (t > LANES || im > G_MAX) continue;
                     const int r = v_reads(kp);
-                    if (r < best_reads || (r == best_reads && t > best_total)) {
+                    const bool over = t > cap, best_over = best_total > cap;
+                    if (r < best_reads || (r == best_reads && (over != best_over ? !over : t > best_total))) {
                         best_reads = r;
                         best_total = t;
                         keep = kp;
@@ -702,7 +705,6 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     (void)reached;
     (void)piece_size;
     (void)piece_imp;
-    (void)piece_depth;
     const int npiece = (int)closed_roots.size();
     const int nedge = P.nedge, maxdepth = P.maxdepth;
     const int nunit = P.nunit;
@@ -970,6 +972,14 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     FlowPlan *fp = new FlowPlan();
     fp->skew_ok = skew_ok;
     fp->skew_lmax = *std::max_element(unit_lmax.begin(), unit_lmax.end());
+    {   // longest jump of a stream over pipeline levels: the ring of such a stream has to hold what the levels in between
+        // need as lead (xh_mrtm_skew.hip, ring size)
+        int span = 1;
+        for (int ed = 0; ed < nedge; ++ed)
+            span = std::max(span, piece_depth[piece[edge_cons_cell[ed]]] - piece_depth[piece[edge_prod_cell[ed]]]);
+        fp->skew_span = span;
+        if (getenv("XH_FLOW_DEBUG")) fprintf(stderr, "  longest stream jump: %d levels\n", span);
+    }
     fp->n_units = nunit;
     fp->n_edges = nedge;
     fp->depth = maxdepth + 1;

@@ -500,10 +500,13 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     SkewArgsK *ap = (SkewArgsK *)ap_;
     __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
     __shared__ uint2 xtab[LANES];
-    // ---- which unit this workgroup runs (see xh_mrtm_flow.hip, "which unit runs where"): every workgroup registers on
-    //      its SIMD, waits until all have (they are all resident: the launch made sure), and then knows whether it has
-    //      the SIMD to itself.  Second arrivals on a SIMD take the cheapest units of the list, the first arrivals on
-    //      those SIMDs the next ones, with issue priority; everybody else takes the rest in list order.
+    // ---- which unit this workgroup runs (see xh_mrtm_flow.hip, "which unit runs where").  The launch has more workgroups
+    //      than units.  Every workgroup registers on its SIMD and waits until all have (they are all resident: the launch
+    //      made sure).  First arrivals run a unit; as many second arrivals as there are units left over also do, the rest
+    //      leave -- so exactly (units - SIMDs in use) SIMDs hold two units however the dispatcher spread the workgroups
+    //      (without the spare workgroups it doubled up 38-65 SIMDs in a pipelined run and left as many empty).  The second
+    //      arrivals that stay take the cheapest units of the list, their SIMD partners the next ones, with issue
+    //      priority, everybody else the rest in list order.
     __shared__ int unit_sh;
     if (threadIdx.x == 0) {
         unsigned *pl = A(place);
@@ -512,34 +515,51 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
         const unsigned key = ((((xcc * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u)) * 4u) +
                              ((hw >> 4) & 3u);
         const int n_units = A(n_units);
-        const unsigned rank = __hip_atomic_fetch_add(pl + 16 + key, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (rank >= 1) __hip_atomic_fetch_add(pl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // second waves
-        if (rank == 1) __hip_atomic_fetch_add(pl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // shared SIMDs
-        __hip_atomic_fetch_add(pl + 0, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        bool ok = true;
-        while (__hip_atomic_load(pl + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_units) {
-            if (ld_relaxed(A(fault)) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
-                __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = false;
-                break;
+        const unsigned n_wg = gridDim.x;
+        unsigned *fault = A(fault);
+        auto wait_for = [&](unsigned *word, unsigned target) {      // bounded; false and the fault word raised on timeout
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (ld_relaxed(fault) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
+                    __hip_atomic_store(fault, FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+                __builtin_amdgcn_s_sleep(8);
             }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        int idx = -1;
-        if (ok) {
-            const unsigned seconds = ld_relaxed(pl + 1), shared = ld_relaxed(pl + 2);
-            const unsigned here = ld_relaxed(pl + 16 + key);
-            if (here >= 2 && rank >= 1) {
-                idx = (int)__hip_atomic_fetch_add(pl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (here >= 2) {
-                idx = (int)(seconds + __hip_atomic_fetch_add(pl + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                __builtin_amdgcn_s_setprio(3);
-            } else {
-                idx = (int)(seconds + shared + __hip_atomic_fetch_add(pl + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            return true;
+        };
+        auto add = [&](int word) { return __hip_atomic_fetch_add(pl + word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        // words: 0 registered, 1 second arrivals, 2 first arrivals, 3 tickets of the second arrivals, 4 second arrivals
+        // decided, 5 / 6 claims of the partners / of everybody else, 7 tickets of the first arrivals
+        const unsigned rank = __hip_atomic_fetch_add(pl + 16 + key, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;
+        if (rank == 0) add(2);
+        else if (rank == 1) add(1);
+        __hip_atomic_fetch_add(pl + 0, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int idx = -1;                                  // -1: fault, -2: spare workgroup, nothing to do
+        if (wait_for(pl + 0, n_wg)) {
+            const int firsts = (int)ld_relaxed(pl + 2), seconds = (int)ld_relaxed(pl + 1);
+            const int need2 = max(n_units - firsts, 0);         // second arrivals that must run a unit
+            if (rank >= 2) {
+                idx = -2;
+            } else if (rank == 1) {
+                const int t = (int)add(3);
+                if (t < need2) __hip_atomic_fetch_or(pl + 16 + key, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(pl + 4, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                idx = t < need2 ? t : -2;
+            } else if (wait_for(pl + 4, (unsigned)seconds)) {
+                const bool shared = (ld_relaxed(pl + 16 + key) & 0x10000u) != 0;
+                if (firsts > n_units && (int)add(7) >= n_units) {
+                    idx = -2;
+                } else if (shared) {
+                    idx = need2 + (int)add(5);
+                    __builtin_amdgcn_s_setprio(3);
+                } else {
+                    idx = 2 * need2 + (int)add(6);
+                }
             }
             if (idx >= n_units) idx = -1;      // cannot happen: the three ranges add up to the units
         }
+        if (idx == -1) __hip_atomic_store(fault, FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unit_sh = idx >= 0 ? A(unit_order)[idx] : -1;
     }
     __syncthreads();
@@ -590,8 +610,15 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         return XH_ERR_LIMIT;
     }
     // ring: a consumer asks for ~2 CH + lag sub-steps ahead of its clock, a producer may run RS - CH - lag ahead
+    // ring: a consumer asks for ~2 CH + lag sub-steps ahead of its clock, a producer may run RS - CH - lag ahead.  A stream
+    // that jumps over k pipeline levels (a tributary that joins the main stem far downstream: its consumer also waits for
+    // units k levels below the producer) needs the lead of all of them in its ring: every level trails the one above by
+    // PUBLAG + RING + lag + CH + GROUP + up to CH of check granularity ~ 400-450 sub-steps.  With a ring shorter than that
+    // nobody deadlocks, but the producer is held at the ring limit, its other consumers starve, and every linked unit ends
+    // up waiting a quarter of the time (measured: 32.7 instead of 26.7 ms with 2,048 sub-steps and a 6-level jump).
     int rs = 2048;
-    while (rs < 8 * CH + 4 * fp->skew_lmax) rs *= 2;
+    while (rs < 8 * CH + 4 * fp->skew_lmax || rs < 1024 + 512 * fp->skew_span) rs *= 2;
+    if (const char *env = getenv("XH_FLOW_RS")) rs = std::max(atoi(env) & ~(atoi(env) - 1) ? 2048 : atoi(env), 2048);      // experiments: a power of two
     const size_t x_streams = (size_t)std::max(fp->n_edges, 1) * (size_t)rs * sizeof(v2d);
     if (x_streams >= ((size_t)1 << 32)) return XH_ERR_LIMIT;      // 32-bit ring offsets
     const size_t x_cnt = ((size_t)(fp->n_edges + fp->n_units + PLACE_WORDS) * sizeof(unsigned) + 255) & ~size_t(255);
@@ -609,7 +636,14 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
 
     // every unit resident at once: see flow_launch for the LDS-share sizing (one workgroup more than the even split)
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    int per_cu = (fp->n_units + cus - 1) / cus + 1;
+    // spare workgroups (k_mrtm_skew, "which unit this workgroup runs"): one per CU, as long as two waves per SIMD hold all
+    int n_wg = fp->n_units + cus;
+    if (n_wg > 8 * cus) n_wg = std::max(fp->n_units, 8 * cus);
+    {
+        const char *env = getenv("XH_FLOW_SPARE");            // experiments only
+        if (env) n_wg = fp->n_units + std::max(atoi(env), 0);
+    }
+    int per_cu = (n_wg + cus - 1) / cus + 1;
     {
         const char *env = getenv("XH_FLOW_PER_CU_EXTRA");     // experiments only
         if (env) per_cu += atoi(env);
@@ -621,7 +655,7 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
                                     (int)lds));
     int resident = 0;
     XH_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k_mrtm_skew, LANES, lds));
-    if ((int64_t)(resident - 1) * cus < fp->n_units) return XH_ERR_LIMIT;
+    if ((int64_t)(resident - 1) * cus < n_wg || n_wg > 8 * cus) return XH_ERR_LIMIT;
 
     SkewArgs a;
     a.cell_of_slot = static_cast<const int *>(fp->d_cell_of_slot.p);
@@ -690,7 +724,7 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     if (!fp->d_skew_args) XH_HIP(ctx, hipMalloc(&fp->d_skew_args, sizeof(SkewArgs)));
     // stream-ordered: the previous launch has finished reading the block before this one rewrites it
     hipLaunchKernelGGL(k_mrtm_skew_args, dim3(1), dim3(64), 0, st, a, static_cast<SkewArgs *>(fp->d_skew_args));
-    hipLaunchKernelGGL(k_mrtm_skew, dim3((unsigned)fp->n_units), dim3(LANES), lds, st,
+    hipLaunchKernelGGL(k_mrtm_skew, dim3((unsigned)n_wg), dim3(LANES), lds, st,
                        static_cast<const SkewArgs *>(fp->d_skew_args));
     XH_HIP(ctx, hipGetLastError());
     return XH_OK;
