@@ -249,6 +249,56 @@ def test_route_synthetic_world_vs_oracle(hip, flags):
     assert um.plan(hip.get_context()).info()['last_tree_kernel'] == {0: 2, 8: 1, 4: 0}[flags]
 
 
+_PARTITION_CHILD = r"""
+import sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from types import SimpleNamespace as NS
+from oracle import months as o_months
+from oracle import mrtm as o_mrtm
+from xanthos_amd import _hip, synth
+from xanthos_amd.routing import mrtm
+w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=5, seed=3, outlet_frac=0.02)
+st = NS(ngridrow=w.nrow, ngridcol=w.ncol)
+ds = mrtm.downstream(w.coords, w.flow_dir, st)
+um = mrtm.upstream_genmatrix(mrtm.upstream(w.coords, ds, st))
+rng = np.random.default_rng(11)
+runoff = rng.gamma(2.0, 30.0, (w.ncell, 12))
+ndays = o_months.set_month_arrays(12, 1973, 1973)[:, 2]
+ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+info = um.plan(_hip.get_context()).info()
+ok = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
+print(json.dumps({'ok': bool(ok), 'kernel': int(info['last_tree_kernel']), 'units': int(info['flow_units']),
+                  'edges': int(info['flow_edges']), 'reroutes': int(info['reroutes'])}))
+"""
+
+
+@pytest.mark.parametrize('env', [{}, {'XH_FLOW_PIECE_CAP': '64', 'XH_FLOW_CHAIN': '0'}, {'XH_FLOW_PIECE_CAP': '20'},
+                                 {'XH_FLOW_CUTRULE': '0', 'XH_FLOW_TLIMIT': '9'}, {'XH_FLOW_SPARE': '0'},
+                                 {'XH_FLOW_SPARE': '700'}, {'XH_FLOW_RS': '16384'}])
+def test_route_partition_variants_bit_exact(env, tmp_path):
+    """The knobs of the dataflow partition (piece capacity, chains, which children become streams, class-aware packing,
+    spare workgroups, ring size) change which cells share a wave and who waits for whom -- never a bit of the result.  Each
+    variant routes the 3000-cell world in a process of its own (the knobs are read once per process) against the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'child.py'
+    script.write_text(_PARTITION_CHILD)
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, str(script), root], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res['ok'] and res['kernel'] == 2 and res['reroutes'] == 0, res
+    if env.get('XH_FLOW_PIECE_CAP') == '20':
+        assert res['edges'] > 150, res          # many more streams than the default cut
+
+
 @pytest.mark.parametrize('basin', [0, 1])
 @pytest.mark.parametrize('unit', ['km3_per_mth', 'mm_per_mth'])
 @pytest.mark.parametrize('tag', ['snow', 'nosnow'])

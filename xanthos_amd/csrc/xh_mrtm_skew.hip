@@ -618,7 +618,10 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     // up waiting a quarter of the time (measured: 32.7 instead of 26.7 ms with 2,048 sub-steps and a 6-level jump).
     int rs = 2048;
     while (rs < 8 * CH + 4 * fp->skew_lmax || rs < 1024 + 512 * fp->skew_span) rs *= 2;
-    if (const char *env = getenv("XH_FLOW_RS")) rs = std::max(atoi(env) & ~(atoi(env) - 1) ? 2048 : atoi(env), 2048);      // experiments: a power of two
+    if (const char *env = getenv("XH_FLOW_RS")) {      // experiments: a power of two
+        const int v = atoi(env);
+        if (v >= 2048 && (v & (v - 1)) == 0) rs = v;
+    }
     const size_t x_streams = (size_t)std::max(fp->n_edges, 1) * (size_t)rs * sizeof(v2d);
     if (x_streams >= ((size_t)1 << 32)) return XH_ERR_LIMIT;      // 32-bit ring offsets
     const size_t x_cnt = ((size_t)(fp->n_edges + fp->n_units + PLACE_WORDS) * sizeof(unsigned) + 255) & ~size_t(255);
