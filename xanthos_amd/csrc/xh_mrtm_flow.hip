@@ -719,28 +719,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     //      kernel's last waves still draining, 38 SIMDs instead of 34 got two workgroups, ids unrelated, and the call
     //      took 31 ms instead of 25.6).  The kernel therefore lets every workgroup find out where it runs and claim its
     //      unit from this list (xh_mrtm_skew.hip, claim_unit): units without streams by rising cost, then the others.
-    std::vector<int> unit_order(nunit);
-    int n_indep = 0;
-    {
-        std::vector<int> cost(nunit, 0), uexp(nunit, 0);
-        for (int p = 0; p < npiece; ++p)
-            if (ds[closed_roots[p]] >= 0) uexp[unit_of_piece[p]] = 1;
-        for (int c = 0; c < n; ++c) {
-            if (piece[c] < 0) continue;
-            int &k = cost[unit_of_piece[piece[c]]];             // longest pre side | longest post side << 8
-            k = std::max(k & 255, cell_pre[c]) | (std::max(k >> 8, cell_post[c]) << 8);
-        }
-        for (int u = 0; u < nunit; ++u)       // measured (tools/flow_stats.py): ~25 cycles per gathered term, ~15 for
-            cost[u] = 25 * (std::max(cost[u] & 255, 1) + std::max(cost[u] >> 8, 1)) + (unit_imp_n[u] > 0 ? 15 : 0) +
-                      15 * uexp[u];                                                                   // imports, outlets
-        auto coupled = [&](int u) { return unit_imp_n[u] > 0 || uexp[u] != 0; };
-        std::iota(unit_order.begin(), unit_order.end(), 0);
-        std::stable_sort(unit_order.begin(), unit_order.end(), [&](int x, int y) {
-            return coupled(x) != coupled(y) ? !coupled(x) : cost[x] < cost[y];
-        });
-        for (int u = 0; u < nunit; ++u) n_indep += coupled(u) ? 0 : 1;
-    }
-    (void)n_indep;
+    std::vector<int> unit_order(nunit);      // filled below, once the row shapes of the units are known
 
     // ---- slots, ghosts, gather offsets
     const int64_t ts = (int64_t)nunit * LANES;
@@ -904,6 +883,18 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
 
     std::vector<int> unit_exp(nunit, 0);
     for (int ed = 0; ed < nedge; ++ed) unit_exp[unit_of_piece[piece[edge_prod_cell[ed]]]]++;
+    {   // the claim list (see "which unit runs where"): units without streams by rising cost, then the others.  Cost as
+        // measured (tools/flow_stats.py): ~25 cycles per pair read per sub-step, ~15 for imports, ~15 for outlets.
+        std::vector<int> cost(nunit);
+        for (int u = 0; u < nunit; ++u)
+            cost[u] = 25 * ((unit_p[u] & 15) + ((unit_p[u] >> 4) & 15) + ((unit_p[u] & 0x100) ? 1 : 0)) +
+                      (unit_imp_n[u] > 0 ? 15 : 0) + (unit_exp[u] > 0 ? 15 : 0);
+        auto coupled = [&](int u) { return unit_imp_n[u] > 0 || unit_exp[u] > 0; };
+        std::iota(unit_order.begin(), unit_order.end(), 0);
+        std::stable_sort(unit_order.begin(), unit_order.end(), [&](int x, int y) {
+            return coupled(x) != coupled(y) ? !coupled(x) : cost[x] < cost[y];
+        });
+    }
     if (getenv("XH_FLOW_DEBUG")) {      // partition statistics on stderr
         std::vector<int> hp(8, 0), hi(9, 0), hx(9, 0), hl(10, 0), hpp(25, 0);
         int n_chain = 0;
