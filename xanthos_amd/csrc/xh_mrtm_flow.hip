@@ -384,7 +384,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     //      imported streams, then pieces packed into units of LANES cells.
     //      A smaller capacity than LANES costs streams (every cut is one) and buys units: pieces of 33..64 cells cannot
     //      share a unit, so the largest capacity leaves every other unit ~10 lanes short of full (67,420 cells: 1,121
-    //      units at 64; 1,054 = every lane used at 40, with 1,490 streams instead of 826).  Units beyond the SIMD count
+    //      units at 64; 1,059 at 36 -- 1,054 would be every lane used -- with 1,699 streams instead of 861).  Units beyond the SIMD count
     //      share a SIMD with another unit and the slowest unit paces the run, so units are what counts.
     struct Partition {
         std::vector<int> queue, piece, closed_roots, piece_of_root, piece_size, piece_imp, piece_depth;
@@ -718,7 +718,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     //      which SIMD cannot be planned: it follows the workgroup id only on an idle device (measured: with the ABCD
     //      kernel's last waves still draining, 38 SIMDs instead of 34 got two workgroups, ids unrelated, and the call
     //      took 31 ms instead of 25.6).  The kernel therefore lets every workgroup find out where it runs and claim its
-    //      unit from this list (xh_mrtm_skew.hip, claim_unit): units without streams by rising cost, then the others.
+    //      unit from this list (xh_mrtm_skew.hip, top of k_mrtm_skew): units without streams by rising cost, then the others.
     std::vector<int> unit_order(nunit);      // filled below, once the row shapes of the units are known
 
     // ---- slots, ghosts, gather offsets
