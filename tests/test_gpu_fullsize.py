@@ -56,6 +56,11 @@ def test_config3_full_length_routing_equals_oracle(full):
         _check(full, tag=flags)
         assert full.pipe.plan.info()['last_tree_kernel'] == kernel
     full.pipe.route_flags = 0
+    # the partition the time-skewed kernel ran on: nearly every lane used (1,054 units would be all of them), far more
+    # streams than the 64-cell cut's ~860, all cells in dataflow units
+    info = full.pipe.plan.info()
+    assert info['flow_cells'] == 67420 and info['fallback_cells'] == 0
+    assert 1054 <= info['flow_units'] <= 1075 and info['flow_edges'] > 1200, info
 
 
 def test_config3_fused_pipeline_equals_oracle(full):
