@@ -18,7 +18,13 @@
 //     [terms before the diagonal] - F [terms after], each side padded with +0.0 (an accumulator that started at +0.0
 //     is never -0.0, so the padding cannot change a bit).  Every operation and its order match scipy's CSR mat-vec,
 //     so results stay bit-identical to numpy/scipy.
-// What remains per sub-step is the recurrence itself (~15 dependent fp64 operations) and ~40 instructions of issue.
+//   - CHAIN specialisations: the cells that feed a cell from in front of its diagonal pass a running sum along their
+//     stored order instead of being read one by one (see skew_unit); the additions are the row sum's own.
+// What remains per sub-step is the recurrence itself (~15 dependent fp64 operations) and ~35 instructions of issue
+// for the median unit (5 pairs read).
+//
+// Which workgroup runs which unit is settled at the top of the kernel, not by the workgroup id: every workgroup finds
+// the SIMD it landed on and claims a unit so that only units without streams ever share a SIMD (k_mrtm_skew).
 //
 // Streams between units are rings of RS sub-steps indexed by the global sub-step (not by month) and move in blocks
 // of 8 sub-steps, once per 8 iterations, by the whole wave: lane (k, i) stores sub-step i of the unit's k-th outlet
