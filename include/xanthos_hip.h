@@ -128,7 +128,7 @@ void xh_route_plan_destroy(xh_route_plan *plan);
  * [11]=most imported streams of one unit, [12]=deepest lane lag of the time-skewed layout in sub-steps (-1: layout
  * not available), [13]=kernel that routed the tree networks in the last xh_route_series call on this plan (0 none,
  * 1 lock-step units with monthly streams, 2 time-skewed units), [14]=calls of this plan re-run with one workgroup per
- * network after a device fault, [15]=0 */
+ * network after a device fault, [15]=calls cross-checked by XH_ROUTE_VALIDATE */
 int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]);
 
 /* Diagnostics: with XH_FLOW_STATS=1 in the environment the dataflow kernel records, per unit, {shader cycles inside the
@@ -164,13 +164,22 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
  * synchronising call (xh_sync, xh_memcpy_d2h) re-routes every call enqueued since the last synchronisation with one
  * workgroup per network (no waits between workgroups) before it returns -- XH_OK if nothing else was enqueued behind
  * the routing, XH_ERR_DEVICE (routing outputs valid, later results not) otherwise.  xh_route_plan_info[14] counts such
- * re-runs.                                                                                                       */
+ * re-runs.  After such a fault the plan's next 8 calls (16, 32 ... 256 when faults repeat) skip the dataflow kernels, so
+ * a device that stays shared does not cost a timeout per call; a fault-free dataflow call resets the back-off.
+ * Bit-exactness of the dataflow kernels rests on a hardware assumption stated at xh_mrtm_skew.hip ("MEMORY-ORDERING
+ * ASSUMPTION": write-through stream stores retire in order under s_waitcnt vmcnt); XH_ROUTE_VALIDATE checks a call
+ * against the kernel that does not need it.                                                                        */
 #define XH_ROUTE_DEFAULT 0
 #define XH_ROUTE_FORCE_FALLBACK 1   /* route every network with the global-memory kernels (testing)        */
 #define XH_ROUTE_ATOMIC 2           /* with the fallback: scatter-add outflow with global_atomic_add_f64   */
 #define XH_ROUTE_NO_DATAFLOW 4      /* one workgroup per network even for tree-shaped networks (testing)   */
 #define XH_ROUTE_NO_SKEW 8          /* dataflow units in lock-step with monthly streams, not time-skewed   */
 #define XH_ROUTE_TEST_FAULT 16      /* testing: the dataflow kernel raises its fault word as a timed-out wait would */
+#define XH_ROUTE_VALIDATE 32        /* cross-check: after a dataflow kernel routed the call, route it again with one
+                                       workgroup per network (barriers only, no streams between units) and compare every
+                                       output bit; synchronous; XH_ERR_DEVICE on a difference.  Also switched on for every
+                                       call by XH_ROUTE_VALIDATE=1 in the environment.  xh_route_plan_info[15] counts the
+                                       validated calls.                                                            */
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,
                     const double *d_flow_dist, const double *d_velocity, const double *d_area,

@@ -55,6 +55,15 @@ def test_config3_full_length_routing_equals_oracle(full):
         full.pipe.run_mrtm()
         _check(full, tag=flags)
         assert full.pipe.plan.info()['last_tree_kernel'] == kernel
+    # validated mode: the dataflow result cross-checked on the device, bit for bit, against the kernel
+    # that needs no ordering assumption between units (one workgroup per network, barriers only)
+    from xanthos_amd import _hip
+    n_val = full.pipe.plan.info()['validated']
+    full.pipe.route_flags = _hip.XH_ROUTE_VALIDATE
+    full.pipe.out['chs'].zero()
+    full.pipe.run_mrtm()
+    _check(full, tag='validated')
+    assert full.pipe.plan.info()['validated'] == n_val + 1 and full.pipe.plan.info()['last_tree_kernel'] == 2
     full.pipe.route_flags = 0
     # the partition the time-skewed kernel ran on: nearly every lane used (1,054 units would be all of them), far more
     # streams than the 64-cell cut's ~860, all cells in dataflow units
@@ -126,9 +135,27 @@ def test_config3_two_contexts_route_concurrently(full):
 def test_config3_forced_fault_is_rerouted(full):
     """XH_ROUTE_TEST_FAULT makes unit 0 of the dataflow kernel raise the device fault word as a timed-out wait would:
     the next synchronising call re-runs the routing with one workgroup per network and the caller sees valid outputs
-    (XH_OK when nothing else was enqueued behind the routing, XH_ERR_DEVICE with valid routing outputs otherwise)."""
+    (XH_OK when nothing else was enqueued behind the routing, XH_ERR_DEVICE with valid routing outputs otherwise).
+    After a fault the plan's next 8 calls skip the dataflow kernels (a device that stays shared must not cost a
+    timeout per call); then they are tried again, and a fault-free call resets the back-off."""
     from xanthos_amd import _hip
-    pipe = full.pipe
+    from xanthos_amd.pipeline import pipeline_from_world
+    # a pipeline (= routing plan) of its own: the back-off must not leak into the tests that share `full`
+    pipe = pipeline_from_world(full.ctx, full.w, 600, 1961, 120, 120)
+    full.ctx._check(_hip.lib().xh_memcpy_d2d(full.ctx.handle, pipe.out['q'].ptr, full.pipe.out['q'].ptr,
+                                             pipe.out['q'].nbytes))
+
+    def backed_off_then_back(tag):
+        skipped = 0
+        while True:
+            pipe.out['chs'].zero()
+            pipe.run_mrtm()
+            _check(full, pipe=pipe, tag=(tag, skipped))
+            if pipe.plan.info()['last_tree_kernel'] == 2:
+                return skipped
+            skipped += 1
+            assert skipped <= 8, 'the dataflow kernels never came back'
+
     before = pipe.plan.info()['reroutes']
     for flags in (_hip.XH_ROUTE_TEST_FAULT, _hip.XH_ROUTE_TEST_FAULT | _hip.XH_ROUTE_NO_SKEW):
         pipe.out['chs'].zero()
@@ -136,7 +163,8 @@ def test_config3_forced_fault_is_rerouted(full):
         pipe.route_flags = flags
         pipe.run_mrtm()
         pipe.route_flags = 0
-        _check(full, tag=flags)                               # the download is the synchronising call
+        _check(full, pipe=pipe, tag=flags)                    # the download is the synchronising call
+        assert backed_off_then_back(flags) == 8
     assert pipe.plan.info()['reroutes'] == before + 2
     # two faulting calls in flight, then a kernel that read the invalid outputs: the error is reported, not lost
     pipe.out['chs'].zero()
@@ -148,12 +176,30 @@ def test_config3_forced_fault_is_rerouted(full):
     full.ctx.agg_time(pipe.ncell, 600, 12, 0, None, pipe.out['avg'], tmp)
     with pytest.raises(_hip.HipError, match='must be recomputed'):
         full.ctx.sync()
-    _check(full, tag='after error')                           # routing outputs were recomputed all the same
+    _check(full, pipe=pipe, tag='after error')                # routing outputs were recomputed all the same
     assert pipe.plan.info()['reroutes'] == before + 4
-    pipe.run_mrtm()                                           # and the dataflow kernel works again afterwards
-    _check(full, tag='recovered')
-    assert pipe.plan.info()['last_tree_kernel'] == 2 and pipe.plan.info()['reroutes'] == before + 4
-    tmp.free()
+    assert backed_off_then_back('recovered') == 8             # one fault event, however many calls it hit
+    # a copy enqueued behind a faulting call is "later work" too (gather / scatter / async copies bump the sequence)
+    pipe.route_flags = _hip.XH_ROUTE_TEST_FAULT
+    pipe.run_mrtm()
+    pipe.route_flags = 0
+    rows = full.ctx.upload(np.arange(100, dtype=np.int64), dtype=np.int64)
+    picked = full.ctx.empty((100, 600))
+    full.ctx.gather_rows(pipe.out['avg'], rows, 100, 600, picked)
+    with pytest.raises(_hip.HipError, match='must be recomputed'):
+        full.ctx.sync()
+    # freeing an input of a faulting call settles (re-routes) it first instead of leaving a dangling pointer behind
+    pipe.out['chs'].zero()
+    pipe.route_flags = _hip.XH_ROUTE_TEST_FAULT
+    pipe.run_mrtm()
+    pipe.route_flags = 0
+    n0 = pipe.plan.info()['reroutes']
+    scratch = full.ctx.empty((16,))
+    scratch.free()                                            # xh_free -> xh_settle -> re-route
+    assert pipe.plan.info()['reroutes'] == n0 + 1
+    _check(full, pipe=pipe, tag='after free')
+    for a in (tmp, rows, picked):
+        a.free()
 
 
 def test_config1_run_model_full_grid(tmp_path):

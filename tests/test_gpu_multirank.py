@@ -1,0 +1,161 @@
+"""xh_comm_gather_rows with MORE THAN ONE rank on a one-GPU box.
+
+RCCL refuses two ranks on one device, so the rank processes of these tests find ``tests/fake_rccl/librccl.so.1`` first on
+their loader path: a test-only stand-in for the eight RCCL entry points csrc/xh_comm.hip binds at run time (host bounce
+through /dev/shm, see fake_rccl.cpp).  Everything above it is the product: libxanthos_hip.so's grouped sends / receives,
+the root's staging offsets and row scatters, ``dist.make_shards`` / ``sub_world`` / ``fill_shard_forcing`` and the
+device pipeline.  The reference has no counterpart (its only parallelism is the joblib pool of abcd.py:369-382).
+
+The rank processes are started by the test BEFORE they touch the GPU (plain child processes, no exec from a process that
+holds a GPU context) and never import torch (which would bring the real librccl into the process).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+FAKE = os.path.join(ROOT, 'tests', 'fake_rccl')
+
+RANK_COMMON = r'''
+import json, os, sys, time
+root_dir, rank, nranks, root, workdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+sys.path.insert(0, root_dir)
+import numpy as np
+from xanthos_amd import _hip as hip
+assert 'torch' not in sys.modules
+ctx = hip.get_context(0)
+id_file = os.path.join(workdir, 'rccl_id')
+if rank == root:
+    uid = hip.comm_unique_id()
+    assert uid[:4] == b'FAKE', 'the stand-in librccl was not the one loaded'
+    with open(id_file + '.tmp', 'wb') as f:
+        f.write(uid)
+    os.rename(id_file + '.tmp', id_file)
+else:
+    t0 = time.time()
+    while not os.path.exists(id_file):
+        assert time.time() - t0 < 120, 'no RCCL id from the root'
+        time.sleep(0.01)
+    uid = open(id_file, 'rb').read()
+comm = hip.Comm(ctx, nranks, rank, uid)
+'''
+
+# ---- 1. synthetic rows: every value encodes (variable, global row, column), so a misplaced block cannot hide
+ROWS_CHILD = RANK_COMMON + r'''
+counts = json.loads(sys.argv[6])
+nvar, ncols = 6, 37
+total = sum(counts)
+perm = np.random.default_rng(7).permutation(total)              # rank-major row -> grid row
+first = sum(counts[:rank])
+mine = perm[first:first + counts[rank]]
+val = lambda v, rows: v * 1e7 + rows[:, None] * 100.0 + np.arange(ncols)[None, :]
+local = [ctx.upload(val(v, mine)) if counts[rank] else ctx.empty((0, ncols)) for v in range(nvar)]
+for rep in range(2):                                            # twice: the staging area is reused, counters restart
+    if rank == root:
+        out = [ctx.empty((total, ncols)).zero() for _ in range(nvar)]
+        comm.gather_rows(local, counts, ncols, perm=ctx.upload(perm, dtype=np.int64), out=out, root=root)
+        ctx.sync()
+        for v in range(nvar):
+            assert np.array_equal(out[v].download(), val(v, np.arange(total))), (rep, v)
+    else:
+        comm.gather_rows(local, counts, ncols, root=root)
+        ctx.sync()
+comm.close()
+print('RANK_OK', rank)
+'''
+
+# ---- 2. the sharded pipeline: each rank runs its shard of one world, the root compares with the unsharded run
+PIPE_CHILD = RANK_COMMON + r'''
+from xanthos_amd import synth
+from xanthos_amd.dist import fill_shard_forcing, make_shards, sub_world
+from xanthos_amd.pipeline import OUTPUTS, pipeline_from_world, topology_from_world
+w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=9, seed=21)
+um = topology_from_world(w)
+nm, seed = 36, 5
+shards = make_shards(w, um, nranks)
+counts = [len(s.cells) for s in shards]
+flags = hip.XH_ROUTE_NO_DATAFLOW       # several processes share this GPU: the all-units-resident kernels are not under test here
+sw, sum_ = sub_world(w, um, shards[rank])
+pipe = pipeline_from_world(ctx, sw, nm, 1971, 25, 6, um=sum_, route_flags=flags)
+pipe.alloc_forcing()
+fill_shard_forcing(ctx, w, shards[rank], pipe, seed, nan_frac=0.002)
+pipe.run()
+local = [pipe.out[k] for k in OUTPUTS]
+if rank == root:
+    perm = ctx.upload(np.concatenate([s.cells for s in shards]), dtype=np.int64)
+    out = [ctx.empty((w.ncell, nm)) for _ in OUTPUTS]
+    ctx.sync()
+    comm.gather_rows(local, counts, nm, perm=perm, out=out, root=root)
+    ctx.sync()
+    whole = pipeline_from_world(ctx, w, nm, 1971, 25, 6, um=um, route_flags=flags)
+    ctx.synth_forcing(seed, w.ncell, nm, ctx.upload(w.latitude), whole.alloc_forcing(), nan_frac=0.002)
+    whole.run()
+    ref = whole.download()
+    for k, o in zip(OUTPUTS, out):
+        got = o.download()
+        assert np.array_equal(got, ref[k], equal_nan=True), k
+    assert np.isnan(ref['q']).any() and np.isfinite(ref['avg']).any()
+else:
+    ctx.sync()
+    comm.gather_rows(local, counts, nm, root=root)
+    ctx.sync()
+comm.close()
+print('RANK_OK', rank, counts)
+'''
+
+
+def _fake_rccl():
+    so = os.path.join(FAKE, 'librccl.so.1')
+    if not os.path.isfile(so):                      # normally built by __graft_entry__.build()
+        subprocess.run(['make', '-C', FAKE], check=True, capture_output=True)
+    return so
+
+
+def _run_ranks(tmp_path, source, nranks, root, extra=()):
+    _fake_rccl()
+    script = tmp_path / 'rank.py'
+    script.write_text(source)
+    env = dict(os.environ)
+    env['LD_LIBRARY_PATH'] = FAKE + os.pathsep + env.get('LD_LIBRARY_PATH', '')
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(nranks), str(root), str(tmp_path), *extra],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(nranks)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=420)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and 'RANK_OK {}'.format(r) in o, 'rank {}:\n{}'.format(r, o[-3000:])
+    leftovers = [f for f in os.listdir('/dev/shm') if f.startswith('xh_fake_rccl_')]
+    assert not leftovers, leftovers                 # every message was received
+    return outs
+
+
+@pytest.mark.parametrize('nranks,root,counts', [
+    (2, 0, [700, 300]),
+    (2, 1, [300, 700]),
+    (3, 1, [250, 0, 410]),          # an empty shard among the senders
+    (3, 2, [0, 500, 77]),           # root last: every remote row lies before the root's own
+    (3, 0, [0, 9, 130]),            # the root itself holds nothing
+    (4, 2, [64, 1, 333, 5]),        # remote rows on both sides of the root's
+])
+def test_gather_rows_several_ranks(tmp_path, nranks, root, counts):
+    """Six variables, unequal and empty shards, every root position: the gathered arrays equal the expected grid."""
+    _run_ranks(tmp_path, ROWS_CHILD, nranks, root, extra=(json.dumps(counts),))
+
+
+@pytest.mark.parametrize('nranks,root', [(2, 0), (3, 1)])
+def test_sharded_pipeline_gathered_equals_unsharded(tmp_path, nranks, root):
+    """PM -> ABCD -> MRTM on basin / network-closed shards in `nranks` processes, ONE xh_comm_gather_rows of the six
+    outputs to `root`: bit-identical (NaN runoff included) to the unsharded run on the same device."""
+    _run_ranks(tmp_path, PIPE_CHILD, nranks, root)

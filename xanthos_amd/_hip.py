@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxanthos_hip.so')
 
 XH_ROUTE_DEFAULT, XH_ROUTE_FORCE_FALLBACK, XH_ROUTE_ATOMIC, XH_ROUTE_NO_DATAFLOW, XH_ROUTE_NO_SKEW = 0, 1, 2, 4, 8
-XH_ROUTE_TEST_FAULT = 16
+XH_ROUTE_TEST_FAULT, XH_ROUTE_VALIDATE = 16, 32
 
 
 class HipUnavailable(RuntimeError):
@@ -453,7 +453,7 @@ class RoutePlan:
         self.ctx._check(lib().xh_route_plan_info(self.handle, arr))
         keys = ('networks', 'largest_network', 'units', 'fallback_cells', 'largest_unit', 'slots', 'single_downstream',
                 'flow_units', 'flow_edges', 'flow_depth', 'flow_cells', 'flow_max_imports', 'skew_max_lag',
-                'last_tree_kernel', 'reroutes')
+                'last_tree_kernel', 'reroutes', 'validated')
         return dict(zip(keys, list(arr)))
 
     def stats(self):

@@ -139,12 +139,25 @@ int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar, con
     const int64_t n_local = h_counts[c->rank];
     XH_REQUIRE(ctx, n_local >= 0, "xh_comm_gather_rows: negative count");
     for (int v = 0; v < nvar; ++v) XH_REQUIRE(ctx, h_d_local[v] || n_local == 0, "xh_comm_gather_rows: NULL local array");
+    ctx->work_seq += 1;      // reads outputs a routing call may still have to recompute (xh_fault_check)
+    // Inside a group the first failure is remembered and the group is still closed: returning between GroupStart and
+    // GroupEnd would leave the group open on this thread and break every later RCCL call.
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
+    auto note = [&](ncclResult_t r, const char *name) {
+        if (r != ncclSuccess && first == ncclSuccess) {
+            first = r;
+            what = name;
+        }
+    };
     if (c->rank != root) {
         if (n_local == 0) return XH_OK;
         XH_NCCL(ctx, api.GroupStart());
-        for (int v = 0; v < nvar; ++v)
-            XH_NCCL(ctx, api.Send(h_d_local[v], (size_t)(n_local * ncols), ncclDouble, root, c->comm, ctx->stream));
-        XH_NCCL(ctx, api.GroupEnd());
+        for (int v = 0; v < nvar && first == ncclSuccess; ++v)
+            note(api.Send(h_d_local[v], (size_t)(n_local * ncols), ncclDouble, root, c->comm, ctx->stream), "ncclSend");
+        note(api.GroupEnd(), "ncclGroupEnd");
+        if (first != ncclSuccess)
+            return xh_fail(ctx, XH_ERR_HIP, "xh_comm_gather_rows: %s failed: %s", what, api.GetErrorString(first));
         return XH_OK;
     }
     XH_REQUIRE(ctx, d_perm && h_d_out, "xh_comm_gather_rows: the root needs d_perm and the output arrays");
@@ -156,7 +169,8 @@ int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar, con
     }
     const size_t need = (size_t)remote * ncols * nvar * sizeof(double);
     if (need > c->stage_bytes) {
-        XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const int rcs = xh_settle(ctx);
+        if (rcs && rcs != XH_ERR_DEVICE) return rcs;
         if (c->d_stage) XH_HIP(ctx, hipFree(c->d_stage));
         c->d_stage = nullptr;
         c->stage_bytes = 0;
@@ -167,16 +181,18 @@ int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar, con
     // staging layout: [variable][remote ranks in rank order][rows][ncols]
     if (remote > 0) {
         XH_NCCL(ctx, api.GroupStart());
-        for (int v = 0; v < nvar; ++v) {
+        for (int v = 0; v < nvar && first == ncclSuccess; ++v) {
             int64_t off = 0;
-            for (int r = 0; r < c->nranks; ++r) {
+            for (int r = 0; r < c->nranks && first == ncclSuccess; ++r) {
                 if (r == root || h_counts[r] == 0) continue;
-                XH_NCCL(ctx, api.Recv(stage + ((int64_t)v * remote + off) * ncols, (size_t)(h_counts[r] * ncols),
-                                      ncclDouble, r, c->comm, ctx->stream));
+                note(api.Recv(stage + ((int64_t)v * remote + off) * ncols, (size_t)(h_counts[r] * ncols), ncclDouble, r,
+                              c->comm, ctx->stream), "ncclRecv");
                 off += h_counts[r];
             }
         }
-        XH_NCCL(ctx, api.GroupEnd());
+        note(api.GroupEnd(), "ncclGroupEnd");
+        if (first != ncclSuccess)
+            return xh_fail(ctx, XH_ERR_HIP, "xh_comm_gather_rows: %s failed: %s", what, api.GetErrorString(first));
     }
     // d_perm is rank-major over ALL ranks: rows [0, before_me) and [before_me + n_local, total) are remote
     for (int v = 0; v < nvar; ++v) {

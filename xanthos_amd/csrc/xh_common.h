@@ -32,6 +32,8 @@ struct xh_route_record {
     uint64_t seq_after = 0;        // ctx->work_seq right after the call was enqueued
 };
 int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r);      // xh_mrtm.hip
+void xh_route_confirm(const xh_route_record &r);                // xh_mrtm.hip: the call's dataflow kernel ran fault-free
+void xh_route_backoff(xh_route_plan *plan);                     // xh_mrtm.hip: a fault was seen on this plan: skip the dataflow kernels for a while
 
 struct xh_ctx {
     int device = 0;
@@ -49,7 +51,7 @@ struct xh_ctx {
     unsigned *h_fault = nullptr;
     bool fault_pending = false;
     std::vector<xh_route_record> pending_routes;
-    uint64_t work_seq = 0;         // bumped by every kernel-launching entry point (xh_span_begin)
+    uint64_t work_seq = 0;         // bumped by every entry point that enqueues work on the stream (kernels, copies, row movers)
     int64_t reroutes = 0;          // routing calls re-run after a device fault
     // xh_run_fused: side stream and events of the block pipeline
     hipStream_t side_stream[2] = {nullptr, nullptr};
@@ -60,6 +62,10 @@ struct xh_ctx {
 int xh_fault_word(xh_ctx *ctx, unsigned **d_word);   // lazily allocated and zeroed ONCE: the word is sticky until a check clears it
 int xh_fault_collect(xh_ctx *ctx);                   // enqueue device -> pinned host copy after the kernel
 int xh_fault_check(xh_ctx *ctx);                     // after a stream sync: XH_ERR_DEVICE if the word was set
+// Stream synchronisation + xh_fault_check.  EVERY entry point that synchronises the context stream, releases or overwrites
+// device memory goes through this, so a routing call that has to be re-run is re-run before its inputs / outputs can be
+// freed or replaced, and the caller hears about it (XH_ERR_DEVICE when work enqueued behind the routing read invalid data).
+int xh_settle(xh_ctx *ctx);
 
 int xh_fail(xh_ctx *ctx, int code, const char *fmt, ...);
 extern std::string g_xh_create_error;

@@ -1,4 +1,6 @@
 // Context, device memory, row gather/scatter, transpose and HIP-event timing for libxanthos_hip.so.
+#include <algorithm>
+
 #include "xh_common.h"
 
 std::string g_xh_create_error;
@@ -19,7 +21,9 @@ int xh_fail(xh_ctx *ctx, int code, const char *fmt, ...) {
 int xh_scratch(xh_ctx *ctx, int which, size_t bytes, void **out) {
     if (bytes > ctx->scratch_bytes[which]) {
         if (ctx->scratch[which]) {
-            XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            // the buffer may be read by a routing call that still has to be confirmed (or re-run): settle before freeing
+            const int rc = xh_settle(ctx);
+            if (rc && rc != XH_ERR_DEVICE) return rc;
             XH_HIP(ctx, hipFree(ctx->scratch[which]));
             ctx->scratch[which] = nullptr;
             ctx->scratch_bytes[which] = 0;
@@ -59,7 +63,10 @@ int xh_fault_check(xh_ctx *ctx) {
     *ctx->h_fault = 0;
     std::vector<xh_route_record> pending;
     pending.swap(ctx->pending_routes);
-    if (!code) return XH_OK;
+    if (!code) {
+        for (const xh_route_record &r : pending) xh_route_confirm(r);
+        return XH_OK;
+    }
     // A bounded wait between routing units timed out: the dataflow kernels of these calls left invalid outputs.
     // Clear the word and route them again with one workgroup per network (no waits between workgroups).
     XH_HIP(ctx, hipMemsetAsync(ctx->d_fault, 0, 64, ctx->stream));
@@ -69,11 +76,14 @@ int xh_fault_check(xh_ctx *ctx) {
     fprintf(stderr, "[libxanthos_hip] routing fault %u (a bounded wait between routing units timed out: the device is "
             "shared and the units were not all resident); re-routing %zu call(s) with one workgroup per network\n",
             code, pending.size());
+    std::vector<xh_route_plan *> plans;
     for (const xh_route_record &r : pending) {
         int rc = xh_route_rerun(ctx, r);
         if (rc) return rc;
         ctx->reroutes += 1;
+        if (std::find(plans.begin(), plans.end(), r.plan) == plans.end()) plans.push_back(r.plan);
     }
+    for (xh_route_plan *p : plans) xh_route_backoff(p);
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (pending.empty())
         return xh_fail(ctx, XH_ERR_DEVICE, "routing kernel fault %u and no record of the call: outputs are invalid", code);
@@ -82,6 +92,11 @@ int xh_fault_check(xh_ctx *ctx) {
                        "workgroup-per-network kernel and are valid now, but results of calls enqueued after "
                        "xh_route_series read the invalid ones and must be recomputed", code);
     return XH_OK;
+}
+
+int xh_settle(xh_ctx *ctx) {
+    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return xh_fault_check(ctx);
 }
 
 xh_span xh_span_begin(xh_ctx *ctx, const char *name) { return xh_span_begin_on(ctx, name, ctx->stream); }
@@ -195,25 +210,27 @@ int xh_malloc(xh_ctx *ctx, size_t bytes, void **d_ptr) {
 int xh_free(xh_ctx *ctx, void *d_ptr) {
     if (!ctx) return XH_ERR_ARG;
     if (!d_ptr) return XH_OK;
-    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // routing calls not yet confirmed fault-free keep raw pointers to their inputs and outputs (pending_routes): a
+    // re-route must happen BEFORE any of that memory is released
+    const int rc = xh_settle(ctx);
     XH_HIP(ctx, hipFree(d_ptr));
-    return XH_OK;
+    return rc;
 }
 
 int xh_memcpy_h2d(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     if (!ctx || (bytes && (!d_dst || !h_src))) return XH_ERR_ARG;
+    int rc = XH_OK;
+    if (ctx->fault_pending) rc = xh_settle(ctx);      // the copy may overwrite the inputs of a call that must be re-routed
+    ctx->work_seq += 1;
     XH_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host buffer may be reused on return
-    return XH_OK;
+    return rc;
 }
 
 int xh_memcpy_d2h(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (!ctx || (bytes && (!h_dst || !d_src))) return XH_ERR_ARG;
     int rc = XH_OK;
-    if (ctx->fault_pending) {      // settle routing calls in flight first: a re-route must precede the copy
-        XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        rc = xh_fault_check(ctx);
-    }
+    if (ctx->fault_pending) rc = xh_settle(ctx);      // settle routing calls in flight first: a re-route must precede the copy
     XH_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return rc;
@@ -229,44 +246,48 @@ int xh_host_alloc(xh_ctx *ctx, size_t bytes, void **h_ptr) {
 int xh_host_free(xh_ctx *ctx, void *h_ptr) {
     if (!ctx) return XH_ERR_ARG;
     if (!h_ptr) return XH_OK;
-    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int rc = xh_settle(ctx);
     XH_HIP(ctx, hipHostFree(h_ptr));
-    return XH_OK;
+    return rc;
 }
 
 int xh_memcpy_h2d_async(xh_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     if (!ctx || (bytes && (!d_dst || !h_src))) return XH_ERR_ARG;
+    ctx->work_seq += 1;      // work that may read the outputs of a routing call still to be confirmed (xh_fault_check)
     XH_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return XH_OK;
 }
 
 int xh_memcpy_d2h_async(xh_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (!ctx || (bytes && (!h_dst || !d_src))) return XH_ERR_ARG;
+    ctx->work_seq += 1;      // work that may read the outputs of a routing call still to be confirmed (xh_fault_check)
     XH_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return XH_OK;
 }
 
 int xh_memcpy_d2d(xh_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
     if (!ctx || (bytes && (!d_dst || !d_src))) return XH_ERR_ARG;
+    ctx->work_seq += 1;      // work that may read the outputs of a routing call still to be confirmed (xh_fault_check)
     XH_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return XH_OK;
 }
 
 int xh_memset(xh_ctx *ctx, void *d_ptr, int value, size_t bytes) {
     if (!ctx || (bytes && !d_ptr)) return XH_ERR_ARG;
+    ctx->work_seq += 1;
     XH_HIP(ctx, hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
     return XH_OK;
 }
 
 int xh_sync(xh_ctx *ctx) {
     if (!ctx) return XH_ERR_ARG;
-    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return xh_fault_check(ctx);
+    return xh_settle(ctx);
 }
 
 int xh_timing_reset(xh_ctx *ctx) {
     if (!ctx) return XH_ERR_ARG;
-    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int rc_settle = xh_settle(ctx);
+    if (rc_settle) return rc_settle;
     for (auto &kv : ctx->timers) {
         for (auto &p : kv.second.pending) {
             ctx->event_pool.push_back(p.first);
@@ -287,7 +308,8 @@ int xh_timing_enable(xh_ctx *ctx, int on) {
 
 int xh_timing_get(xh_ctx *ctx, const char *name, double *total_ms, int64_t *launches) {
     if (!ctx || !name) return XH_ERR_ARG;
-    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int rc_settle = xh_settle(ctx);
+    if (rc_settle) return rc_settle;
     auto it = ctx->timers.find(name);
     double ms = 0.0;
     int64_t n = 0;
@@ -350,6 +372,7 @@ static int move_rows(xh_ctx *ctx, const double *d_src, const int64_t *d_rows, in
     if (!ctx) return XH_ERR_ARG;
     XH_REQUIRE(ctx, d_src && d_rows && d_dst && nrows >= 0 && ncols >= 0, "xh_gather/scatter_rows: bad argument");
     if (nrows == 0 || ncols == 0) return XH_OK;
+    ctx->work_seq += 1;
     int grid = (int)(nrows < 65536 ? nrows : 65536);
     hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, ctx->stream, d_src, d_rows, nrows, ncols, d_dst,
                        scatter);
@@ -371,6 +394,7 @@ int xh_transpose(xh_ctx *ctx, const double *d_src, int64_t rows, int64_t cols, d
     if (!ctx) return XH_ERR_ARG;
     XH_REQUIRE(ctx, d_src && d_dst && rows >= 0 && cols >= 0, "xh_transpose: bad argument");
     if (rows == 0 || cols == 0) return XH_OK;
+    ctx->work_seq += 1;
     dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
     XH_REQUIRE(ctx, grid.y <= 65535u, "xh_transpose: too many rows");
     hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, ctx->stream, d_src, rows, cols, d_dst);

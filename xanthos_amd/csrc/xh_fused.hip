@@ -19,6 +19,7 @@
 // and the call was re-routed.  The dataflow kernel wants the chip to itself.
 // Results are identical to the three separate calls: the same kernels, the same order of operations.
 #include <algorithm>
+#include <string>
 
 #include "xh_stage.h"
 
@@ -47,6 +48,8 @@ extern "C" int xh_run_fused(xh_ctx *ctx, const xh_fused_args *a) {
     const int nmonths = a->nmonths;
     int block = a->block_months > 0 ? a->block_months : 96;
     XH_REQUIRE(ctx, block % 48 == 0, "xh_run_fused: block_months must be a multiple of 48 (whole years and whole lines)");
+    XH_REQUIRE(ctx, nmonths > 0 && nmonths % 12 == 0, "xh_run_fused: nmonths must be whole years (PM runs year by year)");
+    XH_REQUIRE(ctx, a->abcd_spinup >= 1 && a->abcd_spinup <= nmonths, "xh_run_fused: abcd_spinup out of range");
     xh_pm_setup pm;
     int rc = xh_pm_prepare(ctx, a->pm, a->ncell, nmonths, a->start_year, a->n_lc_years, a->h_lc_years, a->water_idx,
                            a->snow_idx, &pm);
@@ -62,29 +65,45 @@ extern "C" int xh_run_fused(xh_ctx *ctx, const xh_fused_args *a) {
     hipEvent_t ev_start = ctx->side_events[0], ev_done = ctx->side_events[1];
     hipEvent_t *ev_pm = &ctx->side_events[3];
 
-    XH_HIP(ctx, hipEventRecord(ev_start, A));                    // everything enqueued before this call
-    XH_HIP(ctx, hipStreamWaitEvent(B, ev_start, 0));
-    for (int k = 0; k < nblk; ++k) {
-        const int m0 = k * block, cnt = std::min(block, nmonths - m0);
-        rc = xh_pm_enqueue(ctx, A, pm, m0, cnt, a->d_tas, a->d_tmin, a->d_rhs, a->d_wind, a->d_rsds, a->d_rlds,
-                           a->d_tairprev, a->d_lct, a->d_elev, a->d_pet);
-        if (rc) return rc;
-        XH_HIP(ctx, hipEventRecord(ev_pm[k], A));
+    // From here on work is enqueued on two streams: every way out -- errors included -- goes through the join below, so
+    // that later calls on the context's stream (and xh_sync) are ordered behind whatever stream B still runs and no
+    // ABCD kernel keeps writing d_q / d_aet / d_sav / the state scratch behind the caller's back.
+    auto enqueue = [&]() -> int {
+        XH_HIP(ctx, hipEventRecord(ev_start, A));                // everything enqueued before this call
+        XH_HIP(ctx, hipStreamWaitEvent(B, ev_start, 0));
+        for (int k = 0; k < nblk; ++k) {
+            const int m0 = k * block, cnt = std::min(block, nmonths - m0);
+            int r = xh_pm_enqueue(ctx, A, pm, m0, cnt, a->d_tas, a->d_tmin, a->d_rhs, a->d_wind, a->d_rsds, a->d_rlds,
+                                  a->d_tairprev, a->d_lct, a->d_elev, a->d_pet);
+            if (r) return r;
+            XH_HIP(ctx, hipEventRecord(ev_pm[k], A));
+        }
+        // spin-up needs PET of months [0, spinup)
+        XH_HIP(ctx, hipStreamWaitEvent(B, ev_pm[(a->abcd_spinup - 1) / block], 0));
+        int r = xh_abcd_enqueue_spinup(ctx, B, ab, a->d_pars, a->d_pet, a->d_precip, a->d_abcd_tmin);
+        if (r) return r;
+        for (int k = 0; k < nblk; ++k) {
+            const int m0 = k * block, m1 = std::min(nmonths, m0 + block);
+            XH_HIP(ctx, hipStreamWaitEvent(B, ev_pm[k], 0));
+            r = xh_abcd_enqueue_sim(ctx, B, ab, m0, m1, a->d_pars, a->d_pet, a->d_precip, a->d_abcd_tmin, a->d_aet,
+                                    a->d_q, a->d_sav);
+            if (r) return r;
+        }
+        XH_HIP(ctx, hipGetLastError());
+        return XH_OK;
+    };
+    rc = enqueue();
+    const std::string first_error = rc ? ctx->err : std::string();
+    const hipError_t j1 = hipEventRecord(ev_done, B);
+    const hipError_t j2 = j1 == hipSuccess ? hipStreamWaitEvent(A, ev_done, 0) : j1;      // join
+    if (j2 != hipSuccess) {                                      // cannot order the streams: wait for B here instead
+        (void)hipStreamSynchronize(B);
+        if (!rc) rc = xh_fail(ctx, XH_ERR_HIP, "xh_run_fused: joining the side stream failed: %s", hipGetErrorString(j2));
     }
-    // spin-up needs PET of months [0, spinup)
-    XH_HIP(ctx, hipStreamWaitEvent(B, ev_pm[(a->abcd_spinup - 1) / block], 0));
-    rc = xh_abcd_enqueue_spinup(ctx, B, ab, a->d_pars, a->d_pet, a->d_precip, a->d_abcd_tmin);
-    if (rc) return rc;
-    for (int k = 0; k < nblk; ++k) {
-        const int m0 = k * block, m1 = std::min(nmonths, m0 + block);
-        XH_HIP(ctx, hipStreamWaitEvent(B, ev_pm[k], 0));
-        rc = xh_abcd_enqueue_sim(ctx, B, ab, m0, m1, a->d_pars, a->d_pet, a->d_precip, a->d_abcd_tmin, a->d_aet, a->d_q,
-                                 a->d_sav);
-        if (rc) return rc;
+    if (rc) {
+        if (!first_error.empty()) ctx->err = first_error;
+        return rc;
     }
-    XH_HIP(ctx, hipGetLastError());
-    XH_HIP(ctx, hipEventRecord(ev_done, B));
-    XH_HIP(ctx, hipStreamWaitEvent(A, ev_done, 0));              // join: later calls on the context see every output
     if (a->plan)
         return xh_route_series(ctx, a->plan, nmonths, a->routing_spinup, a->h_ndays, a->dt, a->d_flow_dist, a->d_velocity,
                                a->d_area, a->d_q, a->d_S0, a->d_chstorage, a->d_avgchflow, nullptr, nullptr,

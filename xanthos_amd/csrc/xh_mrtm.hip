@@ -339,6 +339,11 @@ struct xh_route_plan {
     FlowPlan *flow = nullptr;                    // tree-shaped networks as single-wave dataflow units
     int last_tree_kernel = 0;                    // last xh_route_series: 0 none, 1 monthly streams, 2 time-skewed
     int64_t reroutes = 0;                        // calls re-run with one workgroup per network after a device fault
+    // After a fault the dataflow kernels are skipped for the next `skip_calls` calls of this plan (the device is shared:
+    // every further attempt would first sit out a bounded wait), doubling with every fault in a row up to 256 calls; a
+    // dataflow call confirmed fault-free resets the streak (xh_route_confirm).
+    int fault_streak = 0, skip_calls = 0;
+    int64_t validated = 0;                       // calls cross-checked against the workgroup-per-network kernel (XH_ROUTE_VALIDATE)
     int64_t n_rest_units = 0, n_fb_rest = 0;
     bool fb_rest_single_ds = true;
     DevBuf d_fbr_cells, d_fbr_ptr, d_fbr_col, d_fbr_sgn, d_fbr_ds;
@@ -684,7 +689,7 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
     info[12] = (plan->flow && plan->flow->skew_ok) ? plan->flow->skew_lmax : -1;     // deepest lane lag (sub-steps)
     info[13] = plan->last_tree_kernel;
     info[14] = plan->reroutes;
-    info[15] = 0;
+    info[15] = plan->validated;
     return XH_OK;
 }
 
@@ -704,12 +709,91 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
                              const double *d_area, const double *d_runoff, const double *d_S0, double *d_chstorage,
                              double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow);
 
+// Bitwise comparison of two arrays (NaN payloads included): XH_ROUTE_VALIDATE
+__global__ void __launch_bounds__(256) k_count_diff(const unsigned long long *a, const unsigned long long *b, int64_t n,
+                                                    unsigned long long *count) {
+    unsigned long long local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        local += a[i] != b[i] ? 1ull : 0ull;
+    if (local) atomicAdd(count, local);
+}
+
+// XH_ROUTE_VALIDATE: the call has just been routed by a dataflow kernel into the caller's arrays; route it again with one
+// workgroup per network (barriers, no streams, no reliance on the ordering of write-through stores) into scratch arrays
+// and compare every output bit.  Synchronous; a debugging / CI mode.
+static int route_validate(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months, const int32_t *h_ndays,
+                          double dt, const double *d_flow_dist, const double *d_velocity, const double *d_area,
+                          const double *d_runoff, const double *d_S0, const double *d_chs, const double *d_avg,
+                          const double *d_S_end, const double *d_F_end, int32_t flags) {
+    int rc = xh_settle(ctx);          // a fault of the dataflow run is settled (re-routed) first: then there is nothing to validate
+    if (rc) return rc;
+    const size_t nc = (size_t)plan->ncell, big = nc * (size_t)nmonths * sizeof(double);
+    double *t_chs = nullptr, *t_avg = nullptr, *t_S = nullptr, *t_F = nullptr;
+    unsigned long long *d_cnt = nullptr, h_cnt = 0;
+    auto release = [&]() {
+        for (void *p : {(void *)t_chs, (void *)t_avg, (void *)t_S, (void *)t_F, (void *)d_cnt})
+            if (p) (void)hipFree(p);
+    };
+    hipError_t e = hipSuccess;
+    if (d_chs) e = hipMalloc(reinterpret_cast<void **>(&t_chs), big);
+    if (e == hipSuccess && d_avg) e = hipMalloc(reinterpret_cast<void **>(&t_avg), big);
+    if (e == hipSuccess && d_S_end) e = hipMalloc(reinterpret_cast<void **>(&t_S), nc * sizeof(double));
+    if (e == hipSuccess && d_F_end) e = hipMalloc(reinterpret_cast<void **>(&t_F), nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_cnt), sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        release();
+        return xh_fail(ctx, XH_ERR_HIP, "XH_ROUTE_VALIDATE: no memory for the second set of outputs");
+    }
+    bool used = false;
+    const int routed_by = plan->last_tree_kernel;
+    rc = route_series_impl(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
+                           t_chs, t_avg, t_S, t_F, (flags | XH_ROUTE_NO_DATAFLOW) & ~XH_ROUTE_TEST_FAULT, &used);
+    plan->last_tree_kernel = routed_by;
+    if (!rc) {
+        (void)hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), ctx->stream);
+        auto cmp = [&](const double *a, const double *b, size_t n) {
+            if (a && b && n)
+                hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, ctx->stream,
+                                   reinterpret_cast<const unsigned long long *>(a),
+                                   reinterpret_cast<const unsigned long long *>(b), (int64_t)n, d_cnt);
+        };
+        cmp(d_chs, t_chs, nc * (size_t)nmonths);
+        cmp(d_avg, t_avg, nc * (size_t)nmonths);
+        cmp(d_S_end, t_S, nc);
+        cmp(d_F_end, t_F, nc);
+        if (hipMemcpyAsync(&h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = xh_fail(ctx, XH_ERR_HIP, "XH_ROUTE_VALIDATE: comparison failed to run");
+    }
+    release();
+    if (rc) return rc;
+    plan->validated += 1;
+    if (h_cnt)
+        return xh_fail(ctx, XH_ERR_DEVICE, "XH_ROUTE_VALIDATE: %llu output values of the dataflow routing kernel differ from "
+                       "the workgroup-per-network kernel", h_cnt);
+    return XH_OK;
+}
+
+void xh_route_confirm(const xh_route_record &r) { r.plan->fault_streak = 0; }
+
+void xh_route_backoff(xh_route_plan *plan) {      // once per fault event and plan
+    plan->fault_streak = std::min(plan->fault_streak + 1, 6);
+    plan->skip_calls = 4 << plan->fault_streak;      // 8, 16, ... 256 calls without the dataflow kernels
+}
+
 extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                                const int32_t *h_ndays, double dt, const double *d_flow_dist,
                                const double *d_velocity, const double *d_area, const double *d_runoff,
                                const double *d_S0, double *d_chstorage, double *d_avgchflow, double *d_S_end,
                                double *d_F_end, int32_t flags) {
     bool used_flow = false;
+    if (plan && plan->skip_calls > 0 && (flags & XH_ROUTE_TEST_FAULT) == 0) {      // recently faulted: see xh_route_plan
+        plan->skip_calls -= 1;
+        flags |= XH_ROUTE_NO_DATAFLOW;
+    }
+    static const bool validate_env = getenv("XH_ROUTE_VALIDATE") && getenv("XH_ROUTE_VALIDATE")[0] == '1';
+    const bool validate = validate_env || (flags & XH_ROUTE_VALIDATE) != 0;
+    flags &= ~XH_ROUTE_VALIDATE;
     int rc = route_series_impl(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff,
                                d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end, flags, &used_flow);
     if (rc || !used_flow) return rc;
@@ -732,7 +816,10 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
     r.F_end = d_F_end;
     r.seq_after = ctx->work_seq;
     ctx->pending_routes.push_back(std::move(r));
-    return xh_fault_collect(ctx);
+    rc = xh_fault_collect(ctx);
+    if (rc || !validate) return rc;
+    return route_validate(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
+                          d_chstorage, d_avgchflow, d_S_end, d_F_end, flags);
 }
 
 int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r) {

@@ -164,18 +164,30 @@ class OutputGather:
         self.out, self.d_perm, self.comm, self.kind, self.why = None, None, None, 'torch', ''
         self.bytes = int(self.counts.sum()) * pipe.nmonths * 8 * len(self.names)
         if dist.get_backend() == 'nccl':
+            # Agree on RCCL availability BEFORE ncclCommInitRank: the init is itself a collective, so a rank that cannot
+            # even load librccl must not leave the others blocked inside it.  comm_unique_id() loads the library and
+            # makes an id (cheap, local); only the root's id is used.
+            uid, ok = [None], 1
             try:
-                uid = [_hip.comm_unique_id() if rank == root else None]
+                mine = _hip.comm_unique_id()
+                if rank == root:
+                    uid = [mine]
+            except (_hip.HipError, RuntimeError) as exc:
+                self.why, ok = str(exc), 0
+            flag = torch.tensor([ok], device='cuda')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
                 dist.broadcast_object_list(uid, src=root)
-                self.comm = _hip.Comm(ctx, len(shards), rank, uid[0])
-                self.kind = 'rccl'
-            except (_hip.HipError, RuntimeError) as exc:          # e.g. two ranks on one GPU in a dry run
-                self.why = str(exc)
-            ok = torch.tensor([1 if self.kind == 'rccl' else 0], device='cuda')
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)             # all ranks take the same path
-            if int(ok.item()) == 0 and self.kind == 'rccl':
-                self.comm.close()
-                self.comm, self.kind = None, 'torch'
+                try:
+                    self.comm = _hip.Comm(ctx, len(shards), rank, uid[0])
+                    self.kind = 'rccl'
+                except (_hip.HipError, RuntimeError) as exc:      # e.g. two ranks on one GPU in a dry run
+                    self.why = str(exc)
+                flag = torch.tensor([1 if self.kind == 'rccl' else 0], device='cuda')
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # all ranks take the same path
+                if int(flag.item()) == 0 and self.kind == 'rccl':
+                    self.comm.close()
+                    self.comm, self.kind = None, 'torch'
         if self.kind == 'rccl' and rank == root:
             self.d_perm = ctx.upload(np.concatenate([s.cells for s in shards]), dtype=np.int64)
             self.out = {k: ctx.empty((self.ncell, pipe.nmonths)) for k in self.names}

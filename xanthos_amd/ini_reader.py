@@ -93,7 +93,14 @@ class ConfigReader:
         self.ngridrow = int(p.get('ngridrow', 360))
         self.ngridcol = int(p.get('ngridcol', 720))
         self.n_basins = int(p['n_basins'])
-        self.HistFlag = p.get('HistFlag', 'True')
+        # spelled 'True' / 'False' in the reference's examples; its own code compares the raw string in three different ways
+        # (ini_reader.py:330 == 'False', :582 .lower() in [...], data_load.py:431 == "True"), so a config with 'false' or
+        # 'F' would silently run a mix of both modes there.  Normalised once here: historic iff it reads as true.
+        raw_hist = str(p.get('HistFlag', 'True')).strip()
+        if raw_hist.lower() not in ('true', 't', 'yes', 'y', '1', 'false', 'f', 'no', 'n', '0'):
+            raise ValidationException("HistFlag must be True or False, not '{}'".format(raw_hist))
+        self.historic = raw_hist.lower() in ('true', 't', 'yes', 'y', '1')
+        self.HistFlag = 'True' if self.historic else 'False'
         self.StartYear = int(p['StartYear'])
         self.EndYear = int(p['EndYear'])
         ov = p.get('output_vars', '')
@@ -191,9 +198,13 @@ class ConfigReader:
             # two keys only in its gwam section (ini_reader.py:322-338), so with abcd its loader silently starts from
             # zeros (data_load.py:427-438); here they are honoured in the abcd section as well.
             self.ChStorageFile = self.ChStorageVarName = None
-            if str(self.HistFlag) == 'False':
+            if not self.historic:
                 self.ChStorageFile = m.get('ChStorageFile')
                 self.ChStorageVarName = m.get('ChStorageVarName')
+                if not self.ChStorageFile:
+                    raise ValidationException('HistFlag = False (future mode) needs ChStorageFile (and ChStorageVarName for '
+                                              'NetCDF) in the runoff section: the channel storage the historical run ended '
+                                              'with.  Starting a future run from empty channels is almost never meant.')
         elif self.runoff_module == 'none':
             pass
         elif self.runoff_module in self.RUNOFF_OTHER:
