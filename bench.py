@@ -69,6 +69,19 @@ def cpu_baseline(pipe, world, args, log):
         m = ~np.isnan(ref)
         return float(np.max(np.abs(x[m] - ref[m]) / (np.abs(ref[m]) + 1e-9)))
 
+    def report(name, x, ref):
+        """SURVEY 8(d) parity gate: max relative error, its 99.999-th percentile, values off by more than 1e-9 relative
+        (a flipped branch of a tiered function shows up there long before the 1e-6 gate) and values beyond the gate."""
+        m = ~np.isnan(ref)
+        rel = np.abs(x[m] - ref[m]) / (np.abs(ref[m]) + 1e-9)
+        parity[name] = float(rel.max())
+        parity['tolerance_used'][name] = gate(x, ref)
+        parity.setdefault('p99_999', {})[name] = float(np.percentile(rel, 99.999))
+        parity.setdefault('branch_flip_candidates', {})[name] = int((rel > 1e-9).sum())
+        parity.setdefault('beyond_gate', {})[name] = int((np.abs(x[m] - ref[m]) > 1e-6 * np.abs(ref[m]) + 1e-9).sum())
+        parity.setdefault('values_compared', {})[name] = int(m.sum())
+        parity.setdefault('nan_values', {})[name] = int((~m).sum())
+
     # ---- PM: the whole grid, first pm_years years
     pm_years = min(args.cpu_pm_years, nm // 12)
     k = 12 * pm_years
@@ -79,8 +92,7 @@ def cpu_baseline(pipe, world, args, log):
     t_pm = time.perf_counter() - t
     res['pm'] = world.ncell * k / t_pm
     got_pet = pipe.out['pet'].download()
-    parity['pet'] = relerr(got_pet[:, :k], ref_pet)
-    parity['tolerance_used']['pet'] = gate(got_pet[:, :k], ref_pet)
+    report('pet', got_pet[:, :k], ref_pet)
     del f, d, ref_pet
 
     # ---- ABCD: full size, from the run's own PET (so that the comparison isolates this stage)
@@ -91,9 +103,7 @@ def cpu_baseline(pipe, world, args, log):
     t_abcd = time.perf_counter() - t
     res['abcd'] = world.ncell * nm / t_abcd
     for name, ref in (('aet', aet), ('q', q), ('sav', sav)):
-        got = pipe.out[name].download()
-        parity[name] = relerr(got, ref)
-        parity['tolerance_used'][name] = gate(got, ref)
+        report(name, pipe.out[name].download(), ref)
     del aet, sav, pr, tn, got_pet
 
     # ---- MRTM: the whole grid, scipy CSR like the reference, from the run's own runoff
@@ -138,8 +148,15 @@ def cpu_baseline(pipe, world, args, log):
     sample += '; value = harmonic composition of the stage rates per simulated cell-month'
     log('cpu baseline: ' + sample)
     log('parity: ' + json.dumps(parity))
+    stages = {'pm': 'sample: full grid, {} of {} months (linear in months)'.format(k, nm),
+              'abcd': 'full size: {} cells x ({} + {} spin-up) months'.format(world.ncell, nm, pipe.abcd_spinup)}
+    if 'mrtm' in res:
+        stages['mrtm'] = ('full size: {} spin-up + {} months'.format(pipe.routing_spinup, nm) if args.cpu_full else
+                          'sample: full grid, {} of {} months, scaled by (1 + spin-up / months)'.format(
+                              min(args.cpu_mrtm_months, nm), nm))
     return {'value': value, 'unit': 'cell-months/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': sample,
-            'stage_rates': res}, parity
+            'stage_rates': res, 'stages': stages,
+            'full_size': bool(args.cpu_full and k == nm)}, parity
 
 
 def end_to_end(ctx, pipe, args, log):
@@ -416,7 +433,7 @@ def main():
         pipe = pipeline_from_world(ctx, world, args.months, args.start_year, args.abcd_spinup, args.routing_spinup,
                                    um=um, route_flags=args.route_flags)
         d_lat = ctx.upload(world.latitude)
-        ctx.synth_forcing(seed, pipe.ncell, pipe.nmonths, d_lat, pipe.alloc_forcing(), nan_frac=0.0)
+        ctx.synth_forcing(seed, pipe.ncell, pipe.nmonths, d_lat, pipe.alloc_forcing(), nan_frac=0.001)      # 0.1 % NaN-precipitation cells
         # tairprev[c] = tas[c - 1], zeros for cell 0 (data_load.py:128-129)
         pipe.d_tairprev = ctx.empty((pipe.ncell, pipe.nmonths)).zero()
         ctx._check(_hip.lib().xh_memcpy_d2d(ctx.handle, pipe.d_tairprev.ptr + pipe.nmonths * 8, pipe.forcing['tas'].ptr,

@@ -131,6 +131,20 @@ void xh_route_plan_destroy(xh_route_plan *plan);
  * network after a device fault, [15]=calls cross-checked by XH_ROUTE_VALIDATE */
 int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]);
 
+/* The dataflow kernels run units in two forms.  A PAIR unit gathers {trial flow, adjusted flow} of every upstream
+ * neighbour and forms both row sums of mrtm.py:50-69.  A PLAIN unit gathers one value per neighbour and forms one sum:
+ * valid when no neighbour of its cells can fire (mrtm.py:54), which is decided from velocity * dt / flow distance of the
+ * call (cells with a ratio above 1 - 2^-20 and their downstream cells go to pair units) and GUARDED in the kernel: a plain
+ * lane that fires after all makes the next synchronising call route the series again in pair form.  The typed partition
+ * is built on the first xh_route_series of a plan and rebuilt when later data give another set of such cells.
+ * Cells seen firing without being expected to (storage driven negative by an adjusted inflow, mrtm.py:66-69, can make
+ * cells further downstream fire) are recorded on the device and count as cells that can fire from the next call on, so
+ * a plan settles after a call or two on given data.
+ * info[0] = plain units of the partition that routed the last call (0: every unit in pair form), [1] = typed
+ * partitions built so far, [2] = guard faults so far (-1: more than 8, the plan keeps every unit in pair form),
+ * [3] = units of the typed partition.  XH_ROUTE_TYPED=0 in the environment keeps every unit in pair form.        */
+int xh_route_plan_typed_info(const xh_route_plan *plan, int64_t info[4]);
+
 /* Diagnostics: with XH_FLOW_STATS=1 in the environment the dataflow kernel records, per unit, {shader cycles inside the
  * sub-step loops, shader cycles total, 100 MHz ticks total, shape bits + placement, cycles waiting for data, cycles waiting for ring space}; this call waits for the
  * stream and copies up to max_words 64-bit words (6 per unit) of the last xh_route_series launch. */

@@ -31,18 +31,20 @@ def full():
     w = synth.make_world()
     nm = 600
     pipe = pipeline_from_world(ctx, w, nm, 1961, 120, 120)
-    ctx.synth_forcing(3, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.0)
+    ctx.synth_forcing(3, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.001)
     pipe.run(('pm', 'abcd'), fused=False)
     q = pipe.out['q'].download()
     chs, avg, _ = o_mrtm.route_series(pipe.um.tocsr(), w.flow_dist, w.velocity, w.area, q, pipe.ndays, 120)
-    assert np.isfinite(avg).all() and avg.max() > 0
+    # 0.1 % of the cells have NaN precipitation -> NaN runoff, which routing carries downstream like the reference
+    # (data_load.py:186 keeps precipitation's NaN; mrtm.py has no special case)
+    assert np.isnan(q).any() and np.isnan(avg).any() and np.nanmax(avg) > 0 and np.isfinite(avg).mean() > 0.5
     return SimpleNamespace(ctx=ctx, w=w, pipe=pipe, chs=chs, avg=avg)
 
 
 def _check(full, pipe=None, tag=''):
     got = (pipe or full.pipe).download(('chs', 'avg'))
-    assert np.array_equal(got['chs'], full.chs), tag
-    assert np.array_equal(got['avg'], full.avg), tag
+    assert np.array_equal(got['chs'], full.chs, equal_nan=True), tag
+    assert np.array_equal(got['avg'], full.avg, equal_nan=True), tag
 
 
 def test_config3_full_length_routing_equals_oracle(full):
@@ -180,11 +182,11 @@ def test_config3_forced_fault_is_rerouted(full):
     assert pipe.plan.info()['reroutes'] == before + 4
     assert backed_off_then_back('recovered') == 8             # one fault event, however many calls it hit
     # a copy enqueued behind a faulting call is "later work" too (gather / scatter / async copies bump the sequence)
+    rows = full.ctx.upload(np.arange(100, dtype=np.int64), dtype=np.int64)      # (a synchronous upload would settle the fault)
+    picked = full.ctx.empty((100, 600))
     pipe.route_flags = _hip.XH_ROUTE_TEST_FAULT
     pipe.run_mrtm()
     pipe.route_flags = 0
-    rows = full.ctx.upload(np.arange(100, dtype=np.int64), dtype=np.int64)
-    picked = full.ctx.empty((100, 600))
     full.ctx.gather_rows(pipe.out['avg'], rows, 100, 600, picked)
     with pytest.raises(_hip.HipError, match='must be recomputed'):
         full.ctx.sync()

@@ -17,7 +17,7 @@ from xanthos_amd import _hip, synth           # noqa: E402
 from xanthos_amd.routing import mrtm          # noqa: E402
 
 
-def one_case(rng, k):
+def gen_case(rng):
     ncell = int(rng.choice([12, 70, 300, 900, 2500, 6000]))
     nrow = int(np.ceil(np.sqrt(ncell * 2.2))) + 6
     ncol = 2 * nrow
@@ -38,13 +38,24 @@ def one_case(rng, k):
     if rng.random() < 0.3:
         v[rng.random(w.ncell) < 0.01] = 0.0                    # stagnant channels
     S0 = rng.uniform(0, 1e7, w.ncell) if rng.random() < 0.5 else None
+    return NS(w=w, um=um, nm=nm, spin=spin, dt=dt, ndays=ndays, q=q, L=L, v=v, S0=S0, ncell=ncell)
+
+
+def one_case(rng, k):
+    c = gen_case(rng)
+    w, um, nm, spin, dt, ndays, q, L, v, S0, ncell = c.w, c.um, c.nm, c.spin, c.dt, c.ndays, c.q, c.L, c.v, c.S0, c.ncell
     ref = o_mrtm.route_series(um.tocsr(), L, v, w.area, q, ndays, spin, S0=S0, dt=dt)
     used = []
-    for flags in (0, 8, 4):
+    for flags in (0, 0, 8, 4):      # twice with the default flags: the second call runs on the partition the first one taught
         got = mrtm.route_series(um, L, v, w.area, q, ndays, spin, S0=S0, dt=dt, flags=flags)
         for a, b in zip(got, ref):
             if not np.array_equal(a, b, equal_nan=True):
-                raise AssertionError('case {} flags {}: ncell {} months {} spin {} dt {} mismatch'.format(k, flags, ncell, nm, spin, dt))
+                plan = um.plan(_hip.get_context(0))
+                bad = ~((a == b) | (np.isnan(a) & np.isnan(b)))
+                raise AssertionError('case {} flags {}: ncell {} months {} spin {} dt {} mismatch in {} values of {} cells; '
+                                     'plan {} typed {}'.format(k, flags, ncell, nm, spin, dt, int(bad.sum()),
+                                                               int(bad.reshape(len(bad), -1).any(axis=1).sum()), plan.info(),
+                                                               plan.typed_info()))
         used.append(um.plan(_hip.get_context(0)).info()['last_tree_kernel'])
     return ncell, nm, spin, dt, used
 

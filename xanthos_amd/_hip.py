@@ -79,6 +79,7 @@ SIGNATURES = {
     'xh_route_plan_destroy': (None, [_P]),
     'xh_route_plan_info': (c_int, [_P, POINTER(c_int64)]),
     'xh_route_plan_stats': (c_int, [_P, c_int64, _P, POINTER(c_int64)]),
+    'xh_route_plan_typed_info': (c_int, [_P, _P]),
     'xh_mrtm_downstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     'xh_mrtm_upstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     'xh_mrtm_um_csr': (c_int, [c_int64, _P, _P, _P, _P]),
@@ -455,6 +456,12 @@ class RoutePlan:
                 'flow_units', 'flow_edges', 'flow_depth', 'flow_cells', 'flow_max_imports', 'skew_max_lag',
                 'last_tree_kernel', 'reroutes', 'validated')
         return dict(zip(keys, list(arr)))
+
+    def typed_info(self):
+        """Pair / plain units of the dataflow partition (xh_route_plan_typed_info)."""
+        arr = (c_int64 * 4)()
+        self.ctx._check(lib().xh_route_plan_typed_info(self.handle, arr))
+        return dict(zip(('plain_units', 'typed_builds', 'guard_trips', 'typed_units'), list(arr)))
 
     def stats(self):
         """[units, 6] uint64 per-unit accounting of the last launch (needs XH_FLOW_STATS=1), or None."""

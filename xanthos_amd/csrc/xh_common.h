@@ -31,7 +31,7 @@ struct xh_route_record {
     double *chs = nullptr, *avg = nullptr, *S_end = nullptr, *F_end = nullptr;
     uint64_t seq_after = 0;        // ctx->work_seq right after the call was enqueued
 };
-int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r);      // xh_mrtm.hip
+int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r, bool dataflow_pairs);      // xh_mrtm.hip: workgroup per network, or the dataflow kernel with every unit in pair form
 void xh_route_confirm(const xh_route_record &r);                // xh_mrtm.hip: the call's dataflow kernel ran fault-free
 void xh_route_backoff(xh_route_plan *plan);                     // xh_mrtm.hip: a fault was seen on this plan: skip the dataflow kernels for a while
 
@@ -57,6 +57,11 @@ struct xh_ctx {
     hipStream_t side_stream[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> side_events;
 };
+
+// Fault code of the routing kernel's plain units: an input outside the argument that lets them gather one value per term
+// (a cell that cannot fire did).  Nothing timed out; the call is routed again in pair form (xh_fault_check).
+#define XH_FAULT_GUARD 4u
+#define XH_ROUTE_NO_PLAIN 0x4000      /* internal flag of xh_route_series: every dataflow unit in pair form */
 
 // Device fault word: kernels set it non-zero instead of hanging; the next synchronising call reports XH_ERR_DEVICE.
 int xh_fault_word(xh_ctx *ctx, unsigned **d_word);   // lazily allocated and zeroed ONCE: the word is sticky until a check clears it

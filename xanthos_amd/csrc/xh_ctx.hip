@@ -67,23 +67,48 @@ int xh_fault_check(xh_ctx *ctx) {
         for (const xh_route_record &r : pending) xh_route_confirm(r);
         return XH_OK;
     }
-    // A bounded wait between routing units timed out: the dataflow kernels of these calls left invalid outputs.
-    // Clear the word and route them again with one workgroup per network (no waits between workgroups).
+    // Either a bounded wait between routing units timed out (the device is shared and the units were not all resident)
+    // or a plain unit met an input its shortcut does not cover (XH_FAULT_GUARD): the dataflow kernels of these calls left
+    // invalid outputs.  Clear the word and route them again -- after a guard fault with every unit in pair form (still
+    // the dataflow kernel; the plan stops using plain units), otherwise, or if that faults too, with one workgroup per
+    // network (no waits between workgroups).
     XH_HIP(ctx, hipMemsetAsync(ctx->d_fault, 0, 64, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t seq_now = ctx->work_seq;
     const bool later_work = !pending.empty() && seq_now != pending.back().seq_after;
-    fprintf(stderr, "[libxanthos_hip] routing fault %u (a bounded wait between routing units timed out: the device is "
-            "shared and the units were not all resident); re-routing %zu call(s) with one workgroup per network\n",
-            code, pending.size());
-    std::vector<xh_route_plan *> plans;
-    for (const xh_route_record &r : pending) {
-        int rc = xh_route_rerun(ctx, r);
-        if (rc) return rc;
-        ctx->reroutes += 1;
-        if (std::find(plans.begin(), plans.end(), r.plan) == plans.end()) plans.push_back(r.plan);
+    bool pairs_first = code == XH_FAULT_GUARD;
+    if (pairs_first) {
+        fprintf(stderr, "[libxanthos_hip] a cell that cannot overdraw its channel by velocity * dt / length did (denormal "
+                "storage, negative runoff or initial storage): routing %zu call(s) again with every unit in pair form\n",
+                pending.size());
+        for (const xh_route_record &r : pending) {
+            int rc = xh_route_rerun(ctx, r, true);
+            if (rc) return rc;
+            ctx->reroutes += 1;
+        }
+        XH_HIP(ctx, hipMemcpyAsync(ctx->h_fault, ctx->d_fault, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const unsigned again = *ctx->h_fault;
+        *ctx->h_fault = 0;
+        if (again) {
+            XH_HIP(ctx, hipMemsetAsync(ctx->d_fault, 0, 64, ctx->stream));
+            XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            pairs_first = false;
+        }
     }
-    for (xh_route_plan *p : plans) xh_route_backoff(p);
+    if (!pairs_first) {
+        fprintf(stderr, "[libxanthos_hip] routing fault %u (a bounded wait between routing units timed out: the device is "
+                "shared and the units were not all resident); re-routing %zu call(s) with one workgroup per network\n",
+                code, pending.size());
+        std::vector<xh_route_plan *> plans;
+        for (const xh_route_record &r : pending) {
+            int rc = xh_route_rerun(ctx, r, false);
+            if (rc) return rc;
+            ctx->reroutes += 1;
+            if (std::find(plans.begin(), plans.end(), r.plan) == plans.end()) plans.push_back(r.plan);
+        }
+        for (xh_route_plan *p : plans) xh_route_backoff(p);
+    }
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (pending.empty())
         return xh_fail(ctx, XH_ERR_DEVICE, "routing kernel fault %u and no record of the call: outputs are invalid", code);

@@ -1,0 +1,60 @@
+// Host-side planner of the dataflow routing kernels: cuts the tree-shaped river networks into connected pieces, packs
+// them into single-wave units and emits the tables the kernels read.  Plain C++ on host vectors -- no HIP, no device
+// memory -- so that the same translation unit builds into libxanthos_hip.so and, with -fsanitize=address,undefined,
+// into the host-only fuzzer of tests/plan_fuzz (round 2's 680-line flow_plan_build only ever ran behind GPU tests).
+//
+// Reference semantics the tables must preserve: mrtm.py:50-51 -- row i of UM.dot(F) is accumulated in stored (ascending
+// column) order, which flow_tables_check re-derives from the tables term by term.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+struct FlowPlanOptions {
+    int simds = 0;               // SIMDs of the device (units beyond them share a SIMD); 0 = unknown
+    int piece_cap = 0;           // cells per piece; 0 = try the built-in capacities and keep the best partition
+    bool chain = true;           // sum long front sides on the way along chains of lanes
+    bool cut_rule = true;        // chain-aware choice of the children that become streams
+    int tlimit = 5;              // pair reads per sub-step a unit may reach by taking in another piece
+    int tlimit_typed = 4;        // the same for the pair units of a typed partition (they pace the run: plain units are cheaper)
+    int tlimit_plain = 6;        // the same for the 8-byte reads of a plain unit
+    // Typed partition: capable[c] != 0 for cells that can fire (velocity * dt / length close to or above 1, or seen
+    // firing in an earlier run).  Cells with such an upstream neighbour need both flows of it (mrtm.py:56-69) and go into
+    // pair units; everything else -- the cells that can fire included, as outlets -- may go into plain units.
+    // nullptr: every unit in pair form.
+    const unsigned char *capable = nullptr;
+    int full_join = 6;           // largest plain sub-piece a pair piece swallows instead of importing its outlet
+    bool debug = false;          // partition statistics on stderr
+};
+
+struct FlowTables {
+    int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0, max_exports = 0, n_plain_units = 0;
+    bool skew_ok = false;        // every row has <= 4 terms either side of its diagonal
+    int skew_lmax = 0;           // largest lane lag of any unit (sub-steps)
+    int skew_span = 1;           // most pipeline levels a stream jumps over
+    bool typed = false;
+    std::vector<int> cell_of_slot, export_edge, ghost_edge, edge_cons_unit, unit_terms;
+    std::vector<unsigned> ent;                                   // lock-step kernel: [9][units*64]
+    std::vector<int> lag, ghost_lag, unit_p, unit_lmax, unit_glmax, unit_order;
+    std::vector<unsigned> ent2, eprev;                           // time-skewed kernels: [8][units*64], [units*64]
+    // kept for checks and diagnostics
+    std::vector<int> edge_prod_cell, edge_cons_cell, unit_depth, piece_of_cell, unit_of_cell, height_of_cell, ds;
+    std::vector<char> unit_plain;
+    std::vector<unsigned char> lane_flags;                       // [units*64] bit 0: the cell can fire by construction
+    std::vector<int> ghost_prod;                                 // [units*64] producer cell of imported stream k of the unit
+};
+
+// Partition every tree-shaped network (each cell drains to at most one cell, no cycle, rows = {-1 on the diagonal, +1
+// elsewhere}, at most 9 terms).  handled[c] = 1 for the cells the tables route.  Returns 0, or -1 with `err` set.
+int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign, const int *comp,
+                      int ncomp, const FlowPlanOptions &opt, std::vector<char> &handled, FlowTables &out,
+                      std::string &err);
+
+// Invariants of a built plan (every cell in exactly one slot; streams run strictly down the pipeline; <= 16 imports
+// and outlets per unit; lane lags even and consistent with the "two iterations earlier" rule; every row, expanded
+// through its chains, equals the CSR row in stored order; plain units hold no cell that needs pairs).  Empty = fine.
+std::string flow_tables_check(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
+                              const std::vector<char> &handled, const FlowTables &t, const unsigned char *capable);
+
+// The (terms before, terms after) shapes compiled for plain units; rounds up.  Returns false if none fits.
+bool flow_plain_class(int pre, int post, bool chained, int &cpre, int &cpost);

@@ -336,7 +336,24 @@ struct xh_route_plan {
     DevBuf d_class_units[N_CLASS];
     std::vector<int> rest_units[N_CLASS];        // only the units of networks the dataflow kernel does not route
     DevBuf d_rest_units[N_CLASS];
-    FlowPlan *flow = nullptr;                    // tree-shaped networks as single-wave dataflow units
+    FlowPlan *flow = nullptr;                    // tree-shaped networks as single-wave dataflow units, every unit in pair form
+    // Typed partition (pair + plain units, xh_flow_plan.h): depends on WHICH cells can fire, i.e. on velocity, flow
+    // distance and dt, which only arrive with xh_route_series.  Built on the first call from a copy of the topology and
+    // rebuilt when a later call's data give another set of such cells (one small kernel per call checks).
+    FlowPlan *flow_typed = nullptr;
+    std::vector<int64_t> h_indptr;
+    std::vector<int32_t> h_indices;
+    std::vector<int8_t> h_sign;
+    std::vector<int> h_comp;
+    int h_ncomp = 0;
+    DevBuf d_capable;                            // [ncell] flags the typed plan was built for
+    DevBuf d_learn;                              // [ncell] cells a kernel saw firing although they were not expected to: they
+                                                 // count as cells that can fire from the next call on (k_capable)
+    int guard_trips = 0;
+    unsigned *d_cap_diff = nullptr, *h_cap_diff = nullptr;      // cells whose flag differs this call (device word, pinned mirror)
+    bool typed_disabled = false;                 // a guard fault showed that the plain form does not hold for this data
+    int64_t typed_builds = 0;
+    bool last_typed = false;                     // the last call ran on the typed plan
     int last_tree_kernel = 0;                    // last xh_route_series: 0 none, 1 monthly streams, 2 time-skewed
     int64_t reroutes = 0;                        // calls re-run with one workgroup per network after a device fault
     // After a fault the dataflow kernels are skipped for the next `skip_calls` calls of this plan (the device is shared:
@@ -454,13 +471,24 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
     {
         const char *env = getenv("XH_MRTM_FLOW");
         if (!(env && env[0] == '0')) {
-            const int frc = flow_plan_build(ctx, n, h_indptr, h_indices, h_sign, comp, ncomp, flow_cell, &plan->flow);
+            const int frc = flow_plan_build(ctx, n, h_indptr, h_indices, h_sign, comp, ncomp, nullptr, flow_cell, &plan->flow);
             if (frc) {
                 xh_route_plan_destroy(plan);
                 return frc;
             }
         }
         if (flow_cell.empty()) flow_cell.assign(n, 0);
+        if (plan->flow) {
+            if (hipMalloc(&plan->d_learn.p, (size_t)n + 256) != hipSuccess || hipMemset(plan->d_learn.p, 0, (size_t)n + 256) != hipSuccess) {
+                xh_route_plan_destroy(plan);
+                return xh_fail(ctx, XH_ERR_HIP, "xh_route_plan_create: device allocation failed");
+            }
+            plan->h_indptr.assign(h_indptr, h_indptr + n + 1);
+            plan->h_indices.assign(h_indices, h_indices + nnz);
+            plan->h_sign.assign(h_sign, h_sign + nnz);
+            plan->h_comp = comp;
+            plan->h_ncomp = ncomp;
+        }
     }
     std::vector<char> comp_flow(ncomp, 0);
     for (int i = 0; i < n; ++i)
@@ -667,6 +695,11 @@ extern "C" void xh_route_plan_destroy(xh_route_plan *plan) {
                       &plan->d_fbr_col, &plan->d_fbr_sgn, &plan->d_fbr_ds};
     for (DevBuf *b : bufs) free_buf(*b);
     flow_plan_destroy(plan->flow);
+    flow_plan_destroy(plan->flow_typed);
+    free_buf(plan->d_capable);
+    free_buf(plan->d_learn);
+    if (plan->d_cap_diff) (void)hipFree(plan->d_cap_diff);
+    if (plan->h_cap_diff) (void)hipHostFree(plan->h_cap_diff);
     delete plan;
 }
 
@@ -680,7 +713,7 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
     info[5] = plan->total_slots;
     info[6] = plan->all_single_ds ? 1 : 0;
     int64_t fi[5];
-    flow_plan_info(plan->flow, fi);
+    flow_plan_info(plan->last_typed ? plan->flow_typed : plan->flow, fi);
     info[7] = fi[0];                  // dataflow units
     info[8] = fi[1];                  // stream edges
     info[9] = fi[2];                  // pipeline depth
@@ -696,7 +729,7 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
 extern "C" int xh_route_plan_stats(xh_route_plan *plan, int64_t max_words, uint64_t *h_words, int64_t *n_words) {
     if (!plan || !n_words) return XH_ERR_ARG;
     std::vector<unsigned long long> st;
-    int rc = flow_stats_fetch(plan->ctx, plan->flow, st);
+    int rc = flow_stats_fetch(plan->ctx, plan->last_typed ? plan->flow_typed : plan->flow, st);
     if (rc) return rc;
     *n_words = (int64_t)st.size();
     if (h_words)
@@ -716,6 +749,22 @@ __global__ void __launch_bounds__(256) k_count_diff(const unsigned long long *a,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         local += a[i] != b[i] ? 1ull : 0ull;
     if (local) atomicAdd(count, local);
+}
+
+// Which cells can fire (mrtm.py:54: dSdt * dt < -S).  With non-negative inflows dSdt >= -F = -S * tauinv, so a cell whose
+// tauinv * dt stays below 1 cannot (rounding: three operations of relative error 2^-53 each against a margin of 2^-20;
+// denormal storage and negative inputs are outside the argument and are what the kernel's guard is for).  A NaN ratio
+// counts as "can".  flags_new[c] is written, and compared with the flags the typed plan was built for.
+constexpr double CAPABLE_THRESHOLD = 1.0 - 1.0 / 1048576.0;
+__global__ void __launch_bounds__(256) k_capable(const double *velocity, const double *flow_dist, double dt, int n,
+                                                 const unsigned char *learn, unsigned char *flags_new,
+                                                 const unsigned char *flags_plan, unsigned *diff) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const double tauinv = velocity[c] / flow_dist[c];                          // mrtm.py:40
+    const unsigned char cap = ((tauinv * dt <= CAPABLE_THRESHOLD) ? 0 : 1) | (learn[c] ? 1 : 0);
+    flags_new[c] = cap;
+    if (!flags_plan || flags_plan[c] != cap) atomicAdd(diff, 1u);
 }
 
 // XH_ROUTE_VALIDATE: the call has just been routed by a dataflow kernel into the caller's arrays; route it again with one
@@ -822,12 +871,30 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
                           d_chstorage, d_avgchflow, d_S_end, d_F_end, flags);
 }
 
-int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r) {
+int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r, bool dataflow_pairs) {
     bool used_flow = false;
     r.plan->reroutes += 1;
+    int flags = r.flags & ~XH_ROUTE_TEST_FAULT;
+    if (dataflow_pairs) {
+        // The cells that fired unexpectedly are on record (d_learn) and this pair-form run records every other one of the
+        // series, so the next call's partition knows them.  If the guard keeps tripping all the same, the plain form is
+        // given up for this plan.
+        if (++r.plan->guard_trips > 8) r.plan->typed_disabled = true;
+        flags |= XH_ROUTE_NO_PLAIN;
+    } else {
+        flags |= XH_ROUTE_NO_DATAFLOW;
+    }
     return route_series_impl(ctx, r.plan, r.nmonths, r.spinup_months, r.ndays.data(), r.dt, r.flow_dist, r.velocity,
-                             r.area, r.runoff, r.S0, r.chs, r.avg, r.S_end, r.F_end,
-                             (r.flags | XH_ROUTE_NO_DATAFLOW) & ~XH_ROUTE_TEST_FAULT, &used_flow);
+                             r.area, r.runoff, r.S0, r.chs, r.avg, r.S_end, r.F_end, flags, &used_flow);
+}
+
+extern "C" int xh_route_plan_typed_info(const xh_route_plan *plan, int64_t info[4]) {
+    if (!plan || !info) return XH_ERR_ARG;
+    info[0] = (plan->last_typed && plan->flow_typed) ? plan->flow_typed->n_plain_units : 0;
+    info[1] = plan->typed_builds;
+    info[2] = plan->typed_disabled ? -1 : plan->guard_trips;
+    info[3] = plan->flow_typed ? plan->flow_typed->n_units : 0;
+    return XH_OK;
 }
 
 static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
@@ -876,7 +943,42 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     XH_HIP(ctx, hipMemcpyAsync(d_nt, snt.data(), sizeof(int) * nit, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipMemcpyAsync(d_g, sg.data(), sizeof(int) * (nit + 1), hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipMemcpyAsync(d_wr, swr.data(), (size_t)nit, hipMemcpyHostToDevice, ctx->stream));
+    // typed partition: does the plan at hand fit this call's velocity / flow distance / dt?  (answered by the sync below)
+    static const bool typed_env = !(getenv("XH_ROUTE_TYPED") && getenv("XH_ROUTE_TYPED")[0] == '0');
+    const bool want_typed = typed_env && plan->flow && !plan->typed_disabled && !plan->h_indptr.empty() &&
+                            (flags & (XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_NO_PLAIN)) == 0;
+    unsigned char *d_cap_new = nullptr;
+    if (want_typed) {
+        const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
+        if (!plan->d_capable.p) {
+            XH_HIP(ctx, hipMalloc(&plan->d_capable.p, 2 * nb));
+            XH_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&plan->d_cap_diff), 64));
+            XH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&plan->h_cap_diff), 64, hipHostMallocDefault));
+        }
+        d_cap_new = static_cast<unsigned char *>(plan->d_capable.p) + nb;
+        XH_HIP(ctx, hipMemsetAsync(plan->d_cap_diff, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_capable, dim3((unsigned)((plan->ncell + 255) / 256)), dim3(256), 0, ctx->stream, d_velocity,
+                           d_flow_dist, dt, (int)plan->ncell, static_cast<const unsigned char *>(plan->d_learn.p), d_cap_new,
+                           plan->flow_typed ? static_cast<const unsigned char *>(plan->d_capable.p) : nullptr, plan->d_cap_diff);
+        XH_HIP(ctx, hipMemcpyAsync(plan->h_cap_diff, plan->d_cap_diff, 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (want_typed && (*plan->h_cap_diff != 0 || !plan->flow_typed)) {
+        // (re)build: the set of cells that can fire changed (or this is the first call)
+        const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
+        std::vector<unsigned char> cap((size_t)plan->ncell);
+        XH_HIP(ctx, hipMemcpy(cap.data(), d_cap_new, cap.size(), hipMemcpyDeviceToHost));
+        XH_HIP(ctx, hipMemcpy(plan->d_capable.p, d_cap_new, nb, hipMemcpyDeviceToDevice));
+        flow_plan_destroy(plan->flow_typed);
+        plan->flow_typed = nullptr;
+        std::vector<char> handled;
+        const int frc = flow_plan_build(ctx, (int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
+                                        plan->h_sign.data(), plan->h_comp, plan->h_ncomp, cap.data(), handled,
+                                        &plan->flow_typed);
+        if (frc) return frc;
+        plan->typed_builds += 1;
+    }
+    FlowPlan *tree_plan = (want_typed && plan->flow_typed && plan->flow_typed->n_plain_units > 0) ? plan->flow_typed : plan->flow;
 
     const bool force_fb = (flags & XH_ROUTE_FORCE_FALLBACK) != 0;
     const bool atomic = (flags & XH_ROUTE_ATOMIC) != 0;
@@ -895,13 +997,19 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
             nt_even = nt_even && (v & 1) == 0;
         }
         const FlowSched fs{nmonths, nit, ntmax, ntmin, sg[nit], d_m, d_nt, d_g, d_secs, d_wr, dt,
-                           (flags & XH_ROUTE_TEST_FAULT) != 0, nt_even};
-        const FlowIO fio{d_flow_dist, d_velocity, d_area, d_runoff, d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end};
+                           (flags & XH_ROUTE_TEST_FAULT) != 0, nt_even, sm.data(), snt.data(), sg.data(), ssecs.data(),
+                           swr.data()};
+        const FlowIO fio{d_flow_dist, d_velocity, d_area, d_runoff, d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end,
+                         static_cast<unsigned char *>(plan->d_learn.p)};
         // time-skewed units first; months shorter than the deepest lane lag (long dt) use the monthly-stream kernel
         static const bool skew_env = !(getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] == '0');
         rc = XH_ERR_LIMIT;
         plan->last_tree_kernel = 2;
-        if (skew_env && (flags & XH_ROUTE_NO_SKEW) == 0) rc = skew_launch(ctx, plan->flow, fs, fio, ctx->stream);
+        static const bool old_skew = getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] == '2';      // round 2's kernel, for comparison
+        if (skew_env && (flags & XH_ROUTE_NO_SKEW) == 0)
+            rc = old_skew ? skew_launch(ctx, plan->flow, fs, fio, ctx->stream) : wave_launch(ctx, tree_plan, fs, fio, ctx->stream);
+        if (rc == XH_ERR_LIMIT && tree_plan != plan->flow && !old_skew) rc = wave_launch(ctx, plan->flow, fs, fio, ctx->stream);
+        plan->last_typed = rc == XH_OK && tree_plan != plan->flow && !old_skew;
         if (rc == XH_ERR_LIMIT) {
             plan->last_tree_kernel = 1;
             rc = flow_launch(ctx, plan->flow, fs, fio, ctx->stream);

@@ -11,7 +11,7 @@ struct FlowBuf {
 
 // Partition of the tree-shaped river networks into single-wave units (64 lanes = 64 cells) linked by one-way streams.
 struct FlowPlan {
-    int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0, max_exports = 0;
+    int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0, max_exports = 0, n_plain_units = 0;
     FlowBuf d_cell_of_slot, d_ent, d_export_edge, d_ghost_edge, d_edge_cons_unit, d_unit_terms;
     // time-skewed layout (xh_mrtm_skew.hip); skew_ok = every row has <= 4 terms either side of its diagonal
     bool skew_ok = false;
@@ -24,7 +24,9 @@ struct FlowPlan {
     unsigned long long *d_stats = nullptr;
     unsigned *d_trace = nullptr;         // XH_FLOW_TRACE=<file>: month-end times of every unit, dumped by flow_stats_fetch
     size_t trace_words = 0;
-    void *d_skew_args = nullptr;         // argument block of k_mrtm_skew (rewritten, stream-ordered, by every launch)
+    void *d_skew_args = nullptr;         // argument block of the time-skewed kernel (rewritten, stream-ordered, by every launch)
+    std::vector<char> h_rec, h_fin;      // host copies of the month records of the last launch (sources of asynchronous copies)
+    FlowBuf d_lane_flags, d_ghost_prod;  // typed partition: cells that can fire by construction; producer cell of every imported stream
 };
 
 struct FlowSched {
@@ -36,17 +38,24 @@ struct FlowSched {
     double dt;
     bool test_fault;                  // XH_ROUTE_TEST_FAULT: unit 0 raises the fault word and stops (tests of the re-route)
     bool nt_even;                     // every month has an even number of sub-steps (dt = 3 h: 8 per day)
+    const int *h_m, *h_nt, *h_g;      // the same schedule on the host ([nit], h_g [nit + 1])
+    const double *h_secs;
+    const unsigned char *h_wr;
 };
 
 struct FlowIO {
     const double *flow_dist, *velocity, *area, *runoff, *S0;
     double *chs, *avg, *S_end, *F_end;
+    unsigned char *learn;             // [ncell] cells seen firing unexpectedly (xh_mrtm_wave.hip); never NULL for wave_launch
 };
 
 // Partition every tree-shaped river network (each cell drains to at most one cell, no cycle, standard UP - I rows)
 // into single-wave units linked by one-way streams.  handled[c] = 1 for the cells these units route.
+// capable: nullptr = every unit in pair form; else [n] flags of the cells that can fire (typed partition: pair and plain
+// units, xh_flow_plan.h).
 int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
-                    const std::vector<int> &comp, int ncomp, std::vector<char> &handled, FlowPlan **out);
+                    const std::vector<int> &comp, int ncomp, const unsigned char *capable, std::vector<char> &handled,
+                    FlowPlan **out);
 void flow_plan_destroy(FlowPlan *fp);
 // info: [0] units, [1] stream edges, [2] pipeline depth (levels), [3] cells, [4] max imports of a unit
 void flow_plan_info(const FlowPlan *fp, int64_t info[5]);
@@ -55,6 +64,8 @@ int flow_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
 // Same contract for the time-skewed kernel; XH_ERR_LIMIT also when the schedule does not suit it (months shorter
 // than the deepest lane lag, rows wider than 4 + 1 + 4) -- the caller then uses flow_launch.
 int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st);
+// Round 3's time-skewed kernel (xh_mrtm_wave.hip): same contract, same plan tables, pair and plain units.
+int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st);
 // Per-unit cycle accounting of the last launch (only when XH_FLOW_STATS=1): 6 words per unit
 // {shader cycles in sub-step loops, shader cycles total, 100 MHz ticks total, shape bits, data-wait, ring-wait cycles}.
 int flow_stats_fetch(xh_ctx *ctx, FlowPlan *fp, std::vector<unsigned long long> &out);

@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <numeric>
 
+#include "xh_flow_plan.h"
 #include "xh_mrtm_flow.h"
 
 namespace {
@@ -297,7 +298,8 @@ void flow_plan_destroy(FlowPlan *fp) {
     if (!fp) return;
     FlowBuf *bufs[] = {&fp->d_cell_of_slot, &fp->d_ent,      &fp->d_export_edge, &fp->d_ghost_edge,
                        &fp->d_edge_cons_unit, &fp->d_unit_terms, &fp->d_lag,        &fp->d_ghost_lag,
-                       &fp->d_ent2,         &fp->d_eprev,       &fp->d_unit_order,  &fp->d_unit_p,     &fp->d_unit_lmax,   &fp->d_unit_glmax};
+                       &fp->d_ent2,         &fp->d_eprev,       &fp->d_unit_order,  &fp->d_unit_p,     &fp->d_unit_lmax,   &fp->d_unit_glmax,
+                       &fp->d_lane_flags,   &fp->d_ghost_prod};
     for (FlowBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (fp->d_x) (void)hipFree(fp->d_x);
@@ -315,682 +317,79 @@ void flow_plan_info(const FlowPlan *fp, int64_t info[5]) {
     info[4] = fp ? fp->max_imports : 0;
 }
 
+// The partition itself is host code without any HIP in it (xh_flow_plan.cpp: also built with sanitizers for the host
+// fuzzer, tests/plan_fuzz); here its tables go to the device.  The experiment switches of the planner are read once.
+FlowPlanOptions flow_plan_options(xh_ctx *ctx) {
+    FlowPlanOptions o;
+    o.simds = 4 * (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 0);
+    if (const char *e = getenv("XH_FLOW_PIECE_CAP")) o.piece_cap = std::min(std::max(atoi(e), 1), LANES);
+    o.chain = !(getenv("XH_FLOW_CHAIN") && getenv("XH_FLOW_CHAIN")[0] == '0');
+    o.cut_rule = !(getenv("XH_FLOW_CUTRULE") && getenv("XH_FLOW_CUTRULE")[0] == '0');
+    if (const char *e = getenv("XH_FLOW_TLIMIT")) o.tlimit = o.tlimit_typed = atoi(e);
+    if (const char *e = getenv("XH_FLOW_TLIMIT_PLAIN")) o.tlimit_plain = atoi(e);
+    if (const char *e = getenv("XH_FLOW_FULL_JOIN")) o.full_join = atoi(e);
+    o.debug = getenv("XH_FLOW_DEBUG") != nullptr;
+    return o;
+}
+
 int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
-                    const std::vector<int> &comp, int ncomp, std::vector<char> &handled, FlowPlan **out) {
+                    const std::vector<int> &comp, int ncomp, const unsigned char *capable, std::vector<char> &handled,
+                    FlowPlan **out) {
     *out = nullptr;
     handled.assign(n, 0);
     if (n == 0) return XH_OK;
-
-    // ---- which networks are plain trees: rows are {-1 on the diagonal, +1 elsewhere}, every cell feeds <= 1 row,
-    //      at most W_MAX terms per row, no cycle
-    std::vector<int> ds(n, -1);
-    std::vector<char> comp_ok(ncomp, 1);
-    for (int r = 0; r < n; ++r) {
-        int ndiag = 0;
-        if (indptr[r + 1] - indptr[r] > W_MAX) comp_ok[comp[r]] = 0;
-        for (int64_t j = indptr[r]; j < indptr[r + 1]; ++j) {
-            const int c = indices[j];
-            if (sign[j] < 0) {
-                if (c == r) ++ndiag;
-                else comp_ok[comp[r]] = 0;
-            } else {
-                if (c == r || ds[c] >= 0) comp_ok[comp[r]] = 0;
-                ds[c] = r;
-            }
-        }
-        if (ndiag != 1) comp_ok[comp[r]] = 0;
+    FlowPlanOptions opt = flow_plan_options(ctx);
+    opt.capable = capable;
+    FlowTables t;
+    std::string err;
+    if (flow_tables_build(n, indptr, indices, sign, comp.data(), ncomp, opt, handled, t, err) != 0)
+        return xh_fail(ctx, XH_ERR_ARG, "%s", err.c_str());
+    if (t.n_units == 0) return XH_OK;
+    if (getenv("XH_FLOW_CHECK")) {      // the invariants the host fuzzer holds the planner to, on this very plan
+        const std::string bad = flow_tables_check(n, indptr, indices, sign, handled, t, capable);
+        if (!bad.empty()) return xh_fail(ctx, XH_ERR_ARG, "flow plan check: %s", bad.c_str());
     }
-    {   // cycles: follow the downstream pointers with three colours
-        std::vector<char> colour(n, 0);
-        std::vector<int> path;
-        for (int s = 0; s < n; ++s) {
-            if (colour[s]) continue;
-            path.clear();
-            int v = s;
-            while (v >= 0 && colour[v] == 0) {
-                colour[v] = 1;
-                path.push_back(v);
-                v = ds[v];
-            }
-            if (v >= 0 && colour[v] == 1) comp_ok[comp[v]] = 0;       // ran into the current path: a cycle
-            for (int p : path) colour[p] = 2;
-        }
-    }
-
-    // ---- bottom-up cut into connected pieces of <= LANES cells with <= G_MAX imported streams
-    std::vector<int> nchild(n, 0);
-    for (int c = 0; c < n; ++c)
-        if (ds[c] >= 0) nchild[ds[c]]++;
-    std::vector<int> child_ptr(n + 1, 0);
-    for (int c = 0; c < n; ++c) child_ptr[c + 1] = child_ptr[c] + nchild[c];
-    std::vector<int> child(child_ptr[n]);
-    {
-        std::vector<int> fill(child_ptr.begin(), child_ptr.end() - 1);
-        for (int c = 0; c < n; ++c)
-            if (ds[c] >= 0) child[fill[ds[c]]++] = c;
-    }
-    // longest side of every row either side of its diagonal (the time-skewed kernel reads that many pairs per sub-step)
-    std::vector<int> cell_pre(n, 0), cell_post(n, 0);
-    for (int c = 0; c < n; ++c) {
-        bool past = false;
-        for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {
-            if (indices[j] == c) past = true;
-            else ++(past ? cell_post[c] : cell_pre[c]);
-        }
-    }
-    const int simds = 4 * (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 0);
-
-    // ---- partition for one piece capacity `cap`: bottom-up cut into connected pieces of <= cap cells with <= G_MAX
-    //      imported streams, then pieces packed into units of LANES cells.
-    //      A smaller capacity than LANES costs streams (every cut is one) and buys units: pieces of 33..64 cells cannot
-    //      share a unit, so the largest capacity leaves every other unit ~10 lanes short of full (67,420 cells: 1,121
-    //      units at 64; 1,059 at 36 -- 1,054 would be every lane used -- with 1,699 streams instead of 861).  Units beyond the SIMD count
-    //      share a SIMD with another unit and the slowest unit paces the run, so units are what counts.
-    struct Partition {
-        std::vector<int> queue, piece, closed_roots, piece_of_root, piece_size, piece_imp, piece_depth;
-        std::vector<int> edge_prod_cell, edge_cons_cell, edge_of_prod;
-        std::vector<int> unit_of_piece, unit_cells_n, unit_imp_n, unit_depth;
-        std::vector<char> reached;
-        int nunit = 0, nedge = 0, maxdepth = 0;
-    };
-    auto make_partition = [&](int cap, Partition &P) {
-        P = Partition();
-        std::vector<int> &queue = P.queue;
-        queue.reserve(n);
-        std::vector<int> left(nchild);
-        for (int c = 0; c < n; ++c)
-            if (comp_ok[comp[c]] && nchild[c] == 0) queue.push_back(c);
-        std::vector<int> dsu(n);
-        std::iota(dsu.begin(), dsu.end(), 0);
-        auto find = [&](int x) {
-            while (dsu[x] != x) {
-                dsu[x] = dsu[dsu[x]];
-                x = dsu[x];
-            }
-            return x;
-        };
-        std::vector<int> open_cnt(n, 0), open_imp(n, 0);
-        std::vector<int> &closed_roots = P.closed_roots;            // piece roots in closing order (upstream pieces first)
-        std::vector<int> kids;
-        for (size_t qi = 0; qi < queue.size(); ++qi) {
-            const int v = queue[qi];
-            kids.assign(child.begin() + child_ptr[v], child.begin() + child_ptr[v + 1]);
-            std::sort(kids.begin(), kids.end(), [&](int x, int y) {
-                return open_cnt[x] != open_cnt[y] ? open_cnt[x] < open_cnt[y] : x < y;
-            });
-            int total = 1, imp = (int)kids.size();
-            unsigned keep = 0;                          // bit i: kids[i]'s open piece joins v's
-            for (size_t i = 0; i < kids.size(); ++i) {
-                const int c = kids[i];
-                if (total + open_cnt[c] <= cap && imp - 1 + open_imp[c] <= G_MAX) {
-                    keep |= 1u << i;
-                    total += open_cnt[c];
-                    imp += open_imp[c] - 1;
-                }
-            }
-            static const bool cut_rule = !(getenv("XH_FLOW_CUTRULE") && getenv("XH_FLOW_CUTRULE")[0] == '0');
-            if (cut_rule && keep + 1 != (1u << kids.size()) && cell_pre[v] >= 3 && kids.size() <= 8) {
-                // Not every child fits, and v's row has a long front side: which children become streams decides how many
-                // pairs v reads per sub-step (a stream may only open the chain that sums the front side on the way, see
-                // the time-skewed layout below).  Among the choices that fit: fewest reads for v, then most cells kept.
-                auto v_reads = [&](unsigned kp) {
-                    int j = 0, k = 0;
-                    bool in_prefix = true;
-                    for (int64_t e = indptr[v]; e < indptr[v + 1]; ++e) {
-                        const int src = indices[e];
-                        if (src == v) break;
-                        bool kept = false;
-                        for (size_t i = 0; i < kids.size(); ++i)
-                            if (kids[i] == src) kept = (kp >> i) & 1u;
-                        if (in_prefix && (kept || k == 0)) ++j;
-                        else in_prefix = false;
-                        ++k;
-                    }
-                    const int dir = j >= 2 ? 1 + k - j : k;
-                    return (k - dir >= 2 ? dir + 1 : k) + cell_post[v];
-                };
-                // (the capacity is there for the packing; a piece around such a cell may grow up to a whole unit if that is
-                // what it takes to keep its chain)
-                int best_reads = v_reads(keep), best_total = total;
-                for (unsigned kp = 0; kp < (1u << kids.size()); ++kp) {
-                    int t = 1, im = (int)kids.size();
-                    for (size_t i = 0; i < kids.size(); ++i)
-                        if ((kp >> i) & 1u) {
-                            t += open_cnt[kids[i]];
-                            im += open_imp[kids[i]] - 1;
-                        }
-                    if (t > LANES || im > G_MAX) continue;
-                    const int r = v_reads(kp);
-                    const bool over = t > cap, best_over = best_total > cap;
-                    if (r < best_reads || (r == best_reads && (over != best_over ? !over : t > best_total))) {
-                        best_reads = r;
-                        best_total = t;
-                        keep = kp;
-                    }
-                }
-                total = 1;
-                imp = (int)kids.size();
-                for (size_t i = 0; i < kids.size(); ++i)
-                    if ((keep >> i) & 1u) {
-                        total += open_cnt[kids[i]];
-                        imp += open_imp[kids[i]] - 1;
-                    }
-            }
-            for (size_t i = 0; i < kids.size(); ++i) {
-                const int c = kids[i];
-                if ((keep >> i) & 1u) dsu[find(c)] = v;      // c's open piece joins v's
-                else closed_roots.push_back(c);             // c's piece is final; its outlet streams into v
-            }
-            open_cnt[v] = total;
-            open_imp[v] = imp;
-            if (ds[v] < 0) {
-                closed_roots.push_back(v);
-            } else if (--left[ds[v]] == 0) {
-                queue.push_back(ds[v]);
-            }
-        }
-        // cells of ok networks that were never reached (cannot happen for trees) stay unhandled
-        P.reached.assign(n, 0);
-        for (int v : queue) P.reached[v] = 1;
-
-        // ---- pieces, their stream edges and pipeline depth
-        const int npiece = (int)closed_roots.size();
-        P.piece_of_root.assign(n, -1);
-        for (int p = 0; p < npiece; ++p) P.piece_of_root[closed_roots[p]] = p;
-        P.piece.assign(n, -1);
-        P.piece_size.assign(npiece, 0);
-        P.piece_imp.assign(npiece, 0);
-        P.piece_depth.assign(npiece, 0);
-        std::vector<int> ppre(npiece, 0), ppost(npiece, 0), pdir(npiece, 0);
-        for (int c = 0; c < n; ++c)
-            if (P.reached[c]) {
-                const int q = P.piece_of_root[find(c)];
-                P.piece[c] = q;
-                P.piece_size[q]++;
-                ppre[q] = std::max(ppre[q], cell_pre[c]);
-                ppost[q] = std::max(ppost[q], cell_post[c]);
-            }
-        // front-side terms a cell still reads one by one when its unit is chained (see the time-skewed layout below): the
-        // prefix of cells of its own piece (the first may be an imported stream) counts as one
-        for (int c = 0; c < n; ++c)
-            if (P.reached[c]) {
-                const int q = P.piece[c];
-                int j = 0, k = 0;
-                bool in_prefix = true;
-                for (int64_t e = indptr[c]; e < indptr[c + 1]; ++e) {
-                    const int src = indices[e];
-                    if (src == c) break;
-                    if (in_prefix && (P.piece[src] == q || k == 0)) ++j;
-                    else in_prefix = false;
-                    ++k;
-                }
-                pdir[q] = std::max(pdir[q], j >= 2 ? 1 + k - j : k);
-            }
-        P.edge_of_prod.assign(n, -1);                        // one stream per closed piece that has a downstream cell
-        for (int p = 0; p < npiece; ++p) {                   // closing order: upstream pieces come first
-            const int r = closed_roots[p];
-            if (ds[r] >= 0) {
-                const int cp = P.piece[ds[r]];
-                P.edge_of_prod[r] = (int)P.edge_prod_cell.size();
-                P.edge_prod_cell.push_back(r);
-                P.edge_cons_cell.push_back(ds[r]);
-                P.piece_imp[cp]++;
-                P.piece_depth[cp] = std::max(P.piece_depth[cp], P.piece_depth[p] + 1);
-            }
-        }
-        P.nedge = (int)P.edge_prod_cell.size();
-        P.maxdepth = npiece ? *std::max_element(P.piece_depth.begin(), P.piece_depth.end()) : 0;
-
-        // ---- packing.  Pieces with a stream in or out: equal depth per unit (a unit then only ever waits for units
-        //      strictly upstream or downstream of it), first-fit decreasing.  Pieces without streams -- whole small
-        //      networks -- wait for nobody and go wherever lanes are free; the `cheap_units` cheapest of them (fewest row
-        //      terms) are kept together instead: units for the SIMDs that must hold two waves (see the numbering below).
-        auto has_out = [&](int p) { return ds[closed_roots[p]] >= 0; };
-        // pairs a unit reads per sub-step: chained when that saves a read (front side - one-by-one terms >= 2)
-        auto reads = [](int pre, int dir, int post) {
-            return std::max(pre - dir >= 2 ? dir + 1 : pre, 1) + std::max(post, 1);
-        };
-        auto terms_of = [&](int p) { return reads(ppre[p], pdir[p], ppost[p]); };
-        static const int tlimit = getenv("XH_FLOW_TLIMIT") ? atoi(getenv("XH_FLOW_TLIMIT")) : 5;
-        std::vector<int> dep, fre;
-        for (int p = 0; p < npiece; ++p) (P.piece_imp[p] > 0 || has_out(p) ? dep : fre).push_back(p);
-        std::stable_sort(dep.begin(), dep.end(), [&](int x, int y) {
-            return P.piece_depth[x] != P.piece_depth[y] ? P.piece_depth[x] < P.piece_depth[y]
-                                                        : P.piece_size[x] > P.piece_size[y];
-        });
-        int cheap_units = 0;
-        for (int round = 0; round < 4; ++round) {
-            P.unit_of_piece.assign(npiece, -1);
-            P.unit_cells_n.clear();
-            P.unit_imp_n.clear();
-            P.unit_depth.clear();
-            std::vector<int> unit_out_n;                                   // outlets: <= G_MAX too
-            std::vector<int> upre, udir, upost;                            // longest sides of the unit's rows
-            auto new_unit = [&](int depth) {
-                P.unit_cells_n.push_back(0);
-                P.unit_imp_n.push_back(0);
-                unit_out_n.push_back(0);
-                upre.push_back(0);
-                udir.push_back(0);
-                upost.push_back(0);
-                P.unit_depth.push_back(depth);
-                return (int)P.unit_cells_n.size() - 1;
-            };
-            auto put_piece = [&](int p, int u) {
-                P.unit_of_piece[p] = u;
-                P.unit_cells_n[u] += P.piece_size[p];
-                P.unit_imp_n[u] += P.piece_imp[p];
-                unit_out_n[u] += has_out(p) ? 1 : 0;
-                upre[u] = std::max(upre[u], ppre[p]);
-                udir[u] = std::max(udir[u], pdir[p]);
-                upost[u] = std::max(upost[u], ppost[p]);
-            };
-            // a piece joins a unit only if the unit then reads no more pairs per sub-step than `tlimit`, or than the piece
-            // or the unit need on their own: the slowest unit paces the run, and it is the one with the longest rows
-            auto class_ok = [&](int p, int u) {
-                const int t = reads(std::max(upre[u], ppre[p]), std::max(udir[u], pdir[p]), std::max(upost[u], ppost[p]));
-                return P.unit_cells_n[u] == 0 ||
-                       t <= std::max(tlimit, std::max(terms_of(p), reads(upre[u], udir[u], upost[u])));
-            };
-            {
-                size_t first_open = 0;
-                int cur_depth = -1;
-                for (int p : dep) {
-                    if (P.piece_depth[p] != cur_depth) {
-                        cur_depth = P.piece_depth[p];
-                        first_open = P.unit_cells_n.size();
-                    }
-                    int u = -1;
-                    for (size_t b = first_open; b < P.unit_cells_n.size(); ++b)
-                        if (P.unit_cells_n[b] + P.piece_size[p] <= LANES && P.unit_imp_n[b] + P.piece_imp[p] <= G_MAX &&
-                            unit_out_n[b] + (has_out(p) ? 1 : 0) <= G_MAX && class_ok(p, (int)b)) {
-                            u = (int)b;
-                            break;
-                        }
-                    if (u < 0) u = new_unit(cur_depth);
-                    put_piece(p, u);
-                    while (first_open < P.unit_cells_n.size() && P.unit_cells_n[first_open] >= LANES) ++first_open;
-                }
-            }
-            // the cheap units: free pieces by (row terms, size), filled one unit after the other
-            std::vector<int> by_terms(fre);
-            std::stable_sort(by_terms.begin(), by_terms.end(), [&](int x, int y) {
-                return terms_of(x) != terms_of(y) ? terms_of(x) < terms_of(y) : P.piece_size[x] < P.piece_size[y];
-            });
-            std::vector<char> taken(npiece, 0);
-            {
-                int made = 0, u = -1;
-                for (int p : by_terms) {
-                    if (terms_of(p) > 3) break;
-                    if (u < 0 || P.unit_cells_n[u] + P.piece_size[p] > LANES) {
-                        if (made == cheap_units) break;
-                        u = new_unit(0);
-                        ++made;
-                    }
-                    put_piece(p, u);
-                    taken[p] = 1;
-                }
-            }
-            // the other free pieces: largest first, each into the fullest unit that still takes it
-            std::vector<int> by_size;
-            for (int p : fre)
-                if (!taken[p]) by_size.push_back(p);
-            std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) { return P.piece_size[x] > P.piece_size[y]; });
-            {
-                // units by free lanes: bucket[f] = units with f free lanes
-                std::vector<std::vector<int>> bucket(LANES + 1);
-                for (int u = 0; u < (int)P.unit_cells_n.size(); ++u) bucket[LANES - P.unit_cells_n[u]].push_back(u);
-                for (int p : by_size) {
-                    const int sz = P.piece_size[p];
-                    int u = -1;
-                    for (int pass = 0; pass < 2 && u < 0; ++pass)          // second pass: any unit with room
-                        for (int f = sz; f <= LANES && u < 0; ++f)
-                            for (size_t i = bucket[f].size(); i-- > 0;)
-                                if (pass == 1 || class_ok(p, bucket[f][i])) {
-                                    u = bucket[f][i];
-                                    bucket[f].erase(bucket[f].begin() + (long)i);
-                                    break;
-                                }
-                    if (u < 0) u = new_unit(0);
-                    put_piece(p, u);
-                    bucket[LANES - P.unit_cells_n[u]].push_back(u);
-                }
-            }
-            P.nunit = (int)P.unit_cells_n.size();
-            const int need = simds > 0 ? std::max(P.nunit - simds, 0) : 0;
-            if (need <= cheap_units) break;
-            cheap_units = need + (round > 0 ? 2 : 0);      // the cheap units themselves may add a unit or two
-        }
-    };
-    Partition P;
-    {
-        // the capacity with the fewest units wins (ties: the larger capacity = fewer streams)
-        static const int caps[] = {LANES, 56, 48, 44, 40, 36, 32};
-        int forced = 0;
-        if (const char *env = getenv("XH_FLOW_PIECE_CAP")) forced = std::min(std::max(atoi(env), 1), LANES);      // experiments
-        Partition Q;
-        bool have = false;
-        long best_score = 0;
-        for (int cap : caps) {
-            if (forced) cap = forced;
-            make_partition(cap, Q);
-            // units beyond the SIMD count share a SIMD; only units without streams may (see the numbering below): a unit
-            // with streams that has to share one slows every unit it is linked to, which costs far more than a few units
-            int indep = 0;
-            {
-                std::vector<char> coupled(Q.nunit, 0);
-                for (size_t p = 0; p < Q.closed_roots.size(); ++p)
-                    if (Q.piece_imp[p] > 0 || ds[Q.closed_roots[p]] >= 0) coupled[Q.unit_of_piece[p]] = 1;
-                for (int u = 0; u < Q.nunit; ++u) indep += coupled[u] ? 0 : 1;
-            }
-            const int extra = simds > 0 ? std::max(Q.nunit - simds, 0) : 0;
-            const long score = 1000000L * std::max(2 * extra - indep, 0) + 1000L * Q.nunit + Q.nedge / 8;
-            if (getenv("XH_FLOW_DEBUG"))
-                fprintf(stderr, "flow plan: piece capacity %d -> %d units, %d streams, %d units without streams\n", cap,
-                        Q.nunit, Q.nedge, indep);
-            if (!have || score < best_score) {
-                std::swap(P, Q);
-                best_score = score;
-                have = true;
-            }
-            if (forced || (simds > 0 && P.nunit <= simds)) break;       // every unit has a SIMD of its own: good enough
-        }
-    }
-    std::vector<int> &queue = P.queue, &piece = P.piece, &closed_roots = P.closed_roots, &piece_of_root = P.piece_of_root;
-    std::vector<int> &piece_size = P.piece_size, &piece_imp = P.piece_imp, &piece_depth = P.piece_depth;
-    std::vector<int> &edge_prod_cell = P.edge_prod_cell, &edge_cons_cell = P.edge_cons_cell, &edge_of_prod = P.edge_of_prod;
-    std::vector<int> &unit_of_piece = P.unit_of_piece, &unit_cells_n = P.unit_cells_n, &unit_imp_n = P.unit_imp_n;
-    std::vector<int> &unit_depth = P.unit_depth;
-    std::vector<char> &reached = P.reached;
-    (void)reached;
-    (void)piece_size;
-    (void)piece_imp;
-    const int npiece = (int)closed_roots.size();
-    const int nedge = P.nedge, maxdepth = P.maxdepth;
-    const int nunit = P.nunit;
-    if (nunit == 0) return XH_OK;
-
-    // ---- which unit runs where.  With more units than SIMDs some SIMDs hold two waves; the slowest unit paces the run,
-    //      and two waves on a SIMD take about as long as their instruction streams put together (+50 % for a 5-term unit
-    //      next to a 2-term one).  A unit with streams passes its delay on to every unit downstream and, through the ring
-    //      limits, upstream of it; a unit without streams only delays itself.  So the SIMDs with two waves should hold
-    //      units without streams, a cheap one next to a dearer one that gets issue priority.  Which workgroup lands on
-    //      which SIMD cannot be planned: it follows the workgroup id only on an idle device (measured: with the ABCD
-    //      kernel's last waves still draining, 38 SIMDs instead of 34 got two workgroups, ids unrelated, and the call
-    //      took 31 ms instead of 25.6).  The kernel therefore lets every workgroup find out where it runs and claim its
-    //      unit from this list (xh_mrtm_skew.hip, top of k_mrtm_skew): units without streams by rising cost, then the others.
-    std::vector<int> unit_order(nunit);      // filled below, once the row shapes of the units are known
-
-    // ---- slots, ghosts, gather offsets
-    const int64_t ts = (int64_t)nunit * LANES;
-    std::vector<int> cell_of_slot(ts, -1), export_edge(ts, -1), ghost_edge(ts, -1), slot_of_cell(n, -1);
-    std::vector<int> fill(nunit, 0), gfill(nunit, 0), edge_cons_unit(nedge), edge_ghost(nedge);
-    for (int c = 0; c < n; ++c)
-        if (piece[c] >= 0) {
-            const int u = unit_of_piece[piece[c]];
-            const int s = fill[u]++;
-            cell_of_slot[(int64_t)u * LANES + s] = c;
-            slot_of_cell[c] = s;
-            handled[c] = 1;
-        }
-    for (int ed = 0; ed < nedge; ++ed) {
-        const int u = unit_of_piece[piece[edge_cons_cell[ed]]];
-        const int g = gfill[u]++;
-        edge_cons_unit[ed] = u;
-        edge_ghost[ed] = g;
-        ghost_edge[(int64_t)u * LANES + g] = ed;
-        const int pc = edge_prod_cell[ed];
-        export_edge[(int64_t)unit_of_piece[piece[pc]] * LANES + slot_of_cell[pc]] = ed;
-    }
-    std::vector<unsigned> ent((size_t)W_MAX * ts, (unsigned)(NPAIR - 1) * 16u);
-    std::vector<int> unit_terms(nunit, 1);
-    for (int c = 0; c < n; ++c) {
-        if (piece[c] < 0) continue;
-        const int u = unit_of_piece[piece[c]];
-        unit_terms[u] = std::max(unit_terms[u], (int)(indptr[c + 1] - indptr[c]));
-        const int64_t slot = (int64_t)u * LANES + slot_of_cell[c];
-        int w = 0;
-        for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j, ++w) {
-            const int src = indices[j];
-            unsigned off;
-            if (piece[src] >= 0 && unit_of_piece[piece[src]] == u) {
-                off = (unsigned)slot_of_cell[src] * 16u + (sign[j] < 0 ? 8u : 0u);
-            } else {                                    // the outlet of an upstream piece in another unit
-                const int ed = edge_of_prod[src];
-                if (ed < 0 || edge_cons_unit[ed] != u)
-                    return xh_fail(ctx, XH_ERR_ARG, "flow plan: inconsistent stream edge at cell %d", c);
-                off = (unsigned)(LANES + edge_ghost[ed]) * 16u;
-            }
-            ent[(size_t)w * ts + slot] = off;
-        }
-    }
-
-    // ---- time-skewed layout (xh_mrtm_skew.hip).  Lane lags: a cell `h` edges above its piece's outlet runs
-    //      2 * (H - h) sub-steps behind the unit's clock (H = tallest piece of the unit, an imported stream counting as
-    //      one more level), so that every flow a cell gathers was produced exactly two iterations earlier.  The lags
-    //      of a unit are shifted so that its outlets' lag is a multiple of 16 (stream stores of 16 sub-steps never
-    //      wrap inside a group).  Row terms are split at the diagonal: SK_P before, SK_P after.
-    constexpr int SK_P = 4;
-    constexpr unsigned SK_ZERO = 2u * LANES * 16u;
-    bool skew_ok = true;
-    // Chained units (xh_mrtm_skew.hip, CHAIN): the cells that feed a cell from in front of its diagonal, as far as they
-    // are lanes of the unit from the first one on (an imported stream ends the chain: its pair is dropped into LDS by the
-    // block transfers, not computed by a lane), pass a running sum along their stored order; the fed cell reads the last
-    // one's pair as one term and the rest of its front side term by term.  A unit is chained when that saves at least
-    // one read per sub-step: longest front side (reads saved + 1 for the running pair) at least 2 shorter.
-    std::vector<char> unit_chain(nunit, 0);
-    std::vector<int> chain_extra(n, 0), chain_prev(n, -1), chain_len(n, 0);   // levels below the last of the chain; cell before
-    std::vector<int> edge_reader(edge_cons_cell);      // the cell whose lane reads an imported pair out of LDS
-    {
-        static const bool chain_env = !(getenv("XH_FLOW_CHAIN") && getenv("XH_FLOW_CHAIN")[0] == '0');
-        std::vector<int> upre(nunit, 0), udir(nunit, 0);
-        auto front = [&](int c, int u, int &k) {       // k = terms in front of the diagonal, returns the chainable prefix:
-            int j = 0;                                 // lanes of the unit, the first one possibly an imported stream
-            bool in_prefix = true;
-            k = 0;
-            for (int64_t e = indptr[c]; e < indptr[c + 1]; ++e) {
-                const int src = indices[e];
-                if (src == c) break;
-                const bool inu = piece[src] >= 0 && unit_of_piece[piece[src]] == u;
-                if (in_prefix && (inu || k == 0)) ++j;
-                else in_prefix = false;
-                ++k;
-            }
-            return j;
-        };
-        for (int c = 0; c < n; ++c) {
-            if (piece[c] < 0) continue;
-            const int u = unit_of_piece[piece[c]];
-            int k;
-            const int j = front(c, u, k);
-            upre[u] = std::max(upre[u], k);
-            udir[u] = std::max(udir[u], j >= 2 ? 1 + k - j : k);
-        }
-        for (int u = 0; u < nunit; ++u) unit_chain[u] = chain_env && upre[u] - udir[u] >= 2 && udir[u] <= 2;
-        for (int c = 0; c < n; ++c) {
-            if (piece[c] < 0) continue;
-            const int u = unit_of_piece[piece[c]];
-            if (!unit_chain[u]) continue;
-            int k;
-            const int j = front(c, u, k);
-            if (j < 2) continue;
-            chain_len[c] = j;
-            int prev = -1;
-            for (int i = 0; i < j; ++i) {
-                const int t = indices[indptr[c] + i];
-                const bool inu = piece[t] >= 0 && unit_of_piece[piece[t]] == u;
-                if (!inu) {             // an imported stream opens the chain: the next cell adds its flows to the ghost pair
-                    edge_reader[edge_of_prod[t]] = indices[indptr[c] + 1];
-                    prev = -2 - edge_of_prod[t];
-                    continue;
-                }
-                chain_extra[t] = j - 1 - i;
-                chain_prev[t] = prev;
-                prev = t;
-            }
-        }
-    }
-    std::vector<int> hgt(n, 0), unit_h(nunit, 0);
-    for (size_t qi = queue.size(); qi-- > 0;) {          // reverse bottom-up order: downstream cells first
-        const int c = queue[qi];
-        if (piece[c] < 0) continue;
-        hgt[c] = (piece_of_root[c] == piece[c]) ? 0 : hgt[ds[c]] + 1 + chain_extra[c];
-        int &uh = unit_h[unit_of_piece[piece[c]]];
-        uh = std::max(uh, hgt[c]);
-    }
-    for (int ed = 0; ed < nedge; ++ed) {
-        int &uh = unit_h[edge_cons_unit[ed]];
-        uh = std::max(uh, hgt[edge_reader[ed]] + 1);
-    }
-    std::vector<int> lag(ts, 0), ghost_lag(ts, 0), unit_p(nunit, 0x11), unit_lmax(nunit, 0), unit_glmax(nunit, 0);
-    std::vector<unsigned> ent2((size_t)2 * SK_P * ts, SK_ZERO), eprev(ts, SK_ZERO);
-    for (int u = 0; u < nunit; ++u) unit_lmax[u] = (2 * unit_h[u] + 15) & ~15;
-    for (int c = 0; c < n; ++c) {
-        if (piece[c] < 0) continue;
-        const int u = unit_of_piece[piece[c]];
-        const int64_t slot = (int64_t)u * LANES + slot_of_cell[c];
-        lag[slot] = unit_lmax[u] - 2 * hgt[c];
-        if (chain_prev[c] >= 0) eprev[slot] = (unsigned)slot_of_cell[chain_prev[c]] * 16u;
-        else if (chain_prev[c] <= -2) eprev[slot] = (unsigned)(LANES + edge_ghost[-2 - chain_prev[c]]) * 16u;
-        int npre = 0, npost = 0, seen = 0;
-        bool past = false;
-        for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {
-            const int src = indices[j];
-            if (src == c) {
-                past = true;
-                continue;
-            }
-            if (!past && ++seen < chain_len[c]) continue;      // summed on the way: only the last of the chain is read
-            unsigned off;
-            if (piece[src] >= 0 && unit_of_piece[piece[src]] == u) off = (unsigned)slot_of_cell[src] * 16u;
-            else off = (unsigned)(LANES + edge_ghost[edge_of_prod[src]]) * 16u;
-            int &k = past ? npost : npre;
-            if (k >= SK_P) {
-                skew_ok = false;
-                continue;
-            }
-            ent2[(size_t)((past ? SK_P : 0) + k) * ts + slot] = off;
-            ++k;
-        }
-        unit_p[u] = std::max(unit_p[u] & 15, npre) | (std::max((unit_p[u] >> 4) & 15, npost) << 4) | (unit_chain[u] ? 0x100 : 0);
-    }
-    for (int ed = 0; ed < nedge; ++ed) {
-        const int u = edge_cons_unit[ed];
-        const int gl = unit_lmax[u] - 2 * (hgt[edge_reader[ed]] + 1);
-        ghost_lag[(int64_t)u * LANES + edge_ghost[ed]] = gl;
-        unit_glmax[u] = std::max(unit_glmax[u], gl);
-    }
-
-    std::vector<int> unit_exp(nunit, 0);
-    for (int ed = 0; ed < nedge; ++ed) unit_exp[unit_of_piece[piece[edge_prod_cell[ed]]]]++;
-    {   // the claim list (see "which unit runs where"): units without streams by rising cost, then the others.  Cost as
-        // measured (tools/flow_stats.py): ~25 cycles per pair read per sub-step, ~15 for imports, ~15 for outlets.
-        std::vector<int> cost(nunit);
-        for (int u = 0; u < nunit; ++u)
-            cost[u] = 25 * ((unit_p[u] & 15) + ((unit_p[u] >> 4) & 15) + ((unit_p[u] & 0x100) ? 1 : 0)) +
-                      (unit_imp_n[u] > 0 ? 15 : 0) + (unit_exp[u] > 0 ? 15 : 0);
-        auto coupled = [&](int u) { return unit_imp_n[u] > 0 || unit_exp[u] > 0; };
-        std::iota(unit_order.begin(), unit_order.end(), 0);
-        std::stable_sort(unit_order.begin(), unit_order.end(), [&](int x, int y) {
-            return coupled(x) != coupled(y) ? !coupled(x) : cost[x] < cost[y];
-        });
-    }
-    if (getenv("XH_FLOW_DEBUG")) {      // partition statistics on stderr
-        std::vector<int> hp(8, 0), hi(9, 0), hx(9, 0), hl(10, 0), hpp(25, 0);
-        int n_chain = 0;
-        auto bucket = [](int v) { return v == 0 ? 0 : v <= 1 ? 1 : v <= 2 ? 2 : v <= 4 ? 3 : v <= 8 ? 4 : v <= 16 ? 5 : v <= 32 ? 6 : 7; };
-        for (int u = 0; u < nunit; ++u) {
-            hp[std::max(unit_p[u] & 15, (unit_p[u] >> 4) & 15)]++;
-            hpp[(unit_p[u] & 15) * 5 + ((unit_p[u] >> 4) & 15)]++;
-            if (unit_p[u] & 0x100) ++n_chain;
-            hi[bucket(unit_imp_n[u])]++;
-            hx[bucket(unit_exp[u])]++;
-            hl[std::min(unit_lmax[u] / 16, 9)]++;
-        }
-        fprintf(stderr, "flow plan: %d units, %d pieces, %d edges, depth %d, skew_ok %d\n", nunit, npiece, nedge,
-                maxdepth + 1, (int)skew_ok);
-        {   // pieces by the longest (pre, post) side of their rows, and the cells per class
-            std::vector<int> ppre(npiece, 0), ppost(npiece, 0), hpc(25, 0), hcells(25, 0);
-            for (int c = 0; c < n; ++c) {
-                if (piece[c] < 0) continue;
-                int a = 0, b = 0;
-                bool past = false;
-                for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {
-                    if (indices[j] == c) past = true;
-                    else ++(past ? b : a);
-                }
-                ppre[piece[c]] = std::max(ppre[piece[c]], a);
-                ppost[piece[c]] = std::max(ppost[piece[c]], b);
-            }
-            for (int q = 0; q < npiece; ++q) {
-                hpc[ppre[q] * 5 + ppost[q]]++;
-                hcells[ppre[q] * 5 + ppost[q]] += piece_size[q];
-            }
-            fprintf(stderr, "  pieces (cells) by (pre, post):");
-            for (int a = 0; a <= 4; ++a)
-                for (int b = 0; b <= 4; ++b)
-                    if (hpc[a * 5 + b]) fprintf(stderr, " (%d,%d) %d (%d)", a, b, hpc[a * 5 + b], hcells[a * 5 + b]);
-            fprintf(stderr, "\n");
-        }
-        fprintf(stderr, "  chained units: %d\n", n_chain);
-        fprintf(stderr, "  units by P (1..4):");
-        for (int k = 1; k <= 4; ++k) fprintf(stderr, " %d", hp[k]);
-        fprintf(stderr, "\n  units by (pre, post) terms:");
-        for (int a = 1; a <= 4; ++a)
-            for (int b = 1; b <= 4; ++b) fprintf(stderr, " (%d,%d) %d", a, b, hpp[a * 5 + b]);
-        fprintf(stderr, "\n  units by imports (0,1,2,<=4,<=8,<=16,<=32,more):");
-        for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", hi[k]);
-        fprintf(stderr, "\n  units by exports (0,1,2,<=4,<=8,<=16,<=32,more):");
-        for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", hx[k]);
-        fprintf(stderr, "\n  units by lmax/16 (0..9+):");
-        for (int k = 0; k < 10; ++k) fprintf(stderr, " %d", hl[k]);
-        fprintf(stderr, "\n");
-    }
-
     if (const char *dump = getenv("XH_FLOW_DUMP")) {      // partition as int32 rows [n]: downstream cell, piece, unit, height
         if (FILE *f = fopen(dump, "wb")) {
-            std::vector<int> row(n);
             fwrite(&n, sizeof(int), 1, f);
-            fwrite(ds.data(), sizeof(int), n, f);
-            fwrite(piece.data(), sizeof(int), n, f);
-            for (int c = 0; c < n; ++c) row[c] = piece[c] >= 0 ? unit_of_piece[piece[c]] : -1;
-            fwrite(row.data(), sizeof(int), n, f);
-            fwrite(hgt.data(), sizeof(int), n, f);
+            fwrite(t.ds.data(), sizeof(int), n, f);
+            fwrite(t.piece_of_cell.data(), sizeof(int), n, f);
+            fwrite(t.unit_of_cell.data(), sizeof(int), n, f);
+            fwrite(t.height_of_cell.data(), sizeof(int), n, f);
+            std::vector<int> up(n, -1);      // shape word of the cell's unit (terms | chained << 8 | plain << 9)
+            for (int c = 0; c < n; ++c)
+                if (t.unit_of_cell[c] >= 0) up[c] = t.unit_p[t.unit_of_cell[c]];
+            fwrite(up.data(), sizeof(int), n, f);
             fclose(f);
         }
     }
-
     FlowPlan *fp = new FlowPlan();
-    fp->skew_ok = skew_ok;
-    fp->skew_lmax = *std::max_element(unit_lmax.begin(), unit_lmax.end());
-    {   // longest jump of a stream over pipeline levels: the ring of such a stream has to hold what the levels in between
-        // need as lead (xh_mrtm_skew.hip, ring size)
-        int span = 1;
-        for (int ed = 0; ed < nedge; ++ed)
-            span = std::max(span, piece_depth[piece[edge_cons_cell[ed]]] - piece_depth[piece[edge_prod_cell[ed]]]);
-        fp->skew_span = span;
-        if (getenv("XH_FLOW_DEBUG")) fprintf(stderr, "  longest stream jump: %d levels\n", span);
-    }
-    fp->n_units = nunit;
-    fp->n_edges = nedge;
-    fp->depth = maxdepth + 1;
-    fp->n_cells = (int)std::count(handled.begin(), handled.end(), (char)1);
-    fp->max_imports = *std::max_element(unit_imp_n.begin(), unit_imp_n.end());
-    fp->max_exports = *std::max_element(unit_exp.begin(), unit_exp.end());
-    int rc = put(ctx, fp->d_cell_of_slot, cell_of_slot);
-    rc |= put(ctx, fp->d_ent, ent);
-    rc |= put(ctx, fp->d_export_edge, export_edge);
-    rc |= put(ctx, fp->d_ghost_edge, ghost_edge);
-    rc |= put(ctx, fp->d_edge_cons_unit, edge_cons_unit);
-    rc |= put(ctx, fp->d_unit_terms, unit_terms);
-    rc |= put(ctx, fp->d_lag, lag);
-    rc |= put(ctx, fp->d_ghost_lag, ghost_lag);
-    rc |= put(ctx, fp->d_ent2, ent2);
-    rc |= put(ctx, fp->d_eprev, eprev);
-    rc |= put(ctx, fp->d_unit_p, unit_p);
-    rc |= put(ctx, fp->d_unit_order, unit_order);
-    rc |= put(ctx, fp->d_unit_lmax, unit_lmax);
-    rc |= put(ctx, fp->d_unit_glmax, unit_glmax);
+    fp->skew_ok = t.skew_ok;
+    fp->skew_lmax = t.skew_lmax;
+    fp->skew_span = t.skew_span;
+    fp->n_units = t.n_units;
+    fp->n_edges = t.n_edges;
+    fp->depth = t.depth;
+    fp->n_cells = t.n_cells;
+    fp->max_imports = t.max_imports;
+    fp->max_exports = t.max_exports;
+    fp->n_plain_units = t.n_plain_units;
+    int rc = put(ctx, fp->d_cell_of_slot, t.cell_of_slot);
+    rc |= put(ctx, fp->d_ent, t.ent);
+    rc |= put(ctx, fp->d_export_edge, t.export_edge);
+    rc |= put(ctx, fp->d_ghost_edge, t.ghost_edge);
+    rc |= put(ctx, fp->d_edge_cons_unit, t.edge_cons_unit);
+    rc |= put(ctx, fp->d_unit_terms, t.unit_terms);
+    rc |= put(ctx, fp->d_lag, t.lag);
+    rc |= put(ctx, fp->d_ghost_lag, t.ghost_lag);
+    rc |= put(ctx, fp->d_ent2, t.ent2);
+    rc |= put(ctx, fp->d_eprev, t.eprev);
+    rc |= put(ctx, fp->d_unit_p, t.unit_p);
+    rc |= put(ctx, fp->d_unit_order, t.unit_order);
+    rc |= put(ctx, fp->d_unit_lmax, t.unit_lmax);
+    rc |= put(ctx, fp->d_unit_glmax, t.unit_glmax);
+    rc |= put(ctx, fp->d_lane_flags, t.lane_flags);
+    rc |= put(ctx, fp->d_ghost_prod, t.ghost_prod);
     if (rc) {
         flow_plan_destroy(fp);
         return XH_ERR_HIP;
