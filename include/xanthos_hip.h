@@ -142,7 +142,7 @@ int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]);
  * a plan settles after a call or two on given data.
  * info[0] = plain units of the partition that routed the last call (0: every unit in pair form), [1] = typed
  * partitions built so far, [2] = guard faults so far (-1: more than 8, the plan keeps every unit in pair form),
- * [3] = units of the typed partition.  XH_ROUTE_TYPED=0 in the environment keeps every unit in pair form.        */
+ * [3] = units of the typed partition.  Selected by the flag XH_ROUTE_TYPED or XH_ROUTE_TYPED=1 in the environment.            */
 int xh_route_plan_typed_info(const xh_route_plan *plan, int64_t info[4]);
 
 /* Diagnostics: with XH_FLOW_STATS=1 in the environment the dataflow kernel records, per unit, {shader cycles inside the
@@ -194,6 +194,8 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
                                        output bit; synchronous; XH_ERR_DEVICE on a difference.  Also switched on for every
                                        call by XH_ROUTE_VALIDATE=1 in the environment.  xh_route_plan_info[15] counts the
                                        validated calls.                                                            */
+#define XH_ROUTE_TYPED 64           /* dataflow units in pair AND plain form (xh_route_plan_typed_info); also
+                                       XH_ROUTE_TYPED=1 in the environment.  Off by default: see DESIGN.md 4.3        */
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,
                     const double *d_flow_dist, const double *d_velocity, const double *d_area,

@@ -179,6 +179,7 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
     opt.tlimit_plain = 3 + (int)(rng() % 7);
     opt.tlimit_typed = 3 + (int)(rng() % 5);
     opt.full_join = (int)(rng() % 12);
+    opt.pair_streams = 4 + (int)(rng() % 13);
     std::vector<unsigned char> capable;
     if (rng() % 3 != 0) {
         capable.assign(g.n, 0);
@@ -254,6 +255,7 @@ static int run_file(const char *path, bool typed) {
     if (getenv("TLIMIT")) opt.tlimit = opt.tlimit_typed = atoi(getenv("TLIMIT"));
     if (getenv("TLIMIT_PLAIN")) opt.tlimit_plain = atoi(getenv("TLIMIT_PLAIN"));
     if (getenv("PIECE_CAP")) opt.piece_cap = atoi(getenv("PIECE_CAP"));
+    if (getenv("PAIR_STREAMS")) opt.pair_streams = atoi(getenv("PAIR_STREAMS"));
     int ncap = 0;
     for (unsigned char c : capable) ncap += c;
     printf("%d cells, %lld entries, %d cells can fire\n", n, (long long)nnz, ncap);

@@ -67,6 +67,21 @@ def test_config3_full_length_routing_equals_oracle(full):
     _check(full, tag='validated')
     assert full.pipe.plan.info()['validated'] == n_val + 1 and full.pipe.plan.info()['last_tree_kernel'] == 2
     full.pipe.route_flags = 0
+    # typed partition (XH_ROUTE_TYPED: pair units only where a neighbour can fire, plain units elsewhere), not the default.
+    # The first call finds cells that fire without being expected to (storage driven negative by an adjusted inflow), is
+    # routed again in pair form and teaches the plan; the second call runs on mostly plain units.  Same bits both times.
+    full.pipe.route_flags = _hip.XH_ROUTE_TYPED
+    for rep in range(3):
+        full.pipe.out['chs'].zero()
+        full.pipe.out['avg'].zero()
+        full.pipe.run_mrtm()
+        _check(full, tag=('typed', rep))
+    ti = full.pipe.plan.typed_info()
+    assert ti['plain_units'] > 500 and ti['typed_builds'] >= 1 and 0 <= ti['guard_trips'] <= 3, ti
+    full.pipe.route_flags = 0
+    full.pipe.run_mrtm()
+    _check(full, tag='pairs again')
+    assert full.pipe.plan.typed_info()['plain_units'] == 0
     # the partition the time-skewed kernel ran on: nearly every lane used (1,054 units would be all of them), far more
     # streams than the 64-cell cut's ~860, all cells in dataflow units
     info = full.pipe.plan.info()

@@ -1,5 +1,6 @@
 """CPU tests of the host-side mirror: .ini surface, selector validation, month tables, DE driver, sharding math."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -7,6 +8,8 @@ import pytest
 from xanthos_amd import synth
 from xanthos_amd.calibrate.calibrate_abcd import assign_basins, expand_str_range
 from xanthos_amd.ini_reader import ConfigReader, ValidationException, parse_ini
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 @pytest.fixture(scope='module')
@@ -167,3 +170,46 @@ def test_data_loader_matches_reference_golden(tmp_path, golden):
     s2 = ConfigReader(ini)
     d2 = DataLoader(s2)
     assert np.isnan(d2.tair_load).any() and np.array_equal(np.nan_to_num(d2.tair_load), g['tair_load'])
+
+
+def test_histflag_is_normalised_and_future_mode_needs_channel_storage(tmp_path, golden):
+    """HistFlag in any of the reference's spellings (it compares the raw string three different ways: ini_reader.py:330,
+    :582, data_load.py:431): historic iff it reads as true; future mode without ChStorageFile is an error instead of a
+    silent start from empty channels; anything else is rejected."""
+    import io
+    import zipfile
+    g = golden('loader')
+    root = str(tmp_path)
+    zipfile.ZipFile(io.BytesIO(g['tree_zip'].tobytes())).extractall(root)
+    ini = os.path.join(root, str(g['ini_name']))
+    text = open(ini).read().replace(str(g['old_root']), root)
+
+    def reader(edit):
+        path = os.path.join(root, 'edited.ini')
+        open(path, 'w').write(edit(text))
+        return ConfigReader(path)
+    for spelling in ('false', 'F', 'no', '0', 'False'):
+        s = reader(lambda t, sp=spelling: re.sub(r'(?m)^HistFlag\s*=.*$', 'HistFlag = ' + sp, t))
+        assert s.HistFlag == 'False' and not s.historic and s.ChStorageFile.endswith('ch_storage.npy')
+    for spelling in ('true', 'T', 'yes', '1'):
+        s = reader(lambda t, sp=spelling: re.sub(r'(?m)^HistFlag\s*=.*$', 'HistFlag = ' + sp, t))
+        assert s.HistFlag == 'True' and s.historic and s.ChStorageFile is None
+    with pytest.raises(ValidationException, match='ChStorageFile'):
+        reader(lambda t: re.sub(r'(?m)^ChStorageFile\s*=.*$', '', t))
+    with pytest.raises(ValidationException, match='HistFlag'):
+        reader(lambda t: re.sub(r'(?m)^HistFlag\s*=.*$', 'HistFlag = maybe', t))
+
+
+def test_route_planner_fuzz_under_sanitizers():
+    """The routing planner is host code without any HIP in it (xanthos_amd/csrc/xh_flow_plan.cpp); tests/plan_fuzz builds
+    that translation unit with -fsanitize=address,undefined and runs it over random forests, chains, stars, single cells,
+    ~10^5-cell grids and inputs that are not trees (cycles, two downstream rows, missing diagonals), with and without a
+    typed partition, under random planner options.  Every plan must pass flow_tables_check: every cell in exactly one
+    slot, streams strictly down the pipeline, <= 16 imports / outlets per unit, even lags consistent with the 'two
+    iterations earlier' rule, every row -- expanded through its chains -- equal to the CSR row in stored order
+    (mrtm.py:50-51), plain units free of cells that need pairs."""
+    import subprocess
+    fuzz = os.path.join(ROOT, 'tests', 'plan_fuzz')
+    subprocess.run(['make', '-C', fuzz], check=True, capture_output=True)
+    out = subprocess.run([os.path.join(fuzz, 'plan_fuzz'), '250', '20240807'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and '250 cases, 0 failed' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

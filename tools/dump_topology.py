@@ -10,6 +10,10 @@ from xanthos_amd.pipeline import topology_from_world
 ncell = int(sys.argv[2]) if len(sys.argv) > 2 else 67420
 w = synth.make_world(ncell=ncell, n_basins=max(1, 235 * ncell // 67420))
 um = topology_from_world(w)
+if len(sys.argv) > 4:      # shard `rank` of `n_ranks` of the basin / network-closed partition (xanthos_amd.dist)
+    from xanthos_amd.dist import make_shards, sub_world
+    shard = make_shards(w, um, int(sys.argv[4]))[int(sys.argv[3])]
+    w, um = sub_world(w, um, shard)
 cap = ~((w.velocity / w.flow_dist) * 10800.0 <= 1.0 - 2.0 ** -20)
 with open(sys.argv[1], 'wb') as f:
     f.write(np.int32(w.ncell).tobytes())

@@ -10,7 +10,15 @@ months = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 ctx = _hip.get_context(0)
 ncell_env = int(os.environ.get('XH_STATS_NCELL', '67420'))
 w = synth.make_world(ncell=ncell_env, n_basins=max(1, 235 * ncell_env // 67420))
-pipe = pipeline_from_world(ctx, w, months, 1961, int(os.environ.get('XH_STATS_ABCD_SPIN', '60')), int(os.environ.get('XH_STATS_ROUTE_SPIN', '0')))
+um = None
+if os.environ.get('XH_STATS_SHARD'):      # "rank/ranks": one shard of the basin / network-closed partition (xanthos_amd.dist)
+    from xanthos_amd.dist import make_shards, sub_world
+    from xanthos_amd.pipeline import topology_from_world
+    rk, nr = (int(x) for x in os.environ['XH_STATS_SHARD'].split('/'))
+    um0 = topology_from_world(w)
+    w, um = sub_world(w, um0, make_shards(w, um0, nr)[rk])
+    print('shard', rk, 'of', nr, ':', w.ncell, 'cells')
+pipe = pipeline_from_world(ctx, w, months, 1961, int(os.environ.get('XH_STATS_ABCD_SPIN', '60')), int(os.environ.get('XH_STATS_ROUTE_SPIN', '0')), um=um)
 f = pipe.alloc_forcing()
 ctx.synth_forcing(1, pipe.ncell, pipe.nmonths, ctx.upload(w.latitude), f, nan_frac=0.0)
 pipe.run(('pm', 'abcd'))

@@ -46,7 +46,8 @@ def one_case(rng, k):
     w, um, nm, spin, dt, ndays, q, L, v, S0, ncell = c.w, c.um, c.nm, c.spin, c.dt, c.ndays, c.q, c.L, c.v, c.S0, c.ncell
     ref = o_mrtm.route_series(um.tocsr(), L, v, w.area, q, ndays, spin, S0=S0, dt=dt)
     used = []
-    for flags in (0, 0, 8, 4):      # twice with the default flags: the second call runs on the partition the first one taught
+    # 64 = XH_ROUTE_TYPED, twice: the second call runs on the partition the first one taught (cells seen firing)
+    for flags in (0, 64, 64, 8, 4):
         got = mrtm.route_series(um, L, v, w.area, q, ndays, spin, S0=S0, dt=dt, flags=flags)
         for a, b in zip(got, ref):
             if not np.array_equal(a, b, equal_nan=True):

@@ -1,0 +1,42 @@
+"""run_model() itself at BASELINE config 3 size (67,420 cells x 600 months, pm_abcd_mrtm, spin-ups 120 / 120): writes a
+SURVEY 8(d)-sized input tree (.npy forcing, csv tables), runs ``xanthos_amd.run_model(ini)`` and prints the seconds per
+phase -- load / topology / plan / upload / kernels / download / post / write -- as one JSON line.  Run on the GPU box:
+    python tools/run_model_bench.py [months] [workdir]
+The reference entry point this measures: xanthos/model.py:111-121 (run_model), components.py:298-384, 441-474."""
+import json
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from xanthos_amd import run_model, synth      # noqa: E402
+
+months = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+root = sys.argv[2] if len(sys.argv) > 2 else '/tmp/xh_run_model'
+shutil.rmtree(root, ignore_errors=True)
+os.makedirs(root)
+t = time.time()
+w = synth.make_world()
+f = synth.make_forcing(w, months)
+t_gen = time.time() - t
+t = time.time()
+ini = synth.write_example(root, w, f, 1961, 1961 + months // 12 - 1, runoff_spinup=120, routing_spinup=120,
+                          output_vars=('q', 'avgchflow'), output_format=4)
+t_write_inputs = time.time() - t
+del f
+t = time.time()
+res = run_model(ini)
+wall = time.time() - t
+ph = dict(res.timings)
+kern = sum(v for k, v in ph.items() if k.startswith('kernel_'))
+out = {'workload': 'run_model(pm_abcd_mrtm.ini), {} cells x {} months, spin-ups 120/120, npy inputs'.format(w.ncell, months),
+       'wall_s': wall, 'phases_s': {k: round(v, 4) for k, v in ph.items()},
+       'kernels_share_of_wall': kern / wall, 'other_s': wall - sum(v for k, v in ph.items() if not k.startswith('kernel_')),
+       'inputs': {'generate_s': round(t_gen, 2), 'write_s': round(t_write_inputs, 2)},
+       'outputs_finite_share': float(np.isfinite(res.Avg_ChFlow).mean()),
+       'pageable_outputs': os.environ.get('XH_PAGEABLE_OUTPUTS') == '1'}
+print(json.dumps(out))
+shutil.rmtree(root, ignore_errors=True)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libxanthos_hip.so')
 
 XH_ROUTE_DEFAULT, XH_ROUTE_FORCE_FALLBACK, XH_ROUTE_ATOMIC, XH_ROUTE_NO_DATAFLOW, XH_ROUTE_NO_SKEW = 0, 1, 2, 4, 8
-XH_ROUTE_TEST_FAULT, XH_ROUTE_VALIDATE = 16, 32
+XH_ROUTE_TEST_FAULT, XH_ROUTE_VALIDATE, XH_ROUTE_TYPED = 16, 32, 64
 
 
 class HipUnavailable(RuntimeError):

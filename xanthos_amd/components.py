@@ -28,7 +28,10 @@ class Components:
     def __init__(self, config):
         self.s = config
         self.import_core()
+        self.timings = {}                  # seconds per phase of run_model(): load, topology, plan, upload, kernels, download, ...
+        t0 = time.time()
         self.data = DataLoader(config)
+        self.timings['load'] = time.time() - t0
         self.yr_imth_dys = set_month_arrays(self.s.nmonths, self.s.StartYear, self.s.EndYear)
         self.routing_timestep_hours = 3 * 3600          # seconds, despite the name (components.py:91)
         shape = (self.s.ncell, self.s.nmonths)
@@ -109,7 +112,10 @@ class Components:
                 self.calculate_routing(self.Q)
             return
         ctx = _hip.get_context(s.device)
+        t = time.time()
         um = self.topology() if (run_routing and s.routing_module == 'mrtm') else None
+        self.timings['topology'] = time.time() - t
+        t = time.time()
         pipe = DevicePipeline(ctx, ncell=s.ncell, nmonths=s.nmonths, start_year=s.StartYear, basin_ids=d.basin_ids,
                               abcd_pars=np.load(s.calib_file) if not isinstance(s.calib_file, np.ndarray) else s.calib_file,
                               pm_tables=pet_mod.tables_from(d, s.pm_nlcs), lct=d.lct_load, elev=d.elev,
@@ -119,21 +125,48 @@ class Components:
                               abcd_spinup=s.runoff_spinup, routing_spinup=getattr(s, 'routing_spinup', 0),
                               water_idx=s.pm_water_idx, snow_idx=s.pm_snow_idx, use_snow=d.tmin is not None,
                               chs_prev=getattr(d, 'chs_prev', None))
+        ctx.sync()
+        self.timings['plan'] = time.time() - t          # static uploads + routing partition
+        t = time.time()
         pipe.set_forcing({'tas': d.tair_load, 'tmin': d.TMIN_load, 'rhs': d.rhs_load, 'wind': d.wind_load,
                           'rsds': d.rsds_load, 'rlds': d.rlds_load, 'precip': d.precip, 'abcd_tmin': d.tmin},
                          tairprev=d.tairprev_load)
+        ctx.sync()
+        self.timings['upload'] = time.time() - t
         t = time.time()
+        ctx.timing_reset()
         pipe.run_pm()
         pipe.run_abcd()
         if um is not None:
             pipe.run_mrtm()
         ctx.sync()
+        self.timings['kernels'] = time.time() - t
         logging.info('\tPET + runoff + routing kernels: {:.3f} seconds'.format(time.time() - t))
-        out = pipe.download(('pet', 'aet', 'q', 'sav') + (('chs', 'avg') if um is not None else ()))
+        self._log_stage_rates(ctx, pipe, um is not None)
+        t = time.time()
+        names = ('pet', 'aet', 'q', 'sav') + (('chs', 'avg') if um is not None else ())
+        out = pipe.download_pinned(names)
+        self.timings['download'] = time.time() - t
         self.PET, self.AET, self.Q, self.Sav = out['pet'], out['aet'], out['q'], out['sav']
         if um is not None:
             self.ChStorage, self.Avg_ChFlow = out['chs'], out['avg']
+        self.pipe = pipe
         logging.info('---{0} has finished successfully: {1} seconds ---'.format(notify, time.time() - t0))
+
+    def _log_stage_rates(self, ctx, pipe, routed):
+        """One log line per stage: kernel time (HIP events on the library's stream) and achieved HBM GB/s against the
+        algorithmic bytes of the stage (PM 6 reads + 1 write + land cover, ABCD 3 + 3, MRTM 1 + 2)."""
+        cm = pipe.ncell * pipe.nmonths
+        stages = [('pm_pet', cm * 56 + pipe.ncell * (pipe.nmonths // 12) * self.s.pm_nlcs * 8),
+                  ('abcd_spinup', pipe.ncell * pipe.abcd_spinup * 24), ('abcd_sim', cm * 48)]
+        if routed:
+            stages.append(('mrtm_route', cm * 24 + pipe.ncell * pipe.routing_spinup * 8))
+        for name, nbytes in stages:
+            ms, n = ctx.timing(name)
+            if n:
+                logging.info('\t{:12s} {:8.3f} ms, {:7.1f} GB/s of {} MB algorithmic traffic'.format(
+                    name, ms / n, nbytes / (ms / n) / 1e6, nbytes // 1000000))
+                self.timings['kernel_' + name] = ms / n / 1e3
 
     def calibrate(self):
         """Calibrate the ABCD parameters per basin (components.py:486-497)."""

@@ -22,10 +22,16 @@ class ConfigRunner:
         if not (self.run_pet or self.run_runoff or self.run_routing):
             logging.warning('Selected configuration {0} not supported.'.format(self.config.mod_cfg))
             return None
+        import time
         c = Components(self.config)
         c.simulation(run_pet=self.run_pet, run_runoff=self.run_runoff, run_routing=self.run_routing,
                      pet_num_steps=0, runoff_num_steps=0, routing_num_steps=0, notify='Simulation')
+        t = time.time()
         c.accessible_water()          # post-processors, then the outputs: the reference's order (configurations.py:117-136)
         c.drought()
+        c.timings['post'] = time.time() - t
+        t = time.time()
         c.output_simulation()
+        c.timings['write'] = time.time() - t
+        logging.info('run_model phases (s): ' + ', '.join('{} {:.3f}'.format(k, v) for k, v in c.timings.items()))
         return c

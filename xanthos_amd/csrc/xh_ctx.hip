@@ -84,7 +84,6 @@ int xh_fault_check(xh_ctx *ctx) {
         for (const xh_route_record &r : pending) {
             int rc = xh_route_rerun(ctx, r, true);
             if (rc) return rc;
-            ctx->reroutes += 1;
         }
         XH_HIP(ctx, hipMemcpyAsync(ctx->h_fault, ctx->d_fault, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
         XH_HIP(ctx, hipStreamSynchronize(ctx->stream));

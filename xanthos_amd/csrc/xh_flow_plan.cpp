@@ -165,8 +165,11 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
             bool ok = true;
             if (t.typed) {
                 if (!v_full && open_full[c]) ok = false;
-                // ... nor one with long rows: every row of a pair unit is read as pairs, ~25 cycles per term
-                if (v_full && !open_full[c] && (open_cnt[c] > opt.full_join || open_pre[c] > 2 || open_post[c] > 2)) ok = false;
+                // ... nor one whose rows are longer than its own: every row of a pair unit is read as pairs (~25 cycles
+                // per term), and the pair units are the ones that pace a typed run
+                if (v_full && !open_full[c] &&
+                    (open_cnt[c] > opt.full_join || open_pre[c] > std::max(cell_pre[v], 1) || open_post[c] > std::max(cell_post[v], 1)))
+                    ok = false;
             }
             if (ok) allowed |= 1u << i;
         }
@@ -363,12 +366,15 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
                     first_open = P.unit_cells_n.size();
                 }
                 int u = -1;
-                for (size_t b = first_open; b < P.unit_cells_n.size(); ++b)
-                    if (P.unit_cells_n[b] + P.piece_size[p] <= LANES && P.unit_imp_n[b] + P.piece_imp[p] <= G_MAX &&
-                        unit_out_n[b] + (has_out(p) ? 1 : 0) <= G_MAX && class_ok(p, (int)b)) {
+                for (size_t b = first_open; b < P.unit_cells_n.size(); ++b) {
+                    // pair units of a typed partition: one block-transfer round of imports and of outlets (8 each)
+                    const int gmax = (t.typed && P.unit_full[b]) ? opt.pair_streams : G_MAX;
+                    if (P.unit_cells_n[b] + P.piece_size[p] <= LANES && P.unit_imp_n[b] + P.piece_imp[p] <= gmax &&
+                        unit_out_n[b] + (has_out(p) ? 1 : 0) <= gmax && class_ok(p, (int)b)) {
                         u = (int)b;
                         break;
                     }
+                }
                 if (u < 0) u = new_unit(cur_depth, P.piece_full[p] != 0);
                 put_piece(p, u);
                 while (first_open < P.unit_cells_n.size() && P.unit_cells_n[first_open] >= LANES) ++first_open;

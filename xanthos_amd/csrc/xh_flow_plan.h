@@ -24,6 +24,7 @@ struct FlowPlanOptions {
     // nullptr: every unit in pair form.
     const unsigned char *capable = nullptr;
     int full_join = 6;           // largest plain sub-piece a pair piece swallows instead of importing its outlet
+    int pair_streams = 8;        // imports, and outlets, a pair unit of a typed partition takes on (<= 16)
     bool debug = false;          // partition statistics on stderr
 };
 

@@ -873,7 +873,7 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
 
 int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r, bool dataflow_pairs) {
     bool used_flow = false;
-    r.plan->reroutes += 1;
+    if (!dataflow_pairs) r.plan->reroutes += 1;      // (guard re-runs are counted apart: xh_route_plan_typed_info[2])
     int flags = r.flags & ~XH_ROUTE_TEST_FAULT;
     if (dataflow_pairs) {
         // The cells that fired unexpectedly are on record (d_learn) and this pair-form run records every other one of the
@@ -944,8 +944,11 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     XH_HIP(ctx, hipMemcpyAsync(d_g, sg.data(), sizeof(int) * (nit + 1), hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipMemcpyAsync(d_wr, swr.data(), (size_t)nit, hipMemcpyHostToDevice, ctx->stream));
     // typed partition: does the plan at hand fit this call's velocity / flow distance / dt?  (answered by the sync below)
-    static const bool typed_env = !(getenv("XH_ROUTE_TYPED") && getenv("XH_ROUTE_TYPED")[0] == '0');
-    const bool want_typed = typed_env && plan->flow && !plan->typed_disabled && !plan->h_indptr.empty() &&
+    // Off by default: measured on MI355X (profiles/round3), the typed partition does not beat the all-pair one yet -- its
+    // pair units (the cells downstream of cells that can fire, with their imports) pace the run.  XH_ROUTE_TYPED (flag) or
+    // XH_ROUTE_TYPED=1 (environment) selects it; results are bit-identical either way.
+    static const bool typed_env = getenv("XH_ROUTE_TYPED") && getenv("XH_ROUTE_TYPED")[0] == '1';
+    const bool want_typed = (typed_env || (flags & XH_ROUTE_TYPED) != 0) && plan->flow && !plan->typed_disabled && !plan->h_indptr.empty() &&
                             (flags & (XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_NO_PLAIN)) == 0;
     unsigned char *d_cap_new = nullptr;
     if (want_typed) {

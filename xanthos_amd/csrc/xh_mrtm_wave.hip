@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
+#include <type_traits>
 
 #include "xh_mrtm_flow.h"
 
@@ -162,7 +163,8 @@ template <> struct Val<true> {
 };
 
 template <bool PLAIN, int PRE, int POST, bool HAS_G, bool CHAIN>
-__device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint2 *xtab, const int unit) {
+__device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint2 *xtab,
+                                          __attribute__((address_space(3))) unsigned *qstage, const int unit) {
     typedef Val<PLAIN> V;
     typedef typename V::T val_t;
     typedef typename V::lds_c lds_cv;
@@ -176,6 +178,10 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     const int gc = A(cell_of_slot)[slot];
     const bool valid = gc >= 0;
     const int gc_safe = valid ? gc : 0;      // idle lanes load cell 0's runoff, and ignore it
+    // byte offset of this lane's row in the [ncell, nmonths] arrays: a 32-bit register that is never redefined, so that the
+    // monthly loads / stores address memory as (uniform base + this) and no address register of an access in flight is ever
+    // overwritten (the compiler answers that with s_waitcnt vmcnt(0): ~2 us per month behind the output stores)
+    const unsigned row_off = (unsigned)gc_safe * (unsigned)A(nmonths) * 8u;
     const double tauinv = valid ? A(velocity)[gc] / A(flow_dist)[gc] : 0.0;      // mrtm.py:40
     const double area = valid ? A(area)[gc] : 0.0;
     const double S0v = (valid && A(S0)) ? A(S0)[gc] : 0.0;
@@ -288,12 +294,39 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     };
     unsigned *p_trace = A(trace);
     const int nmo = A(nmonths);
-    double erl_n = 0.0, qn = 0.0;                          // lateral inflow of the month to enter / runoff after that
+    // The runoff of the month after next travels global memory -> LDS without a register (global_load_lds_dword, lane L's
+    // dword lands at M0 + instruction offset + 4 L: tools/micro/lds_dma.hip) and is read out of LDS a month later.  As an
+    // ordinary load its result was a register in flight across the sub-step loop, and the compiler answered that with
+    // s_waitcnt vmcnt(0) in front of the next sub-step -- behind the month's output stores, ~2 us per month and unit
+    // (round 3 profile: ~30 cycles per sub-step of every unit, whatever the order of loads and stores).
+    const unsigned q_lds = (unsigned)(size_t)qstage;
+    auto runoff_fetch = [&](int m) {       // asynchronous; complete before the next month bookkeeping (see runoff_take)
+        const char *src = reinterpret_cast<const char *>(p_runoff + m) + (size_t)row_off;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_add_u32 m0, m0, 252\n\t"
+                     "global_load_lds_dword %1, off offset:4\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(q_lds)
+                     : "memory");
+    };
+    auto runoff_take = [&]() {
+        // vmcnt retires in order.  A unit with streams has issued at least one stream access per block of 8 sub-steps since
+        // the fetch (>= 6 blocks: a month is at least lmax + 32 >= 48 sub-steps), so "at most 4 still in flight" covers the
+        // fetch without draining the import loads; a unit without streams has nothing else in flight.
+        if (any_x || any_g) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned lo = qstage[lane], hi = qstage[LANES + lane];
+        return __hiloint2double((int)hi, (int)lo);
+    };
+    double erl_n = 0.0;                                    // lateral inflow of the month to enter
     {
         const MonthRec r0 = ld_rec(0), r1 = ld_rec(1);
-        const double q0 = p_runoff[(int64_t)gc_safe * nmo + r0.m];
+        auto ld_q = [&](int m) {
+            return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(p_runoff + m) + (size_t)row_off);
+        };
+        const double q0 = ld_q(r0.m);
         erl_n = ((valid ? q0 : 0.0) * area) * 1000.0 / r0.secs;                  // mrtm.py:45
-        if (nit > 1) qn = p_runoff[(int64_t)gc_safe * nmo + r1.m];
+        if (nit > 1) runoff_fetch(r1.m);
     }
     // month outputs leave as groups of OB months per cell (32 bytes = one memory sector)
     constexpr int OB = 4;
@@ -372,6 +405,13 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         if (p_trace && lane == 0) p_trace[(int64_t)unit * (nit + 1) + it] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt_begin);
         const FinRec f = fc;
         fc = ld_fin(it + 1 <= nit ? it + 1 : nit + 1);      // used a month from now: nobody waits for it
+        // The runoff loaded a month ago is consumed BEFORE this month's output stores are issued: after them, the wait for
+        // it would also wait for the stores (vmcnt counts in order), ~2 us per month and unit (round 3 profile: ~30 cycles
+        // per sub-step of every unit).
+        if (it + 1 < nit) {
+            const double qn = runoff_take();
+            erl_n = ((valid ? qn : 0.0) * area) * 1000.0 / f.secs_next1;
+        }
         if (it >= 1) {
             const int m = f.m_prev;
 #pragma unroll
@@ -401,19 +441,25 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
                 }
             }
         }
-        if (it + 1 < nit) erl_n = ((valid ? qn : 0.0) * area) * 1000.0 / f.secs_next1;
-        if (it + 2 < nit) qn = p_runoff[(int64_t)gc_safe * nmo + f.m_next2];      // consumed by the next month bookkeeping
+        if (it + 2 < nit) runoff_fetch(f.m_next2);      // after runoff_take: one staging area
         return f.g_next1;
     };
 
     // gathered values of the current sub-step (issued one iteration ago); import blocks in flight (two ahead)
-    val_t ac[PRE], bc[POST];
+    // Two register sets that swap roles every sub-step (set j & 1 is consumed, the other one is being read into): with
+    // "current" and "next" variables copied at the end of each sub-step, the values in flight at the loop's back-edge did
+    // not sit in the registers the loop header expects, and the compiler moved them there -- behind s_waitcnt vmcnt(0) and
+    // lgkmcnt waits, i.e. every group of 16 sub-steps drained the import loads it had just issued (round 3 profile).
+    val_t va[2][PRE], vb[2][POST], vr[2];
     v4u gbuf[2][SK_R];                   // imported pairs as raw words (see import_drop)
-    val_t rc = V::zero();                // CHAIN: running value of the cell before this one, current sub-step
 #pragma unroll
-    for (int w = 0; w < PRE; ++w) ac[w] = V::zero();
+    for (int q = 0; q < 2; ++q) {
 #pragma unroll
-    for (int w = 0; w < POST; ++w) bc[w] = V::zero();
+        for (int w = 0; w < PRE; ++w) va[q][w] = V::zero();
+#pragma unroll
+        for (int w = 0; w < POST; ++w) vb[q][w] = V::zero();
+        vr[q] = V::zero();                // CHAIN: running value of the cell before this one
+    }
     auto import_load = [&](int r) {      // the block at gfull[r]; the position then moves on by one block
         const v4u v = __builtin_amdgcn_raw_buffer_load_b128(xr, gfull[r], 0, AUX_SC1);
         gfull[r] = (gfull[r] & ~maskb) | ((gfull[r] + RING * 16u) & maskb);
@@ -483,8 +529,10 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     int ntz = nit > 0 ? p_rec[0].nt : 0;
 
     // zone: some lanes cross a month start in this group; first: it is the start of the series (the lanes pick up S0)
-    auto substep = [&](const int n, const int j, const bool zone, const bool first, const int rel) {
-        if (zone && ((j & 1) == 0 || odd_ok)) {
+    auto substep = [&](auto zone_c, const int n, const int j, const bool first, const int rel) {
+        // (a compile-time flag: as a run-time argument the optimiser folded the two variants of the group back into one
+        // body with a branch around the boundary code in every sub-step)
+        if (decltype(zone_c)::value && ((j & 1) == 0 || odd_ok)) {
             // The lanes whose lag puts them on the month start at this iteration: branch-free (a branch per lane set cost
             // 15 instructions per sub-step of the boundary groups and made the compiler copy the gathered values around)
             const bool c = rel == j;
@@ -498,9 +546,10 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         // values for the NEXT sub-step: produced during the previous iteration.  The scheduling barriers keep the reads
         // here, a whole sub-step ahead of the sums that consume them.
         __builtin_amdgcn_sched_barrier(0);
-        val_t an[PRE], bn[POST], rn = V::zero();
+        val_t(&ac)[PRE] = va[j & 1], (&bc)[POST] = vb[j & 1], (&an)[PRE] = va[(j & 1) ^ 1], (&bn)[POST] = vb[(j & 1) ^ 1];
+        const val_t rc = vr[j & 1];
         const unsigned so = (unsigned)((j + RING - 1) & (RING - 1)) * SLOTB;
-        if (CHAIN) rn = *(lds_cv *)(eprv + so);
+        if (CHAIN) vr[(j & 1) ^ 1] = *(lds_cv *)(eprv + so);
 #pragma unroll
         for (int w = 0; w < PRE; ++w) an[w] = *(lds_cv *)(epre[w] + so);
 #pragma unroll
@@ -561,11 +610,6 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             F = f2;
             favg += f2;                                                        // mrtm.py:78
         }
-        if (CHAIN) rc = rn;
-#pragma unroll
-        for (int w = 0; w < PRE; ++w) ac[w] = an[w];
-#pragma unroll
-        for (int w = 0; w < POST; ++w) bc[w] = bn[w];
     };
 
 #ifdef XH_WAVE_PROFILE      // diagnostic build (make PROFILE=1): where a unit's cycles go; st[0] / st[4] / st[5] change meaning
@@ -580,36 +624,50 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
 #else
 #define PROF_MARK(acc)
 #endif
-    for (int n = 0; n < N && alive; n += GROUP) {
-        if (n > 0 && (n & (CH - 1)) == 0) {
-            check(n);
-            if (!alive) break;
-        }
-        if (n == nf) {
+    // Two inner loops -- runs of ordinary groups and runs of boundary groups -- instead of one loop that picks a variant
+    // per group: a loop with two unrolled bodies left the values in flight (gathered pairs, import blocks) in different
+    // registers on its two paths and the compiler reconciled them at the back-edge with ~30 moves behind
+    // s_waitcnt vmcnt(0), draining every import load a group had just issued.
+    auto housekeeping = [&](int n) {
+        if (n > 0 && (n & (CH - 1)) == 0) check(n);
+        if (alive && n == nf) {
             const int g_next = finalize(itf);
             ++itf;
             nf = itf <= nit ? ((g_next + lmax + 1 + GROUP - 1) & ~(GROUP - 1)) : INT_MAX;
         }
         PROF_MARK(prof_fin)
-        const bool zone = itz <= nit && n + GROUP > gz && n <= gz + lmax;
-        if (zone) {
-            ++zone_groups;
-            const int rel = nx - n;      // the sub-step of this group at which the lane crosses (outside 0..15: not in this group)
+    };
+    int n = 0;
+    while (n < N && alive) {
+        if (itz <= nit && n + GROUP > gz && n <= gz + lmax) {      // boundary groups of month itz
             const bool first = itz == 0;
+            do {
+                housekeeping(n);
+                if (!alive) break;
+                ++zone_groups;
+                const int rel = nx - n;      // the sub-step of this group at which the lane crosses (outside 0..15: not in this group)
 #pragma unroll
-            for (int j = 0; j < GROUP; ++j) substep(n, j, true, first, rel);
-            if (n + GROUP > gz + lmax) {      // every lane has crossed: next boundary
+                for (int j = 0; j < GROUP; ++j) substep(std::true_type(), n, j, first, rel);
+                n += GROUP;
+                PROF_MARK(prof_zone)
+            } while (n <= gz + lmax && n < N);
+            if (alive) {      // every lane has crossed: next boundary
                 nx = itz < nit ? nx + ntz : INT_MAX;
                 ++itz;
                 gz = p_rec[itz <= nit ? itz : nit].g;
                 if (itz > nit) gz = INT_MAX;
                 ntz = p_rec[itz <= nit ? itz : nit].nt;
             }
-            PROF_MARK(prof_zone)
-        } else {
+        } else {                                                   // ordinary groups up to the next boundary
+            const int n_end = itz <= nit ? min(N, gz & ~(GROUP - 1)) : N;
+            do {
+                housekeeping(n);
+                if (!alive) break;
 #pragma unroll
-            for (int j = 0; j < GROUP; ++j) substep(n, j, false, false, 0);
-            PROF_MARK(prof_plain)
+                for (int j = 0; j < GROUP; ++j) substep(std::false_type(), n, j, false, 0);
+                n += GROUP;
+                PROF_MARK(prof_plain)
+            } while (n < n_end);
         }
     }
     if (alive) {
@@ -663,6 +721,7 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     WaveArgsK *ap = (WaveArgsK *)ap_;
     __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
     __shared__ uint2 xtab[LANES];
+    __shared__ unsigned qstage_sh[2 * LANES];      // runoff of the month after next, low / high words (runoff_fetch)
     // ---- which unit this workgroup runs.  The launch has more workgroups than units.  Every workgroup registers on its
     //      SIMD and waits until all have (they are all resident: the launch made sure).  First arrivals run a unit; as
     //      many second arrivals as there are units left over also do, the rest leave -- so exactly (units - SIMDs in use)
@@ -730,17 +789,18 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     const int p = A(unit_p)[unit];       // uniform per workgroup: terms before | after the diagonal << 4 | chained << 8 | plain << 9
     const bool g = __any(A(ghost_edge)[(int64_t)unit * LANES + threadIdx.x] >= 0);
     char *l = reinterpret_cast<char *>(lds);
+    __attribute__((address_space(3))) unsigned *qst = (__attribute__((address_space(3))) unsigned *)qstage_sh;
     // one specialisation per (terms before, terms after, imports?, chained?, plain?): an LDS read costs a lone wave 8-15
     // cycles of issue, so no unit should read padding it does not need
 #define WAVE_PAIR(PRE, POST, CHAINED)                                              \
     case (PRE) | ((POST) << 4) | ((CHAINED) ? 0x100 : 0):                          \
-        if (g) wave_unit<false, PRE, POST, true, CHAINED>(ap, l, xtab, unit);            \
-        else wave_unit<false, PRE, POST, false, CHAINED>(ap, l, xtab, unit);             \
+        if (g) wave_unit<false, PRE, POST, true, CHAINED>(ap, l, xtab, qst, unit);            \
+        else wave_unit<false, PRE, POST, false, CHAINED>(ap, l, xtab, qst, unit);             \
         break;
 #define WAVE_PLAIN(PRE, POST, CHAINED)                                             \
     case (PRE) | ((POST) << 4) | ((CHAINED) ? 0x100 : 0) | 0x200:                  \
-        if (g) wave_unit<true, PRE, POST, true, CHAINED>(ap, l, xtab, unit);             \
-        else wave_unit<true, PRE, POST, false, CHAINED>(ap, l, xtab, unit);              \
+        if (g) wave_unit<true, PRE, POST, true, CHAINED>(ap, l, xtab, qst, unit);             \
+        else wave_unit<true, PRE, POST, false, CHAINED>(ap, l, xtab, qst, unit);              \
         break;
     switch (p) {
         WAVE_PAIR(1, 1, false) WAVE_PAIR(1, 2, false) WAVE_PAIR(1, 3, false) WAVE_PAIR(1, 4, false)
@@ -852,7 +912,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         const char *env = getenv("XH_FLOW_PER_CU_EXTRA");     // experiments only
         if (env) per_cu += atoi(env);
     }
-    const size_t lds_static = (size_t)RING * NSLOT * sizeof(v2d) + LANES * sizeof(uint2) + 64;      // + unit_sh, padded
+    const size_t lds_static = (size_t)RING * NSLOT * sizeof(v2d) + LANES * sizeof(uint2) + 2 * LANES * sizeof(unsigned) + 64;      // + unit_sh, padded
     const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
     size_t lds = share > lds_static + 1024 ? share - lds_static : 0;
     XH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mrtm_wave), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -130,6 +130,19 @@ class DevicePipeline:
     def download(self, names=OUTPUTS):
         return {k: self.out[k].download() for k in names}
 
+    def download_pinned(self, names=OUTPUTS):
+        """All outputs into page-locked host arrays with asynchronous copies and ONE synchronisation (run_model()'s
+        result arrays: numpy views of memory the context keeps until it is closed).  XH_PAGEABLE_OUTPUTS=1 falls back to
+        plain numpy arrays filled by synchronous copies."""
+        if os.environ.get('XH_PAGEABLE_OUTPUTS') == '1':
+            return self.download(names)
+        host = {k: self.ctx.pinned((self.ncell, self.nmonths)) for k in names}
+        self.ctx.sync()                      # settles a routing fault (re-route) before anything is copied
+        for k in names:
+            self.ctx.d2h_async(host[k], self.out[k])
+        self.ctx.sync()
+        return host
+
     def rows(self, darr, cells):
         """Download selected rows of a [ncell, nmonths] device array."""
         cells = np.ascontiguousarray(cells, dtype=np.int64)

@@ -216,7 +216,7 @@ def data_bag(world, forcing):
 
 def write_example(root, world, forcing, start_year, end_year, project='pm_abcd_mrtm_synth', runoff_spinup=36,
                   routing_spinup=None, output_vars=('q', 'avgchflow'), obs=None, post=False, aggregates=False,
-                  hist_flag=True, ch_storage=None):
+                  hist_flag=True, ch_storage=None, output_format=1, output_in_year=0):
     """Write ``world`` + ``forcing`` as a Xanthos-style input tree under ``root`` and return the .ini path.
 
     Layout and file names follow the reference's example (ini_reader.py:254-279, 353-381, 399-416, 425-437):
@@ -314,9 +314,9 @@ ngridcol = {ncol}
 StartYear = {y0}
 EndYear = {y1}
 output_vars = {ov}
-OutputFormat = 1
+OutputFormat = {ofmt}
 OutputUnit = 0
-OutputInYear = 0
+OutputInYear = {oyear}
 Calibrate = {cal}
 {post_project}
 [PET]
@@ -353,7 +353,7 @@ routing_spinup = {rtsp}
 channel_velocity = velocity.npy
 flow_distance = flow_dist.npy
 flow_direction = flow_dir.npy
-{calib}{post_sections}'''.format(chs=chs_lines, hist='True' if hist_flag else 'False', post_project=post_project, post_sections=post_sections, project=project, root=root, nb=world.n_basins, ncell=world.ncell, nrow=world.nrow, ncol=world.ncol,
+{calib}{post_sections}'''.format(ofmt=int(output_format), oyear=int(output_in_year), chs=chs_lines, hist='True' if hist_flag else 'False', post_project=post_project, post_sections=post_sections, project=project, root=root, nb=world.n_basins, ncell=world.ncell, nrow=world.nrow, ncol=world.ncol,
                   y0=start_year, y1=end_year, ov=', '.join(output_vars), cal=int(obs is not None), nlcs=world.nlcs,
                   lcy=', '.join(str(y) for y in world.lc_years), rsp=runoff_spinup,
                   rtsp=nmonths if routing_spinup is None else routing_spinup,
