@@ -180,6 +180,7 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
     opt.tlimit_typed = 3 + (int)(rng() % 5);
     opt.full_join = (int)(rng() % 12);
     opt.pair_streams = 4 + (int)(rng() % 13);
+    opt.plain_min_reads = rng() % 2 ? 0 : 2 + (int)(rng() % 6);      // selective plain form in half of the cases
     std::vector<unsigned char> capable;
     if (rng() % 3 != 0) {
         capable.assign(g.n, 0);
@@ -252,6 +253,7 @@ static int run_file(const char *path, bool typed) {
     opt.simds = 1024;
     opt.debug = true;
     if (getenv("FULL_JOIN")) opt.full_join = atoi(getenv("FULL_JOIN"));
+    if (getenv("PLAIN_MIN_READS")) opt.plain_min_reads = atoi(getenv("PLAIN_MIN_READS"));
     if (getenv("TLIMIT")) opt.tlimit = opt.tlimit_typed = atoi(getenv("TLIMIT"));
     if (getenv("TLIMIT_PLAIN")) opt.tlimit_plain = atoi(getenv("TLIMIT_PLAIN"));
     if (getenv("PIECE_CAP")) opt.piece_cap = atoi(getenv("PIECE_CAP"));

@@ -302,3 +302,32 @@ def test_fused_pipeline_equals_stage_by_stage(nm, block):
     got = pipe.download(('pet', 'aet', 'q', 'sav'))
     for k in ('pet', 'aet', 'q', 'sav'):
         assert np.array_equal(got[k], ref[k], equal_nan=True), k
+
+
+def test_file_movers_round_trip(tmp_path):
+    """xh_upload_file / xh_download_file: the body of a .npy to HBM and back, several 8 MiB chunks with a ragged tail,
+    byte-exact; a short or missing file is an error, not a partial array (loader: data_load.py:186-195, :342-350)."""
+    from xanthos_amd import _hip
+    ctx = _hip.get_context(0)
+    rng = np.random.default_rng(5)
+    for shape in ((3, 5), (1201, 2503)):                      # 120 B and 24 MB (3 chunks, the last one 7.2 MiB short)
+        a = rng.standard_normal(shape)
+        a[0, 0] = np.nan
+        src = str(tmp_path / 'in_{}.npy'.format(shape[0]))
+        np.save(src, a)
+        mm = np.load(src, mmap_mode='r')
+        d = ctx.empty(shape)
+        ctx.upload_file(d, mm.filename, mm.offset, mm.nbytes, threads=3)
+        assert np.array_equal(d.download(), a, equal_nan=True)
+        dst = str(tmp_path / 'out_{}.npy'.format(shape[0]))
+        ctx.save_npy(dst, d)
+        assert np.array_equal(np.load(dst), a, equal_nan=True)
+        with pytest.raises(RuntimeError):
+            ctx.upload_file(d, mm.filename, mm.offset + 8, mm.nbytes)           # runs past the end of the file
+        with pytest.raises(ValueError):
+            ctx.upload_file(d, mm.filename, mm.offset, mm.nbytes - 8)
+        d.free()
+    d = ctx.empty((4,))
+    with pytest.raises(RuntimeError):
+        ctx.upload_file(d, str(tmp_path / 'missing.npy'), 0, 32)
+    d.free()

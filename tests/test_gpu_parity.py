@@ -266,20 +266,27 @@ rng = np.random.default_rng(11)
 runoff = rng.gamma(2.0, 30.0, (w.ncell, 12))
 ndays = o_months.set_month_arrays(12, 1973, 1973)[:, 2]
 ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
-got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
-info = um.plan(_hip.get_context()).info()
-ok = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
+import os
+ok = True
+for rep in range(3 if os.environ.get('XH_ROUTE_TYPED') else 1):      # typed: first build, re-build with what was learnt, steady
+    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+    ok = ok and all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
+plan = um.plan(_hip.get_context())
+info = plan.info()
 print(json.dumps({'ok': bool(ok), 'kernel': int(info['last_tree_kernel']), 'units': int(info['flow_units']),
-                  'edges': int(info['flow_edges']), 'reroutes': int(info['reroutes'])}))
+                  'edges': int(info['flow_edges']), 'reroutes': int(info['reroutes']), 'typed': plan.typed_info()}))
 """
 
 
 @pytest.mark.parametrize('env', [{}, {'XH_FLOW_PIECE_CAP': '64', 'XH_FLOW_CHAIN': '0'}, {'XH_FLOW_PIECE_CAP': '20'},
                                  {'XH_FLOW_CUTRULE': '0', 'XH_FLOW_TLIMIT': '9'}, {'XH_FLOW_SPARE': '0'},
-                                 {'XH_FLOW_SPARE': '700'}, {'XH_FLOW_RS': '16384'}])
+                                 {'XH_FLOW_SPARE': '700'}, {'XH_FLOW_RS': '16384'}, {'XH_ROUTE_TYPED': '1'},
+                                 {'XH_ROUTE_TYPED': '1', 'XH_FLOW_PLAIN_MIN_READS': '5'},
+                                 {'XH_ROUTE_TYPED': '1', 'XH_FLOW_PLAIN_MIN_READS': '3'}])
 def test_route_partition_variants_bit_exact(env, tmp_path):
     """The knobs of the dataflow partition (piece capacity, chains, which children become streams, class-aware packing,
-    spare workgroups, ring size) change which cells share a wave and who waits for whom -- never a bit of the result.  Each
+    spare workgroups, ring size; typed partition, and its selective form: only the units with the longest rows run in
+    plain form) change which cells share a wave and who waits for whom -- never a bit of the result.  Each
     variant routes the 3000-cell world in a process of its own (the knobs are read once per process) against the oracle."""
     import json
     import os
@@ -297,6 +304,8 @@ def test_route_partition_variants_bit_exact(env, tmp_path):
     assert res['ok'] and res['kernel'] == 2 and res['reroutes'] == 0, res
     if env.get('XH_FLOW_PIECE_CAP') == '20':
         assert res['edges'] > 150, res          # many more streams than the default cut
+    if env.get('XH_ROUTE_TYPED'):
+        assert res['typed']['typed_builds'] >= 1 and res['typed']['plain_units'] >= 1, res
 
 
 @pytest.mark.parametrize('basin', [0, 1])

@@ -111,6 +111,14 @@ for k in sorted(set(per_cu[cu_key])):
         if sel.sum() >= 3:
             print('units on a CU holding %d, alone on their SIMD, %d gathered terms: n=%3d loop cyc/substep median %.0f max %.0f' % (
                 k, t - 1, sel.sum(), np.median(cps[sel]), cps[sel].max()))
+plain = ((raw3 >> np.uint64(6)) & np.uint64(1)).astype(int)
+for pl in (0, 1):
+    for t in sorted(set(terms)):
+        for flag, name in ((0, 'isolated'), (16, 'imports'), (32, 'exports'), (48, 'both')):
+            sel = (plain == pl) & (terms == t) & (share == 1) & ((shape & 48) == flag)
+            if sel.sum() >= 1:
+                print('%s units, alone on their SIMD, %d values read, %-8s: n=%3d own cyc/substep median %.0f min %.0f max %.0f' % (
+                    'plain' if pl else 'pair ', t - 1, name, sel.sum(), np.median(cps[sel]), cps[sel].min(), cps[sel].max()))
 # block index -> CU: which blocks share a CU
 cu_blocks = {}
 for i, ck in enumerate(cu_key):

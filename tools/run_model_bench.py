@@ -30,11 +30,18 @@ del f
 t = time.time()
 res = run_model(ini)
 wall = time.time() - t
-ph = dict(res.timings)
+first = dict(res.timings)
+t = time.time()
+res = run_model(ini)               # same process again: library loaded, HIP context and page-locked rings exist
+wall2 = time.time() - t
+ph = first
 kern = sum(v for k, v in ph.items() if k.startswith('kernel_'))
+kern2 = sum(v for k, v in res.timings.items() if k.startswith('kernel_'))
 out = {'workload': 'run_model(pm_abcd_mrtm.ini), {} cells x {} months, spin-ups 120/120, npy inputs'.format(w.ncell, months),
        'wall_s': wall, 'phases_s': {k: round(v, 4) for k, v in ph.items()},
-       'kernels_share_of_wall': kern / wall, 'other_s': wall - sum(v for k, v in ph.items() if not k.startswith('kernel_')),
+       'kernels_share_of_wall': kern / wall,
+       'second_call': {'wall_s': wall2, 'phases_s': {k: round(v, 4) for k, v in res.timings.items()},
+                       'kernels_share_of_wall': kern2 / wall2}, 'other_s': wall - sum(v for k, v in ph.items() if not k.startswith('kernel_')),
        'inputs': {'generate_s': round(t_gen, 2), 'write_s': round(t_write_inputs, 2)},
        'outputs_finite_share': float(np.isfinite(res.Avg_ChFlow).mean()),
        'pageable_outputs': os.environ.get('XH_PAGEABLE_OUTPUTS') == '1'}

@@ -64,6 +64,8 @@ SIGNATURES = {
     'xh_host_free': (c_int, [_P, _P]),
     'xh_memcpy_h2d_async': (c_int, [_P, _P, _P, c_size_t]),
     'xh_memcpy_d2h_async': (c_int, [_P, _P, _P, c_size_t]),
+    'xh_upload_file': (c_int, [_P, _P, c_char_p, ctypes.c_uint64, c_size_t, c_int]),
+    'xh_download_file': (c_int, [_P, _P, c_char_p, ctypes.c_uint64, c_size_t, c_int]),
     'xh_memset': (c_int, [_P, _P, c_int, c_size_t]),
     'xh_sync': (c_int, [_P]),
     'xh_gather_rows': (c_int, [_P, _P, _P, c_int64, c_int64, _P]),
@@ -277,6 +279,26 @@ class Context:
 
     def d2h_async(self, host, src):
         self._check(lib().xh_memcpy_d2h_async(self.handle, _host_ptr(host), _dptr(src), host.nbytes))
+
+    def upload_file(self, dst, path, offset, nbytes, threads=0):
+        """``nbytes`` of file ``path`` from byte ``offset`` -> DeviceArray ``dst`` (xh_upload_file: threaded reads into
+        page-locked slots, overlapped copies; no pageable host copy of the data)."""
+        if nbytes != dst.nbytes:
+            raise ValueError('size mismatch: file range {} vs device {}'.format(nbytes, dst.nbytes))
+        self._check(lib().xh_upload_file(self.handle, _dptr(dst), os.fsencode(path), int(offset), int(nbytes), threads))
+        return dst
+
+    def download_file(self, src, path, offset, threads=0):
+        """DeviceArray ``src`` -> bytes ``offset ...`` of file ``path`` (xh_download_file)."""
+        self._check(lib().xh_download_file(self.handle, _dptr(src), os.fsencode(path), int(offset), src.nbytes, threads))
+
+    def save_npy(self, path, src):
+        """np.save(path, src.download()) without the host array: header here, body by xh_download_file."""
+        with open(path, 'wb') as fh:
+            np.lib.format.write_array_header_1_0(fh, {'descr': np.lib.format.dtype_to_descr(np.dtype(src.dtype)),
+                                                      'fortran_order': False, 'shape': tuple(src.shape)})
+            offset = fh.tell()
+        self.download_file(src, path, offset)
 
     def timing_reset(self):
         self._check(lib().xh_timing_reset(self.handle))

@@ -22,8 +22,33 @@ from .utils import set_month_arrays
 
 pet_mod = runoff_mod = routing_mod = None
 
+# result attribute -> name of the array in the device pipeline
+_RESULTS = {'PET': 'pet', 'AET': 'aet', 'Q': 'q', 'Sav': 'sav', 'ChStorage': 'chs', 'Avg_ChFlow': 'avg'}
+
+
+def _result(attr):
+    """Host float64 [ncell, nmonths] result attribute (components.py:95-100).  After a device-resident simulation the
+    array is fetched from HBM the first time it is read: a run that writes two of the six variables moves two across PCIe."""
+    def get(self):
+        if attr not in self._host:
+            pipe = self.pipe
+            key = _RESULTS[attr]
+            if pipe is not None and (key in ('pet', 'aet', 'q', 'sav') or pipe.plan is not None):
+                t = time.time()
+                self._host[attr] = pipe.out[key].download()
+                self.timings['download'] = self.timings.get('download', 0.0) + time.time() - t
+            else:
+                self._host[attr] = np.zeros((self.s.ncell, self.s.nmonths))
+        return self._host[attr]
+
+    def put(self, value):
+        self._host[attr] = value
+    return property(get, put)
+
 
 class Components:
+    PET, AET, Q, Sav = _result('PET'), _result('AET'), _result('Q'), _result('Sav')
+    ChStorage, Avg_ChFlow = _result('ChStorage'), _result('Avg_ChFlow')
 
     def __init__(self, config):
         self.s = config
@@ -34,12 +59,26 @@ class Components:
         self.timings['load'] = time.time() - t0
         self.yr_imth_dys = set_month_arrays(self.s.nmonths, self.s.StartYear, self.s.EndYear)
         self.routing_timestep_hours = 3 * 3600          # seconds, despite the name (components.py:91)
-        shape = (self.s.ncell, self.s.nmonths)
-        self.PET, self.AET, self.Q = np.zeros(shape), np.zeros(shape), np.zeros(shape)
-        self.Sav, self.ChStorage, self.Avg_ChFlow = np.zeros(shape), np.zeros(shape), np.zeros(shape)
+        self._host = {}                    # result arrays already on the host (the rest: zeros, or still in HBM)
+        self.pipe = None                   # DevicePipeline of the last device-resident simulation
         self.um = self.dsid = self.upid = None
         self.instream_flow = None
-        self.q = self.ac = None
+        self._writer = None                # OutWriter of output_simulation(): q / ac come from it
+        self._q = self._ac = None
+
+    @property
+    def q(self):
+        """Runoff as written (aggregated / converted), or Q when 'q' is not an output variable (components.py:461-466)."""
+        if self._q is None and self._writer is not None:
+            self._q = self._writer.get('q') if 'q' in self._writer.output_names else self.Q
+        return self._q
+
+    @property
+    def ac(self):
+        """Channel flow as written, or Avg_ChFlow (components.py:467-472)."""
+        if self._ac is None and self._writer is not None:
+            self._ac = self._writer.get('avgchflow') if 'avgchflow' in self._writer.output_names else self.Avg_ChFlow
+        return self._ac
 
     def import_core(self):
         """Bind the selected plugins (components.py:114-142)."""
@@ -130,7 +169,7 @@ class Components:
         t = time.time()
         pipe.set_forcing({'tas': d.tair_load, 'tmin': d.TMIN_load, 'rhs': d.rhs_load, 'wind': d.wind_load,
                           'rsds': d.rsds_load, 'rlds': d.rlds_load, 'precip': d.precip, 'abcd_tmin': d.tmin},
-                         tairprev=d.tairprev_load)
+                         tairprev=d._tairprev if hasattr(d, '_tairprev') else d.tairprev_load)
         ctx.sync()
         self.timings['upload'] = time.time() - t
         t = time.time()
@@ -143,14 +182,9 @@ class Components:
         self.timings['kernels'] = time.time() - t
         logging.info('\tPET + runoff + routing kernels: {:.3f} seconds'.format(time.time() - t))
         self._log_stage_rates(ctx, pipe, um is not None)
-        t = time.time()
-        names = ('pet', 'aet', 'q', 'sav') + (('chs', 'avg') if um is not None else ())
-        out = pipe.download_pinned(names)
-        self.timings['download'] = time.time() - t
-        self.PET, self.AET, self.Q, self.Sav = out['pet'], out['aet'], out['q'], out['sav']
-        if um is not None:
-            self.ChStorage, self.Avg_ChFlow = out['chs'], out['avg']
+        self._host = {}                    # the six results stay in HBM until they are read (or written)
         self.pipe = pipe
+        self.timings['download'] = 0.0
         logging.info('---{0} has finished successfully: {1} seconds ---'.format(notify, time.time() - t0))
 
     def _log_stage_rates(self, ctx, pipe, routed):
@@ -194,12 +228,15 @@ class Components:
     def output_simulation(self):
         """Aggregate / convert on the device and write the selected variables (components.py:441-474)."""
         from .data_writer.out_writer import OutWriter
-        all_outputs = {'pet': self.PET, 'aet': self.AET, 'q': self.Q, 'soilmoisture': self.Sav,
-                       'avgchflow': self.Avg_ChFlow}
+        names = {'pet': 'PET', 'aet': 'AET', 'q': 'Q', 'soilmoisture': 'Sav', 'avgchflow': 'Avg_ChFlow'}
+        # arrays still in HBM go to the writer as they are (it aggregates / converts / saves from there)
+        all_outputs = {k: (self.pipe.out[_RESULTS[a]] if self.pipe is not None and a not in self._host
+                           and (a != 'Avg_ChFlow' or self.pipe.plan is not None) else getattr(self, a))
+                       for k, a in names.items() if k in self.s.output_vars or k in ('q', 'avgchflow')}
         writer = OutWriter(self.s, self.data.area, all_outputs)
         writer.write()
-        self.q = writer.get('q') if 'q' in writer.output_names else self.Q
-        self.ac = writer.get('avgchflow') if 'avgchflow' in writer.output_names else self.Avg_ChFlow
+        self._writer, self._q, self._ac = writer, None, None
+        q_written = writer.get('q', host=False) if 'q' in writer.output_names else all_outputs['q']
         # always from the written runoff, or from self.Q when 'q' is not among the output variables (:461-472)
-        writer.write_aggregates(self.data, self.q, self.s.AggregateRunoffBasin, self.s.AggregateRunoffCountry,
+        writer.write_aggregates(self.data, q_written, self.s.AggregateRunoffBasin, self.s.AggregateRunoffCountry,
                                 self.s.AggregateRunoffGCAMRegion)

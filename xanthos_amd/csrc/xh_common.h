@@ -56,6 +56,9 @@ struct xh_ctx {
     // xh_run_fused: side stream and events of the block pipeline
     hipStream_t side_stream[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> side_events;
+    // xh_upload_file / xh_download_file: page-locked chunk ring of the file movers (grow-only)
+    void *io_ring = nullptr;
+    size_t io_ring_bytes = 0;
 };
 
 // Fault code of the routing kernel's plain units: an input outside the argument that lets them gather one value per term

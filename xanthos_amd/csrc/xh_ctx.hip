@@ -212,6 +212,7 @@ void xh_ctx_destroy(xh_ctx *ctx) {
     for (auto e : ctx->side_events) (void)hipEventDestroy(e);
     if (ctx->d_fault) (void)hipFree(ctx->d_fault);
     if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
+    if (ctx->io_ring) (void)hipHostFree(ctx->io_ring);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -29,6 +29,7 @@ struct Tree {
     const int8_t *sign = nullptr;
     std::vector<int> ds, nchild, child_ptr, child, cell_pre, cell_post;
     std::vector<char> ok;                 // per cell: its network is a plain tree
+    int sel_reads = 0;                    // selective plain form: pieces / units that hold a cell needing pairs stay below this many reads
     std::vector<char> must_full;          // typed: the cell has an upstream neighbour that can fire (it gathers both of its flows)
     const unsigned char *capable = nullptr;
     bool typed = false;
@@ -112,7 +113,7 @@ void tree_analyse(int n, const int64_t *indptr, const int32_t *indices, const in
 // Partition for one piece capacity: pieces, their stream edges and pipeline depth, units.
 struct Partition {
     std::vector<int> queue, piece, closed_roots, piece_of_root, piece_size, piece_imp, piece_depth;
-    std::vector<char> piece_full;
+    std::vector<char> piece_full, piece_must;
     std::vector<int> edge_prod_cell, edge_cons_cell, edge_of_prod;
     std::vector<int> unit_of_piece, unit_cells_n, unit_imp_n, unit_depth;
     std::vector<char> unit_full;
@@ -144,7 +145,12 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
         return x;
     };
     std::vector<int> open_cnt(n, 0), open_imp(n, 0), open_pre(n, 0), open_post(n, 0);
-    std::vector<char> open_full(n, 0);
+    std::vector<char> open_full(n, 0), open_must(n, 0);
+    // Selective plain form: the units that read sel_reads values or more are to run in plain form, which a single cell
+    // that needs pairs forbids.  Such cells have short rows themselves (they sit below a fast, short reach), so a piece
+    // that holds one is kept from growing into long rows: the child piece that would bring them becomes a stream.
+    const int sel = t.sel_reads;
+    auto sel_bad = [&](bool must, int pre, int post) { return sel > 0 && must && std::max(pre, 1) + std::max(post, 1) >= sel; };
     std::vector<int> &closed_roots = P.closed_roots;            // piece roots in closing order (upstream pieces first)
     std::vector<int> kids;
     for (size_t qi = 0; qi < queue.size(); ++qi) {
@@ -175,12 +181,21 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
         }
         int total = 1, imp = (int)kids.size();
         unsigned keep = 0;                          // bit i: kids[i]'s open piece joins v's
-        for (size_t i = 0; i < kids.size(); ++i) {
-            const int c = kids[i];
-            if (((allowed >> i) & 1u) && total + open_cnt[c] <= cap && imp - 1 + open_imp[c] <= G_MAX) {
-                keep |= 1u << i;
-                total += open_cnt[c];
-                imp += open_imp[c] - 1;
+        {
+            bool must = sel > 0 && t.must_full[v];
+            int pre = cell_pre[v], post = cell_post[v];
+            for (size_t i = 0; i < kids.size(); ++i) {
+                const int c = kids[i];
+                if (((allowed >> i) & 1u) && total + open_cnt[c] <= cap && imp - 1 + open_imp[c] <= G_MAX &&
+                    (!sel_bad(must || open_must[c], std::max(pre, open_pre[c]), std::max(post, open_post[c])) ||
+                     sel_bad(must, pre, post))) {
+                    keep |= 1u << i;
+                    total += open_cnt[c];
+                    imp += open_imp[c] - 1;
+                    must = must || open_must[c];
+                    pre = std::max(pre, open_pre[c]);
+                    post = std::max(post, open_post[c]);
+                }
             }
         }
         if (opt.cut_rule && keep + 1 != (1u << kids.size()) && cell_pre[v] >= 3 && kids.size() <= 8) {
@@ -209,12 +224,18 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
             for (unsigned kp = 0; kp < (1u << kids.size()); ++kp) {
                 if (kp & ~allowed) continue;
                 int tt = 1, im = (int)kids.size();
+                bool must = sel > 0 && t.must_full[v];
+                int pre = cell_pre[v], post = cell_post[v];
                 for (size_t i = 0; i < kids.size(); ++i)
                     if ((kp >> i) & 1u) {
                         tt += open_cnt[kids[i]];
                         im += open_imp[kids[i]] - 1;
+                        must = must || open_must[kids[i]];
+                        pre = std::max(pre, open_pre[kids[i]]);
+                        post = std::max(post, open_post[kids[i]]);
                     }
                 if (tt > LANES || im > G_MAX) continue;
+                if (sel_bad(must, pre, post) && !sel_bad(sel > 0 && t.must_full[v], cell_pre[v], cell_post[v])) continue;
                 const int r = v_reads(kp);
                 const bool over = tt > cap, best_over = best_total > cap;
                 if (r < best_reads || (r == best_reads && (over != best_over ? !over : tt > best_total))) {
@@ -231,7 +252,7 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
                     imp += open_imp[kids[i]] - 1;
                 }
         }
-        bool full = v_full;
+        bool full = v_full, must = sel > 0 && t.must_full[v];
         open_pre[v] = cell_pre[v];
         open_post[v] = cell_post[v];
         for (size_t i = 0; i < kids.size(); ++i) {
@@ -239,6 +260,7 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
             if ((keep >> i) & 1u) {
                 dsu[find(c)] = v;      // c's open piece joins v's
                 full = full || open_full[c];
+                must = must || open_must[c];
                 open_pre[v] = std::max(open_pre[v], open_pre[c]);
                 open_post[v] = std::max(open_post[v], open_post[c]);
             } else {
@@ -248,6 +270,7 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
         open_cnt[v] = total;
         open_imp[v] = imp;
         open_full[v] = full ? 1 : 0;
+        open_must[v] = must ? 1 : 0;
         if (ds[v] < 0) {
             closed_roots.push_back(v);
         } else if (--left[ds[v]] == 0) {
@@ -264,6 +287,7 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
     P.piece_imp.assign(npiece, 0);
     P.piece_depth.assign(npiece, 0);
     P.piece_full.assign(npiece, 0);
+    P.piece_must.assign(npiece, 0);
     std::vector<int> ppre(npiece, 0), ppost(npiece, 0), pdir(npiece, 0);
     for (int v : queue) {
         const int q = P.piece_of_root[find(v)];
@@ -272,6 +296,7 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
         ppre[q] = std::max(ppre[q], cell_pre[v]);
         ppost[q] = std::max(ppost[q], cell_post[v]);
         if (t.typed && t.must_full[v]) P.piece_full[q] = 1;
+        if (sel > 0 && t.must_full[v]) P.piece_must[q] = 1;
     }
     // front-side terms a cell still reads one by one when its unit is chained (see emit_tables): the prefix of cells of
     // its own piece (the first may be an imported stream) counts as one
@@ -325,7 +350,9 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
         P.unit_full.clear();
         std::vector<int> unit_out_n;                                   // outlets: <= G_MAX too
         std::vector<int> upre, udir, upost;                            // longest sides of the unit's rows
+        std::vector<char> umust;                                       // selective: the unit holds a cell that needs pairs
         auto new_unit = [&](int depth, bool full) {
+            umust.push_back(0);
             P.unit_cells_n.push_back(0);
             P.unit_imp_n.push_back(0);
             unit_out_n.push_back(0);
@@ -344,12 +371,21 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
             upre[u] = std::max(upre[u], ppre[p]);
             udir[u] = std::max(udir[u], pdir[p]);
             upost[u] = std::max(upost[u], ppost[p]);
+            umust[u] = umust[u] || P.piece_must[p];
+        };
+        // selective plain form: a unit is heavy (reads sel or more values, to run in plain form) or holds cells that need
+        // pairs, never both -- unless the piece alone is both, which no packing can help
+        auto sel_ok = [&](int p, int u) {
+            if (sel <= 0 || P.unit_cells_n[u] == 0 || !(umust[u] || P.piece_must[p])) return true;
+            const int tt = reads_of(std::max(upre[u], ppre[p]), std::max(udir[u], pdir[p]), std::max(upost[u], ppost[p]));
+            return tt < sel;
         };
         // a piece joins a unit only if the unit then reads no more values per sub-step than the limit of its kind, or than
         // the piece or the unit need on their own: the slowest unit paces the run, and it is the one with the longest
         // rows.  A piece that needs pairs never joins a plain unit (it would turn every row of it into pairs); a plain
         // piece may fill the free lanes of a pair unit.
         auto class_ok = [&](int p, int u) {
+            if (!sel_ok(p, u)) return false;
             if (t.typed && P.piece_full[p] && !P.unit_full[u]) return P.unit_cells_n[u] == 0;
             const int tl = !t.typed ? opt.tlimit : (P.unit_full[u] ? opt.tlimit_typed : opt.tlimit_plain);
             const int tt = reads_of(std::max(upre[u], ppre[p]), std::max(udir[u], pdir[p]), std::max(upost[u], ppost[p]));
@@ -419,6 +455,7 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
                         for (size_t i = bucket[f].size(); i-- > 0;) {
                             const int b = bucket[f][i];
                             if (pfull && !P.unit_full[b]) continue;
+                            if (!sel_ok(p, b)) continue;
                             if ((pass == 1 && !(t.typed && P.unit_full[b] && !pfull)) || class_ok(p, b)) {
                                 u = b;
                                 bucket[f].erase(bucket[f].begin() + (long)i);
@@ -463,6 +500,12 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
     Tree t;
     tree_analyse(n, indptr, indices, sign, comp, ncomp, opt.capable, t);
     const std::vector<int> &ds = t.ds;
+    const bool have_cap = t.typed;                                  // which cells can fire is known
+    const bool selective = have_cap && opt.plain_min_reads > 0;     // all-pairs partition, heavy units without such cells plain
+    if (selective) {
+        t.typed = false;
+        t.sel_reads = opt.plain_min_reads;
+    }
 
     // ---- the piece capacity.  A smaller capacity than LANES costs streams (every cut is one) and buys units: pieces of
     //      33..64 cells cannot share a unit, so the largest capacity leaves every other unit ~10 lanes short of full
@@ -682,12 +725,27 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
     }
     // plain units: the kernel is compiled for fewer row shapes; round up (the extra terms read the constant zero)
     out.unit_plain.assign(nunit, 0);
-    out.typed = t.typed;
-    if (t.typed)
+    out.typed = have_cap;
+    std::vector<char> unit_pair(nunit, 1);
+    if (have_cap && !selective)
+        for (int u = 0; u < nunit; ++u) unit_pair[u] = P.unit_full[u];
+    if (selective) {
         for (int u = 0; u < nunit; ++u) {
-            if (P.unit_full[u]) continue;
+            const int reads = (out.unit_p[u] & 15) + ((out.unit_p[u] >> 4) & 15);
+            unit_pair[u] = reads < opt.plain_min_reads;
+        }
+        for (int c = 0; c < n; ++c)
+            if (piece[c] >= 0 && t.must_full[c]) unit_pair[unit_of_piece[piece[c]]] = 1;
+    }
+    if (have_cap)
+        for (int u = 0; u < nunit; ++u) {
+            if (unit_pair[u]) continue;
             int cp = 0, cq = 0;
             if (!flow_plain_class(out.unit_p[u] & 15, (out.unit_p[u] >> 4) & 15, unit_chain[u] != 0, cp, cq)) continue;
+            // selective: the plain shapes are fewer and round up ((4,1) runs as (4,4)); measured per sub-step, one more
+            // 8-byte read costs ~10 cycles, one more pair ~25, and the plain form starts ~55 cycles behind -- switch only
+            // where that comes out ahead
+            if (selective && 193 + 10 * (cp + cq) >= 138 + 25 * ((out.unit_p[u] & 15) + ((out.unit_p[u] >> 4) & 15))) continue;
             out.unit_p[u] = cp | (cq << 4) | (unit_chain[u] ? 0x100 : 0) | 0x200;
             out.unit_plain[u] = 1;
             out.n_plain_units++;
@@ -701,7 +759,7 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
 
     out.lane_flags.assign(ts, 0);
     out.ghost_prod.assign(ts, 0);
-    if (t.typed)
+    if (have_cap)
         for (int c = 0; c < n; ++c)
             if (piece[c] >= 0 && t.capable[c]) out.lane_flags[(int64_t)unit_of_piece[piece[c]] * LANES + slot_of_cell[c]] = 1;
     for (int ed = 0; ed < nedge; ++ed) out.ghost_prod[(int64_t)edge_cons_unit[ed] * LANES + edge_ghost[ed]] = edge_prod_cell[ed];
@@ -767,7 +825,7 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
         }
         fprintf(stderr, "flow plan: %d units (%d plain), %d pieces, %d edges, depth %d, skew_ok %d\n", nunit,
                 out.n_plain_units, npiece, nedge, maxdepth + 1, (int)skew_ok);
-        if (t.typed) {
+        if (have_cap) {
             int nfull_cells = 0, nmust = 0, nfull_pieces = 0;
             for (int c = 0; c < n; ++c) {
                 if (piece[c] < 0) continue;

@@ -25,6 +25,11 @@ struct FlowPlanOptions {
     const unsigned char *capable = nullptr;
     int full_join = 6;           // largest plain sub-piece a pair piece swallows instead of importing its outlet
     int pair_streams = 8;        // imports, and outlets, a pair unit of a typed partition takes on (<= 16)
+    // Selective form (> 0, with `capable` given): the partition is the one of the all-pairs plan, untouched; afterwards the
+    // units that read at least this many values per sub-step and hold no cell that needs pairs switch to the plain form.
+    // The heavy units pace the run (every stream-linked unit follows the slowest one), and they are where one 8-byte
+    // read per term instead of a 16-byte pair pays most.
+    int plain_min_reads = 0;
     bool debug = false;          // partition statistics on stderr
 };
 

@@ -329,6 +329,7 @@ FlowPlanOptions flow_plan_options(xh_ctx *ctx) {
     if (const char *e = getenv("XH_FLOW_TLIMIT_PLAIN")) o.tlimit_plain = atoi(e);
     if (const char *e = getenv("XH_FLOW_FULL_JOIN")) o.full_join = atoi(e);
     if (const char *e = getenv("XH_FLOW_PAIR_STREAMS")) o.pair_streams = std::min(std::max(atoi(e), 1), G_MAX);
+    if (const char *e = getenv("XH_FLOW_PLAIN_MIN_READS")) o.plain_min_reads = atoi(e);
     o.debug = getenv("XH_FLOW_DEBUG") != nullptr;
     return o;
 }

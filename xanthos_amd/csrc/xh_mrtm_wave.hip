@@ -803,6 +803,9 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
         else wave_unit<true, PRE, POST, false, CHAINED>(ap, l, xtab, qst, unit);              \
         break;
     switch (p) {
+#ifdef XH_WAVE_STUDY      // ISA study build (hipcc -S -DXH_WAVE_STUDY): one pair and one plain shape, nothing else
+        WAVE_PAIR(2, 3, false) WAVE_PLAIN(2, 3, false)
+#else
         WAVE_PAIR(1, 1, false) WAVE_PAIR(1, 2, false) WAVE_PAIR(1, 3, false) WAVE_PAIR(1, 4, false)
         WAVE_PAIR(2, 1, false) WAVE_PAIR(2, 2, false) WAVE_PAIR(2, 3, false) WAVE_PAIR(2, 4, false)
         WAVE_PAIR(3, 1, false) WAVE_PAIR(3, 2, false) WAVE_PAIR(3, 3, false) WAVE_PAIR(3, 4, false)
@@ -814,6 +817,7 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
         WAVE_PLAIN(1, 1, false) WAVE_PLAIN(1, 2, false) WAVE_PLAIN(1, 3, false) WAVE_PLAIN(2, 2, false)
         WAVE_PLAIN(2, 3, false) WAVE_PLAIN(2, 4, false) WAVE_PLAIN(3, 3, false) WAVE_PLAIN(4, 4, false)
         WAVE_PLAIN(1, 2, true) WAVE_PLAIN(1, 3, true) WAVE_PLAIN(1, 4, true) WAVE_PLAIN(2, 3, true) WAVE_PLAIN(2, 4, true)
+#endif
         default:      // not produced by the plan; a fault rather than wrong results
             if (threadIdx.x == 0) __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -42,8 +42,13 @@ class OutWriter:
             logging.warning('Output format {} is invalid; writing output as .csv'.format(self.out_format))
             self.out_format = FORMAT_CSV
 
-    def get(self, varstr):
-        return self.outputs[self.output_names.index(varstr)]
+    def get(self, varstr, host=True):
+        """The written array of a variable (:77-79).  host=False may return the DeviceArray a monthly, unconverted
+        variable was saved from."""
+        i = self.output_names.index(varstr)
+        if host and isinstance(self.outputs[i], _hip.DeviceArray):
+            self.outputs[i] = self.outputs[i].download()
+        return self.outputs[i]
 
     # ---- device helpers
     def _on_device(self, arr):
@@ -96,7 +101,9 @@ class OutWriter:
                 self.outputs[i] = self._agg(self.inputs[var], 1, 0, scale)
             else:
                 a = self.inputs[var]
-                self.outputs[i] = a.download() if isinstance(a, _hip.DeviceArray) else np.asarray(a)
+                # a device array is saved from HBM (npy) or fetched for the csv writer
+                keep = isinstance(a, _hip.DeviceArray) and self.out_format == FORMAT_NPY
+                self.outputs[i] = a if keep else (a.download() if isinstance(a, _hip.DeviceArray) else np.asarray(a))
             filename = os.path.join(self.out_folder, '{}_{}_{}'.format(var, unit, self.proj_name))
             self.write_data(filename, var, self.outputs[i], self.time_steps, first_id=1)
 
@@ -133,7 +140,10 @@ class OutWriter:
     def write_data(self, filename, var, data, col_names, first_id=1, names=None):
         os.makedirs(self.out_folder, exist_ok=True)
         if self.out_format == FORMAT_NPY:
-            np.save(filename + '.npy', data)
+            if isinstance(data, _hip.DeviceArray):
+                self.ctx.save_npy(filename + '.npy', data)
+            else:
+                np.save(filename + '.npy', data)
         elif self.out_format == FORMAT_CSV:
             ids = np.arange(first_id, first_id + data.shape[0])
             header = 'id,' + ('name,' if names is not None else '') + ','.join(col_names[:data.shape[1]])

@@ -60,17 +60,25 @@ class DevicePipeline:
         return self.forcing
 
     def set_forcing(self, host, tairprev=None):
-        """host: dict of [ncell, nmonths] arrays keyed by FORCING (abcd_tmin optional when use_snow is False)."""
+        """host: dict of [ncell, nmonths] arrays keyed by FORCING (abcd_tmin optional when use_snow is False).
+        A read-only memory map of a .npy (np.load(mmap_mode='r'), what DataLoader keeps) goes from the file to HBM
+        through xh_upload_file; tairprev=None leaves the previous-cell temperature to the PM kernel (it reads the row
+        above of ``tas``, data_load.py:127-128)."""
         for k in FORCING:
             if k in host and host[k] is not None:
-                arr = np.asarray(host[k], dtype=np.float64)
+                src = host[k]
+                direct = (isinstance(src, np.memmap) and src.dtype == np.float64 and src.dtype.isnative
+                          and src.flags.c_contiguous and getattr(src, 'filename', None) is not None)
+                arr = src if direct else np.asarray(src, dtype=np.float64)
                 if arr.shape != (self.ncell, self.nmonths):
                     raise ValueError('forcing {} has shape {}, expected {}'.format(k, arr.shape,
                                                                                    (self.ncell, self.nmonths)))
-                if k in self.forcing:
-                    self.forcing[k].upload(arr)
+                if k not in self.forcing:
+                    self.forcing[k] = self.ctx.empty((self.ncell, self.nmonths))
+                if direct:
+                    self.ctx.upload_file(self.forcing[k], src.filename, src.offset, src.nbytes)
                 else:
-                    self.forcing[k] = self.ctx.upload(arr)
+                    self.forcing[k].upload(arr)
                 if k != 'precip':                       # loader transform: everything but precipitation loses its NaNs
                     self.ctx.nan_to_num(self.forcing[k])
         if tairprev is not None:
