@@ -509,7 +509,7 @@ def main():
             pm = json.load(open(f))
             traffic = {'pm_pet': pm.get('k_pm_pet', {}).get('hbm_bytes'), 'abcd_spinup': pm.get('k_abcd<true>', {}).get('hbm_bytes'),
                        'abcd_sim': (pm.get('k_abcd_tile<false') or pm.get('k_abcd<false>', {})).get('hbm_bytes'),
-                       'mrtm_route': (pm.get('k_mrtm_skew') or pm.get('k_mrtm_flow', {})).get('hbm_bytes')}
+                       'mrtm_route': (pm.get('k_mrtm_wave') or pm.get('k_mrtm_skew') or pm.get('k_mrtm_flow', {})).get('hbm_bytes')}
             traffic_src = os.path.relpath(f, ROOT)
         except (OSError, ValueError):
             pass

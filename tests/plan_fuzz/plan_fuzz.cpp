@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <numeric>
 #include <random>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -265,10 +266,13 @@ static int run_file(const char *path, bool typed) {
     std::vector<char> handled;
     FlowTables t;
     std::string err;
+    if (getenv("SIMDS")) opt.simds = atoi(getenv("SIMDS"));
+    const auto t0 = std::chrono::steady_clock::now();
     if (flow_tables_build(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)) {
         printf("build failed: %s\n", err.c_str());
         return 1;
     }
+    printf("flow_tables_build: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     const std::string bad = flow_tables_check(n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, t, opt.capable);
     printf("check: %s\n", bad.empty() ? "ok" : bad.c_str());
     return bad.empty() ? 0 : 1;

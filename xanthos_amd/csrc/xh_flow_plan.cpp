@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <numeric>
+#include <thread>
 
 namespace {
 
@@ -514,12 +515,24 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
     Partition P;
     {
         static const int caps[] = {LANES, 56, 48, 44, 40, 36, 32};
-        Partition Q;
+        constexpr int NCAP = (int)(sizeof(caps) / sizeof(caps[0]));
+        // the candidate partitions do not depend on each other: one host thread each (67,420 cells: 7 x ~10 ms otherwise,
+        // inside run_model()'s wall time); the choice below walks them in the order of the list as before
+        std::vector<Partition> cand(opt.piece_cap > 0 ? 1 : NCAP);
+        if (cand.size() == 1 || n < 4096) {
+            for (size_t k = 0; k < cand.size(); ++k)
+                make_partition(t, opt, opt.piece_cap > 0 ? std::min(opt.piece_cap, LANES) : caps[k], cand[k]);
+        } else {
+            std::vector<std::thread> pool;
+            for (size_t k = 0; k < cand.size(); ++k)
+                pool.emplace_back([&, k] { make_partition(t, opt, caps[k], cand[k]); });
+            for (auto &th : pool) th.join();
+        }
         bool have = false;
         long best_score = 0;
-        for (int cap : caps) {
-            if (opt.piece_cap > 0) cap = std::min(opt.piece_cap, LANES);
-            make_partition(t, opt, cap, Q);
+        for (size_t k = 0; k < cand.size(); ++k) {
+            Partition &Q = cand[k];
+            const int cap = opt.piece_cap > 0 ? std::min(opt.piece_cap, LANES) : caps[k];
             // units beyond the SIMD count share a SIMD; only units without streams may (see the claim order below): a unit
             // with streams that has to share one slows every unit it is linked to, which costs far more than a few units
             int indep = 0;
@@ -539,7 +552,7 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
                 best_score = score;
                 have = true;
             }
-            if (opt.piece_cap > 0 || (opt.simds > 0 && P.nunit <= opt.simds)) break;       // every unit has a SIMD of its own
+            if (opt.simds > 0 && P.nunit <= opt.simds) break;       // every unit has a SIMD of its own
         }
     }
     const std::vector<int> &queue = P.queue, &piece = P.piece, &closed_roots = P.closed_roots, &piece_of_root = P.piece_of_root;
