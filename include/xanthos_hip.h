@@ -67,6 +67,9 @@ int xh_memcpy_d2h_async(xh_ctx *ctx, void *h_dst, const void *d_src, size_t byte
  * complete.  XH_ERR_ARG: file missing / too short / write error (xh_last_error has errno's text). */
 int xh_upload_file(xh_ctx *ctx, void *d_dst, const char *path, uint64_t offset, size_t bytes, int threads);
 int xh_download_file(xh_ctx *ctx, const void *d_src, const char *path, uint64_t offset, size_t bytes, int threads);
+/* Several device arrays to several files at once (n <= 16), one writer thread per file: the output variables of one run. */
+int xh_download_files(xh_ctx *ctx, int n, const void *const *d_srcs, const char *const *paths, const uint64_t *offsets,
+                      const size_t *bytes);
 int xh_memset(xh_ctx *ctx, void *d_ptr, int value, size_t bytes);
 int xh_sync(xh_ctx *ctx);
 /* Gather / scatter whole rows of a [nrows_total, ncols] device array by row index (shard packing, samples). */
@@ -188,7 +191,7 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
  * the routing, XH_ERR_DEVICE (routing outputs valid, later results not) otherwise.  xh_route_plan_info[14] counts such
  * re-runs.  After such a fault the plan's next 8 calls (16, 32 ... 256 when faults repeat) skip the dataflow kernels, so
  * a device that stays shared does not cost a timeout per call; a fault-free dataflow call resets the back-off.
- * Bit-exactness of the dataflow kernels rests on a hardware assumption stated at xh_mrtm_skew.hip ("MEMORY-ORDERING
+ * Bit-exactness of the dataflow kernels rests on a hardware assumption stated at xh_mrtm_wave.hip ("MEMORY-ORDERING
  * ASSUMPTION": write-through stream stores retire in order under s_waitcnt vmcnt); XH_ROUTE_VALIDATE checks a call
  * against the kernel that does not need it.                                                                        */
 #define XH_ROUTE_DEFAULT 0

@@ -322,6 +322,11 @@ def test_file_movers_round_trip(tmp_path):
         dst = str(tmp_path / 'out_{}.npy'.format(shape[0]))
         ctx.save_npy(dst, d)
         assert np.array_equal(np.load(dst), a, equal_nan=True)
+        d2 = ctx.upload(a[::-1].copy())                        # two files side by side (xh_download_files)
+        pair = [str(tmp_path / 'p0_{}.npy'.format(shape[0])), str(tmp_path / 'p1_{}.npy'.format(shape[0]))]
+        ctx.save_npy_many([(pair[0], d), (pair[1], d2)])
+        assert np.array_equal(np.load(pair[0]), a, equal_nan=True) and np.array_equal(np.load(pair[1]), a[::-1], equal_nan=True)
+        d2.free()
         with pytest.raises(RuntimeError):
             ctx.upload_file(d, mm.filename, mm.offset + 8, mm.nbytes)           # runs past the end of the file
         with pytest.raises(ValueError):

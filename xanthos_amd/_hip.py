@@ -66,6 +66,7 @@ SIGNATURES = {
     'xh_memcpy_d2h_async': (c_int, [_P, _P, _P, c_size_t]),
     'xh_upload_file': (c_int, [_P, _P, c_char_p, ctypes.c_uint64, c_size_t, c_int]),
     'xh_download_file': (c_int, [_P, _P, c_char_p, ctypes.c_uint64, c_size_t, c_int]),
+    'xh_download_files': (c_int, [_P, c_int, POINTER(c_void_p), POINTER(c_char_p), POINTER(ctypes.c_uint64), POINTER(c_size_t)]),
     'xh_memset': (c_int, [_P, _P, c_int, c_size_t]),
     'xh_sync': (c_int, [_P]),
     'xh_gather_rows': (c_int, [_P, _P, _P, c_int64, c_int64, _P]),
@@ -294,11 +295,25 @@ class Context:
 
     def save_npy(self, path, src):
         """np.save(path, src.download()) without the host array: header here, body by xh_download_file."""
-        with open(path, 'wb') as fh:
-            np.lib.format.write_array_header_1_0(fh, {'descr': np.lib.format.dtype_to_descr(np.dtype(src.dtype)),
-                                                      'fortran_order': False, 'shape': tuple(src.shape)})
-            offset = fh.tell()
-        self.download_file(src, path, offset)
+        self.save_npy_many([(path, src)])
+
+    def save_npy_many(self, items):
+        """[(path, DeviceArray), ...] -> .npy files, the bodies written side by side (xh_download_files, <= 16 per call)."""
+        items = list(items)
+        for k in range(0, len(items), 16):
+            part = items[k:k + 16]
+            offsets = []
+            for path, src in part:
+                with open(path, 'wb') as fh:
+                    np.lib.format.write_array_header_1_0(fh, {'descr': np.lib.format.dtype_to_descr(np.dtype(src.dtype)),
+                                                              'fortran_order': False, 'shape': tuple(src.shape)})
+                    offsets.append(fh.tell())
+            n = len(part)
+            srcs = (c_void_p * n)(*[_dptr(src) for _, src in part])
+            paths = (c_char_p * n)(*[os.fsencode(path) for path, _ in part])
+            offs = (ctypes.c_uint64 * n)(*offsets)
+            sizes = (c_size_t * n)(*[src.nbytes for _, src in part])
+            self._check(lib().xh_download_files(self.handle, n, srcs, paths, offs, sizes))
 
     def timing_reset(self):
         self._check(lib().xh_timing_reset(self.handle))

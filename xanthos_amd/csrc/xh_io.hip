@@ -4,8 +4,8 @@
 // full grid that is 8 x 324 MB which then has to cross PCIe.  xh_upload_file reads a byte range of a file (the body of a
 // .npy) with a few host threads, each pread()-ing 8 MiB chunks into its own page-locked slots and sending them on with
 // asynchronous copies on its own stream, so the page-cache reads and the PCIe transfers overlap and no pageable 324 MB
-// intermediate exists.  xh_download_file is the mirror for the writer (data_writer/out_writer.py: np.save of an output),
-// with one thread: copy of chunk i + 1 under the write of chunk i.
+// intermediate exists.  xh_download_file(s) is the mirror for the writer (data_writer/out_writer.py: np.save of the
+// outputs): one thread per file, copy of chunk i + 1 under the write of chunk i.
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -116,44 +116,74 @@ void io_worker(int device, int fd, uint64_t offset, char *dev, size_t bytes, cha
     (void)hipStreamDestroy(st);
 }
 
-int io_run(xh_ctx *ctx, void *dev, const char *path, uint64_t offset, size_t bytes, int threads, bool up) {
-    if (!ctx || !path || (bytes && !dev)) return XH_ERR_ARG;
-    // earlier work on the context's stream may still read (upload) or write (download) the device range; a routing call
+struct IoJob {
+    void *dev;
+    const char *path;
+    uint64_t offset;
+    size_t bytes;
+};
+
+// Upload: ONE job, its chunks dealt to `threads` workers.  Download: one worker per job (file) -- buffered writes to one
+// file are serialised by the file system (one inode lock), so a second writer on the same file only adds contention,
+// but different files do run side by side; within a file the copy of chunk i + 1 overlaps the write of chunk i.
+int io_run(xh_ctx *ctx, const IoJob *jobs, int njobs, int threads, bool up) {
+    if (!ctx || njobs < 0 || (njobs && !jobs)) return XH_ERR_ARG;
+    for (int j = 0; j < njobs; ++j)
+        if (!jobs[j].path || (jobs[j].bytes && !jobs[j].dev)) return XH_ERR_ARG;
+    if (njobs > IO_MAX_THREADS) return xh_fail(ctx, XH_ERR_LIMIT, "at most %d files per call", IO_MAX_THREADS);
+    // earlier work on the context's stream may still read (upload) or write (download) the device ranges; a routing call
     // that has to be re-run is re-run here
     const int rc = xh_settle(ctx);
     if (rc != XH_OK && rc != XH_ERR_DEVICE) return rc;
     ctx->work_seq += 1;
-    if (bytes == 0 && up) return rc;
-    const int fd = up ? open(path, O_RDONLY) : open(path, O_WRONLY | O_CREAT, 0644);
-    if (fd < 0) return xh_fail(ctx, XH_ERR_ARG, "%s: %s", path, strerror(errno));
-    if (up) {
+    if (njobs == 0 || (up && jobs[0].bytes == 0)) return rc;
+    int fds[IO_MAX_THREADS];
+    auto close_all = [&](int upto) {
+        int bad = 0;
+        for (int j = 0; j < upto; ++j)
+            if (close(fds[j]) != 0 && !up) bad = errno ? errno : EIO;
+        return bad;
+    };
+    for (int j = 0; j < njobs; ++j) {
+        fds[j] = up ? open(jobs[j].path, O_RDONLY) : open(jobs[j].path, O_WRONLY | O_CREAT, 0644);
+        if (fds[j] < 0) {
+            const int e = errno;
+            close_all(j);
+            return xh_fail(ctx, XH_ERR_ARG, "%s: %s", jobs[j].path, strerror(e));
+        }
         struct stat sb;
-        if (fstat(fd, &sb) != 0 || (uint64_t)sb.st_size < offset + bytes) {
-            close(fd);
-            return xh_fail(ctx, XH_ERR_ARG, "%s: shorter than offset %llu + %zu bytes", path, (unsigned long long)offset,
-                           bytes);
+        if (up && (fstat(fds[j], &sb) != 0 || (uint64_t)sb.st_size < jobs[j].offset + jobs[j].bytes)) {
+            close_all(j + 1);
+            return xh_fail(ctx, XH_ERR_ARG, "%s: shorter than offset %llu + %zu bytes", jobs[j].path,
+                           (unsigned long long)jobs[j].offset, jobs[j].bytes);
         }
     }
-    // buffered writes to one file are serialised by the file system (one inode lock): a second writer only adds contention,
-    // so the download runs ONE thread whose device -> host copy of chunk i + 1 overlaps the write of chunk i
-    threads = up ? io_threads(threads) : 1;
-    const size_t nchunks = (bytes + IO_CHUNK - 1) / IO_CHUNK;
-    if ((size_t)threads > nchunks) threads = nchunks ? (int)nchunks : 1;
+    if (up) {
+        threads = io_threads(threads);
+        const size_t nchunks = (jobs[0].bytes + IO_CHUNK - 1) / IO_CHUNK;
+        if ((size_t)threads > nchunks) threads = nchunks ? (int)nchunks : 1;
+    } else {
+        threads = njobs;
+    }
     const int rr = io_ring(ctx, threads);
     if (rr != XH_OK) {
-        close(fd);
+        close_all(njobs);
         return rr;
     }
-    std::atomic<size_t> next{0};
+    std::atomic<size_t> next[IO_MAX_THREADS];
+    for (auto &x : next) x.store(0);
     std::atomic<int> err{0};
     std::thread pool[IO_MAX_THREADS];
-    for (int t = 0; t < threads; ++t)
-        pool[t] = std::thread(io_worker, ctx->device, fd, offset, (char *)dev, bytes,
-                              (char *)ctx->io_ring + (size_t)t * IO_SLOTS * IO_CHUNK, &next, &err, up);
+    for (int t = 0; t < threads; ++t) {
+        const IoJob &job = jobs[up ? 0 : t];
+        pool[t] = std::thread(io_worker, ctx->device, fds[up ? 0 : t], job.offset, (char *)job.dev, job.bytes,
+                              (char *)ctx->io_ring + (size_t)t * IO_SLOTS * IO_CHUNK, &next[up ? 0 : t], &err, up);
+    }
     for (int t = 0; t < threads; ++t) pool[t].join();
-    if (close(fd) != 0 && !up && err.load() == 0) err.store(errno ? errno : EIO);
-    if (err.load() > 0) return xh_fail(ctx, XH_ERR_ARG, "%s: %s", path, strerror(err.load()));
-    if (err.load() < 0) return xh_fail(ctx, XH_ERR_HIP, "%s: a copy of the file transfer failed", path);
+    const int cerr = close_all(njobs);
+    if (cerr && err.load() == 0) err.store(cerr);
+    if (err.load() > 0) return xh_fail(ctx, XH_ERR_ARG, "%s: %s", jobs[0].path, strerror(err.load()));
+    if (err.load() < 0) return xh_fail(ctx, XH_ERR_HIP, "%s: a copy of the file transfer failed", jobs[0].path);
     return rc;
 }
 
@@ -162,11 +192,21 @@ int io_run(xh_ctx *ctx, void *dev, const char *path, uint64_t offset, size_t byt
 extern "C" {
 
 int xh_upload_file(xh_ctx *ctx, void *d_dst, const char *path, uint64_t offset, size_t bytes, int threads) {
-    return io_run(ctx, d_dst, path, offset, bytes, threads, true);
+    const IoJob job{d_dst, path, offset, bytes};
+    return io_run(ctx, &job, 1, threads, true);
 }
 
 int xh_download_file(xh_ctx *ctx, const void *d_src, const char *path, uint64_t offset, size_t bytes, int threads) {
-    return io_run(ctx, const_cast<void *>(d_src), path, offset, bytes, threads, false);
+    const IoJob job{const_cast<void *>(d_src), path, offset, bytes};
+    return io_run(ctx, &job, 1, threads, false);
+}
+
+int xh_download_files(xh_ctx *ctx, int n, const void *const *d_srcs, const char *const *paths, const uint64_t *offsets,
+                      const size_t *bytes) {
+    if (n < 0 || n > IO_MAX_THREADS || (n && (!d_srcs || !paths || !offsets || !bytes))) return XH_ERR_ARG;
+    IoJob jobs[IO_MAX_THREADS];
+    for (int j = 0; j < n; ++j) jobs[j] = IoJob{const_cast<void *>(d_srcs[j]), paths[j], offsets[j], bytes[j]};
+    return io_run(ctx, jobs, n, 0, false);
 }
 
 }  // extern "C"

@@ -91,6 +91,7 @@ class OutWriter:
         if not self.output_names:
             logging.debug('No valid output variables specified')
             return
+        self._npy_from_device = []                      # monthly, unconverted npy outputs still in HBM: saved side by side
         for i, var in enumerate(self.output_names):
             flow = var == 'avgchflow'
             unit = 'm3persec' if flow else self.out_unit_str
@@ -106,6 +107,9 @@ class OutWriter:
                 self.outputs[i] = a if keep else (a.download() if isinstance(a, _hip.DeviceArray) else np.asarray(a))
             filename = os.path.join(self.out_folder, '{}_{}_{}'.format(var, unit, self.proj_name))
             self.write_data(filename, var, self.outputs[i], self.time_steps, first_id=1)
+        if self._npy_from_device:
+            self.ctx.save_npy_many(self._npy_from_device)
+            self._npy_from_device = []
 
     def write_aggregates(self, ref, values, basin, country, region):
         """Spatial sums of ``values`` (the written runoff) by basin / country / GCAM region (:126-158).
@@ -141,7 +145,10 @@ class OutWriter:
         os.makedirs(self.out_folder, exist_ok=True)
         if self.out_format == FORMAT_NPY:
             if isinstance(data, _hip.DeviceArray):
-                self.ctx.save_npy(filename + '.npy', data)
+                if getattr(self, '_npy_from_device', None) is not None and var in self.output_names:
+                    self._npy_from_device.append((filename + '.npy', data))      # flushed at the end of write()
+                else:
+                    self.ctx.save_npy(filename + '.npy', data)
             else:
                 np.save(filename + '.npy', data)
         elif self.out_format == FORMAT_CSV:
