@@ -170,6 +170,20 @@ def test_data_loader_matches_reference_golden(tmp_path, golden):
     s2 = ConfigReader(ini)
     d2 = DataLoader(s2)
     assert np.isnan(d2.tair_load).any() and np.array_equal(np.nan_to_num(d2.tair_load), g['tair_load'])
+    # ... and stay on disk: read-only memory maps of the .npy files (the pipeline sends the files' bytes to the GPU itself);
+    # tairprev_load is only built when somebody asks for it, from the NaN-free temperatures like the reference's
+    npy_backed = [k for k in ('tair_load', 'precip', 'rhs_load') if isinstance(getattr(d2, k), np.memmap)]
+    assert len(npy_backed) == 3
+    for k in npy_backed:
+        mm = getattr(d2, k)
+        assert not mm.flags.writeable and mm.dtype == np.float64 and os.path.isfile(mm.filename) and mm.offset > 0
+    assert d2._tairprev is None
+    assert np.array_equal(d2.tairprev_load, g['tairprev_load']) and d2._tairprev is not None
+    s3 = ConfigReader(ini)
+    s3.mmap_inputs = False                          # eager host arrays, writable, as the reference keeps them
+    d3 = DataLoader(s3)
+    assert not isinstance(d3.precip, np.memmap) and d3.precip.flags.writeable
+    assert np.array_equal(d3.precip, d2.precip, equal_nan=True)
 
 
 def test_histflag_is_normalised_and_future_mode_needs_channel_storage(tmp_path, golden):
