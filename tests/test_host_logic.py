@@ -227,3 +227,23 @@ def test_route_planner_fuzz_under_sanitizers():
     subprocess.run(['make', '-C', fuzz], check=True, capture_output=True)
     out = subprocess.run([os.path.join(fuzz, 'plan_fuzz'), '250', '20240807'], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and '250 cases, 0 failed' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_file_range_of_memory_map(tmp_path):
+    """pipeline.file_range_of: where a float64 memory map starts in its file -- from the addresses, because a slice of a
+    np.memmap keeps its parent's ``offset`` (the direct file -> HBM upload would otherwise send the wrong rows)."""
+    from xanthos_amd.pipeline import file_range_of
+    a = np.arange(5000 * 7, dtype=np.float64).reshape(5000, 7)
+    path = str(tmp_path / 'a.npy')
+    np.save(path, a)
+    mm = np.load(path, mmap_mode='r')
+    assert file_range_of(mm) == (path, mm.offset)
+    sl = mm[1200:]
+    assert sl.offset == mm.offset                          # numpy's pitfall
+    fn, off = file_range_of(sl)
+    raw = open(path, 'rb').read()
+    assert np.array_equal(np.frombuffer(raw[off:off + sl.nbytes]).reshape(sl.shape), a[1200:])
+    assert file_range_of(mm[:, :3]) is None                # not contiguous
+    assert file_range_of(a) is None and file_range_of(np.asarray(mm)) is None
+    np.save(str(tmp_path / 'f4.npy'), a.astype(np.float32))
+    assert file_range_of(np.load(str(tmp_path / 'f4.npy'), mmap_mode='r')) is None

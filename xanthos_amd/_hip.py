@@ -282,8 +282,8 @@ class Context:
         self._check(lib().xh_memcpy_d2h_async(self.handle, _host_ptr(host), _dptr(src), host.nbytes))
 
     def upload_file(self, dst, path, offset, nbytes, threads=0):
-        """``nbytes`` of file ``path`` from byte ``offset`` -> DeviceArray ``dst`` (xh_upload_file: threaded reads into
-        page-locked slots, overlapped copies; no pageable host copy of the data)."""
+        """``nbytes`` of file ``path`` from byte ``offset`` -> DeviceArray ``dst`` (xh_upload_file: the range is mapped
+        read-only and copied out of the mapping; no host copy of the data)."""
         if nbytes != dst.nbytes:
             raise ValueError('size mismatch: file range {} vs device {}'.format(nbytes, dst.nbytes))
         self._check(lib().xh_upload_file(self.handle, _dptr(dst), os.fsencode(path), int(offset), int(nbytes), threads))

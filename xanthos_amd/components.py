@@ -22,6 +22,8 @@ from .utils import set_month_arrays
 
 pet_mod = runoff_mod = routing_mod = None
 
+_TOPOLOGIES = {}      # (digest of coords + flow directions, grid shape) -> (dsid, upid, UM with its cached device plan)
+
 # result attribute -> name of the array in the device pipeline
 _RESULTS = {'PET': 'pet', 'AET': 'aet', 'Q': 'q', 'Sav': 'sav', 'ChStorage': 'chs', 'Avg_ChFlow': 'avg'}
 
@@ -114,11 +116,24 @@ class Components:
             self.Q = np.load(self.s.alt_runoff)
 
     def topology(self):
-        """dsid -> upid -> UM, built once per Components (the reference rebuilds it on every call, :268-270)."""
+        """dsid -> upid -> UM, built once per Components (the reference rebuilds it on every call, :268-270) -- and once
+        per process for one grid: the UM of the last two distinct (coords, flow directions) is kept with its device
+        routing plan, so a second run_model() on the same grid (a scenario sweep) does not partition the networks again."""
         if self.um is None:
-            self.dsid = routing_mod.downstream(self.data.coords, self.data.flow_dir, self.s)
-            self.upid = routing_mod.upstream(self.data.coords, self.dsid, self.s)
-            self.um = routing_mod.upstream_genmatrix(self.upid)
+            import hashlib
+            h = hashlib.blake2b(digest_size=16)
+            for a in (self.data.coords, self.data.flow_dir):
+                h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+            key = (h.hexdigest(), int(self.s.ngridrow), int(self.s.ngridcol))
+            hit = _TOPOLOGIES.get(key)
+            if hit is None:
+                dsid = routing_mod.downstream(self.data.coords, self.data.flow_dir, self.s)
+                upid = routing_mod.upstream(self.data.coords, dsid, self.s)
+                hit = (dsid, upid, routing_mod.upstream_genmatrix(upid))
+                while len(_TOPOLOGIES) >= 2:
+                    _TOPOLOGIES.pop(next(iter(_TOPOLOGIES)))
+                _TOPOLOGIES[key] = hit
+            self.dsid, self.upid, self.um = hit
         return self.um
 
     def calculate_routing(self, runoff):

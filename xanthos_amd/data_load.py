@@ -170,7 +170,7 @@ class DataLoader:
     def load_to_array(self, f, var_name, nan_to_num=False, key=None):
         # the big forcing files stay on disk as read-only memory maps (mmap_inputs = False restores host arrays)
         lazy = getattr(self.s, 'device_transforms', True) and getattr(self.s, 'mmap_inputs', True)
-        arr = np.asarray(load_file(f, key=key, mmap=lazy), dtype=float)
+        arr = np.asanyarray(load_file(f, key=key, mmap=lazy), dtype=float)      # a float64 memory map stays one
         # np.nan_to_num of the big forcing arrays (data_load.py:120-125, :194-195) is applied on the device right after
         # the upload (xh_nan_to_num) unless device_transforms is switched off: a host pass over 2.6 GB costs seconds
         if nan_to_num and not getattr(self.s, 'device_transforms', True):

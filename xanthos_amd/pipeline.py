@@ -18,6 +18,22 @@ FORCING = ('tas', 'tmin', 'rhs', 'wind', 'rsds', 'rlds', 'precip', 'abcd_tmin')
 OUTPUTS = ('pet', 'aet', 'q', 'sav', 'chs', 'avg')
 
 
+def file_range_of(arr):
+    """(path, byte offset) of the first element of a C-contiguous float64 np.memmap in its file, or None.  The position
+    is taken from the addresses (the array's data pointer against the start of its mapping), not from ``arr.offset``,
+    which a slice of a memory map inherits unchanged from its parent."""
+    import mmap
+    if not (isinstance(arr, np.memmap) and arr.dtype == np.float64 and arr.dtype.isnative and arr.flags.c_contiguous
+            and getattr(arr, 'filename', None) is not None and getattr(arr, '_mmap', None) is not None):
+        return None
+    base = np.frombuffer(arr._mmap, dtype=np.uint8)
+    delta = arr.ctypes.data - base.ctypes.data
+    if delta < 0 or delta + arr.nbytes > base.size:
+        return None
+    map_start = arr.offset - arr.offset % mmap.ALLOCATIONGRANULARITY        # where numpy placed the mapping in the file
+    return str(arr.filename), map_start + delta
+
+
 class DevicePipeline:
     """PM -> ABCD -> MRTM for one set of cells (the whole grid, or one rank's shard) on one GPU."""
 
@@ -61,14 +77,16 @@ class DevicePipeline:
 
     def set_forcing(self, host, tairprev=None):
         """host: dict of [ncell, nmonths] arrays keyed by FORCING (abcd_tmin optional when use_snow is False).
-        A read-only memory map of a .npy (np.load(mmap_mode='r'), what DataLoader keeps) goes from the file to HBM
-        through xh_upload_file; tairprev=None leaves the previous-cell temperature to the PM kernel (it reads the row
+        A read-only memory map of a .npy (np.load(mmap_mode='r'), what DataLoader keeps) is copied straight out of the
+        mapping (no host copy: the runtime pins the page-cache pages); tairprev=None leaves the previous-cell temperature to the PM kernel (it reads the row
         above of ``tas``, data_load.py:127-128)."""
         for k in FORCING:
             if k in host and host[k] is not None:
                 src = host[k]
-                direct = (isinstance(src, np.memmap) and src.dtype == np.float64 and src.dtype.isnative
-                          and src.flags.c_contiguous and getattr(src, 'filename', None) is not None)
+                # XH_UPLOAD_FROM_FILE=1: through xh_upload_file (maps the file range itself: 34 GB/s with its own map /
+                # unmap per array); default: xh_memcpy_h2d out of numpy's mapping, which stays alive in the loader (51 GB/s)
+                where = file_range_of(src) if os.environ.get('XH_UPLOAD_FROM_FILE', '0') == '1' else None
+                direct = where is not None
                 arr = src if direct else np.asarray(src, dtype=np.float64)
                 if arr.shape != (self.ncell, self.nmonths):
                     raise ValueError('forcing {} has shape {}, expected {}'.format(k, arr.shape,
@@ -76,7 +94,7 @@ class DevicePipeline:
                 if k not in self.forcing:
                     self.forcing[k] = self.ctx.empty((self.ncell, self.nmonths))
                 if direct:
-                    self.ctx.upload_file(self.forcing[k], src.filename, src.offset, src.nbytes)
+                    self.ctx.upload_file(self.forcing[k], where[0], where[1], src.nbytes)
                 else:
                     self.forcing[k].upload(arr)
                 if k != 'precip':                       # loader transform: everything but precipitation loses its NaNs
