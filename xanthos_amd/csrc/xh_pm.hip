@@ -10,7 +10,9 @@
 // Arithmetic follows the reference expression by expression (same association order; compiled with
 // -ffp-contract=off) except where a quotient is only ever used as a divisor again: the parallel resistances and their
 // caps are carried as reciprocals (1/ra = 1/rc + 1/rr, min -> max), per-class constants are multiplied by their
-// host-computed reciprocals, and 1/cc is formed as gsum / numerator.  Differences from numpy therefore come from the
+// host-computed reciprocals, 1/cc is formed as gsum / numerator, rc / (lai fwet) as rc (1/lai) (1/fwet) with 1/lai from a
+// table and 1/fwet shared by the classes, and the three quotients that make up a class's ET (:306-327) are put over one
+// common denominator (one reciprocal per class instead of three).  Differences from numpy therefore come from the
 // exp/log/sqrt implementations, from fdiv() below and from those regroupings -- a few ulp each, 5e-13 in PET overall.
 #include <algorithm>
 
@@ -34,7 +36,7 @@ struct PmTablesDev {
     int nlcs, n_lc_years, water_idx, snow_idx, start_year, nyears;
     double wind_pow;                     // (2/10)^0.11 (:99)
     double vec[PM_NVEC][XH_MAX_LCS];
-    double one_m_alpha[XH_MAX_LCS][12], lai[XH_MAX_LCS][12], fc[XH_MAX_LCS][12];
+    double one_m_alpha[XH_MAX_LCS][12], lai[XH_MAX_LCS][12], fc[XH_MAX_LCS][12], inv_lai[XH_MAX_LCS][12];
 };
 
 // The per-(class, month) tables are indexed by the thread's month and live in LDS; the per-class vectors are indexed by
@@ -42,7 +44,7 @@ struct PmTablesDev {
 // memory, which the compiler turns into scalar loads -- as LDS reads they were 85 % of the kernel's 46 M LDS
 // wave-instructions, each ~16 cycles of a lone wave's issue.
 struct PmLds {
-    double one_m_alpha[XH_MAX_LCS][12], lai[XH_MAX_LCS][12], fc[XH_MAX_LCS][12];
+    double one_m_alpha[XH_MAX_LCS][12], lai[XH_MAX_LCS][12], fc[XH_MAX_LCS][12], inv_lai[XH_MAX_LCS][12];
 };
 
 __device__ __forceinline__ int days_in_month(int year, int moy) {
@@ -76,16 +78,16 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
                                            const double *__restrict__ lct_cell, int lct_stride, double totpct) {
     // ---- terms shared by every land class (SetData :83-99, et_veg :226-282)
     const double esx = 6.10588 * xh_exp(fdiv(17.32491 * T, T + 238.102), K);
-    const double vap = esx * fdiv(RH, 100.0);
+    const double vap = esx * (RH * 0.01);                             // constant divisors are multiplied by their reciprocal
     const double tk1 = T + 238.1;
     const double sx = fdiv(238.1 * 17.325 * esx, tk1 * tk1);
     const double vpd = esx - vap;
-    const double xr = fdiv(273.15 + T, 293.15);
+    const double xr = (273.15 + T) * (1.0 / 293.15);
     const double sq = sqrt(xr);
     const double rcorr = fdiv(p, 101300.0 * (xr * sq * sqrt(sq)));      // pow(x, 1.75) = x * x^(1/2) * x^(1/4)
     const double gcu = 0.00001 * rcorr;
     const double rh = RH > 99.9999 ? 99.9 : RH;                       // calc_rh :205-209
-    const double r100 = fdiv(rh, 100.0);
+    const double r100 = rh * 0.01;
     const double r2 = r100 * r100, r4 = r2 * r2, r8 = r4 * r4;
     double fwet = rh < 70.0 ? 0.0 : rh;                               // calc_fwet :165-172
     fwet = rh >= 70.0 ? r8 : fwet;
@@ -100,12 +102,12 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
     const double secs = 86400.0 * dz;
     const double tk = T + 273.15;
     const double rho = fdiv(p, tk * 287.058);
-    const double rr = fdiv(rho * CP, 4.0 * SIGMA2 * (tk * tk * tk));
     const double rho_cp = rho * CP;
-    const double inv_rr = fdiv(1.0, rr);
+    const double inv_rr = fdiv(4.0 * SIGMA2 * (tk * tk * tk), rho_cp);    // 1 / rr, rr = rho CP / (4 sigma tk^3) (:268-269): only 1 / rr is used
     const double inv_secs = fdiv(1.0, secs);
     const double log_r100 = log(r100);
     const double one_m_fwet = 1.0 - fwet;
+    const double inv_fwet = fwet == 0.0 ? 1.0 : frcp(fwet);          // rc / (lai fwet) below, once for all classes
 
     double acc = 0.0;
     for (int l = 0; l < nlcs; ++l) {
@@ -117,7 +119,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             const double rnl = sig_t4 * 0.85 * dz - rl_term;
             double rn = oma * RS * 86400.0 * dz - rnl;
             rn = rn < 0.0 ? 0.0 : rn;
-            et = fdiv(fdiv(rn, secs) * dz * 0.6, 2845.0);
+            et = (rn * inv_secs) * dz * 0.6 * (1.0 / 2845.0);
             et = et < 0.0 ? 0.0 : et;
         } else if (l == water_idx) {
             // et_water (:337-361): emissivity 0.98, albedo of land class 0
@@ -126,9 +128,9 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             double rn = rsn - rnl;
             rn = rn < 0.0 ? 0.0 : rn;
             const double qt = 0.5 * rsn - (moy <= 5 ? 0.8 : 1.3) * rnl;
-            double ax = fdiv(rn - qt, secs);
+            double ax = (rn - qt) * inv_secs;
             ax = ax < 0.0 ? 0.0 : ax;
-            const double ewetx = fdiv(fdiv(rn, secs) * dz * 0.6, 2845.0);
+            const double ewetx = (rn * inv_secs) * dz * 0.6 * (1.0 / 2845.0);
             const double wind2 = W * wind_pow;
             const double ewety = fdiv(dz * 86400.0 * (sx * ax + GAMMA * 6.43 * (0.5 + 0.54 * wind2) * vpd),
                                       (sx + GAMMA) * LAMBDA1);
@@ -180,29 +182,32 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             const double lf = lai * fwet;                             // :296-301
             const double lai_fwet = lf == 0.0 ? 1.0 : lf;
             const double inv_rslimit = tab->vec[V_INVRSLIMIT][l];
-            double rhc = lai > 0.00001 ? fdiv(rc, lai_fwet) : rslimit;
+            // rc / (lai fwet) as rc (1/lai) (1/fwet): 1/lai from the table, 1/fwet shared by the classes (lai fwet == 0 with
+            // lai > 1e-5 means fwet == 0: the reference divides by 1 then)
+            double rhc = lai > 0.00001 ? rc * (lf == 0.0 ? 1.0 : L.inv_lai[l][moy] * inv_fwet) : rslimit;
             double inv_rhc = lai > 0.00001 ? lai_fwet * inv_rc : inv_rslimit;
             inv_rhc = rhc > rslimit ? inv_rslimit : inv_rhc;
             rhc = rhc > rslimit ? rslimit : rhc;
             double inv_rhrc = inv_rhc + inv_rr;                       // 1 / (rhc rr / (rhc + rr))
             inv_rhrc = inv_rhrc < inv_rtot ? inv_rtot : inv_rhrc;     // rhrc = min(rhrc, rtot)
 
-            const double apres = fdiv(dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_rhrc) * fwet,
-                                      (sx + p * 0.01 * CP * rhc * inv_rhrc * (1.0 / (LAMBDA1 * 0.622))) * LAMBDA1);   // :306-307
-            const double ewet_c = rh >= 70.0 ? apres : 0.0;
+            // the three quotients of :306-327 (canopy evaporation, soil evaporation, transpiration) over one common
+            // denominator: one reciprocal instead of three
+            const double n_apres = rh >= 70.0 ? dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_rhrc) * fwet : 0.0;      // :306-307
+            const double d_apres = (sx + p * 0.01 * CP * rhc * inv_rhrc * (1.0 / (LAMBDA1 * 0.622))) * LAMBDA1;
 
             const double inv_rasoil = inv_rtot + inv_rr;              // 1 / (rtot rr / (rtot + rr))
             const double soil_num = 86400.0 * dz * (sx * asoil + rho_cp * (1.0 - fc) * vpd * inv_rasoil);
-            const double soil_den = (sx + GAMMA * rtot * inv_rasoil) * LAMBDA1;
-            const double inv_soil_den = frcp(soil_den);                    // both quotients share the divisor
-            const double ewet_soil = (soil_num * fwet) * inv_soil_den;      // :314-315
-            const double esoilpot = (soil_num * one_m_fwet) * inv_soil_den; // :316-317
-            const double esoil = ewet_soil + esoilpot * xh_exp(vpd * tab->vec[V_INVBETA][l] * log_r100, K);   // pow(rh/100, vpd/beta) :323
+            const double d_soil = (sx + GAMMA * rtot * inv_rasoil) * LAMBDA1;
+            // ewet_soil + esoilpot pow(rh/100, vpd/beta) (:314-323), both over d_soil
+            const double n_soil = soil_num * fwet + (soil_num * one_m_fwet) * xh_exp(vpd * tab->vec[V_INVBETA][l] * log_r100, K);
 
-            double trans = fdiv(dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_ra) * one_m_fwet,
-                                (sx + GAMMA * (1.0 + rs * inv_ra)) * LAMBDA1);                   // :326-327
-            trans = fc == 0.0 ? 0.0 : trans;
-            et = trans + ewet_c + esoil;
+            const double n_trans = fc == 0.0 ? 0.0 : dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_ra) * one_m_fwet;  // :326-327
+            const double d_trans = (sx + GAMMA * (1.0 + rs * inv_ra)) * LAMBDA1;
+
+            const double d_as = d_apres * d_soil;
+            const double num = (n_trans * d_as + n_apres * (d_trans * d_soil)) + n_soil * (d_trans * d_apres);
+            et = num * frcp(d_trans * d_as);
             et = et < 0.0 ? 0.0 : et;
         }
         const double term = et * lct_cell[l * lct_stride];            // arr *= lct (:467)
@@ -228,6 +233,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             L.one_m_alpha[l][m] = tab->one_m_alpha[l][m];
             L.lai[l][m] = tab->lai[l][m];
             L.fc[l][m] = tab->fc[l][m];
+            L.inv_lai[l][m] = tab->inv_lai[l][m];
         }
     }
     __syncthreads();
@@ -346,6 +352,7 @@ int xh_pm_prepare(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int32_t nmo
             h.one_m_alpha[l][m] = 1.0 - t->alpha[l * 12 + m];
             h.lai[l][m] = lai;
             h.fc[l][m] = fc;
+            h.inv_lai[l][m] = lai > 0.00001 ? 1.0 / lai : 0.0;      // only read where lai > 1e-5 (:296-301)
         }
     }
     std::vector<int> sorted(h_lc_years, h_lc_years + n_lc_years);
