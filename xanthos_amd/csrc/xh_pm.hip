@@ -118,24 +118,24 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             // et_snow (:364-377): emissivity 0.85, albedo of land class 6
             const double rnl = sig_t4 * 0.85 * dz - rl_term;
             double rn = oma * RS * 86400.0 * dz - rnl;
-            rn = rn < 0.0 ? 0.0 : rn;
+            rn = fmax(rn, 0.0);
             et = (rn * inv_secs) * dz * 0.6 * (1.0 / 2845.0);
-            et = et < 0.0 ? 0.0 : et;
+            et = fmax(et, 0.0);
         } else if (l == water_idx) {
             // et_water (:337-361): emissivity 0.98, albedo of land class 0
             const double rsn = oma * RS * 86400.0 * dz;
             const double rnl = sig_t4 * 0.98 * dz - rl_term;
             double rn = rsn - rnl;
-            rn = rn < 0.0 ? 0.0 : rn;
+            rn = fmax(rn, 0.0);
             const double qt = 0.5 * rsn - (moy <= 5 ? 0.8 : 1.3) * rnl;
             double ax = (rn - qt) * inv_secs;
-            ax = ax < 0.0 ? 0.0 : ax;
+            ax = fmax(ax, 0.0);
             const double ewetx = (rn * inv_secs) * dz * 0.6 * (1.0 / 2845.0);
             const double wind2 = W * wind_pow;
             const double ewety = fdiv(dz * 86400.0 * (sx * ax + GAMMA * 6.43 * (0.5 + 0.54 * wind2) * vpd),
                                       (sx + GAMMA) * LAMBDA1);
             et = T < -1.0 ? ewetx : ewety;
-            et = et < 0.0 ? 0.0 : et;
+            et = fmax(et, 0.0);
         } else {
             // et_veg (:223-334)
             const double topen = tab->vec[V_TOPEN][l], tclose = tab->vec[V_TCLOSE][l];
@@ -164,20 +164,21 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             const double ac = fc * a;
             const double asoil = (1.0 - fc) * a - g;
             double rtot = rtotc * rcorr;
-            rtot = rtot > 80.0 ? 80.0 : rtot;
+            rtot = fmin(rtot, 80.0);                                  // one v_min_f64 instead of compare + two selects: no operand
+                                                                      // here can be NaN (the loader's nan_to_num, guarded quotients)
             const double rc = tab->vec[V_RC][l], inv_rc = tab->vec[V_INVRC][l], rslimit = tab->vec[V_RSLIMIT][l];
             // Resistances in parallel / capped: only their reciprocals are used below, so they are formed directly:
             // 1 / (x rr / (x + rr)) = 1/x + 1/rr, and min(r, rtot) becomes max(1/r, 1/rtot) (same NaN selection).
             const double inv_rtot = fdiv(1.0, rtot);
             double inv_ra = inv_rc + inv_rr;                          // 1 / (rc rr / (rc + rr))
-            inv_ra = inv_ra < inv_rtot ? inv_rtot : inv_ra;           // ra = min(ra, rtot)
+            inv_ra = fmax(inv_ra, inv_rtot);                          // ra = min(ra, rtot)
 
             const double gsum = gs1 + inv_rc + gcu;                   // calc_cc :192-197
             double cc = gsum < 0.0001 ? 10000.0 : (fwet == 1.0 ? 0.00001 : (lai < 0.0001 ? 0.00001 : 0.0));
             const double cnum = inv_rc * (gs1 + gcu) * lai * one_m_fwet;      // cc = cnum / gsum in the general case
             double rs = cc != 0.0 ? (cc == 10000.0 ? 0.0001 : 100000.0)       // 1 / cc for the two fixed values of cc
                                   : (cnum == 0.0 ? 100000.0 : fdiv(gsum, cnum));   // :285-291 (cc == 0 -> 1e5)
-            rs = rs > rslimit ? rslimit : rs;
+            rs = fmin(rs, rslimit);
 
             const double lf = lai * fwet;                             // :296-301
             const double lai_fwet = lf == 0.0 ? 1.0 : lf;
@@ -189,7 +190,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             inv_rhc = rhc > rslimit ? inv_rslimit : inv_rhc;
             rhc = rhc > rslimit ? rslimit : rhc;
             double inv_rhrc = inv_rhc + inv_rr;                       // 1 / (rhc rr / (rhc + rr))
-            inv_rhrc = inv_rhrc < inv_rtot ? inv_rtot : inv_rhrc;     // rhrc = min(rhrc, rtot)
+            inv_rhrc = fmax(inv_rhrc, inv_rtot);                      // rhrc = min(rhrc, rtot)
 
             // the three quotients of :306-327 (canopy evaporation, soil evaporation, transpiration) over one common
             // denominator: one reciprocal instead of three
@@ -208,7 +209,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             const double d_as = d_apres * d_soil;
             const double num = (n_trans * d_as + n_apres * (d_trans * d_soil)) + n_soil * (d_trans * d_apres);
             et = num * frcp(d_trans * d_as);
-            et = et < 0.0 ? 0.0 : et;
+            et = fmax(et, 0.0);
         }
         const double term = et * lct_cell[l * lct_stride];            // arr *= lct (:467)
         acc = (l == 0) ? term : acc + term;                           // np.sum over classes, in order (:470)
