@@ -139,22 +139,23 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
         } else {
             // et_veg (:223-334)
             const double topen = tab->vec[V_TOPEN][l], tclose = tab->vec[V_TCLOSE][l];
-            double mtmin = 0.0;                                       // calc_mtmin :102-114
+            // The three piecewise-linear factors (calc_mtmin :102-114, calc_vpd :117-129, calc_rtotc :132-145): the linear
+            // piece first, then the two plateaus in the reference's order of assignment (no input is NaN here, so one of
+            // the three branches always applies and the value the reference starts from is never seen)
+            double mtmin = (TN - tclose) * tab->vec[V_INVTSPAN][l];
             mtmin = TN >= topen ? 1.0 : mtmin;
             mtmin = TN <= tclose ? 0.1 : mtmin;
-            mtmin = (TN < topen && TN > tclose) ? (TN - tclose) * tab->vec[V_INVTSPAN][l] : mtmin;
             const double vclose = tab->vec[V_VCLOSE][l], vopen = tab->vec[V_VOPEN][l], inv_vspan = tab->vec[V_INVVSPAN][l];
-            const bool vmid = (vpd > vopen) && (vpd < vclose);
-            double mvpd = vpd;                                        // calc_vpd :117-129
-            mvpd = vpd <= vopen ? 1.0 : mvpd;
-            mvpd = vpd >= vclose ? 0.1 : mvpd;
-            mvpd = vmid ? (vclose - vpd) * inv_vspan : mvpd;
+            const double vlin = (vclose - vpd) * inv_vspan;
+            const bool v_lo = vpd <= vopen, v_hi = vpd >= vclose;
+            double mvpd = vlin;
+            mvpd = v_lo ? 1.0 : mvpd;
+            mvpd = v_hi ? 0.1 : mvpd;
             const double gs1 = tab->vec[V_CL][l] * mtmin * mvpd * rcorr;    // :242
             const double rblmin = tab->vec[V_RBLMIN][l], rblmax = tab->vec[V_RBLMAX][l];
-            double rtotc = 0.0;                                       // calc_rtotc :132-145
-            rtotc = vpd <= vopen ? rblmax : rtotc;
-            rtotc = vpd >= vclose ? rblmin : rtotc;
-            rtotc = vmid ? rblmax - tab->vec[V_RBLSPAN][l] * (vclose - vpd) * inv_vspan : rtotc;
+            double rtotc = rblmax - tab->vec[V_RBLSPAN][l] * (vclose - vpd) * inv_vspan;      // the reference's association
+            rtotc = v_lo ? rblmax : rtotc;
+            rtotc = v_hi ? rblmin : rtotc;
 
             const double rnl = sig_t4 * tab->vec[V_EMISS][l] * dz - rl_term;  // calc_a :148-162
             const double rn = oma * RS * 86400.0 * dz - rnl;
