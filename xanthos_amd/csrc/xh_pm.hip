@@ -175,10 +175,12 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             inv_ra = fmax(inv_ra, inv_rtot);                          // ra = min(ra, rtot)
 
             const double gsum = gs1 + inv_rc + gcu;                   // calc_cc :192-197
-            double cc = gsum < 0.0001 ? 10000.0 : (fwet == 1.0 ? 0.00001 : (lai < 0.0001 ? 0.00001 : 0.0));
-            const double cnum = inv_rc * (gs1 + gcu) * lai * one_m_fwet;      // cc = cnum / gsum in the general case
-            double rs = cc != 0.0 ? (cc == 10000.0 ? 0.0001 : 100000.0)       // 1 / cc for the two fixed values of cc
-                                  : (cnum == 0.0 ? 100000.0 : fdiv(gsum, cnum));   // :285-291 (cc == 0 -> 1e5)
+            // cc (:192-197) and rs = 1 / cc (:285-291) in one step: gsum < 1e-4 -> cc = 1e4; else fwet == 1 or lai < 1e-4 ->
+            // cc = 1e-5; else cc = cnum / gsum, and cc == 0 -> rs = 1e5.  fwet == 1 makes cnum zero, so two tests cover the
+            // three ways to 1e5.
+            const double cnum = inv_rc * (gs1 + gcu) * lai * one_m_fwet;
+            double rs = (lai < 0.0001 || cnum == 0.0) ? 100000.0 : fdiv(gsum, cnum);
+            rs = gsum < 0.0001 ? 0.0001 : rs;
             rs = fmin(rs, rslimit);
 
             const double lf = lai * fwet;                             // :296-301
@@ -186,16 +188,18 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             const double inv_rslimit = tab->vec[V_INVRSLIMIT][l];
             // rc / (lai fwet) as rc (1/lai) (1/fwet): 1/lai from the table, 1/fwet shared by the classes (lai fwet == 0 with
             // lai > 1e-5 means fwet == 0: the reference divides by 1 then)
-            double rhc = lai > 0.00001 ? rc * (lf == 0.0 ? 1.0 : L.inv_lai[l][moy] * inv_fwet) : rslimit;
-            double inv_rhc = lai > 0.00001 ? lai_fwet * inv_rc : inv_rslimit;
-            inv_rhc = rhc > rslimit ? inv_rslimit : inv_rhc;
-            rhc = rhc > rslimit ? rslimit : rhc;
+            const double rhc_raw = rc * (lf == 0.0 ? 1.0 : L.inv_lai[l][moy] * inv_fwet);
+            const bool use_rhc = lai > 0.00001 && rhc_raw <= rslimit;   // else the cap (:299-301): rhc = rslimit
+            const double rhc = use_rhc ? rhc_raw : rslimit;
+            const double inv_rhc = use_rhc ? lai_fwet * inv_rc : inv_rslimit;
             double inv_rhrc = inv_rhc + inv_rr;                       // 1 / (rhc rr / (rhc + rr))
             inv_rhrc = fmax(inv_rhrc, inv_rtot);                      // rhrc = min(rhrc, rtot)
 
             // the three quotients of :306-327 (canopy evaporation, soil evaporation, transpiration) over one common
             // denominator: one reciprocal instead of three
-            const double n_apres = rh >= 70.0 ? dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_rhrc) * fwet : 0.0;      // :306-307
+            // (rh < 70 makes fwet zero and fc == 0 makes ac zero: the reference's two np.where(..., 0, ...) of :309-310 and :328 only
+            // ever replace a zero by a zero)
+            const double n_apres = dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_rhrc) * fwet;      // :306-307
             const double d_apres = (sx + p * 0.01 * CP * rhc * inv_rhrc * (1.0 / (LAMBDA1 * 0.622))) * LAMBDA1;
 
             const double inv_rasoil = inv_rtot + inv_rr;              // 1 / (rtot rr / (rtot + rr))
@@ -204,7 +208,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             // ewet_soil + esoilpot pow(rh/100, vpd/beta) (:314-323), both over d_soil
             const double n_soil = soil_num * fwet + (soil_num * one_m_fwet) * xh_exp(vpd * tab->vec[V_INVBETA][l] * log_r100, K);
 
-            const double n_trans = fc == 0.0 ? 0.0 : dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_ra) * one_m_fwet;  // :326-327
+            const double n_trans = dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_ra) * one_m_fwet;  // :326-327
             const double d_trans = (sx + GAMMA * (1.0 + rs * inv_ra)) * LAMBDA1;
 
             const double d_as = d_apres * d_soil;
