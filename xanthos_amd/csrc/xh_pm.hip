@@ -108,6 +108,11 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
     const double log_r100 = log(r100);
     const double one_m_fwet = 1.0 - fwet;
     const double inv_fwet = fwet == 0.0 ? 1.0 : frcp(fwet);          // rc / (lai fwet) below, once for all classes
+    // products every class would form again (the association differs from the reference's left-to-right by an ulp)
+    const double rs_secs = RS * 86400.0 * dz;                         // oma RS 86400 dz (:150-152)
+    const double sig_t4_dz = sig_t4 * dz;                             // sigma T^4 emiss dz
+    const double p_cp = p * 0.01 * CP * (1.0 / (LAMBDA1 * 0.622));    // :307
+    const double vpd_log = vpd * log_r100;                            // exponent of :323 is vpd_log / beta
 
     double acc = 0.0;
     for (int l = 0; l < nlcs; ++l) {
@@ -116,15 +121,15 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
                                             : ((l == snow_idx) ? L.one_m_alpha[6][moy] : L.one_m_alpha[l][moy]);
         if (l == snow_idx) {
             // et_snow (:364-377): emissivity 0.85, albedo of land class 6
-            const double rnl = sig_t4 * 0.85 * dz - rl_term;
-            double rn = oma * RS * 86400.0 * dz - rnl;
+            const double rnl = sig_t4_dz * 0.85 - rl_term;
+            double rn = oma * rs_secs - rnl;
             rn = fmax(rn, 0.0);
             et = (rn * inv_secs) * dz * 0.6 * (1.0 / 2845.0);
             et = fmax(et, 0.0);
         } else if (l == water_idx) {
             // et_water (:337-361): emissivity 0.98, albedo of land class 0
-            const double rsn = oma * RS * 86400.0 * dz;
-            const double rnl = sig_t4 * 0.98 * dz - rl_term;
+            const double rsn = oma * rs_secs;
+            const double rnl = sig_t4_dz * 0.98 - rl_term;
             double rn = rsn - rnl;
             rn = fmax(rn, 0.0);
             const double qt = 0.5 * rsn - (moy <= 5 ? 0.8 : 1.3) * rnl;
@@ -157,8 +162,8 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             rtotc = v_lo ? rblmax : rtotc;
             rtotc = v_hi ? rblmin : rtotc;
 
-            const double rnl = sig_t4 * tab->vec[V_EMISS][l] * dz - rl_term;  // calc_a :148-162
-            const double rn = oma * RS * 86400.0 * dz - rnl;
+            const double rnl = sig_t4_dz * tab->vec[V_EMISS][l] - rl_term;    // calc_a :148-162
+            const double rn = oma * rs_secs - rnl;
             const double a = rn * inv_secs;
 
             const double lai = L.lai[l][moy], fc = L.fc[l][moy];
@@ -200,13 +205,13 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             // (rh < 70 makes fwet zero and fc == 0 makes ac zero: the reference's two np.where(..., 0, ...) of :309-310 and :328 only
             // ever replace a zero by a zero)
             const double n_apres = dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_rhrc) * fwet;      // :306-307
-            const double d_apres = (sx + p * 0.01 * CP * rhc * inv_rhrc * (1.0 / (LAMBDA1 * 0.622))) * LAMBDA1;
+            const double d_apres = (sx + p_cp * rhc * inv_rhrc) * LAMBDA1;
 
             const double inv_rasoil = inv_rtot + inv_rr;              // 1 / (rtot rr / (rtot + rr))
             const double soil_num = 86400.0 * dz * (sx * asoil + rho_cp * (1.0 - fc) * vpd * inv_rasoil);
             const double d_soil = (sx + GAMMA * rtot * inv_rasoil) * LAMBDA1;
             // ewet_soil + esoilpot pow(rh/100, vpd/beta) (:314-323), both over d_soil
-            const double n_soil = soil_num * fwet + (soil_num * one_m_fwet) * xh_exp(vpd * tab->vec[V_INVBETA][l] * log_r100, K);
+            const double n_soil = soil_num * fwet + (soil_num * one_m_fwet) * xh_exp(vpd_log * tab->vec[V_INVBETA][l], K);
 
             const double n_trans = dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_ra) * one_m_fwet;  // :326-327
             const double d_trans = (sx + GAMMA * (1.0 + rs * inv_ra)) * LAMBDA1;
