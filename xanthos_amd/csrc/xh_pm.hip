@@ -113,6 +113,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
     const double sig_t4_dz = sig_t4 * dz;                             // sigma T^4 emiss dz
     const double p_cp = p * 0.01 * CP * (1.0 / (LAMBDA1 * 0.622));    // :307
     const double vpd_log = vpd * log_r100;                            // exponent of :323 is vpd_log / beta
+    const double secs_lambda = secs * (1.0 / LAMBDA1);                // 86400 dz / lambda1 of :306-327
 
     double acc = 0.0;
     for (int l = 0; l < nlcs; ++l) {
@@ -204,21 +205,23 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             // denominator: one reciprocal instead of three
             // (rh < 70 makes fwet zero and fc == 0 makes ac zero: the reference's two np.where(..., 0, ...) of :309-310 and :328 only
             // ever replace a zero by a zero)
-            const double n_apres = dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_rhrc) * fwet;      // :306-307
-            const double d_apres = (sx + p_cp * rhc * inv_rhrc) * LAMBDA1;
+            // Every numerator carries 86400 dz and every denominator lambda1: both leave the class loop as secs_lambda.
+            const double rcv = rho_cp * vpd;
+            const double m_apres = (sx * ac + rcv * fc * inv_rhrc) * fwet;      // :306-307
+            const double x_apres = sx + p_cp * rhc * inv_rhrc;
 
             const double inv_rasoil = inv_rtot + inv_rr;              // 1 / (rtot rr / (rtot + rr))
-            const double soil_num = 86400.0 * dz * (sx * asoil + rho_cp * (1.0 - fc) * vpd * inv_rasoil);
-            const double d_soil = (sx + GAMMA * rtot * inv_rasoil) * LAMBDA1;
-            // ewet_soil + esoilpot pow(rh/100, vpd/beta) (:314-323), both over d_soil
-            const double n_soil = soil_num * fwet + (soil_num * one_m_fwet) * xh_exp(vpd_log * tab->vec[V_INVBETA][l], K);
+            // ewet_soil + esoilpot pow(rh/100, vpd/beta) (:314-323): one numerator, fwet + (1 - fwet) pow(...) of it
+            const double m_soil = (sx * asoil + rho_cp * (1.0 - fc) * vpd * inv_rasoil) *
+                                  (fwet + one_m_fwet * xh_exp(vpd_log * tab->vec[V_INVBETA][l], K));
+            const double x_soil = sx + GAMMA * rtot * inv_rasoil;
 
-            const double n_trans = dz * 86400.0 * (sx * ac + rho_cp * vpd * fc * inv_ra) * one_m_fwet;  // :326-327
-            const double d_trans = (sx + GAMMA * (1.0 + rs * inv_ra)) * LAMBDA1;
+            const double m_trans = (sx * ac + rcv * fc * inv_ra) * one_m_fwet;  // :326-327
+            const double x_trans = sx + GAMMA * (1.0 + rs * inv_ra);
 
-            const double d_as = d_apres * d_soil;
-            const double num = (n_trans * d_as + n_apres * (d_trans * d_soil)) + n_soil * (d_trans * d_apres);
-            et = num * frcp(d_trans * d_as);
+            const double x_as = x_apres * x_soil;
+            const double num = (m_trans * x_as + m_apres * (x_trans * x_soil)) + m_soil * (x_trans * x_apres);
+            et = secs_lambda * (num * frcp(x_trans * x_as));
             et = fmax(et, 0.0);
         }
         const double term = et * lct_cell[l * lct_stride];            // arr *= lct (:467)
