@@ -35,7 +35,7 @@ enum { V_CL = 0, V_BETA, V_RSLIMIT, V_TOPEN, V_TCLOSE, V_TSPAN, V_VCLOSE, V_VOPE
 struct PmTablesDev {
     int nlcs, n_lc_years, water_idx, snow_idx, start_year, nyears;
     double wind_pow;                     // (2/10)^0.11 (:99)
-    double vec[PM_NVEC][XH_MAX_LCS];
+    double vec[XH_MAX_LCS][PM_NVEC];     // [class][row]: the rows of one class are contiguous, so its ~19 scalar loads merge into a few wide ones
     double one_m_alpha[XH_MAX_LCS][12], lai[XH_MAX_LCS][12], fc[XH_MAX_LCS][12], inv_lai[XH_MAX_LCS][12];
 };
 
@@ -144,26 +144,26 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             et = fmax(et, 0.0);
         } else {
             // et_veg (:223-334)
-            const double topen = tab->vec[V_TOPEN][l], tclose = tab->vec[V_TCLOSE][l];
+            const double topen = tab->vec[l][V_TOPEN], tclose = tab->vec[l][V_TCLOSE];
             // The three piecewise-linear factors (calc_mtmin :102-114, calc_vpd :117-129, calc_rtotc :132-145): the linear
             // piece first, then the two plateaus in the reference's order of assignment (no input is NaN here, so one of
             // the three branches always applies and the value the reference starts from is never seen)
-            double mtmin = (TN - tclose) * tab->vec[V_INVTSPAN][l];
+            double mtmin = (TN - tclose) * tab->vec[l][V_INVTSPAN];
             mtmin = TN >= topen ? 1.0 : mtmin;
             mtmin = TN <= tclose ? 0.1 : mtmin;
-            const double vclose = tab->vec[V_VCLOSE][l], vopen = tab->vec[V_VOPEN][l], inv_vspan = tab->vec[V_INVVSPAN][l];
+            const double vclose = tab->vec[l][V_VCLOSE], vopen = tab->vec[l][V_VOPEN], inv_vspan = tab->vec[l][V_INVVSPAN];
             const double vlin = (vclose - vpd) * inv_vspan;
             const bool v_lo = vpd <= vopen, v_hi = vpd >= vclose;
             double mvpd = vlin;
             mvpd = v_lo ? 1.0 : mvpd;
             mvpd = v_hi ? 0.1 : mvpd;
-            const double gs1 = tab->vec[V_CL][l] * mtmin * mvpd * rcorr;    // :242
-            const double rblmin = tab->vec[V_RBLMIN][l], rblmax = tab->vec[V_RBLMAX][l];
-            double rtotc = rblmax - tab->vec[V_RBLSPAN][l] * (vclose - vpd) * inv_vspan;      // the reference's association
+            const double gs1 = tab->vec[l][V_CL] * mtmin * mvpd * rcorr;    // :242
+            const double rblmin = tab->vec[l][V_RBLMIN], rblmax = tab->vec[l][V_RBLMAX];
+            double rtotc = rblmax - tab->vec[l][V_RBLSPAN] * (vclose - vpd) * inv_vspan;      // the reference's association
             rtotc = v_lo ? rblmax : rtotc;
             rtotc = v_hi ? rblmin : rtotc;
 
-            const double rnl = sig_t4_dz * tab->vec[V_EMISS][l] - rl_term;    // calc_a :148-162
+            const double rnl = sig_t4_dz * tab->vec[l][V_EMISS] - rl_term;    // calc_a :148-162
             const double rn = oma * rs_secs - rnl;
             const double a = rn * inv_secs;
 
@@ -173,7 +173,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             double rtot = rtotc * rcorr;
             rtot = fmin(rtot, 80.0);                                  // one v_min_f64 instead of compare + two selects: no operand
                                                                       // here can be NaN (the loader's nan_to_num, guarded quotients)
-            const double rc = tab->vec[V_RC][l], inv_rc = tab->vec[V_INVRC][l], rslimit = tab->vec[V_RSLIMIT][l];
+            const double rc = tab->vec[l][V_RC], inv_rc = tab->vec[l][V_INVRC], rslimit = tab->vec[l][V_RSLIMIT];
             // Resistances in parallel / capped: only their reciprocals are used below, so they are formed directly:
             // 1 / (x rr / (x + rr)) = 1/x + 1/rr, and min(r, rtot) becomes max(1/r, 1/rtot) (same NaN selection).
             const double inv_rtot = fdiv(1.0, rtot);
@@ -191,7 +191,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
 
             const double lf = lai * fwet;                             // :296-301
             const double lai_fwet = lf == 0.0 ? 1.0 : lf;
-            const double inv_rslimit = tab->vec[V_INVRSLIMIT][l];
+            const double inv_rslimit = tab->vec[l][V_INVRSLIMIT];
             // rc / (lai fwet) as rc (1/lai) (1/fwet): 1/lai from the table, 1/fwet shared by the classes (lai fwet == 0 with
             // lai > 1e-5 means fwet == 0: the reference divides by 1 then)
             const double rhc_raw = rc * (lf == 0.0 ? 1.0 : L.inv_lai[l][moy] * inv_fwet);
@@ -213,7 +213,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             const double inv_rasoil = inv_rtot + inv_rr;              // 1 / (rtot rr / (rtot + rr))
             // ewet_soil + esoilpot pow(rh/100, vpd/beta) (:314-323): one numerator, fwet + (1 - fwet) pow(...) of it
             const double m_soil = (sx * asoil + rho_cp * (1.0 - fc) * vpd * inv_rasoil) *
-                                  (fwet + one_m_fwet * xh_exp(vpd_log * tab->vec[V_INVBETA][l], K));
+                                  (fwet + one_m_fwet * xh_exp(vpd_log * tab->vec[l][V_INVBETA], K));
             const double x_soil = sx + GAMMA * rtot * inv_rasoil;
 
             const double m_trans = (sx * ac + rcv * fc * inv_ra) * one_m_fwet;  // :326-327
@@ -338,25 +338,25 @@ int xh_pm_prepare(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int32_t nmo
     h.nyears = nyears;
     h.wind_pow = pow(2.0 / 10.0, 0.11);
     for (int l = 0; l < nlcs; ++l) {
-        h.vec[V_CL][l] = t->cL[l];
-        h.vec[V_BETA][l] = t->beta[l];
-        h.vec[V_RSLIMIT][l] = t->rslimit[l];
-        h.vec[V_TOPEN][l] = t->Tminopen[l];
-        h.vec[V_TCLOSE][l] = t->Tminclose[l];
-        h.vec[V_TSPAN][l] = t->Tminopen[l] - t->Tminclose[l];
-        h.vec[V_VCLOSE][l] = t->VPDclose[l];
-        h.vec[V_VOPEN][l] = t->VPDopen[l];
-        h.vec[V_VSPAN][l] = t->VPDclose[l] - t->VPDopen[l];
-        h.vec[V_RBLMIN][l] = t->RBLmin[l];
-        h.vec[V_RBLMAX][l] = t->RBLmax[l];
-        h.vec[V_RBLSPAN][l] = t->RBLmax[l] - t->RBLmin[l];
-        h.vec[V_RC][l] = t->rc[l];
-        h.vec[V_INVRC][l] = 1.0 / t->rc[l];
-        h.vec[V_EMISS][l] = t->emiss[l];
-        h.vec[V_INVTSPAN][l] = 1.0 / h.vec[V_TSPAN][l];          // reciprocals of per-class constants: the kernel multiplies
-        h.vec[V_INVVSPAN][l] = 1.0 / h.vec[V_VSPAN][l];
-        h.vec[V_INVBETA][l] = 1.0 / t->beta[l];
-        h.vec[V_INVRSLIMIT][l] = 1.0 / t->rslimit[l];
+        h.vec[l][V_CL] = t->cL[l];
+        h.vec[l][V_BETA] = t->beta[l];
+        h.vec[l][V_RSLIMIT] = t->rslimit[l];
+        h.vec[l][V_TOPEN] = t->Tminopen[l];
+        h.vec[l][V_TCLOSE] = t->Tminclose[l];
+        h.vec[l][V_TSPAN] = t->Tminopen[l] - t->Tminclose[l];
+        h.vec[l][V_VCLOSE] = t->VPDclose[l];
+        h.vec[l][V_VOPEN] = t->VPDopen[l];
+        h.vec[l][V_VSPAN] = t->VPDclose[l] - t->VPDopen[l];
+        h.vec[l][V_RBLMIN] = t->RBLmin[l];
+        h.vec[l][V_RBLMAX] = t->RBLmax[l];
+        h.vec[l][V_RBLSPAN] = t->RBLmax[l] - t->RBLmin[l];
+        h.vec[l][V_RC] = t->rc[l];
+        h.vec[l][V_INVRC] = 1.0 / t->rc[l];
+        h.vec[l][V_EMISS] = t->emiss[l];
+        h.vec[l][V_INVTSPAN] = 1.0 / h.vec[l][V_TSPAN];          // reciprocals of per-class constants: the kernel multiplies
+        h.vec[l][V_INVVSPAN] = 1.0 / h.vec[l][V_VSPAN];
+        h.vec[l][V_INVBETA] = 1.0 / t->beta[l];
+        h.vec[l][V_INVRSLIMIT] = 1.0 / t->rslimit[l];
         for (int m = 0; m < 12; ++m) {
             const double lai = t->lai[l * 12 + m], lmin = t->laimin[l * 12 + m], lmax = t->laimax[l * 12 + m];
             double den = exp(-0.5 * lmin) - exp(-0.5 * lmax);           // :257-261
