@@ -45,3 +45,22 @@ __device__ __forceinline__ double xh_exp(double x, const XhExpConsts &K) {
     e = (-1075.0 > x) ? 0.0 : e;
     return e;
 }
+
+// exp(x) for x <= 0 where 1e-11 relative is enough (Penman-Monteith's pow(rh / 100, vpd / beta), :323: its result is one
+// of three addends of a class's ET, and PET is held to 1e-9): the same reduction, the polynomial two terms shorter
+// (degree 9: the dropped terms are < r^10 / 10! = 7e-12 for |r| <= ln2 / 2), no overflow select.
+__device__ __forceinline__ double xh_exp_nonpos(double x, const XhExpConsts &K) {
+    const double log2e = __longlong_as_double(0x3ff71547652b82fell);
+    const double neg_ln2_hi = __longlong_as_double((long long)0xbfe62e42fefa39efull);
+    const double neg_ln2_lo = __longlong_as_double((long long)0xbc7abc9e3b39803full);
+    const double k = __builtin_rint(x * log2e);
+    double r = __builtin_fma(neg_ln2_hi, k, x);
+    r = __builtin_fma(neg_ln2_lo, k, r);
+    double p = __builtin_fma(K.c[7], r, K.c[6]);
+#pragma unroll
+    for (int i = 5; i >= 0; --i) p = __builtin_fma(r, p, K.c[i]);
+    p = __builtin_fma(r, p, 1.0);
+    p = __builtin_fma(r, p, 1.0);
+    const double e = __builtin_ldexp(p, (int)k);
+    return (-1075.0 > x) ? 0.0 : e;               // also x = -inf (rh = 0)
+}

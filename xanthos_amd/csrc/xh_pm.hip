@@ -213,7 +213,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             const double inv_rasoil = inv_rtot + inv_rr;              // 1 / (rtot rr / (rtot + rr))
             // ewet_soil + esoilpot pow(rh/100, vpd/beta) (:314-323): one numerator, fwet + (1 - fwet) pow(...) of it
             const double m_soil = (sx * asoil + rho_cp * (1.0 - fc) * vpd * inv_rasoil) *
-                                  (fwet + one_m_fwet * xh_exp(vpd_log * tab->vec[l][V_INVBETA], K));
+                                  (fwet + one_m_fwet * xh_exp_nonpos(vpd_log * tab->vec[l][V_INVBETA], K));   // vpd >= 0, log(rh / 100) <= 0
             const double x_soil = sx + GAMMA * rtot * inv_rasoil;
 
             const double m_trans = (sx * ac + rcv * fc * inv_ra) * one_m_fwet;  // :326-327
