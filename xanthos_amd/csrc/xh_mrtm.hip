@@ -19,6 +19,7 @@
 // Networks that do not fit a workgroup (more than 3072 cells, or a row with more than 9 entries) are routed by
 // the global-memory kernels at the bottom (two launches per sub-step; optional fp64 atomic scatter-add variant).
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <numeric>
@@ -425,6 +426,16 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
     XH_REQUIRE(ctx, nnz < ((int64_t)1 << 31), "xh_route_plan_create: too many entries");
     const int n = (int)ncell;
 
+    XH_HIP(ctx, hipSetDevice(ctx->device));                      // may be called from a host thread of its own (run_model())
+    const bool timing = getenv("XH_PLAN_TIMING") != nullptr;      // stderr: where the host time of a plan goes
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto t = now();
+        fprintf(stderr, "[libxanthos_hip] plan: %-28s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     // ---- networks = weakly connected components of the entries
     std::vector<int> parent(n);
     std::iota(parent.begin(), parent.end(), 0);
@@ -466,6 +477,7 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
     plan->n_networks = ncomp;
     plan->largest_network = ncomp ? *std::max_element(comp_size.begin(), comp_size.end()) : 0;
 
+    lap("validation + components");
     // ---- tree-shaped networks also get a dataflow layout (xh_mrtm_flow.hip); XH_MRTM_FLOW=0 disables it
     std::vector<char> flow_cell;
     {
@@ -494,6 +506,7 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
     for (int i = 0; i < n; ++i)
         if (flow_cell[i]) comp_flow[comp[i]] = 1;
 
+    lap("dataflow plan");
     // ---- units: big networks alone, small ones first-fit-decreasing into bins of BIN_CELLS.  Two passes keep
     //      every unit either wholly routed by the dataflow kernel or wholly not.
     std::vector<int> order(ncomp);
@@ -591,6 +604,7 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
         }
     }
 
+    lap("workgroup units + slots");
     // ---- fallback CSR (subset) and whole-graph CSR
     auto build_csr = [&](const std::vector<int> &cells, std::vector<int> &ptr, std::vector<int> &col,
                          std::vector<signed char> &sgn, std::vector<int> &ds, bool &single) {
@@ -673,6 +687,7 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
         xh_route_plan_destroy(plan);
         return xh_fail(ctx, XH_ERR_HIP, "xh_route_plan_create: device allocation failed");
     }
+    lap("tables + uploads");
     *out = plan;
     return XH_OK;
 }

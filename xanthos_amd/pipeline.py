@@ -39,7 +39,7 @@ class DevicePipeline:
 
     def __init__(self, ctx, *, ncell, nmonths, start_year, basin_ids, abcd_pars, pm_tables, lct, elev, lc_years,
                  um, flow_dist, velocity, area, abcd_spinup, routing_spinup, water_idx=0, snow_idx=6, use_snow=True,
-                 route_flags=0, chs_prev=None):
+                 route_flags=0, chs_prev=None, plan_async=False):
         self.ctx = ctx
         self.ncell, self.nmonths, self.start_year = int(ncell), int(nmonths), int(start_year)
         self.end_year = self.start_year + self.nmonths // 12 - 1
@@ -66,7 +66,32 @@ class DevicePipeline:
         self.forcing = {}
         self.d_tairprev = None
         self.out = {k: ctx.empty((self.ncell, self.nmonths)) for k in OUTPUTS}
-        self.plan = um.plan(ctx) if um is not None else None
+        # The routing plan (partition of the networks, 50-70 ms of host time at the full grid) touches neither the
+        # context's stream nor the arrays above; with plan_async it is made on a host thread while the caller uploads the
+        # forcing (run_model()), and `plan` waits for it.
+        self._plan, self._plan_thread, self._plan_error = None, None, None
+        if um is not None and plan_async:
+            import threading
+
+            def make():
+                try:
+                    self._plan = um.plan(ctx)
+                except BaseException as exc:      # re-raised by `plan`
+                    self._plan_error = exc
+            self._plan_thread = threading.Thread(target=make, name='xh-route-plan')
+            self._plan_thread.start()
+        elif um is not None:
+            self._plan = um.plan(ctx)
+
+    @property
+    def plan(self):
+        """The device routing plan (None without routing)."""
+        if self._plan_thread is not None:
+            self._plan_thread.join()
+            self._plan_thread = None
+            if self._plan_error is not None:
+                raise self._plan_error
+        return self._plan
 
     # ---- forcing
     def alloc_forcing(self):
