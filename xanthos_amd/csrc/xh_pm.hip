@@ -225,7 +225,7 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             et = fmax(et, 0.0);
         }
         const double term = et * lct_cell[l * lct_stride];            // arr *= lct (:467)
-        acc = (l == 0) ? term : acc + term;                           // np.sum over classes, in order (:470)
+        acc += term;                                                  // np.sum over classes, in order (:470); 0 + x is x
     }
     return fdiv(acc, totpct);
 }
