@@ -159,6 +159,37 @@ def cpu_baseline(pipe, world, args, log):
             'full_size': bool(args.cpu_full and k == nm)}, parity
 
 
+def routing_selective(ctx, pipe, log):
+    """Secondary measurement, never `value`: the routing alone with the opt-in selective plain form (the units
+    that read >= 5 values per sub-step and hold no cell needing both flows gather one 8-byte value per term).  The first
+    calls pay a guard trip and a second plan, which is why the form is not the default; the steady state is what is timed."""
+    from xanthos_amd import _hip
+    os.environ['XH_FLOW_PLAIN_MIN_READS'] = '5'        # read when the typed plan is built, i.e. at the first flagged call
+    flags0 = pipe.route_flags
+    try:
+        pipe.route_flags = flags0 | _hip.XH_ROUTE_TYPED
+        for _ in range(3):                             # plan, guard trip + re-plan with what was learnt, steady
+            pipe.run_mrtm()
+            ctx.sync()                                 # (a guard trip is settled, and learnt from, at a synchronisation)
+        trips0 = int(pipe.plan.typed_info()['guard_trips'])
+        ctx.timing_reset()
+        for _ in range(3):
+            pipe.run_mrtm()
+        ctx.sync()
+        ms, n = ctx.timing('mrtm_route')
+        info = pipe.plan.typed_info()
+    finally:
+        pipe.route_flags = flags0
+        os.environ.pop('XH_FLOW_PLAIN_MIN_READS', None)
+    out = {'mrtm_route_ms': ms / max(n, 1), 'plain_units': int(info['plain_units']), 'units': int(info['typed_units']),
+           'guard_trips': int(info['guard_trips']), 'guard_trips_while_timed': int(info['guard_trips']) - trips0,
+           'typed_builds': int(info['typed_builds']),
+           'note': 'opt-in (XH_ROUTE_TYPED + XH_FLOW_PLAIN_MIN_READS=5); bit-exact; default plan timed in `kernels.mrtm_route`'}
+    log('routing with the selective plain form: {:.2f} ms ({} of {} units plain)'.format(out['mrtm_route_ms'], out['plain_units'],
+                                                                                      out['units']))
+    return out
+
+
 def end_to_end(ctx, pipe, args, log):
     """PCIe-inclusive rate (never `value`): the eight forcing arrays start in page-locked host memory and the six outputs
     end there, as a loader / writer around the boundary would hold them: H2D + loader transform (nan_to_num) + the
@@ -556,6 +587,8 @@ def main():
                                   'unit': 'cell-months/s', 'ms_per_step': 1e3 * r_elapsed / args.steps,
                                   'scaling': 'weak', 'note': '{} independent scenarios, one per GPU'.format(world_size)}
     if rank == 0 and world_size == 1:
+        if 'mrtm' in args.stages and not args.no_end_to_end:
+            result['routing_selective_plain'] = routing_selective(ctx, pipe, log)
         if not args.no_end_to_end:
             result['end_to_end'] = end_to_end(ctx, pipe, args, log)
             pipe.run(args.stages)                      # outputs of the resident run again, for the parity check below
