@@ -160,9 +160,9 @@ def cpu_baseline(pipe, world, args, log):
 
 
 def routing_selective(ctx, pipe, log):
-    """Secondary measurement, never `value`: the routing alone with the opt-in selective plain form (the units
-    that read >= 5 values per sub-step and hold no cell needing both flows gather one 8-byte value per term).  The first
-    calls pay a guard trip and a second plan, which is why the form is not the default; the steady state is what is timed."""
+    """Secondary measurement, never `value`: the routing alone with the selective plain form asked for explicitly (DESIGN.md
+    4.3: the units that read >= 5 values per sub-step and hold no cell needing both flows gather one 8-byte value per term)
+    -- the form the adaptive default reaches by itself after a few calls on one plan; the steady state is what is timed."""
     from xanthos_amd import _hip
     os.environ['XH_FLOW_PLAIN_MIN_READS'] = '5'        # read when the typed plan is built, i.e. at the first flagged call
     flags0 = pipe.route_flags
@@ -184,7 +184,8 @@ def routing_selective(ctx, pipe, log):
     out = {'mrtm_route_ms': ms / max(n, 1), 'plain_units': int(info['plain_units']), 'units': int(info['typed_units']),
            'guard_trips': int(info['guard_trips']), 'guard_trips_while_timed': int(info['guard_trips']) - trips0,
            'typed_builds': int(info['typed_builds']),
-           'note': 'opt-in (XH_ROUTE_TYPED + XH_FLOW_PLAIN_MIN_READS=5); bit-exact; default plan timed in `kernels.mrtm_route`'}
+           'note': 'XH_ROUTE_TYPED + XH_FLOW_PLAIN_MIN_READS=5 from the first call; bit-exact; the default (adaptive) plan is '
+                   'the one timed in `kernels.mrtm_route`, see routing_plan.form'}
     log('routing with the selective plain form: {:.2f} ms ({} of {} units plain)'.format(out['mrtm_route_ms'], out['plain_units'],
                                                                                       out['units']))
     return out
@@ -382,8 +383,8 @@ def cfg_bounds():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='pm_abcd_mrtm', choices=['pm_abcd_mrtm', 'pm_abcd', 'calib'])
     ap.add_argument('--members', type=int, default=512, help='calib: population per basin')
     ap.add_argument('--cpu-calib-seconds', type=float, default=15.0, help='calib: seconds of oracle evaluations to time')
@@ -514,6 +515,13 @@ def main():
         parallelism = ('{} independent scenarios, one per GPU'.format(world_size) if world_size > 1 else
                        'one world on one GPU')
     info = pipe.plan.info() if pipe.plan is not None else {}
+    if pipe.plan is not None:
+        # which form the routing units ran in at the end of the timed steps: a plan that is routed on again and again
+        # switches from the all-pairs partition to the selective plain form after a few calls (adaptive)
+        ti = pipe.plan.typed_info()
+        info['form'] = ('selective plain form ({} of {} units plain; adaptive, tables built on a host thread during the first '
+                        'calls)'.format(ti['plain_units'], ti['typed_units']) if ti['plain_units'] > 0 else 'all units in pair form')
+        info['guard_trips'] = int(ti['guard_trips'])
     log('routing plan: ' + json.dumps(info))
     value = units_per_step * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps

@@ -207,8 +207,13 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
                                        output bit; synchronous; XH_ERR_DEVICE on a difference.  Also switched on for every
                                        call by XH_ROUTE_VALIDATE=1 in the environment.  xh_route_plan_info[15] counts the
                                        validated calls.                                                            */
-#define XH_ROUTE_TYPED 64           /* dataflow units in pair AND plain form (xh_route_plan_typed_info); also
-                                       XH_ROUTE_TYPED=1 in the environment.  Off by default: see DESIGN.md 4.3        */
+#define XH_ROUTE_TYPED 64           /* dataflow units in pair AND plain form from this call on (xh_route_plan_typed_info); also
+                                       XH_ROUTE_TYPED=1 in the environment; XH_FLOW_PLAIN_MIN_READS=n picks the selective
+                                       form (only the units that read >= n values per sub-step).  Without the flag a plan
+                                       that is routed on repeatedly takes up the selective form (n = 5) by itself: the
+                                       tables are built on a host thread from the second plain call on and used once
+                                       they are ready, no call waits for them (XH_ROUTE_AUTO=0 switches that off).  Same
+                                       bits in every form; DESIGN.md 4.3                                            */
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,
                     const double *d_flow_dist, const double *d_velocity, const double *d_area,

@@ -266,11 +266,15 @@ rng = np.random.default_rng(11)
 runoff = rng.gamma(2.0, 30.0, (w.ncell, 12))
 ndays = o_months.set_month_arrays(12, 1973, 1973)[:, 2]
 ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
-import os
+import os, time
 ok = True
-for rep in range(3 if os.environ.get('XH_ROUTE_TYPED') else 1):      # typed: first build, re-build with what was learnt, steady
+# typed: first build, re-build with what was learnt, steady.  XH_TEST_CALLS: repeated plain calls (the adaptive plain form
+# builds its tables on a host thread from the second call on; the pause lets them be ready for the next call)
+for rep in range(3 if os.environ.get('XH_ROUTE_TYPED') else int(os.environ.get('XH_TEST_CALLS', '1'))):
     got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
     ok = ok and all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
+    if os.environ.get('XH_TEST_CALLS'):
+        time.sleep(0.3)
 plan = um.plan(_hip.get_context())
 info = plan.info()
 print(json.dumps({'ok': bool(ok), 'kernel': int(info['last_tree_kernel']), 'units': int(info['flow_units']),
@@ -282,7 +286,9 @@ print(json.dumps({'ok': bool(ok), 'kernel': int(info['last_tree_kernel']), 'unit
                                  {'XH_FLOW_CUTRULE': '0', 'XH_FLOW_TLIMIT': '9'}, {'XH_FLOW_SPARE': '0'},
                                  {'XH_FLOW_SPARE': '700'}, {'XH_FLOW_RS': '16384'}, {'XH_ROUTE_TYPED': '1'},
                                  {'XH_ROUTE_TYPED': '1', 'XH_FLOW_PLAIN_MIN_READS': '5'},
-                                 {'XH_ROUTE_TYPED': '1', 'XH_FLOW_PLAIN_MIN_READS': '3'}])
+                                 {'XH_ROUTE_TYPED': '1', 'XH_FLOW_PLAIN_MIN_READS': '3'}, {'XH_TEST_CALLS': '6'},
+                                 {'XH_TEST_CALLS': '6', 'XH_ROUTE_AUTO': '0'},
+                                 {'XH_TEST_CALLS': '6', 'XH_FLOW_PLAIN_MIN_READS': '3'}])
 def test_route_partition_variants_bit_exact(env, tmp_path):
     """The knobs of the dataflow partition (piece capacity, chains, which children become streams, class-aware packing,
     spare workgroups, ring size; typed partition, and its selective form: only the units with the longest rows run in
@@ -306,6 +312,11 @@ def test_route_partition_variants_bit_exact(env, tmp_path):
         assert res['edges'] > 150, res          # many more streams than the default cut
     if env.get('XH_ROUTE_TYPED'):
         assert res['typed']['typed_builds'] >= 1 and res['typed']['plain_units'] >= 1, res
+    if env.get('XH_TEST_CALLS'):        # repeated plain calls: the adaptive plain form takes over, unless switched off
+        if env.get('XH_ROUTE_AUTO') == '0':
+            assert res['typed']['typed_builds'] == 0 and res['typed']['plain_units'] == 0, res
+        else:
+            assert res['typed']['typed_builds'] >= 1 and res['typed']['plain_units'] >= 1, res
 
 
 @pytest.mark.parametrize('basin', [0, 1])

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 mkdir -p gpurun_out
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end > gpurun_out/bench_under_rocprof.json 2> gpurun_out/bench_under_rocprof.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end > gpurun_out/bench_under_rocprof.json 2> gpurun_out/bench_under_rocprof.log
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
 # counter calibration on the streams' own access shapes: 1 GiB (past the Infinity Cache) and 128 MiB
@@ -23,7 +23,7 @@ cp gpurun_out/prof_trace/*/*kernel_stats.csv gpurun_out/kernel_stats.csv
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d gpurun_out/prof_insts -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/prof_cyc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
 (python3 tools/pmc_summary.py gpurun_out/prof_insts; python3 tools/pmc_summary.py gpurun_out/prof_cyc) | grep -E "k_pm_pet|k_abcd|k_mrtm_wave" > gpurun_out/pmc_insts.txt
-timeout 900 python3 bench.py --steps 5 --warmup 1 > gpurun_out/bench.json 2> gpurun_out/bench.log
+timeout 900 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.log
 timeout 300 python3 bench.py --workload pm_abcd --steps 10 --warmup 2 > gpurun_out/bench_pm_abcd.json 2> gpurun_out/bench_pm_abcd.log
 timeout 600 python3 bench.py --workload calib --steps 5 --warmup 1 > gpurun_out/bench_calib.json 2> gpurun_out/bench_calib.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace_calib -- python3 bench.py --workload calib --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1

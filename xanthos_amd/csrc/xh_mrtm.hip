@@ -22,7 +22,9 @@
 #include <chrono>
 #include <climits>
 #include <cmath>
+#include <atomic>
 #include <numeric>
+#include <thread>
 
 #include "xh_common.h"
 #include "xh_mrtm_flow.h"
@@ -355,6 +357,20 @@ struct xh_route_plan {
     bool typed_disabled = false;                 // a guard fault showed that the plain form does not hold for this data
     int64_t typed_builds = 0;
     bool last_typed = false;                     // the last call ran on the typed plan
+    int typed_sel = -1;                          // plain_min_reads the typed plan at hand was built with (0 = full typed form)
+    // Adaptive plain form (default; XH_ROUTE_AUTO=0 switches it off).  A plan that is routed on again and again -- a
+    // scenario sweep, the bench loop -- is worth a second partition: from the second plain call on, a host thread builds the
+    // SELECTIVE tables (xh_flow_plan.h: all-pairs partition, only the units with the longest rows in plain form) for the
+    // cells seen firing so far; the call that finds them ready uploads them and routes on them from then on (-4 to -5 % per
+    // call).  A caller who routes once or twice never pays for it.  What can go wrong is covered by the
+    // machinery of the typed form: a guard trip re-routes the call in pair form and the tables are rebuilt, in the
+    // background again, with what was learnt.
+    int64_t auto_calls = 0;
+    std::thread auto_thread;
+    std::atomic<int> auto_state{0};              // 0 idle, 1 thread building, 2 tables ready, 3 failed (stays off)
+    FlowTables auto_tables;
+    std::vector<unsigned char> auto_cap;         // the flags the tables in the making are for
+    std::string auto_err;
     int last_tree_kernel = 0;                    // last xh_route_series: 0 none, 1 monthly streams, 2 time-skewed
     int64_t reroutes = 0;                        // calls re-run with one workgroup per network after a device fault
     // After a fault the dataflow kernels are skipped for the next `skip_calls` calls of this plan (the device is shared:
@@ -709,6 +725,7 @@ extern "C" void xh_route_plan_destroy(xh_route_plan *plan) {
                       &plan->d_all_col, &plan->d_all_sgn, &plan->d_all_ds, &plan->d_fbr_cells, &plan->d_fbr_ptr,
                       &plan->d_fbr_col, &plan->d_fbr_sgn, &plan->d_fbr_ds};
     for (DevBuf *b : bufs) free_buf(*b);
+    if (plan->auto_thread.joinable()) plan->auto_thread.join();
     flow_plan_destroy(plan->flow);
     flow_plan_destroy(plan->flow_typed);
     free_buf(plan->d_capable);
@@ -963,8 +980,18 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     // pair units (the cells downstream of cells that can fire, with their imports) pace the run.  XH_ROUTE_TYPED (flag) or
     // XH_ROUTE_TYPED=1 (environment) selects it; results are bit-identical either way.
     static const bool typed_env = getenv("XH_ROUTE_TYPED") && getenv("XH_ROUTE_TYPED")[0] == '1';
-    const bool want_typed = (typed_env || (flags & XH_ROUTE_TYPED) != 0) && plan->flow && !plan->typed_disabled && !plan->h_indptr.empty() &&
-                            (flags & (XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_NO_PLAIN)) == 0;
+    static const bool auto_env = !(getenv("XH_ROUTE_AUTO") && getenv("XH_ROUTE_AUTO")[0] == '0');
+    static const bool old_skew_env = getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] != '1';
+    const bool typed_ok = plan->flow && !plan->typed_disabled && !plan->h_indptr.empty() &&
+                          (flags & (XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_NO_PLAIN)) == 0;
+    const bool explicit_typed = (typed_env || (flags & XH_ROUTE_TYPED) != 0) && typed_ok;
+    // adaptive: plain calls only (no test / validation / variant flag), time-skewed kernel in use, months long enough for it
+    const bool auto_typed = !explicit_typed && auto_env && typed_ok && !old_skew_env && plan->flow->skew_ok &&
+                            (flags & (XH_ROUTE_ATOMIC | XH_ROUTE_TEST_FAULT)) == 0 && plan->auto_state.load() != 3;
+    if (auto_typed) plan->auto_calls += 1;
+    const bool want_typed = explicit_typed || (auto_typed && plan->auto_calls >= 2);
+    const int sel_env = getenv("XH_FLOW_PLAIN_MIN_READS") ? atoi(getenv("XH_FLOW_PLAIN_MIN_READS")) : -1;
+    const int sel_want = sel_env >= 0 ? sel_env : (explicit_typed ? 0 : 5);
     unsigned char *d_cap_new = nullptr;
     if (want_typed) {
         const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
@@ -981,8 +1008,13 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         XH_HIP(ctx, hipMemcpyAsync(plan->h_cap_diff, plan->d_cap_diff, 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (want_typed && (*plan->h_cap_diff != 0 || !plan->flow_typed)) {
-        // (re)build: the set of cells that can fire changed (or this is the first call)
+    // does the typed plan at hand fit this call (same cells that can fire, same form)?
+    const bool typed_fits = want_typed && plan->flow_typed && *plan->h_cap_diff == 0 && plan->typed_sel == sel_want;
+    bool use_typed = typed_fits;
+    if (explicit_typed && !typed_fits) {
+        // (re)build at once: the set of cells that can fire changed, the other form was asked for, or this is the first call
+        if (plan->auto_thread.joinable()) plan->auto_thread.join();      // its tables are for another request
+        if (plan->auto_state.load() != 3) plan->auto_state.store(0);
         const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
         std::vector<unsigned char> cap((size_t)plan->ncell);
         XH_HIP(ctx, hipMemcpy(cap.data(), d_cap_new, cap.size(), hipMemcpyDeviceToHost));
@@ -990,13 +1022,55 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         flow_plan_destroy(plan->flow_typed);
         plan->flow_typed = nullptr;
         std::vector<char> handled;
-        const int frc = flow_plan_build(ctx, (int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
-                                        plan->h_sign.data(), plan->h_comp, plan->h_ncomp, cap.data(), handled,
-                                        &plan->flow_typed);
+        FlowTables t;
+        std::string err;
+        if (flow_tables_host(flow_plan_options(ctx), (int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
+                             plan->h_sign.data(), plan->h_comp, plan->h_ncomp, cap.data(), sel_want, handled, t, err) != 0)
+            return xh_fail(ctx, XH_ERR_ARG, "%s", err.c_str());
+        const int frc = flow_plan_upload(ctx, t, &plan->flow_typed);
         if (frc) return frc;
         plan->typed_builds += 1;
+        plan->typed_sel = sel_want;
+        use_typed = plan->flow_typed != nullptr;
+    } else if (auto_typed && want_typed && !typed_fits) {
+        // adaptive: never wait for a partition.  Tables ready -> take them if they are for today's cells; nothing in the
+        // making -> start a host thread on them; this call routes in pair form either way unless the tables fit.
+        const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
+        int st = plan->auto_state.load();
+        if (st == 2) {
+            plan->auto_thread.join();
+            std::vector<unsigned char> cap((size_t)plan->ncell);
+            XH_HIP(ctx, hipMemcpy(cap.data(), d_cap_new, cap.size(), hipMemcpyDeviceToHost));
+            if (cap == plan->auto_cap) {
+                flow_plan_destroy(plan->flow_typed);
+                plan->flow_typed = nullptr;
+                const int frc = flow_plan_upload(ctx, plan->auto_tables, &plan->flow_typed);
+                plan->auto_tables = FlowTables();
+                if (frc) return frc;
+                XH_HIP(ctx, hipMemcpy(plan->d_capable.p, d_cap_new, nb, hipMemcpyDeviceToDevice));
+                plan->typed_builds += 1;
+                plan->typed_sel = sel_want;
+                use_typed = plan->flow_typed != nullptr;
+            }
+            plan->auto_state.store(0);
+            st = 0;
+        }
+        if (st == 0 && !use_typed) {
+            plan->auto_cap.resize((size_t)plan->ncell);
+            XH_HIP(ctx, hipMemcpy(plan->auto_cap.data(), d_cap_new, plan->auto_cap.size(), hipMemcpyDeviceToHost));
+            plan->auto_state.store(1);
+            xh_route_plan *pl = plan;
+            const FlowPlanOptions opt = flow_plan_options(ctx);      // read here: the thread must not need the context
+            plan->auto_thread = std::thread([pl, opt, sel_want] {
+                std::vector<char> handled;
+                const int rc2 = flow_tables_host(opt, (int)pl->ncell, pl->h_indptr.data(), pl->h_indices.data(), pl->h_sign.data(),
+                                                 pl->h_comp, pl->h_ncomp, pl->auto_cap.data(), sel_want, handled, pl->auto_tables,
+                                                 pl->auto_err);
+                pl->auto_state.store(rc2 == 0 && pl->auto_tables.n_plain_units > 0 ? 2 : 3);
+            });
+        }
     }
-    FlowPlan *tree_plan = (want_typed && plan->flow_typed && plan->flow_typed->n_plain_units > 0) ? plan->flow_typed : plan->flow;
+    FlowPlan *tree_plan = (use_typed && plan->flow_typed && plan->flow_typed->n_plain_units > 0) ? plan->flow_typed : plan->flow;
 
     const bool force_fb = (flags & XH_ROUTE_FORCE_FALLBACK) != 0;
     const bool atomic = (flags & XH_ROUTE_ATOMIC) != 0;

@@ -1,9 +1,11 @@
 // Internal interface between xh_mrtm.hip (plan + API), xh_mrtm_flow.hip (tree partition + monthly-stream dataflow
 // kernel) and xh_mrtm_skew.hip (time-skewed dataflow kernel on the same partition).
 #pragma once
+#include <string>
 #include <vector>
 
 #include "xh_common.h"
+#include "xh_flow_plan.h"
 
 struct FlowBuf {
     void *p = nullptr;
@@ -56,6 +58,14 @@ struct FlowIO {
 int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
                     const std::vector<int> &comp, int ncomp, const unsigned char *capable, std::vector<char> &handled,
                     FlowPlan **out);
+// The two halves of flow_plan_build.  flow_tables_host is plain host work (no HIP call, no context: it may run on a
+// thread of its own while the context is busy, or gone); plain_min_reads >= 0 overrides the environment's
+// XH_FLOW_PLAIN_MIN_READS.  flow_plan_upload allocates and fills the device tables.
+FlowPlanOptions flow_plan_options(const xh_ctx *ctx);      // device size + the XH_FLOW_* switches of the environment
+int flow_tables_host(FlowPlanOptions opt, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
+                     const std::vector<int> &comp, int ncomp, const unsigned char *capable, int plain_min_reads,
+                     std::vector<char> &handled, FlowTables &t, std::string &err);
+int flow_plan_upload(xh_ctx *ctx, const FlowTables &t, FlowPlan **out);
 void flow_plan_destroy(FlowPlan *fp);
 // info: [0] units, [1] stream edges, [2] pipeline depth (levels), [3] cells, [4] max imports of a unit
 void flow_plan_info(const FlowPlan *fp, int64_t info[5]);

@@ -319,7 +319,7 @@ void flow_plan_info(const FlowPlan *fp, int64_t info[5]) {
 
 // The partition itself is host code without any HIP in it (xh_flow_plan.cpp: also built with sanitizers for the host
 // fuzzer, tests/plan_fuzz); here its tables go to the device.  The experiment switches of the planner are read once.
-FlowPlanOptions flow_plan_options(xh_ctx *ctx) {
+FlowPlanOptions flow_plan_options(const xh_ctx *ctx) {
     FlowPlanOptions o;
     o.simds = 4 * (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 0);
     if (const char *e = getenv("XH_FLOW_PIECE_CAP")) o.piece_cap = std::min(std::max(atoi(e), 1), LANES);
@@ -334,22 +334,22 @@ FlowPlanOptions flow_plan_options(xh_ctx *ctx) {
     return o;
 }
 
-int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
-                    const std::vector<int> &comp, int ncomp, const unsigned char *capable, std::vector<char> &handled,
-                    FlowPlan **out) {
-    *out = nullptr;
+int flow_tables_host(FlowPlanOptions opt, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
+                     const std::vector<int> &comp, int ncomp, const unsigned char *capable, int plain_min_reads,
+                     std::vector<char> &handled, FlowTables &t, std::string &err) {
     handled.assign(n, 0);
-    if (n == 0) return XH_OK;
-    FlowPlanOptions opt = flow_plan_options(ctx);
+    t = FlowTables();
+    if (n == 0) return 0;
     opt.capable = capable;
-    FlowTables t;
-    std::string err;
-    if (flow_tables_build(n, indptr, indices, sign, comp.data(), ncomp, opt, handled, t, err) != 0)
-        return xh_fail(ctx, XH_ERR_ARG, "%s", err.c_str());
-    if (t.n_units == 0) return XH_OK;
+    if (plain_min_reads >= 0) opt.plain_min_reads = plain_min_reads;
+    if (flow_tables_build(n, indptr, indices, sign, comp.data(), ncomp, opt, handled, t, err) != 0) return -1;
+    if (t.n_units == 0) return 0;
     if (getenv("XH_FLOW_CHECK")) {      // the invariants the host fuzzer holds the planner to, on this very plan
         const std::string bad = flow_tables_check(n, indptr, indices, sign, handled, t, capable);
-        if (!bad.empty()) return xh_fail(ctx, XH_ERR_ARG, "flow plan check: %s", bad.c_str());
+        if (!bad.empty()) {
+            err = "flow plan check: " + bad;
+            return -1;
+        }
     }
     if (const char *dump = getenv("XH_FLOW_DUMP")) {      // partition as int32 rows [n]: downstream cell, piece, unit, height
         if (FILE *f = fopen(dump, "wb")) {
@@ -365,6 +365,23 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
             fclose(f);
         }
     }
+    return 0;
+}
+
+int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
+                    const std::vector<int> &comp, int ncomp, const unsigned char *capable, std::vector<char> &handled,
+                    FlowPlan **out) {
+    *out = nullptr;
+    FlowTables t;
+    std::string err;
+    if (flow_tables_host(flow_plan_options(ctx), n, indptr, indices, sign, comp, ncomp, capable, -1, handled, t, err) != 0)
+        return xh_fail(ctx, XH_ERR_ARG, "%s", err.c_str());
+    return flow_plan_upload(ctx, t, out);
+}
+
+int flow_plan_upload(xh_ctx *ctx, const FlowTables &t, FlowPlan **out) {
+    *out = nullptr;
+    if (t.n_units == 0) return XH_OK;
     FlowPlan *fp = new FlowPlan();
     fp->skew_ok = t.skew_ok;
     fp->skew_lmax = t.skew_lmax;
