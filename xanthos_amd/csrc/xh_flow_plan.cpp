@@ -478,10 +478,10 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
 }  // namespace
 
 bool flow_plain_class(int pre, int post, bool chained, int &cpre, int &cpost) {
-    static const int plain_nc[][2] = {{1, 1}, {1, 2}, {1, 3}, {2, 2}, {2, 3}, {2, 4}, {3, 3}, {4, 4}};
+    static const int plain_nc[][2] = {{1, 1}, {1, 2}, {1, 3}, {2, 2}, {2, 3}, {2, 4}, {3, 3}, {4, 2}, {3, 4}, {4, 3}, {4, 4}};
     static const int plain_ch[][2] = {{1, 2}, {1, 3}, {1, 4}, {2, 3}, {2, 4}};
     const int(*tab)[2] = chained ? plain_ch : plain_nc;
-    const int cnt = chained ? 5 : 8;
+    const int cnt = chained ? 5 : 11;
     int best = -1;
     for (int i = 0; i < cnt; ++i)
         if (tab[i][0] >= pre && tab[i][1] >= post && (best < 0 || tab[i][0] + tab[i][1] < tab[best][0] + tab[best][1]))
@@ -739,6 +739,7 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
     // plain units: the kernel is compiled for fewer row shapes; round up (the extra terms read the constant zero)
     out.unit_plain.assign(nunit, 0);
     out.typed = have_cap;
+    const std::vector<int> shape_as_cut = out.unit_p;               // before plain units are rounded up to a compiled shape
     std::vector<char> unit_pair(nunit, 1);
     if (have_cap && !selective)
         for (int u = 0; u < nunit; ++u) unit_pair[u] = P.unit_full[u];
@@ -864,6 +865,14 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
         for (int a = 1; a <= 4; ++a)
             for (int b = 1; b <= 4; ++b)
                 if (hpp[a * 5 + b]) fprintf(stderr, " (%d,%d) %d", a, b, hpp[a * 5 + b]);
+        {
+            std::vector<int> up(256, 0);
+            for (int u = 0; u < nunit; ++u)
+                if (out.unit_plain[u] && ((shape_as_cut[u] ^ out.unit_p[u]) & 0xff)) up[shape_as_cut[u] & 0xff]++;
+            fprintf(stderr, "\n  plain units rounded up to a compiled shape, by their own (pre, post):");
+            for (int k = 0; k < 256; ++k)
+                if (up[k]) fprintf(stderr, " (%d,%d) %d", k & 15, k >> 4, up[k]);
+        }
         fprintf(stderr, "\n  plain units by (pre, post) terms:");
         for (int a = 1; a <= 4; ++a)
             for (int b = 1; b <= 4; ++b)

@@ -816,6 +816,8 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
         // plain units come in fewer shapes (a padded 8-byte term costs ~13 cycles): flow_plain_class rounds up to these
         WAVE_PLAIN(1, 1, false) WAVE_PLAIN(1, 2, false) WAVE_PLAIN(1, 3, false) WAVE_PLAIN(2, 2, false)
         WAVE_PLAIN(2, 3, false) WAVE_PLAIN(2, 4, false) WAVE_PLAIN(3, 3, false) WAVE_PLAIN(4, 4, false)
+        // (the few units with the longest rows: in the selective plan they are the ones that pace the run)
+        WAVE_PLAIN(4, 2, false) WAVE_PLAIN(3, 4, false) WAVE_PLAIN(4, 3, false)
         WAVE_PLAIN(1, 2, true) WAVE_PLAIN(1, 3, true) WAVE_PLAIN(1, 4, true) WAVE_PLAIN(2, 3, true) WAVE_PLAIN(2, 4, true)
 #endif
         default:      // not produced by the plan; a fault rather than wrong results
