@@ -786,11 +786,12 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
         //      streams, a cheap one next to a dearer one that gets issue priority.  Which workgroup lands on which SIMD
         //      cannot be planned (it follows the workgroup id only on an idle device), so every workgroup finds out where
         //      it runs and claims its unit from this list (top of k_mrtm_wave): units without streams by rising cost, then
-        //      the others.  Cost per value read: ~25 cycles for a pair (read + two additions), ~13 in a plain unit.
+        //      the others.
         std::vector<int> cost(nunit);
         for (int u = 0; u < nunit; ++u) {
             const int reads = (out.unit_p[u] & 15) + ((out.unit_p[u] >> 4) & 15) + ((out.unit_p[u] & 0x100) ? 1 : 0);
-            cost[u] = (out.unit_plain[u] ? 13 : 25) * reads + (unit_imp_n[u] > 0 ? 15 : 0) + (unit_exp[u] > 0 ? 15 : 0);
+            // measured per sub-step (profiles/round3): pair form 138 + 25 per value read, plain form 193 + 10
+            cost[u] = (out.unit_plain[u] ? 193 + 10 * reads : 138 + 25 * reads) + (unit_imp_n[u] > 0 ? 15 : 0) + (unit_exp[u] > 0 ? 15 : 0);
         }
         auto coupled = [&](int u) { return unit_imp_n[u] > 0 || unit_exp[u] > 0; };
         out.unit_order.resize(nunit);
