@@ -162,9 +162,12 @@ template <> struct Val<true> {
     static __device__ __forceinline__ T zero() { return 0.0; }
 };
 
-template <bool PLAIN, int PRE, int POST, bool HAS_G, bool CHAIN>
+// NG: rounds of 8 imported streams the unit takes part in (0, 1, 2).  Most units with imports have at most 8: a second
+// round that loads nothing still costs its load, its LDS store and its address arithmetic in every block of 8 sub-steps.
+template <bool PLAIN, int PRE, int POST, int NG, bool CHAIN>
 __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint2 *xtab,
                                           __attribute__((address_space(3))) unsigned *qstage, const int unit) {
+    constexpr bool HAS_G = NG > 0;
     typedef Val<PLAIN> V;
     typedef typename V::T val_t;
     typedef typename V::lds_c lds_cv;
@@ -486,10 +489,11 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         xb0[r] = 0.0;
     }
     auto block_io = [&](const int b) {
-        if (HAS_G) {      // both rounds, unconditionally: with a branch around the second one the compiler can no longer count the
-                          // loads in flight and waits for ALL of them (vmcnt(0)) at every block: +60-100 cycles per sub-step
+        if (HAS_G) {      // the unit's rounds, unconditionally (NG is a template argument): with a run-time branch around the
+                          // second one the compiler can no longer count the loads in flight and waits for ALL of them
+                          // (vmcnt(0)) at every block: +60-100 cycles per sub-step
 #pragma unroll
-            for (int r = 0; r < SK_R; ++r) {
+            for (int r = 0; r < NG; ++r) {
                 import_drop(r, gbuf[b][r]);
                 gbuf[b][r] = import_load(r);
             }
@@ -519,9 +523,9 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
 
     check(0);
 #pragma unroll
-    for (int r = 0; r < SK_R; ++r) gbuf[0][r] = HAS_G ? import_load(r) : v4u{0u, 0u, 0u, 0u};      // blocks of iterations 0..7
+    for (int r = 0; r < SK_R; ++r) gbuf[0][r] = r < NG ? import_load(r) : v4u{0u, 0u, 0u, 0u};      // blocks of iterations 0..7
 #pragma unroll
-    for (int r = 0; r < SK_R; ++r) gbuf[1][r] = HAS_G ? import_load(r) : v4u{0u, 0u, 0u, 0u};      // and 8..15
+    for (int r = 0; r < SK_R; ++r) gbuf[1][r] = r < NG ? import_load(r) : v4u{0u, 0u, 0u, 0u};      // and 8..15
 
     const int N = (total + lmax + 1 + GROUP - 1) & ~(GROUP - 1);
     int itz = 0, gz = 0;                 // month whose start zone [gz, gz + lmax] is next (itz == nit: the end zone)
@@ -787,44 +791,50 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     const int unit = unit_sh;
     if (unit < 0) return;
     const int p = A(unit_p)[unit];       // uniform per workgroup: terms before | after the diagonal << 4 | chained << 8 | plain << 9
-    const bool g = __any(A(ghost_edge)[(int64_t)unit * LANES + threadIdx.x] >= 0);
+    const bool has_ghost = A(ghost_edge)[(int64_t)unit * LANES + threadIdx.x] >= 0;      // lane k: the unit's k-th import
+    const bool g = __any(has_ghost), g2 = __any(has_ghost && threadIdx.x >= 8);
     char *l = reinterpret_cast<char *>(lds);
     __attribute__((address_space(3))) unsigned *qst = (__attribute__((address_space(3))) unsigned *)qstage_sh;
     // one specialisation per (terms before, terms after, imports?, chained?, plain?): an LDS read costs a lone wave 8-15
     // cycles of issue, so no unit should read padding it does not need
-#define WAVE_PAIR(PRE, POST, CHAINED)                                              \
-    case (PRE) | ((POST) << 4) | ((CHAINED) ? 0x100 : 0):                          \
-        if (g) wave_unit<false, PRE, POST, true, CHAINED>(ap, l, xtab, qst, unit);            \
-        else wave_unit<false, PRE, POST, false, CHAINED>(ap, l, xtab, qst, unit);             \
+    // NG1 = true compiles the one-round form too (the shapes most units have; each form is ~45 KB of code and ~10 s of
+    // compile time, so the rare shapes send every unit with imports through the two-round form)
+#define WAVE_FORM(PLAINF, PRE, POST, CHAINED, NG1)                                                        \
+    case (PRE) | ((POST) << 4) | ((CHAINED) ? 0x100 : 0) | ((PLAINF) ? 0x200 : 0):                        \
+        if (g2 || (g && !(NG1))) wave_unit<PLAINF, PRE, POST, 2, CHAINED>(ap, l, xtab, qst, unit);        \
+        else if (g) wave_unit<PLAINF, PRE, POST, (NG1) ? 1 : 2, CHAINED>(ap, l, xtab, qst, unit);         \
+        else wave_unit<PLAINF, PRE, POST, 0, CHAINED>(ap, l, xtab, qst, unit);                            \
         break;
-#define WAVE_PLAIN(PRE, POST, CHAINED)                                             \
-    case (PRE) | ((POST) << 4) | ((CHAINED) ? 0x100 : 0) | 0x200:                  \
-        if (g) wave_unit<true, PRE, POST, true, CHAINED>(ap, l, xtab, qst, unit);             \
-        else wave_unit<true, PRE, POST, false, CHAINED>(ap, l, xtab, qst, unit);              \
-        break;
+#define WAVE_PAIR(PRE, POST, CHAINED) WAVE_FORM(false, PRE, POST, CHAINED, false)
+#define WAVE_PAIR1(PRE, POST, CHAINED) WAVE_FORM(false, PRE, POST, CHAINED, true)
+#define WAVE_PLAIN(PRE, POST, CHAINED) WAVE_FORM(true, PRE, POST, CHAINED, false)
+#define WAVE_PLAIN1(PRE, POST, CHAINED) WAVE_FORM(true, PRE, POST, CHAINED, true)
     switch (p) {
 #ifdef XH_WAVE_STUDY      // ISA study build (hipcc -S -DXH_WAVE_STUDY): one pair and one plain shape, nothing else
         WAVE_PAIR(2, 3, false) WAVE_PLAIN(2, 3, false)
 #else
-        WAVE_PAIR(1, 1, false) WAVE_PAIR(1, 2, false) WAVE_PAIR(1, 3, false) WAVE_PAIR(1, 4, false)
-        WAVE_PAIR(2, 1, false) WAVE_PAIR(2, 2, false) WAVE_PAIR(2, 3, false) WAVE_PAIR(2, 4, false)
-        WAVE_PAIR(3, 1, false) WAVE_PAIR(3, 2, false) WAVE_PAIR(3, 3, false) WAVE_PAIR(3, 4, false)
+        WAVE_PAIR1(1, 1, false) WAVE_PAIR1(1, 2, false) WAVE_PAIR1(1, 3, false) WAVE_PAIR1(1, 4, false)
+        WAVE_PAIR(2, 1, false) WAVE_PAIR1(2, 2, false) WAVE_PAIR1(2, 3, false) WAVE_PAIR1(2, 4, false)
+        WAVE_PAIR(3, 1, false) WAVE_PAIR1(3, 2, false) WAVE_PAIR(3, 3, false) WAVE_PAIR(3, 4, false)
         WAVE_PAIR(4, 1, false) WAVE_PAIR(4, 2, false) WAVE_PAIR(4, 3, false) WAVE_PAIR(4, 4, false)
         // chained units: front side 3 or 4 summed on the way, 1 or 2 terms left to read (flow_plan_build)
-        WAVE_PAIR(1, 1, true) WAVE_PAIR(1, 2, true) WAVE_PAIR(1, 3, true) WAVE_PAIR(1, 4, true)
-        WAVE_PAIR(2, 1, true) WAVE_PAIR(2, 2, true) WAVE_PAIR(2, 3, true) WAVE_PAIR(2, 4, true)
+        WAVE_PAIR(1, 1, true) WAVE_PAIR1(1, 2, true) WAVE_PAIR1(1, 3, true) WAVE_PAIR(1, 4, true)
+        WAVE_PAIR(2, 1, true) WAVE_PAIR1(2, 2, true) WAVE_PAIR1(2, 3, true) WAVE_PAIR(2, 4, true)
         // plain units come in fewer shapes (a padded 8-byte term costs ~13 cycles): flow_plain_class rounds up to these
         WAVE_PLAIN(1, 1, false) WAVE_PLAIN(1, 2, false) WAVE_PLAIN(1, 3, false) WAVE_PLAIN(2, 2, false)
-        WAVE_PLAIN(2, 3, false) WAVE_PLAIN(2, 4, false) WAVE_PLAIN(3, 3, false) WAVE_PLAIN(4, 4, false)
+        WAVE_PLAIN1(2, 3, false) WAVE_PLAIN1(2, 4, false) WAVE_PLAIN1(3, 3, false) WAVE_PLAIN(4, 4, false)
         // (the few units with the longest rows: in the selective plan they are the ones that pace the run)
         WAVE_PLAIN(4, 2, false) WAVE_PLAIN(3, 4, false) WAVE_PLAIN(4, 3, false)
-        WAVE_PLAIN(1, 2, true) WAVE_PLAIN(1, 3, true) WAVE_PLAIN(1, 4, true) WAVE_PLAIN(2, 3, true) WAVE_PLAIN(2, 4, true)
+        WAVE_PLAIN(1, 2, true) WAVE_PLAIN1(1, 3, true) WAVE_PLAIN1(1, 4, true) WAVE_PLAIN1(2, 3, true) WAVE_PLAIN(2, 4, true)
 #endif
         default:      // not produced by the plan; a fault rather than wrong results
             if (threadIdx.x == 0) __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#undef WAVE_PLAIN1
 #undef WAVE_PLAIN
+#undef WAVE_PAIR1
 #undef WAVE_PAIR
+#undef WAVE_FORM
 }
 #undef A
 
