@@ -8,20 +8,26 @@ ABCD runoff (spin-up + simulation) -> MRTM routing (spin-up + simulation at 3-ho
 x 600 months (BASELINE.json configs[2]; ``--workload pm_abcd`` runs configs[1]).  Forcing is synthetic
 (xanthos_amd/synth.py distributions), generated on the device and resident in HBM before the timed region.
 
-N > 1 (launched with torch.distributed.run, one rank per GPU): the 235 basins of ONE world are sharded over the ranks
-(BASELINE.json configs[3]; strong scaling) and every step ends with a single gather of the six outputs to rank 0; the
-timed region is bracketed by a barrier and a device synchronise on both sides and the slowest rank's time is used.
+N > 1, one rank process per GPU -- started by torch.distributed.run, or by this script itself when it is run plainly as
+``python bench.py --gpus N`` (it then starts the N rank processes BEFORE anything touches a GPU, relays rank 0's JSON
+line and exits with the worst exit code): the 235 basins of ONE world are sharded over the ranks (BASELINE.json
+configs[3]; strong scaling) and every step ends with a single gather of the six outputs to rank 0 -- PET / AET / Q / Sav
+travel on a second stream while the routing runs; the timed region is bracketed by a barrier and a device synchronise
+on both sides and the slowest rank's time is used.
 The figure for N independent whole-world scenarios (one per GPU, no collective) is measured afterwards and printed as
 the secondary object ``replicas``; ``--replicas`` makes that mode the primary one (weak scaling).
 ``--workload calib`` runs BASELINE configs[4] (one step = one differential-evolution generation of all 235 basins).
 
 Rank 0 prints ONE JSON line: metric cell-months/s (whole job), the roofline object for the dominant kernel
 (HIP-event durations measured on the library's stream inside this run), per-kernel figures, and -- at N = 1 -- the
-CPU baseline: the numpy oracle (a port of the reference's algorithm) timed on this host on a bounded sample.
+CPU baseline: the numpy oracle (a port of the reference's algorithm) timed on this host.  The run is also a GATE: it exits
+with code 3 (after printing the line, which says why in ``gate``) when a value lies beyond the north-star tolerance,
+a NaN pattern differs or the routed series is not bit-identical to the oracle's.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,6 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+SHADER_CLOCK_HZ = 2.4e9        # MI355X peak engine clock (MI355X_MICROARCH.md); s_memtime showed 2.37 GHz under this load
+SUBSTEP_FLOOR_CYCLES = {'pair': 186.0, 'plain': 137.0}      # lone-wave cost of one routing sub-step (tools/micro/substep_plain.hip)
 NCELL, NBASINS = 67420, 235
 
 
@@ -45,42 +53,64 @@ def algorithmic_bytes(ncell, nmonths, nlcs, abcd_spinup, routing_spinup):
     }
 
 
+def cpu_mrtm_child(workdir):
+    """``python bench.py --cpu-mrtm-child DIR``: the whole routed series on the CPU, in a process that never touches the GPU
+    (nothing of xanthos_amd is imported here).  Reads the run's own runoff and the routing inputs from DIR, routes spin-up +
+    every month with the oracle -- river networks dealt over worker processes, every cell's bits those of the serial loops
+    (oracle/mrtm.py) -- and leaves ChStorage / Avg_ChFlow and the timing there."""
+    import scipy.sparse as sparse
+    from oracle import mrtm as o_mrtm
+    z = np.load(os.path.join(workdir, 'inputs.npz'))
+    um = sparse.csr_matrix((z['data'], z['indices'], z['indptr']), shape=(len(z['area']), len(z['area'])))
+    q = np.load(os.path.join(workdir, 'q.npy'), mmap_mode='r')
+    n_procs = int(z['n_procs'])
+    t = time.perf_counter()
+    chs, avg, _, cpu = o_mrtm.route_series_by_network(um, z['flow_dist'], z['velocity'], z['area'], q, z['ndays'],
+                                                      int(z['spinup']), n_procs=n_procs)
+    wall = time.perf_counter() - t
+    np.save(os.path.join(workdir, 'chs.npy'), chs)
+    np.save(os.path.join(workdir, 'avg.npy'), avg)
+    json.dump({'wall_s': wall, 'cpu_s': cpu, 'n_procs': n_procs}, open(os.path.join(workdir, 'timing.json'), 'w'))
+
+
 def cpu_baseline(pipe, world, args, log):
     """Time the numpy oracle (a port of the reference's algorithm) on this host and check the GPU outputs against it.
 
     Sizes: PM on the FULL grid for the first ``--cpu-pm-years`` years (it is linear in years), 1 thread
     like the reference; ABCD at FULL size (67,420 cells x all months + spin-up) on joblib threads like the reference's
-    ``jobs = -1``; MRTM on the full grid (networks cannot be sampled) for ``--cpu-mrtm-months`` months, 1 thread,
-    scipy CSR like the reference -- ``--cpu-full`` routes the whole series (spin-up + all months, ~3-4 min) and
-    compares every value of the run's ChStorage / Avg_ChFlow bit for bit."""
+    ``jobs = -1``; MRTM at FULL size (spin-up + every month of the full grid) in a child process that never touches the
+    GPU, the river networks dealt over ``--cpu-mrtm-procs`` worker processes; its rate is quoted per thread (work / summed
+    process time of the workers: the reference routes on one thread) and every value of the run's ChStorage / Avg_ChFlow
+    is compared bit for bit.  ``--cpu-mrtm-months K`` (K > 0) routes only the first K months instead (quick runs).
+
+    Returns (baseline object, parity object, gate failures)."""
     from types import SimpleNamespace
     from oracle import abcd as o_abcd, mrtm as o_mrtm, pm as o_pm
     from xanthos_amd import synth
     nm, y0 = pipe.nmonths, pipe.start_year
-    res, parity = {}, {'tolerance_used': {}}
-
-    def gate(x, ref):
-        """Worst |x - ref| as a fraction of the north-star tolerance 1e-6 |ref| + 1e-9 (must stay <= 1)."""
-        m = ~np.isnan(ref)
-        assert np.array_equal(np.isnan(x), np.isnan(ref))
-        return float(np.max(np.abs(x[m] - ref[m]) / (1e-6 * np.abs(ref[m]) + 1e-9)))
-
-    def relerr(x, ref):
-        m = ~np.isnan(ref)
-        return float(np.max(np.abs(x[m] - ref[m]) / (np.abs(ref[m]) + 1e-9)))
+    res, parity, failures = {}, {'tolerance_used': {}}, []
 
     def report(name, x, ref):
         """SURVEY 8(d) parity gate: max relative error, its 99.999-th percentile, values off by more than 1e-9 relative
-        (a flipped branch of a tiered function shows up there long before the 1e-6 gate) and values beyond the gate."""
-        m = ~np.isnan(ref)
-        rel = np.abs(x[m] - ref[m]) / (np.abs(ref[m]) + 1e-9)
+        (a flipped branch of a tiered function shows up there long before the 1e-6 gate) and values beyond the gate
+        1e-6 |ref| + 1e-9 (the north star's tolerance; any such value, or a differing NaN pattern, fails the run)."""
+        nan_equal = bool(np.array_equal(np.isnan(x), np.isnan(ref)))
+        parity.setdefault('nan_pattern_equal', {})[name] = nan_equal
+        if not nan_equal:
+            failures.append('{}: NaN pattern differs from the oracle'.format(name))
+        m = ~(np.isnan(ref) | np.isnan(x))
+        diff = np.abs(x[m] - ref[m])
+        rel = diff / (np.abs(ref[m]) + 1e-9)
         parity[name] = float(rel.max())
-        parity['tolerance_used'][name] = gate(x, ref)
+        parity['tolerance_used'][name] = float(np.max(diff / (1e-6 * np.abs(ref[m]) + 1e-9)))
         parity.setdefault('p99_999', {})[name] = float(np.percentile(rel, 99.999))
         parity.setdefault('branch_flip_candidates', {})[name] = int((rel > 1e-9).sum())
-        parity.setdefault('beyond_gate', {})[name] = int((np.abs(x[m] - ref[m]) > 1e-6 * np.abs(ref[m]) + 1e-9).sum())
+        beyond = int((diff > 1e-6 * np.abs(ref[m]) + 1e-9).sum())
+        parity.setdefault('beyond_gate', {})[name] = beyond
+        if beyond:
+            failures.append('{}: {} values beyond 1e-6 |ref| + 1e-9'.format(name, beyond))
         parity.setdefault('values_compared', {})[name] = int(m.sum())
-        parity.setdefault('nan_values', {})[name] = int((~m).sum())
+        parity.setdefault('nan_values', {})[name] = int(np.isnan(ref).sum())
 
     # ---- PM: the whole grid, first pm_years years
     pm_years = min(args.cpu_pm_years, nm // 12)
@@ -107,20 +137,41 @@ def cpu_baseline(pipe, world, args, log):
     del aet, sav, pr, tn, got_pet
 
     # ---- MRTM: the whole grid, scipy CSR like the reference, from the run's own runoff
+    mrtm_full = 'mrtm' in args.stages and args.cpu_mrtm_months <= 0
     if 'mrtm' in args.stages:
-        from xanthos_amd.routing import mrtm
         q_run = pipe.out['q'].download()
         um = pipe.um.tocsr()
-        if args.cpu_full:
-            t = time.perf_counter()
-            r_chs, r_avg, _ = o_mrtm.route_series(um, world.flow_dist, world.velocity, world.area, q_run, pipe.ndays,
-                                                  pipe.routing_spinup)
-            t_mrtm = time.perf_counter() - t
+        if mrtm_full:
+            import shutil
+            import tempfile
+            n_procs = args.cpu_mrtm_procs if args.cpu_mrtm_procs > 0 else max(1, min(os.cpu_count() or 1, 16))
+            base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else None
+            work = tempfile.mkdtemp(prefix='xh_cpu_mrtm_', dir=base)
+            try:
+                np.save(os.path.join(work, 'q.npy'), q_run)
+                np.savez(os.path.join(work, 'inputs.npz'), data=um.data, indices=um.indices, indptr=um.indptr,
+                         flow_dist=world.flow_dist, velocity=world.velocity, area=world.area, ndays=pipe.ndays,
+                         spinup=pipe.routing_spinup, n_procs=n_procs)
+                env = dict(os.environ)
+                env['HIP_VISIBLE_DEVICES'] = env['ROCR_VISIBLE_DEVICES'] = ''      # belt and braces: it imports no GPU code
+                for v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+                    env[v] = '1'
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-mrtm-child', work], env=env)
+                if child.returncode != 0:
+                    raise RuntimeError('the CPU routing child exited with code {}'.format(child.returncode))
+                tm = json.load(open(os.path.join(work, 'timing.json')))
+                r_chs, r_avg = np.load(os.path.join(work, 'chs.npy')), np.load(os.path.join(work, 'avg.npy'))
+            finally:
+                shutil.rmtree(work, ignore_errors=True)
+            t_mrtm, t_wall = tm['cpu_s'], tm['wall_s']
             res['mrtm'] = world.ncell * (nm + pipe.routing_spinup) / t_mrtm
-            parity['routing_bit_exact'] = bool(np.array_equal(pipe.out['chs'].download(), r_chs, equal_nan=True) and
-                                               np.array_equal(pipe.out['avg'].download(), r_avg, equal_nan=True))
-            parity['routing_months_checked'] = '{} spin-up + {} (the whole run)'.format(pipe.routing_spinup, nm)
+            g_chs, g_avg = pipe.out['chs'].download(), pipe.out['avg'].download()
+            parity['routing_months_checked'] = '{} spin-up + {} (the whole run, every cell)'.format(pipe.routing_spinup, nm)
+            mrtm_note = ('MRTM whole series ({} + {} months) in a child process, {} worker processes over river networks: '
+                         '{:.3g} cm/s per thread ({:.1f} s of process time, {:.1f} s wall)'.format(
+                             pipe.routing_spinup, nm, n_procs, res['mrtm'], t_mrtm, t_wall))
         else:
+            from xanthos_amd.routing import mrtm
             km = min(args.cpu_mrtm_months, nm)
             q_host = q_run[:, :km].copy()
             t = time.perf_counter()
@@ -130,33 +181,39 @@ def cpu_baseline(pipe, world, args, log):
             res['mrtm'] = world.ncell * km / t_mrtm
             g_chs, g_avg, _ = mrtm.route_series(pipe.um, world.flow_dist, world.velocity, world.area, q_host,
                                                 pipe.ndays[:km], 0)
-            parity['routing_bit_exact'] = bool(np.array_equal(g_chs, r_chs, equal_nan=True) and
-                                               np.array_equal(g_avg, r_avg, equal_nan=True))
-            parity['routing_months_checked'] = '{} (no spin-up); --cpu-full checks the whole run'.format(km)
+            parity['routing_months_checked'] = '{} (no spin-up); the default checks the whole run'.format(km)
+            mrtm_note = 'MRTM {} months 1 thread = {:.3g} cm/s ({:.1f} s), x{:.2f} for routing spin-up'.format(
+                km, res['mrtm'], t_mrtm, 1.0 + pipe.routing_spinup / nm)
+        parity['routing_bit_exact'] = bool(np.array_equal(g_chs, r_chs, equal_nan=True) and
+                                           np.array_equal(g_avg, r_avg, equal_nan=True))
+        parity['routing_values_compared'] = int(g_chs.size + g_avg.size)
+        if not parity['routing_bit_exact']:
+            bad = int((~((g_chs == r_chs) | (np.isnan(g_chs) & np.isnan(r_chs)))).sum() +
+                      (~((g_avg == r_avg) | (np.isnan(g_avg) & np.isnan(r_avg)))).sum())
+            failures.append('routing: {} values of ChStorage / Avg_ChFlow differ from the oracle'.format(bad))
     inv = 1.0 / res['pm'] + 1.0 / res['abcd']        # the ABCD rate already includes its spin-up pass
     if 'mrtm' in res:
-        inv += (1.0 + pipe.routing_spinup / nm) / res['mrtm'] if not args.cpu_full else \
-            (1.0 + pipe.routing_spinup / nm) / res['mrtm']
+        # the full-size rate counts the spin-up months as work done; the sampled one is scaled by them
+        inv += (1.0 + pipe.routing_spinup / nm) / res['mrtm']
     value = 1.0 / inv
     sample = ('numpy oracle on the full 67,420-cell grid: PM {} months 1 thread = {:.3g} cm/s ({:.1f} s); ABCD {}+{} '
               'months joblib {} threads = {:.3g} cm/s ({:.1f} s)'.format(k, res['pm'], t_pm, nm, pipe.abcd_spinup,
                                                                        os.cpu_count(), res['abcd'], t_abcd))
     if 'mrtm' in res:
-        sample += '; MRTM {} 1 thread = {:.3g} cm/s ({:.1f} s), x{:.2f} for routing spin-up'.format(
-            'whole series' if args.cpu_full else '{} months'.format(min(args.cpu_mrtm_months, nm)), res['mrtm'],
-            t_mrtm, 1.0 + pipe.routing_spinup / nm)
+        sample += '; ' + mrtm_note
     sample += '; value = harmonic composition of the stage rates per simulated cell-month'
     log('cpu baseline: ' + sample)
     log('parity: ' + json.dumps(parity))
     stages = {'pm': 'sample: full grid, {} of {} months (linear in months)'.format(k, nm),
               'abcd': 'full size: {} cells x ({} + {} spin-up) months'.format(world.ncell, nm, pipe.abcd_spinup)}
     if 'mrtm' in res:
-        stages['mrtm'] = ('full size: {} spin-up + {} months'.format(pipe.routing_spinup, nm) if args.cpu_full else
+        stages['mrtm'] = ('full size: {} spin-up + {} months'.format(pipe.routing_spinup, nm) if mrtm_full else
                           'sample: full grid, {} of {} months, scaled by (1 + spin-up / months)'.format(
                               min(args.cpu_mrtm_months, nm), nm))
     return {'value': value, 'unit': 'cell-months/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': sample,
             'stage_rates': res, 'stages': stages,
-            'full_size': bool(args.cpu_full and k == nm)}, parity
+            'full_size': bool(mrtm_full or 'mrtm' not in args.stages),      # full size for ABCD / MRTM
+            'full_size_stages': {'pm': bool(k == nm), 'abcd': True, 'mrtm': bool(mrtm_full)}}, parity, failures
 
 
 def routing_selective(ctx, pipe, log):
@@ -380,6 +437,44 @@ def cfg_bounds():
     return BOUNDS
 
 
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start the N rank processes here, BEFORE anything in this process
+    has touched a GPU (never exec, never after a HIP call), one per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would; relay rank 0's JSON line as this process's stdout and return the worst exit code."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(args.gpus), 'LOCAL_WORLD_SIZE': str(args.gpus),
+                    'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # a rank that dies leaves the others inside a collective: once one has failed, the rest get a grace period
+    import threading
+    worst, deadline, got = 0, None, []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()))      # drained while the ranks run
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        codes = [p.poll() for p in procs]
+        if deadline is None and any(c not in (None, 0) for c in codes):
+            deadline = time.time() + 30.0
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    reader.join()
+    for p in procs:
+        worst = max(worst, abs(p.returncode) if p.returncode else 0)
+    sys.stdout.write((got[0] if got else b'').decode(errors='replace'))
+    sys.stdout.flush()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -396,14 +491,25 @@ def main():
                     help='N > 1: every rank runs its own whole world (weak scaling) instead of sharding ONE world')
     ap.add_argument('--strong', action='store_true', help='(default for N > 1; kept for compatibility)')
     ap.add_argument('--no-replica-figure', action='store_true', help='N > 1: skip the secondary replica measurement')
+    ap.add_argument('--check-gather', action='store_true',
+                    help='N > 1: rank 0 also runs the WHOLE world unsharded and compares the gathered arrays bit for bit')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-end-to-end', action='store_true')
-    ap.add_argument('--cpu-full', action='store_true', help='CPU baseline routes the whole series (3-4 min) and '
-                                                            'checks every routed value of the run bit for bit')
+    ap.add_argument('--cpu-full', action='store_true', help='(the default now; kept for compatibility)')
     ap.add_argument('--cpu-pm-years', type=int, default=5)
-    ap.add_argument('--cpu-mrtm-months', type=int, default=60)
+    ap.add_argument('--cpu-mrtm-months', type=int, default=0,
+                    help='0 (default): the CPU baseline routes the WHOLE series in a child process and every routed value '
+                         'of the run is checked bit for bit; K > 0: only the first K months (quick runs)')
+    ap.add_argument('--cpu-mrtm-procs', type=int, default=0,
+                    help='worker processes of the CPU routing (river networks dealt over them); 0 = min(cores, 16)')
+    ap.add_argument('--cpu-mrtm-child', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--no-gate', action='store_true', help='report parity failures in the line but exit 0')
     ap.add_argument('--route-flags', type=int, default=0)
     args = ap.parse_args()
+    if args.cpu_mrtm_child:                                     # CPU-only child of the baseline leg: no GPU code is imported
+        return cpu_mrtm_child(args.cpu_mrtm_child)
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))                            # before any GPU call in this process
     args.stages = ('pm', 'abcd', 'mrtm') if args.workload == 'pm_abcd_mrtm' else ('pm', 'abcd')
     if args.workload == 'calib' and args.months == 600:
         args.months = 480                                       # BASELINE configs[4]: 480 + 120 spin-up months
@@ -412,9 +518,6 @@ def main():
     world_size = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node {} '
-                             '--master-addr 127.0.0.1 bench.py --gpus {} ...'.format(args.gpus, args.gpus))
         raise SystemExit('--gpus {} does not match WORLD_SIZE {}'.format(args.gpus, world_size))
 
     def log(msg):
@@ -500,7 +603,7 @@ def main():
         run_world, run_um = xdist.sub_world(world, um, shard)
         pipe = pipeline_from_world(ctx, run_world, args.months, args.start_year, args.abcd_spinup,
                                    args.routing_spinup, um=run_um, route_flags=args.route_flags)
-        xdist.fill_shard_forcing(ctx, world, shard, pipe, synth.MASTER_SEED + 1)
+        xdist.fill_shard_forcing(ctx, world, shard, pipe, synth.MASTER_SEED + 1, nan_frac=0.001)      # the whole world's rows
         gather = xdist.OutputGather(ctx, pipe, shards, rank, world.ncell, dist, torch,
                                     names=('pet', 'aet', 'q', 'sav') + (('chs', 'avg') if 'mrtm' in args.stages else ()))
         elapsed = timed(pipe, gather.run)
@@ -539,36 +642,82 @@ def main():
                 k['frac_of_hbm_peak'] = k['achieved_GBs'] / HBM_PEAK_GBS
             kernels[name] = k
     args._kernel_s = sum(k['avg_ms'] for k in kernels.values()) * 1e-3
-    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (profiles/roundN/
-    # pmc_traffic.json, made by tools/pmc_to_json.py): counters cannot be read from inside the run itself
-    traffic, traffic_src = {}, None
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', 'pmc_traffic.json'))):
-        try:
-            pm = json.load(open(f))
-            traffic = {'pm_pet': pm.get('k_pm_pet', {}).get('hbm_bytes'), 'abcd_spinup': pm.get('k_abcd<true>', {}).get('hbm_bytes'),
-                       'abcd_sim': (pm.get('k_abcd_tile<false') or pm.get('k_abcd<false>', {})).get('hbm_bytes'),
-                       'mrtm_route': (pm.get('k_mrtm_wave') or pm.get('k_mrtm_skew') or pm.get('k_mrtm_flow', {})).get('hbm_bytes')}
-            traffic_src = os.path.relpath(f, ROOT)
-        except (OSError, ValueError):
-            pass
+    # HBM traffic and instruction counts per launch come from the committed rocprofv3 PMC passes of this same command
+    # (profiles/roundN/pmc_traffic.json and pmc_insts.json, made by tools/pmc_to_json.py / tools/pmc_insts_json.py):
+    # counters cannot be read from inside the run itself.  Each figure carries the device kernel it was taken from and the
+    # date of the pass, and is REFUSED (null, with the reason) when that is not the kernel that ran here.
+    ran = {'pm_pet': 'k_pm_pet', 'abcd_spinup': 'k_abcd<true>', 'abcd_sim': 'k_abcd_tile<false',
+           'mrtm_route': {2: 'k_mrtm_wave', 3: 'k_mrtm_skew', 1: 'k_mrtm_flow'}.get(int(info.get('last_tree_kernel', 0)),
+                                                                                      'k_mrtm_units')}
+    if os.environ.get('XH_ABCD_KERNEL') in ('0', '64'):
+        ran['abcd_sim'] = 'k_abcd<false>' if os.environ['XH_ABCD_KERNEL'] == '0' else 'k_abcd_tile<false'
+    if os.environ.get('XH_MRTM_SKEW') == '2':
+        ran['mrtm_route'] = 'k_mrtm_skew'
     full_config = (args.months == 600 and args.abcd_spinup == 120 and args.routing_spinup == 120 and not sharded)
-    for k, v in traffic.items():
-        if k in kernels and v and full_config:
-            kernels[k]['traffic_bytes'] = v
+
+    def committed(fname):
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', fname)))
+        for f in reversed(files):
+            try:
+                return json.load(open(f)), os.path.relpath(f, ROOT)
+            except (OSError, ValueError):
+                continue
+        return {}, None
+    pmc_t, traffic_src = committed('pmc_traffic.json')
+    pmc_i, insts_src = committed('pmc_insts.json')
+    traffic_note = {}
+    for k, dev in ran.items():
+        if k not in kernels:
+            continue
+        kernels[k]['device_kernel'] = dev
+        rec = pmc_t.get(dev)
+        if not full_config:
+            traffic_note[k] = 'not the configuration the counters were collected on'
+        elif not rec or not rec.get('hbm_bytes'):
+            traffic_note[k] = 'no counter pass of {} in {}'.format(dev, traffic_src)
+        else:
+            kernels[k]['traffic_bytes'] = rec['hbm_bytes']
     dominant = max((k for k in kernels if k in algo), key=lambda k: kernels[k]['avg_ms'])
     roofline = {'kernel': dominant, 'bound': 'hbm', 'achieved': kernels[dominant]['achieved_GBs'],
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dominant]['frac_of_hbm_peak'],
-                'traffic': kernels[dominant].get('traffic_bytes'), 'traffic_source': traffic_src,
+                'traffic': kernels[dominant].get('traffic_bytes'),
+                'traffic_source': {'file': traffic_src, 'device_kernel': ran[dominant],
+                                   'collected': pmc_t.get('_meta', {}).get('collected'),
+                                   'refused': traffic_note.get(dominant)},
                 'note': 'mrtm_route is bound by the sub-step latency / instruction issue of one wave per unit, not by '
-                        'HBM; see DESIGN.md 4.3' if dominant == 'mrtm_route' else ''}
+                        'HBM (critical_path below is the figure of merit); see DESIGN.md 4.3' if dominant == 'mrtm_route' else ''}
+    # Penman-Monteith is bound by fp64 VALU issue -- wave-instructions x 4 cycles / (SIMDs x cycles of the launch)
+    if 'pm_pet' in kernels:
+        rec = pmc_i.get('k_pm_pet', {})
+        simds = 4 * int(ctx.cu_count())
+        k = kernels['pm_pet']
+        if rec.get('SQ_INSTS_VALU') and full_config:
+            k['valu_wave_insts'] = rec['SQ_INSTS_VALU']
+            k['valu_frac'] = rec['SQ_INSTS_VALU'] * 4.0 / (simds * k['avg_ms'] * 1e-3 * SHADER_CLOCK_HZ)
+            k['lane_insts_per_cell_month'] = rec['SQ_INSTS_VALU'] * 64.0 / (pipe.ncell * pipe.nmonths)
+        roofline['pm_pet'] = {'bound': 'fp64 valu issue', 'valu_frac': k.get('valu_frac'),
+                              'valu_wave_insts': k.get('valu_wave_insts'), 'cycles_per_wave_inst': 4, 'simds': simds,
+                              'clock_hz': SHADER_CLOCK_HZ, 'avg_ms': k['avg_ms'],
+                              'source': {'file': insts_src, 'device_kernel': 'k_pm_pet',
+                                         'collected': pmc_i.get('_meta', {}).get('collected')}}
     if dominant == 'mrtm_route':
         nsub = int(sum(int(d * 86400 / 10800) for d in pipe.ndays)) + \
             int(sum(int(d * 86400 / 10800) for d in pipe.ndays[:args.routing_spinup]))
+        us = kernels['mrtm_route']['avg_ms'] * 1e3 / nsub
         roofline['substeps'] = nsub
-        roofline['us_per_substep'] = kernels['mrtm_route']['avg_ms'] * 1e3 / nsub
+        roofline['us_per_substep'] = us
         roofline['cell_substeps_per_s'] = pipe.ncell * nsub / (kernels['mrtm_route']['avg_ms'] * 1e-3)
-        roofline['cycles_per_substep_at_2.4GHz'] = roofline['us_per_substep'] * 2400.0
+        # T >= N_substeps x t_substep.  The floor is what ONE sub-step of a lone wave costs with nothing else on
+        # the device (tools/micro/substep_plain.hip, MI355X, round 3: a (2,3)-term unit in pair form / a (2,4)-term unit in
+        # plain form); achieved = the launch's time per sub-step in shader cycles.
+        achieved = us * 1e-6 * SHADER_CLOCK_HZ
+        roofline['critical_path'] = {'substeps': nsub, 'floor_cycles': SUBSTEP_FLOOR_CYCLES['pair'],
+                                     'floor_cycles_plain_form': SUBSTEP_FLOOR_CYCLES['plain'],
+                                     'achieved_cycles': achieved, 'frac': SUBSTEP_FLOOR_CYCLES['pair'] / achieved,
+                                     'frac_plain_form': SUBSTEP_FLOOR_CYCLES['plain'] / achieved,
+                                     'clock_hz': SHADER_CLOCK_HZ,
+                                     'floor_source': 'tools/micro/substep_plain.hip (lone wave, no neighbours, no streams)'}
 
     result = {
         'metric': 'cell-months/sec (pm_abcd_mrtm, 67,420 cells)' if args.workload == 'pm_abcd_mrtm'
@@ -582,8 +731,28 @@ def main():
                    'parallelism': parallelism},
         'roofline': roofline, 'kernels': kernels, 'routing_plan': info,
     }
+    gate_failed = False
     if sharded:
         result['gather'] = gather.report()
+        if args.check_gather:
+            # what rank 0 holds after the gather against the same world run unsharded on its own GPU (same seed: the random
+            # streams are keyed on the global cell index), every output, bit for bit
+            ok, diff = True, {}
+            if rank == 0:
+                got = gather.last()
+                wpipe = whole_world_pipeline(synth.MASTER_SEED + 1)
+                wpipe.run(args.stages)
+                ctx.sync()
+                for k in gather.names:
+                    same = bool(np.array_equal(got[k], wpipe.out[k].download(), equal_nan=True))
+                    diff[k] = same
+                    ok = ok and same
+                for a in list(wpipe.out.values()) + list(wpipe.forcing.values()) + [wpipe.d_tairprev]:
+                    a.free()
+            result['gather']['equals_unsharded'] = ok
+            result['gather']['equals_unsharded_by_output'] = diff
+            if rank == 0 and not ok:
+                gate_failed = not args.no_gate
         if not args.no_replica_figure:
             # secondary figure: N independent whole-world scenarios, one per GPU (no collective on the data path)
             gather.close()
@@ -602,15 +771,32 @@ def main():
             pipe.run(args.stages)                      # outputs of the resident run again, for the parity check below
             ctx.sync()
         if not args.no_cpu_baseline:
-            base, parity = cpu_baseline(pipe, world, args, log)
+            base, parity, failures = cpu_baseline(pipe, world, args, log)
             result['cpu_baseline'] = base
             result['parity'] = parity
             result['speedup_vs_cpu_baseline'] = value / base['value']
+            # the run is a gate: a value beyond the north-star tolerance, a differing NaN pattern or a routed value that is
+            # not the oracle's bit for bit makes the process exit non-zero (after the line, which says why)
+            result['gate'] = {'passed': not failures, 'failures': failures,
+                              'checks': 'PET / AET / Q / Sav within 1e-6 |ref| + 1e-9 of the oracle with identical NaN '
+                                        'patterns; ChStorage / Avg_ChFlow bit-identical ({})'.format(
+                                            parity.get('routing_months_checked', 'no routing'))}
+            gate_failed = bool(failures) and not args.no_gate
+    if dist is not None:
+        # ranks the collective layer really sees (a sum over the process group, not the launcher's word for it)
+        tt = torch.tensor([1.0], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        result['n_ranks_seen'] = int(tt.item())
+    else:
+        result['n_ranks_seen'] = 1
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if gate_failed:
+        log('GATE FAILED: ' + '; '.join(result['gate']['failures']))
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -140,7 +140,8 @@ void xh_route_plan_destroy(xh_route_plan *plan);
  * [7]=dataflow units, [8]=stream edges between them, [9]=pipeline depth, [10]=cells routed by the dataflow kernel,
  * [11]=most imported streams of one unit, [12]=deepest lane lag of the time-skewed layout in sub-steps (-1: layout
  * not available), [13]=kernel that routed the tree networks in the last xh_route_series call on this plan (0 none,
- * 1 lock-step units with monthly streams, 2 time-skewed units), [14]=calls of this plan re-run with one workgroup per
+ * 1 lock-step units with monthly streams, 2 time-skewed units, 3 time-skewed units on round 2's kernel because the
+ * grid's rows lie beyond the 32-bit offsets of the current one), [14]=calls of this plan re-run with one workgroup per
  * network after a device fault, [15]=calls cross-checked by XH_ROUTE_VALIDATE */
 int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]);
 

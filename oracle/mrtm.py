@@ -141,3 +141,63 @@ def route_series(UM, flow_dist, velocity, area, runoff, ndays, spinup_months, S0
         chs[:, nm] = S
         avg[:, nm] = favg
     return chs, avg, F
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same month loops, river network by river network (checker / CPU baseline at full size; test infrastructure).
+#
+# Rows of UM only couple cells of one river network, so routing a union of whole networks on its own gives every cell
+# of it the bits of the whole-grid run: a row's sum is taken over the same terms in the same stored (ascending column)
+# order -- `network_groups` keeps each group's cells ascending, so the re-indexed columns keep their order -- and the
+# reference's global ``sx.any()`` branch (mrtm.py:56-76) recomputes ``UM.dot(F)`` only to the same bits for rows none of
+# whose terms changed.  ``tests/test_oracle_golden.py`` holds this to the serial loops bit for bit.
+
+
+def network_groups(UM, n_groups):
+    """Cells of whole river networks, dealt largest-first onto ``n_groups`` groups (each sorted ascending)."""
+    from scipy.sparse.csgraph import connected_components
+    ncomp, label = connected_components(UM, directed=False)
+    sizes = np.bincount(label, minlength=ncomp)
+    load = np.zeros(n_groups, dtype=np.int64)
+    owner = np.empty(ncomp, dtype=np.int64)
+    for comp in np.argsort(-sizes, kind='stable'):
+        g = int(np.argmin(load))
+        owner[comp] = g
+        load[g] += sizes[comp]
+    cell_group = owner[label]
+    return [np.nonzero(cell_group == g)[0] for g in range(n_groups) if load[g] > 0]
+
+
+def _route_group(job):
+    import time
+    UM, cells, flow_dist, velocity, area, runoff, ndays, spinup_months, S0, dt = job
+    sub = UM[cells][:, cells].tocsr()
+    sub.sort_indices()
+    t = time.process_time()
+    chs, avg, F = route_series(sub, flow_dist[cells], velocity[cells], area[cells], np.ascontiguousarray(runoff[cells]),
+                               ndays, spinup_months, None if S0 is None else np.asarray(S0)[cells], dt)
+    return cells, chs, avg, F, time.process_time() - t
+
+
+def route_series_by_network(UM, flow_dist, velocity, area, runoff, ndays, spinup_months, S0=None, dt=10800,
+                            n_procs=1):
+    """``route_series`` over disjoint groups of whole river networks, ``n_procs`` worker processes.
+
+    Returns (ChStorage, Avg_ChFlow, F_end, cpu_seconds) -- ``cpu_seconds`` is the process time the workers spent in the
+    month loops, summed: the one-thread cost of the run (the reference routes on one thread)."""
+    UM = UM.tocsr()
+    ncell, nmonths = runoff.shape
+    groups = network_groups(UM, max(1, int(n_procs)))
+    jobs = [(UM, c, flow_dist, velocity, area, runoff, ndays, spinup_months, S0, dt) for c in groups]
+    if len(jobs) > 1 and n_procs > 1:
+        import multiprocessing as mp
+        with mp.get_context('fork').Pool(min(int(n_procs), len(jobs))) as pool:      # fork: the arrays are not copied
+            parts = pool.map(_route_group, jobs, chunksize=1)
+    else:
+        parts = [_route_group(j) for j in jobs]
+    chs, avg, F = np.zeros((ncell, nmonths)), np.zeros((ncell, nmonths)), np.zeros(ncell)
+    cpu = 0.0
+    for cells, c, a, f, t in parts:
+        chs[cells], avg[cells], F[cells] = c, a, f
+        cpu += t
+    return chs, avg, F, cpu

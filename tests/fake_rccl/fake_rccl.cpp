@@ -44,8 +44,10 @@ thread_local int g_depth = 0;
 thread_local std::vector<Op> g_ops;
 
 std::string msg_path(const ncclComm *c, int src, int dst, unsigned seq) {
-    char b[256];
-    snprintf(b, sizeof(b), "/dev/shm/xh_fake_rccl_%s_%d_%d_%u", c->id.c_str(), src, dst, seq);
+    // XH_FAKE_RCCL_DIR: where the messages travel (default /dev/shm; a test that moves gigabytes points it at a disk)
+    const char *dir = getenv("XH_FAKE_RCCL_DIR");
+    char b[512];
+    snprintf(b, sizeof(b), "%s/xh_fake_rccl_%s_%d_%d_%u", (dir && dir[0]) ? dir : "/dev/shm", c->id.c_str(), src, dst, seq);
     return b;
 }
 

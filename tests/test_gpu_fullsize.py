@@ -34,7 +34,11 @@ def full():
     ctx.synth_forcing(3, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.001)
     pipe.run(('pm', 'abcd'), fused=False)
     q = pipe.out['q'].download()
-    chs, avg, _ = o_mrtm.route_series(pipe.um.tocsr(), w.flow_dist, w.velocity, w.area, q, pipe.ndays, 120)
+    # river networks dealt over worker processes: every cell's bits are those of the serial month loops
+    # (tests/test_oracle_golden.py::test_route_series_by_network_equals_serial), in ~1/10 of their 3 minutes
+    import os
+    chs, avg, _, _ = o_mrtm.route_series_by_network(pipe.um.tocsr(), w.flow_dist, w.velocity, w.area, q, pipe.ndays, 120,
+                                                    n_procs=max(1, min(os.cpu_count() or 1, 16)))
     # 0.1 % of the cells have NaN precipitation -> NaN runoff, which routing carries downstream like the reference
     # (data_load.py:186 keeps precipitation's NaN; mrtm.py has no special case)
     assert np.isnan(q).any() and np.isnan(avg).any() and np.nanmax(avg) > 0 and np.isfinite(avg).mean() > 0.5
@@ -87,6 +91,42 @@ def test_config3_full_length_routing_equals_oracle(full):
     info = full.pipe.plan.info()
     assert info['flow_cells'] == 67420 and info['fallback_cells'] == 0
     assert 1054 <= info['flow_units'] <= 1075 and info['flow_edges'] > 1200, info
+
+
+def test_config3_all_cell_pm_abcd_parity(full):
+    """EVERY cell of the full grid, not a sample: PET of 67,420 cells x 60 months against oracle.pm (penman_monteith.py:394-477)
+    and AET / Q / Sav of 67,420 cells x (600 + 120 spin-up) months against oracle.abcd (abcd.py:357-391) fed with the run's own
+    PET, on SURVEY 8(d)'s world with 0.1 % NaN-precipitation cells.  The gate is the north star's tolerance
+    1e-6 |ref| + 1e-9 with identical NaN masks; values off by more than 1e-9 relative (a flipped branch of a tiered
+    function shows up there long before the gate) are bounded too."""
+    from oracle import abcd as o_abcd, pm as o_pm
+    from xanthos_amd import synth
+    w, pipe = full.w, full.pipe
+    nm, k = pipe.nmonths, 60
+
+    def gate(name, x, ref, max_flips):
+        assert np.array_equal(np.isnan(x), np.isnan(ref)), name + ': NaN masks differ'
+        m = ~np.isnan(ref)
+        diff = np.abs(x[m] - ref[m])
+        beyond = int((diff > 1e-6 * np.abs(ref[m]) + 1e-9).sum())
+        flips = int((diff / (np.abs(ref[m]) + 1e-9) > 1e-9).sum())          # bench.py's branch_flip_candidates
+        assert beyond == 0, '{}: {} of {} values beyond 1e-6 |ref| + 1e-9 (worst {:.3e})'.format(
+            name, beyond, int(m.sum()), float((diff / (1e-6 * np.abs(ref[m]) + 1e-9)).max()))
+        assert flips <= max_flips, '{}: {} branch-flip candidates'.format(name, flips)
+        return int(m.sum())
+
+    f = {n: pipe.forcing[n].download()[:, :k].copy() for n in ('tas', 'tmin', 'rhs', 'wind', 'rsds', 'rlds')}
+    ref_pet = o_pm.run_pmpet(synth.data_bag(w, f), w.ncell, w.nlcs, 1961, 1961 + k // 12 - 1, 0, 6, w.lc_years)
+    got_pet = pipe.out['pet'].download()
+    assert gate('pet', got_pet[:, :k], ref_pet, 20) == w.ncell * k
+    del f, ref_pet
+    pr, tn = pipe.forcing['precip'].download(), pipe.forcing['abcd_tmin'].download()
+    assert np.isnan(pr).any(axis=1).sum() >= 30                    # the NaN-precipitation cells are there
+    aet, q, sav = o_abcd.abcd_parallel(w.n_basins, w.abcd_pars, w.basin_ids, got_pet, pr, tn, nm, pipe.abcd_spinup, jobs=-1)
+    n = 0
+    for name, ref in (('aet', aet), ('q', q), ('sav', sav)):
+        n += gate(name, pipe.out[name].download(), ref, 200)
+    assert n > 3 * 0.99 * w.ncell * nm                              # 40 M values each, less the NaN cells
 
 
 def test_config3_fused_pipeline_equals_oracle(full):

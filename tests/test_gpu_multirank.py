@@ -159,3 +159,32 @@ def test_sharded_pipeline_gathered_equals_unsharded(tmp_path, nranks, root):
     """PM -> ABCD -> MRTM on basin / network-closed shards in `nranks` processes, ONE xh_comm_gather_rows of the six
     outputs to `root`: bit-identical (NaN runoff included) to the unsharded run on the same device."""
     _run_ranks(tmp_path, PIPE_CHILD, nranks, root)
+
+
+def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2 --steps 3 --warmup 1`` with NO launcher and no RANK in the environment: the script starts
+    its two rank processes itself (before anything touches the GPU), both on this box's one GPU (XH_BENCH_ONE_DEVICE=1, the
+    process group on gloo), the write-out gather through libxanthos_hip.so's grouped sends / receives with the test-only
+    stand-in first on the loader path; rank 0's JSON line is relayed, says two ranks were seen and which gather ran, and the
+    gathered arrays equal the same world run unsharded (--check-gather), all six outputs, bit for bit.  Routing runs with
+    one workgroup per network (--route-flags 4): two processes cannot both keep every dataflow unit resident on one GPU."""
+    _fake_rccl()
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update({'XH_BENCH_ONE_DEVICE': '1', 'XH_BENCH_BACKEND': 'gloo', 'XH_FAKE_RCCL_DIR': str(tmp_path),
+                'LD_LIBRARY_PATH': FAKE + os.pathsep + env.get('LD_LIBRARY_PATH', '')})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--route-flags', '4', '--check-gather', '--no-replica-figure'],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['n_ranks_seen'] == 2 and res['steps'] == 3 and res['scaling'] == 'strong'
+    g = res['gather']
+    assert g['kind'] == 'rccl' and 'stand-in' in g['library'], g
+    assert g['equals_unsharded'] is True and all(g['equals_unsharded_by_output'].values()), g
+    assert len(g['rows_per_rank']) == 2 and sum(g['rows_per_rank']) == 67420
+    assert 'exposed_ms' in g and res['value'] > 0
+    assert not [f for f in os.listdir(str(tmp_path)) if f.startswith('xh_fake_rccl_')]      # every message was received

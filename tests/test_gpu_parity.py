@@ -319,6 +319,28 @@ def test_route_partition_variants_bit_exact(env, tmp_path):
             assert res['typed']['typed_builds'] >= 1 and res['typed']['plain_units'] >= 1, res
 
 
+@pytest.mark.parametrize('limit,kernel', [(3000 * 12 * 8, 2), (3000 * 12 * 8 - 1, 3)])
+def test_route_row_offset_limit(limit, kernel, tmp_path):
+    """k_mrtm_wave addresses a cell's runoff row with a 32-bit byte offset: a grid whose rows reach 4 GiB must be routed
+    by a kernel with 64-bit offsets instead of wrapping silently.  XH_WAVE_ROW_LIMIT moves the limit down to the 3000-cell x
+    12-month world: exactly at the limit the current kernel routes it, one byte below round 2's kernel does -- bit-exact
+    either way."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'child.py'
+    script.write_text(_PARTITION_CHILD)
+    e = dict(os.environ)
+    e['XH_WAVE_ROW_LIMIT'] = str(limit)
+    out = subprocess.run([sys.executable, str(script), root], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res['ok'] and res['kernel'] == kernel and res['reroutes'] == 0, res
+
+
 @pytest.mark.parametrize('basin', [0, 1])
 @pytest.mark.parametrize('unit', ['km3_per_mth', 'mm_per_mth'])
 @pytest.mark.parametrize('tag', ['snow', 'nosnow'])

@@ -186,10 +186,10 @@ def test_data_loader_matches_reference_golden(tmp_path, golden):
     assert np.array_equal(d3.precip, d2.precip, equal_nan=True)
 
 
-def test_histflag_is_normalised_and_future_mode_needs_channel_storage(tmp_path, golden):
+def test_histflag_is_normalised_and_future_mode_needs_channel_storage(tmp_path, golden, caplog, monkeypatch):
     """HistFlag in any of the reference's spellings (it compares the raw string three different ways: ini_reader.py:330,
-    :582, data_load.py:431): historic iff it reads as true; future mode without ChStorageFile is an error instead of a
-    silent start from empty channels; anything else is rejected."""
+    :582, data_load.py:431): historic iff it reads as true; future mode without ChStorageFile starts from empty channels like the
+    reference, with a warning (an error under XH_STRICT_FUTURE=1); anything else is rejected."""
     import io
     import zipfile
     g = golden('loader')
@@ -208,8 +208,15 @@ def test_histflag_is_normalised_and_future_mode_needs_channel_storage(tmp_path, 
     for spelling in ('true', 'T', 'yes', '1'):
         s = reader(lambda t, sp=spelling: re.sub(r'(?m)^HistFlag\s*=.*$', 'HistFlag = ' + sp, t))
         assert s.HistFlag == 'True' and s.historic and s.ChStorageFile is None
+    # the reference accepts future mode without ChStorageFile and starts from empty channels (data_load.py:427-438): a
+    # warning here, an error only on request
+    with caplog.at_level('WARNING'):
+        s = reader(lambda t: re.sub(r'(?m)^ChStorageFile\s*=.*$', '', t))
+    assert not s.historic and s.ChStorageFile is None and 'EMPTY channels' in caplog.text
+    monkeypatch.setenv('XH_STRICT_FUTURE', '1')
     with pytest.raises(ValidationException, match='ChStorageFile'):
         reader(lambda t: re.sub(r'(?m)^ChStorageFile\s*=.*$', '', t))
+    monkeypatch.delenv('XH_STRICT_FUTURE')
     with pytest.raises(ValidationException, match='HistFlag'):
         reader(lambda t: re.sub(r'(?m)^HistFlag\s*=.*$', 'HistFlag = maybe', t))
 

@@ -176,3 +176,29 @@ def test_accessible_water_matches_reference(golden):
     assert (totals[3] == 0).all() and table.max() > 0   # basin 4 has no cells
     assert np.array_equal(o_ac.rolling_mean_rows(g['demo'], 5), g['demo_roll5'])
     assert np.array_equal(o_ac.rolling_mean_rows(g['demo'], 9), g['demo_roll9'])
+
+
+def test_route_series_by_network_equals_serial():
+    """The full-size checker routes river networks in worker processes (oracle.mrtm.route_series_by_network: the bench's
+    CPU child and the full-grid GPU tests): every output bit equals the serial month loops of route_series -- NaN runoff,
+    cells that fire (velocity * dt / length > 1), spin-up and initial storage included."""
+    from types import SimpleNamespace as NS
+    from oracle import months, mrtm as o
+    from xanthos_amd import synth
+    w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=5, seed=3, outlet_frac=0.02)
+    st = NS(ngridrow=w.nrow, ngridcol=w.ncol)
+    um = o.upstream_genmatrix(o.upstream(w.coords, o.downstream(w.coords, w.flow_dir, st), st)).tocsr()
+    rng = np.random.default_rng(1)
+    q = rng.gamma(2.0, 30.0, (w.ncell, 12))
+    q[rng.random(w.ncell) < 0.01] = np.nan
+    s0 = rng.gamma(2.0, 1e5, w.ncell)
+    nd = months.set_month_arrays(12, 1973, 1973)[:, 2]
+    assert (w.velocity * 10800.0 / w.flow_dist > 1.0).sum() > 5           # cells that fire are in the world
+    for S0, procs in ((None, 1), (None, 3), (s0, 4)):
+        a = o.route_series(um, w.flow_dist, w.velocity, w.area, q, nd, 2, S0)
+        b = o.route_series_by_network(um, w.flow_dist, w.velocity, w.area, q, nd, 2, S0, n_procs=procs)
+        assert b[3] > 0
+        for x, y in zip(a, b[:3]):
+            assert np.array_equal(x, y, equal_nan=True)
+    groups = o.network_groups(um, 4)
+    assert sorted(np.concatenate(groups).tolist()) == list(range(w.ncell))

@@ -57,5 +57,10 @@ for k in sorted(set(f) | set(w)):
               'hbm_bytes': (f.get(k, 0) * kr + w.get(k, 0) * kw) * 1024, 'note': note}
 if calib:
     res['_calibration'] = calib
+import datetime
+res['_meta'] = {'collected': datetime.datetime.now().strftime('%Y-%m-%d %H:%M'),
+                'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 '
+                           '--no-cpu-baseline --no-end-to-end',
+                'kernels': sorted(k for k in res if not k.startswith('_'))}
 json.dump(res, open(out, 'w'), indent=1)
 print(json.dumps(res, indent=1))

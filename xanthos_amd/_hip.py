@@ -232,6 +232,12 @@ class Context:
         self._check(lib().xh_device_name(self.handle, buf, 256))
         return buf.value.decode()
 
+    def cu_count(self):
+        """Compute units of the device (xh_device_name ends in "(<arch>, <n> CUs)")."""
+        import re
+        m = re.search(r'(\d+) CUs\)', self.name())
+        return int(m.group(1)) if m else 256
+
     def close(self):
         if self.handle is not None:
             for a in list(self._live):

@@ -168,9 +168,11 @@ int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar, con
         if (r < root) before_me += h_counts[r];
     }
     const size_t need = (size_t)remote * ncols * nvar * sizeof(double);
+    int rc_device = XH_OK;      // XH_ERR_DEVICE of the settle below, returned once the gather has been enqueued
     if (need > c->stage_bytes) {
         const int rcs = xh_settle(ctx);
         if (rcs && rcs != XH_ERR_DEVICE) return rcs;
+        rc_device = rcs;
         if (c->d_stage) XH_HIP(ctx, hipFree(c->d_stage));
         c->d_stage = nullptr;
         c->stage_bytes = 0;
@@ -212,7 +214,7 @@ int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar, con
             if (rc) return rc;
         }
     }
-    return XH_OK;
+    return rc_device;
 }
 
 }  // extern "C"

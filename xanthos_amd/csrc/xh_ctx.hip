@@ -1,5 +1,6 @@
 // Context, device memory, row gather/scatter, transpose and HIP-event timing for libxanthos_hip.so.
 #include <algorithm>
+#include <mutex>
 
 #include "xh_common.h"
 
@@ -11,6 +12,10 @@ int xh_fail(xh_ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
+    // (a routing plan may be made on a host thread of its own while the main thread works on the same context:
+    // the error text is the one field both may write)
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (ctx)
         ctx->err = buf;
     else
@@ -19,11 +24,13 @@ int xh_fail(xh_ctx *ctx, int code, const char *fmt, ...) {
 }
 
 int xh_scratch(xh_ctx *ctx, int which, size_t bytes, void **out) {
+    int rc_device = XH_OK;      // XH_ERR_DEVICE of the settle below: reported after the buffer has been replaced
     if (bytes > ctx->scratch_bytes[which]) {
         if (ctx->scratch[which]) {
             // the buffer may be read by a routing call that still has to be confirmed (or re-run): settle before freeing
             const int rc = xh_settle(ctx);
             if (rc && rc != XH_ERR_DEVICE) return rc;
+            rc_device = rc;
             XH_HIP(ctx, hipFree(ctx->scratch[which]));
             ctx->scratch[which] = nullptr;
             ctx->scratch_bytes[which] = 0;
@@ -33,7 +40,9 @@ int xh_scratch(xh_ctx *ctx, int which, size_t bytes, void **out) {
         ctx->scratch_bytes[which] = want;
     }
     *out = ctx->scratch[which];
-    return XH_OK;
+    // A re-routed call whose invalid outputs later work had already consumed: the settle has cleared the bookkeeping, so
+    // this is the one place the caller can still hear about it (xh_common.h, contract of xh_settle).
+    return rc_device;
 }
 
 int xh_fault_word(xh_ctx *ctx, unsigned **d_word) {
@@ -112,9 +121,10 @@ int xh_fault_check(xh_ctx *ctx) {
     if (pending.empty())
         return xh_fail(ctx, XH_ERR_DEVICE, "routing kernel fault %u and no record of the call: outputs are invalid", code);
     if (later_work)
-        return xh_fail(ctx, XH_ERR_DEVICE, "routing kernel fault %u: the routing outputs were recomputed with the "
-                       "workgroup-per-network kernel and are valid now, but results of calls enqueued after "
-                       "xh_route_series read the invalid ones and must be recomputed", code);
+        return xh_fail(ctx, XH_ERR_DEVICE, "routing kernel fault %u: the routing outputs were recomputed %s and are valid "
+                       "now, but results of calls enqueued after xh_route_series read the invalid ones and must be recomputed",
+                       code, pairs_first ? "by the dataflow kernel with every unit in pair form (a plain unit's guard had tripped)"
+                                         : "with the workgroup-per-network kernel");
     return XH_OK;
 }
 

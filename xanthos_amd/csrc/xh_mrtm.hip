@@ -432,6 +432,8 @@ void launch_units(const xh_route_plan *plan, int cls, RouteArgs args, hipStream_
 
 }  // namespace
 
+static void route_plan_free(xh_route_plan *plan, bool settle);
+
 extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h_indptr, const int32_t *h_indices,
                                     const int8_t *h_sign, xh_route_plan **out) {
     if (!ctx || !out) return XH_ERR_ARG;
@@ -501,14 +503,14 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
         if (!(env && env[0] == '0')) {
             const int frc = flow_plan_build(ctx, n, h_indptr, h_indices, h_sign, comp, ncomp, nullptr, flow_cell, &plan->flow);
             if (frc) {
-                xh_route_plan_destroy(plan);
+                route_plan_free(plan, false);
                 return frc;
             }
         }
         if (flow_cell.empty()) flow_cell.assign(n, 0);
         if (plan->flow) {
             if (hipMalloc(&plan->d_learn.p, (size_t)n + 256) != hipSuccess || hipMemset(plan->d_learn.p, 0, (size_t)n + 256) != hipSuccess) {
-                xh_route_plan_destroy(plan);
+                route_plan_free(plan, false);
                 return xh_fail(ctx, XH_ERR_HIP, "xh_route_plan_create: device allocation failed");
             }
             plan->h_indptr.assign(h_indptr, h_indptr + n + 1);
@@ -700,7 +702,7 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
     for (int k = 0; k <= N_CLASS; ++k)
         if (hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming) != hipSuccess) rc |= XH_ERR_HIP;
     if (rc) {
-        xh_route_plan_destroy(plan);
+        route_plan_free(plan, false);
         return xh_fail(ctx, XH_ERR_HIP, "xh_route_plan_create: device allocation failed");
     }
     lap("tables + uploads");
@@ -708,9 +710,12 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
     return XH_OK;
 }
 
-extern "C" void xh_route_plan_destroy(xh_route_plan *plan) {
+// settle = false: teardown of a plan that xh_route_plan_create could not finish.  Nothing was ever routed on it, so no
+// call in flight refers to it, and the context's stream and fault bookkeeping are left alone: run_model() makes the plan
+// on a host thread while the main thread uploads forcing on the same context (pipeline.py, plan_async).
+static void route_plan_free(xh_route_plan *plan, bool settle) {
     if (!plan) return;
-    (void)xh_sync(plan->ctx);                    // settles (and if needed re-runs) routing calls still in flight
+    if (settle) (void)xh_sync(plan->ctx);        // settles (and if needed re-runs) routing calls still in flight
     for (int k = 0; k < N_CLASS; ++k) {
         free_buf(plan->d_class_units[k]);
         free_buf(plan->d_rest_units[k]);
@@ -734,6 +739,8 @@ extern "C" void xh_route_plan_destroy(xh_route_plan *plan) {
     if (plan->h_cap_diff) (void)hipHostFree(plan->h_cap_diff);
     delete plan;
 }
+
+extern "C" void xh_route_plan_destroy(xh_route_plan *plan) { route_plan_free(plan, true); }
 
 extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
     if (!plan || !info) return XH_ERR_ARG;
@@ -989,17 +996,32 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     const bool auto_typed = !explicit_typed && auto_env && typed_ok && !old_skew_env && plan->flow->skew_ok &&
                             (flags & (XH_ROUTE_ATOMIC | XH_ROUTE_TEST_FAULT)) == 0 && plan->auto_state.load() != 3;
     if (auto_typed) plan->auto_calls += 1;
-    const bool want_typed = explicit_typed || (auto_typed && plan->auto_calls >= 2);
+    bool want_typed = explicit_typed || (auto_typed && plan->auto_calls >= 2);
     const int sel_env = getenv("XH_FLOW_PLAIN_MIN_READS") ? atoi(getenv("XH_FLOW_PLAIN_MIN_READS")) : -1;
     const int sel_want = sel_env >= 0 ? sel_env : (explicit_typed ? 0 : 5);
     unsigned char *d_cap_new = nullptr;
     if (want_typed) {
         const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
-        if (!plan->d_capable.p) {
-            XH_HIP(ctx, hipMalloc(&plan->d_capable.p, 2 * nb));
-            XH_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&plan->d_cap_diff), 64));
-            XH_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&plan->h_cap_diff), 64, hipHostMallocDefault));
+        if (!plan->d_capable.p || !plan->d_cap_diff || !plan->h_cap_diff) {
+            // all three or none: a partial failure must not leave a plan that later calls take for ready
+            const bool ok = (plan->d_capable.p || hipMalloc(&plan->d_capable.p, 2 * nb) == hipSuccess) &&
+                            (plan->d_cap_diff || hipMalloc(reinterpret_cast<void **>(&plan->d_cap_diff), 64) == hipSuccess) &&
+                            (plan->h_cap_diff || hipHostMalloc(reinterpret_cast<void **>(&plan->h_cap_diff), 64,
+                                                               hipHostMallocDefault) == hipSuccess);
+            if (!ok) {
+                (void)hipGetLastError();
+                free_buf(plan->d_capable);
+                if (plan->d_cap_diff) (void)hipFree(plan->d_cap_diff);
+                if (plan->h_cap_diff) (void)hipHostFree(plan->h_cap_diff);
+                plan->d_cap_diff = plan->h_cap_diff = nullptr;
+                if (explicit_typed) return xh_fail(ctx, XH_ERR_HIP, "xh_route_series: no memory for the typed plan's cell flags");
+                plan->auto_state.store(3);      // adaptive plain form stays off for this plan: pair form from here on
+                want_typed = false;
+            }
         }
+    }
+    if (want_typed) {
+        const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
         d_cap_new = static_cast<unsigned char *>(plan->d_capable.p) + nb;
         XH_HIP(ctx, hipMemsetAsync(plan->d_cap_diff, 0, 4, ctx->stream));
         hipLaunchKernelGGL(k_capable, dim3((unsigned)((plan->ncell + 255) / 256)), dim3(256), 0, ctx->stream, d_velocity,
@@ -1102,6 +1124,11 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
             rc = old_skew ? skew_launch(ctx, plan->flow, fs, fio, ctx->stream) : wave_launch(ctx, tree_plan, fs, fio, ctx->stream);
         if (rc == XH_ERR_LIMIT && tree_plan != plan->flow && !old_skew) rc = wave_launch(ctx, plan->flow, fs, fio, ctx->stream);
         plan->last_typed = rc == XH_OK && tree_plan != plan->flow && !old_skew;
+        // what the round-3 kernel cannot take (rows beyond its 32-bit offsets) the round-2 time-skewed kernel may still
+        if (rc == XH_ERR_LIMIT && skew_env && !old_skew && (flags & XH_ROUTE_NO_SKEW) == 0) {
+            rc = skew_launch(ctx, plan->flow, fs, fio, ctx->stream);
+            if (rc == XH_OK) plan->last_tree_kernel = 3;
+        }
         if (rc == XH_ERR_LIMIT) {
             plan->last_tree_kernel = 1;
             rc = flow_launch(ctx, plan->flow, fs, fio, ctx->stream);

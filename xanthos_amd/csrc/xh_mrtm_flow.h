@@ -14,6 +14,7 @@ struct FlowBuf {
 // Partition of the tree-shaped river networks into single-wave units (64 lanes = 64 cells) linked by one-way streams.
 struct FlowPlan {
     int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0, max_exports = 0, n_plain_units = 0;
+    int max_cell = -1;                   // largest grid index of a routed cell (the time-skewed kernel's 32-bit row offsets)
     FlowBuf d_cell_of_slot, d_ent, d_export_edge, d_ghost_edge, d_edge_cons_unit, d_unit_terms;
     // time-skewed layout (xh_mrtm_skew.hip); skew_ok = every row has <= 4 terms either side of its diagonal
     bool skew_ok = false;

@@ -853,6 +853,19 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
                     (int)fp->skew_ok, fp->max_imports, fp->max_exports, s.ntmin, fp->skew_lmax);
         return XH_ERR_LIMIT;
     }
+    // The kernel addresses a cell's row of runoff as (uniform base + 32-bit byte offset) (row_off in wave_unit): a grid whose
+    // last routed row starts at or beyond 4 GiB is left to the round-2 kernels, which use 64-bit row offsets
+    // (XH_WAVE_ROW_LIMIT: the limit in bytes, for the test that exercises this on a small grid).
+    {
+        uint64_t limit = (uint64_t)1 << 32;
+        if (const char *env = getenv("XH_WAVE_ROW_LIMIT")) limit = std::min<uint64_t>(limit, strtoull(env, nullptr, 10));
+        if ((uint64_t)(fp->max_cell + 1) * (uint64_t)s.nmonths * 8u > limit) {
+            if (getenv("XH_FLOW_DEBUG"))
+                fprintf(stderr, "round-3 time-skewed kernel not used: %d rows x %d months x 8 B exceed its 32-bit row offsets\n",
+                        fp->max_cell + 1, s.nmonths);
+            return XH_ERR_LIMIT;
+        }
+    }
     // Ring size.  A consumer asks for ~2 CH + lag sub-steps ahead of its clock, a producer may run RS - CH - lag ahead.  A
     // stream that jumps over k pipeline levels (a tributary that joins the main stem far downstream: its consumer also
     // waits for units k levels below the producer) needs the lead of all of them in its ring: every level trails the one

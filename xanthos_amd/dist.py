@@ -163,31 +163,38 @@ class OutputGather:
         self.counts = np.array([len(s.cells) for s in shards], dtype=np.int64)
         self.out, self.d_perm, self.comm, self.kind, self.why = None, None, None, 'torch', ''
         self.bytes = int(self.counts.sum()) * pipe.nmonths * 8 * len(self.names)
-        if dist.get_backend() == 'nccl':
-            # Agree on RCCL availability BEFORE ncclCommInitRank: the init is itself a collective, so a rank that cannot
-            # even load librccl must not leave the others blocked inside it.  comm_unique_id() loads the library and
-            # makes an id (cheap, local); only the root's id is used.
-            uid, ok = [None], 1
+        # The library's own gather (RCCL bound at run time) whatever backend the launcher's process group uses: the group
+        # only carries the 128-byte id and the agreement below (with "gloo" on host tensors -- the dry run with every rank
+        # on one GPU, where a test-only stand-in for librccl.so.1 may be first on the loader path).
+        # Agree on RCCL availability BEFORE ncclCommInitRank: the init is itself a collective, so a rank that cannot even
+        # load librccl must not leave the others blocked inside it.  comm_unique_id() loads the library and makes an id
+        # (cheap, local); only the root's id is used.
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        uid, ok = [None], 1
+        try:
+            mine = _hip.comm_unique_id()
+            if rank == root:
+                uid = [mine]
+        except (_hip.HipError, RuntimeError) as exc:
+            self.why, ok = str(exc), 0
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            dist.broadcast_object_list(uid, src=root)
             try:
-                mine = _hip.comm_unique_id()
-                if rank == root:
-                    uid = [mine]
-            except (_hip.HipError, RuntimeError) as exc:
-                self.why, ok = str(exc), 0
-            flag = torch.tensor([ok], device='cuda')
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                dist.broadcast_object_list(uid, src=root)
-                try:
-                    self.comm = _hip.Comm(ctx, len(shards), rank, uid[0])
-                    self.kind = 'rccl'
-                except (_hip.HipError, RuntimeError) as exc:      # e.g. two ranks on one GPU in a dry run
-                    self.why = str(exc)
-                flag = torch.tensor([1 if self.kind == 'rccl' else 0], device='cuda')
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # all ranks take the same path
-                if int(flag.item()) == 0 and self.kind == 'rccl':
-                    self.comm.close()
-                    self.comm, self.kind = None, 'torch'
+                self.comm = _hip.Comm(ctx, len(shards), rank, uid[0])
+                self.kind = 'rccl'
+            except (_hip.HipError, RuntimeError) as exc:      # e.g. two ranks on one GPU in a dry run
+                self.why = str(exc)
+            flag = torch.tensor([1 if self.kind == 'rccl' else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # all ranks take the same path
+            if int(flag.item()) == 0 and self.kind == 'rccl':
+                self.comm.close()
+                self.comm, self.kind = None, 'torch'
+        # which library answered: the test-only stand-in of tests/fake_rccl marks its ids (the report must say so)
+        self.library = None
+        if self.kind == 'rccl':
+            self.library = 'test stand-in (tests/fake_rccl)' if bytes(uid[0][:4]) == b'FAKE' else 'librccl.so.1'
         if self.kind == 'rccl' and rank == root:
             self.d_perm = ctx.upload(np.concatenate([s.cells for s in shards]), dtype=np.int64)
             self.out = {k: ctx.empty((self.ncell, pipe.nmonths)) for k in self.names}
@@ -204,10 +211,18 @@ class OutputGather:
                              names=self.names)
         if self.torch.cuda.is_available() and self.dist.get_backend() == 'nccl':
             self.torch.cuda.synchronize()
+        self._last = got
         return got
 
+    def last(self):
+        """On the root: the arrays of the last gather as host arrays, by name (grid order)."""
+        if self.kind == 'rccl':
+            self.ctx.sync()
+            return {k: self.out[k].download() for k in self.names}
+        return {k: self._last[i].cpu().numpy() for i, k in enumerate(self.names)}
+
     def report(self):
-        return {'kind': self.kind, 'bytes_per_step': self.bytes, 'variables': list(self.names),
+        return {'kind': self.kind, 'library': self.library, 'bytes_per_step': self.bytes, 'variables': list(self.names),
                 'rows_per_rank': self.counts.tolist(), 'fallback_reason': self.why}
 
     def close(self):

@@ -9,6 +9,7 @@ reference (:214, :309, :397); selectors that belong to other reference modules a
 because only the MI355X hot path is implemented here.  ``update()`` keeps the in-memory override hook (:598-607).
 """
 import os
+import logging
 
 
 class ValidationException(Exception):
@@ -202,9 +203,15 @@ class ConfigReader:
                 self.ChStorageFile = m.get('ChStorageFile')
                 self.ChStorageVarName = m.get('ChStorageVarName')
                 if not self.ChStorageFile:
-                    raise ValidationException('HistFlag = False (future mode) needs ChStorageFile (and ChStorageVarName for '
-                                              'NetCDF) in the runoff section: the channel storage the historical run ended '
-                                              'with.  Starting a future run from empty channels is almost never meant.')
+                    # the reference accepts this configuration and starts from empty channels (its abcd section never
+                    # reads the key; load_chs_data, data_load.py:427-438, falls back to zeros): so does this package,
+                    # loudly -- XH_STRICT_FUTURE=1 turns the warning into the error it almost always deserves
+                    msg = ('HistFlag = False (future mode) without ChStorageFile (and ChStorageVarName for NetCDF) in the '
+                           'runoff section: routing starts from EMPTY channels, as in the reference, instead of the '
+                           'channel storage the historical run ended with.')
+                    if os.environ.get('XH_STRICT_FUTURE') == '1':
+                        raise ValidationException(msg)
+                    logging.warning(msg)
         elif self.runoff_module == 'none':
             pass
         elif self.runoff_module in self.RUNOFF_OTHER:
