@@ -505,6 +505,10 @@ def main():
     ap.add_argument('--cpu-mrtm-child', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--no-gate', action='store_true', help='report parity failures in the line but exit 0')
     ap.add_argument('--route-flags', type=int, default=0)
+    ap.add_argument('--order', default='auto', choices=['auto', 'fed', 'staged'],
+                    help='pm_abcd_mrtm: "staged" = the three stages strictly one after the other; "fed" = the routing kernel '
+                         'starts after the first max(spin-ups) months and the rest of PM and ABCD runs beside it (xh_run_fused '
+                         'mode 1, DESIGN.md 4.7); "auto" = the library default')
     args = ap.parse_args()
     if args.cpu_mrtm_child:                                     # CPU-only child of the baseline leg: no GPU code is imported
         return cpu_mrtm_child(args.cpu_mrtm_child)
@@ -577,9 +581,11 @@ def main():
         d_lat.free()
         return pipe
 
+    fed = {'auto': None, 'fed': True, 'staged': False}[args.order]
+
     def timed(pipe, after_step=None):
         for _ in range(args.warmup):
-            pipe.run(args.stages)
+            pipe.run(args.stages, fed=fed)
             if after_step:
                 after_step()
         ctx.sync()
@@ -587,7 +593,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            pipe.run(args.stages)
+            pipe.run(args.stages, fed=fed)
             if after_step:
                 after_step()
         ctx.sync()
@@ -631,16 +637,41 @@ def main():
 
     # per-kernel device time from HIP events on the library's stream (this run, timed region only)
     algo = algorithmic_bytes(pipe.ncell, pipe.nmonths, run_world.nlcs, args.abcd_spinup, args.routing_spinup)
-    kernels = {}
-    for name in ('pm_pet', 'abcd_spinup', 'abcd_basin_mean', 'abcd_sim', 'mrtm_route'):
-        ms, n = ctx.timing(name)
-        if n:
-            k = {'avg_ms': ms / n, 'launches': n}
-            if name in algo:
-                k['algorithmic_bytes'] = algo[name]
-                k['achieved_GBs'] = algo[name] / (ms / n * 1e-3) / 1e9
-                k['frac_of_hbm_peak'] = k['achieved_GBs'] / HBM_PEAK_GBS
-            kernels[name] = k
+    def kernel_times(steps):
+        """Device time per STEP of each kernel family (a fed step launches PM and the ABCD march twice: two blocks of months)."""
+        out = {}
+        for name in ('pm_pet', 'abcd_spinup', 'abcd_basin_mean', 'abcd_sim', 'mrtm_route'):
+            ms, n = ctx.timing(name)
+            if n:
+                k = {'avg_ms': ms / steps, 'launches': n, 'launches_per_step': n / steps}
+                if name in algo:
+                    k['algorithmic_bytes'] = algo[name]
+                    k['achieved_GBs'] = algo[name] / (ms / steps * 1e-3) / 1e9
+                    k['frac_of_hbm_peak'] = k['achieved_GBs'] / HBM_PEAK_GBS
+                out[name] = k
+        return out
+    kernels = kernel_times(args.steps)
+    n_fed = ctx.timing('feed_gate')[1]
+    order = {'order': 'fed' if n_fed else 'staged', 'fed_steps': int(n_fed),
+             'note': ('the routing kernel is launched after the first max(spin-ups) months of PM and ABCD and fed the other '
+                      'months, produced beside it on a second stream (xh_run_fused mode 1): kernel times below overlap, their '
+                      'sum exceeds the step' if n_fed else 'the three stages strictly one after the other')}
+    if n_fed:
+        # PM and ABCD share the chip with the routing kernel in a fed step: their stand-alone times (the figures their
+        # rooflines are about) come from three stage-by-stage steps outside the timed region
+        gate_ms = ctx.timing('feed_gate')[0] / n_fed
+        fed_kernels = kernels
+        ctx.timing_reset()
+        for _ in range(3):
+            pipe.run(args.stages, fed=False)
+        ctx.sync()
+        alone = kernel_times(3)
+        kernels = {k: dict(alone[k]) for k in alone}
+        for k in fed_kernels:
+            kernels[k]['avg_ms_in_fed_step'] = fed_kernels[k]['avg_ms']
+        kernels['mrtm_route'].update({k: v for k, v in fed_kernels['mrtm_route'].items()})      # the dominant kernel: as timed
+        kernels['mrtm_route']['avg_ms_alone'] = alone['mrtm_route']['avg_ms']
+        order['side_stream_gate_ms'] = gate_ms
     args._kernel_s = sum(k['avg_ms'] for k in kernels.values()) * 1e-3
     # HBM traffic and instruction counts per launch come from the committed rocprofv3 PMC passes of this same command
     # (profiles/roundN/pmc_traffic.json and pmc_insts.json, made by tools/pmc_to_json.py / tools/pmc_insts_json.py):
@@ -729,7 +760,7 @@ def main():
                                'dt 10800 s'.format(args.workload, NCELL, args.months, NBASINS, run_world.nlcs,
                                                    args.abcd_spinup, args.routing_spinup),
                    'parallelism': parallelism},
-        'roofline': roofline, 'kernels': kernels, 'routing_plan': info,
+        'roofline': roofline, 'kernels': kernels, 'routing_plan': info, 'stage_order': order,
     }
     gate_failed = False
     if sharded:

@@ -251,6 +251,10 @@ typedef struct xh_fused_args {
     int32_t route_flags;
     double *d_pet, *d_aet, *d_q, *d_sav, *d_chstorage, *d_avgchflow;
     int32_t block_months;
+    int32_t mode;       /* 0: PM blocks with the ABCD march one block behind, then routing (above).  1 (needs plan): the first
+                         * max(spin-ups) months of PM and ABCD, then the ROUTING KERNEL, and the remaining months of PM and ABCD
+                         * beside it on a second stream, fed to the running kernel through a months-ready word; falls back to
+                         * the stage-by-stage order when the plan is not routed by the time-skewed dataflow kernel. Same results. */
 } xh_fused_args;
 int xh_run_fused(xh_ctx *ctx, const xh_fused_args *args);
 

@@ -141,6 +141,19 @@ def test_config3_fused_pipeline_equals_oracle(full):
         for k, ref in keep.items():
             assert np.array_equal(full.pipe.out[k].download(), ref, equal_nan=True), (k, rep)
     assert full.pipe.plan.info()['reroutes'] == 0 and full.pipe.plan.info()['last_tree_kernel'] == 2
+    # round 4: the FED order (xh_run_fused mode 1) -- the routing kernel launched after the first 128 months of runoff and
+    # fed the other 472 while it runs -- eight times in a row (the plan moves from the all-pairs to the selective plain form on
+    # the way): all six outputs identical, no re-route
+    n0 = full.ctx.timing('feed_gate')[1]
+    for rep in range(8):
+        for k in full.pipe.out:
+            full.pipe.out[k].zero()
+        full.pipe.run(fed=True, fused=False)
+        _check(full, tag=('fed', rep))
+        for k, ref in keep.items():
+            assert np.array_equal(full.pipe.out[k].download(), ref, equal_nan=True), (k, rep)
+    assert full.ctx.timing('feed_gate')[1] == n0 + 8
+    assert full.pipe.plan.info()['reroutes'] == 0 and full.pipe.plan.info()['last_tree_kernel'] == 2
 
 
 def test_config3_twenty_repetitions_and_background_load(full):

@@ -172,8 +172,10 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     env = dict(os.environ)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
+    # (the rank processes import torch for the gloo process group, and PyTorch's bundled RCCL has the soname librccl.so.1:
+    # the stand-in is named by its path)
     env.update({'XH_BENCH_ONE_DEVICE': '1', 'XH_BENCH_BACKEND': 'gloo', 'XH_FAKE_RCCL_DIR': str(tmp_path),
-                'LD_LIBRARY_PATH': FAKE + os.pathsep + env.get('LD_LIBRARY_PATH', '')})
+                'XH_RCCL_LIBRARY': _fake_rccl()})
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
                           '--route-flags', '4', '--check-gather', '--no-replica-figure'],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)

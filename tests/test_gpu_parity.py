@@ -551,3 +551,40 @@ def test_pm_abcd_parity_fuzz(hip):
     rng = np.random.default_rng(4242)
     worst = max(max(fz.one_case(rng, k)[3]) for k in range(10))
     assert worst < 1e-2, worst
+
+
+@pytest.mark.parametrize('nm,abcd_spin,route_spin', [(240, 25, 24), (120, 36, 12), (600, 120, 120)])
+def test_fed_routing_equals_stage_by_stage(hip, nm, abcd_spin, route_spin):
+    """xh_run_fused mode 1 (components.py:344-370 is the hand-over it replaces): the routing kernel starts once the first
+    max(spin-ups) months of runoff exist and is fed the remaining months, produced beside it on a second stream, through the
+    months-ready word.  Same kernels, same arithmetic: all six outputs bit-identical to the stages run one after the other,
+    call after call (the staged runoff, the words and the stream rings are reused), NaN-precipitation cells included."""
+    from xanthos_amd import synth
+    from xanthos_amd.pipeline import OUTPUTS, pipeline_from_world
+    ctx = hip.get_context()
+    w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=7, seed=17, outlet_frac=0.02)
+    pipe = pipeline_from_world(ctx, w, nm, 1971, abcd_spin, route_spin)
+    ctx.synth_forcing(23, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.004)
+    pipe.run(fed=False, fused=False)
+    ref = pipe.download()
+    assert np.isnan(ref['q']).any() and np.isfinite(ref['avg']).any() and np.nanmax(ref['chs']) > 0
+    n0 = ctx.timing('feed_gate')[1]
+    for rep in range(4):
+        for k in OUTPUTS:
+            pipe.out[k].zero()
+        pipe.run(fed=True, fused=False)
+        got = pipe.download()
+        for k in OUTPUTS:
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (k, rep)
+    # the calls really were routed that way (the gate kernel of the side stream ran once per call), without a re-route
+    assert ctx.timing('feed_gate')[1] == n0 + 4
+    assert pipe.plan.info()['reroutes'] == 0 and pipe.plan.info()['last_tree_kernel'] == 2
+    # flags the fed call cannot take fall back to the stage-by-stage order inside the same entry point: same results
+    pipe.route_flags = hip.XH_ROUTE_NO_DATAFLOW
+    for k in OUTPUTS:
+        pipe.out[k].zero()
+    pipe.run(fed=True, fused=False)
+    got = pipe.download()
+    for k in OUTPUTS:
+        assert np.array_equal(got[k], ref[k], equal_nan=True), k
+    assert ctx.timing('feed_gate')[1] == n0 + 4 and pipe.plan.info()['last_tree_kernel'] == 0

@@ -43,7 +43,7 @@ class FusedArgs(Structure):
                  ('d_flow_dist', c_void_p), ('d_velocity', c_void_p), ('d_area', c_void_p), ('d_S0', c_void_p),
                  ('route_flags', c_int32)] +
                 [(n, c_void_p) for n in ('d_pet', 'd_aet', 'd_q', 'd_sav', 'd_chstorage', 'd_avgchflow')] +
-                [('block_months', c_int32)])
+                [('block_months', c_int32), ('mode', c_int32)])
 
 
 _P = c_void_p
@@ -113,7 +113,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 3        # xh_abi_version() of the library these signatures describe
+ABI_VERSION = 4        # xh_abi_version() of the library these signatures describe
 
 
 def lib():
@@ -357,8 +357,9 @@ class Context:
     def run_fused(self, *, tables, ncell, nmonths, start_year, lc_years, water_idx, snow_idx, tas, tmin, rhs, wind, rsds,
                   rlds, tairprev, lct, elev, abcd_spinup, n_groups, basin_index, par_index, npar_rows, pars, precip,
                   abcd_tmin, pet, aet, q, sav, plan=None, routing_spinup=0, ndays=None, dt=10800.0, flow_dist=None,
-                  velocity=None, area=None, S0=None, chs=None, avg=None, route_flags=0, block_months=0):
-        """PM -> ABCD -> MRTM as one pipelined call (xh_run_fused); arguments as in pm_pet / abcd / route_series."""
+                  velocity=None, area=None, S0=None, chs=None, avg=None, route_flags=0, block_months=0, mode=0):
+        """PM -> ABCD -> MRTM as one pipelined call (xh_run_fused); arguments as in pm_pet / abcd / route_series.
+        mode 1: the routing kernel starts after the first max(spin-ups) months and is fed the rest while it runs."""
         t, keep = self._pm_tables(tables)
         lcy = np.ascontiguousarray(lc_years, dtype=np.int32)
         bi = np.ascontiguousarray(basin_index, dtype=np.int32)
@@ -381,6 +382,7 @@ class Context:
         a.plan = None if plan is None else plan.handle
         a.routing_spinup, a.dt, a.route_flags, a.block_months = routing_spinup, float(dt), int(route_flags), int(block_months)
         a.h_ndays = None if nd is None else nd.ctypes.data
+        a.mode = int(mode)
         self._check(lib().xh_run_fused(self.handle, byref(a)))
 
     def pm_pet(self, tables, ncell, nmonths, start_year, lc_years, water_idx, snow_idx, tas, tmin, rhs, wind, rsds,

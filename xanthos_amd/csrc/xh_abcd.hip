@@ -145,15 +145,18 @@ __global__ void __launch_bounds__(64) k_abcd(int64_t ncell, int nmonths, int nst
 constexpr int TMS = 16;            // months per LDS tile = one 128-byte line per row and array
 constexpr int TLD = TMS + 1;       // padded row length (doubles)
 
+// (two waves per SIMD: at most 256 registers, AGPRs included -- CPW = 32 relies on its two waves per SIMD, and in a fed run
+// (xh_fused.hip, mode 1) one of these waves has to fit beside a routing wave's 256)
 template <bool SPINUP, int CPW>
-__global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, int nsteps, int m_begin, int m_end,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CPW == 32 ? 2 : 1, CPW == 32 ? 2 : 1))) k_abcd_tile(int64_t ncell, int nmonths, int nsteps, int m_begin, int m_end,
                                                   double *__restrict__ state,      // [3][ncell] carried between month blocks
                                                   const int *__restrict__ par_index, const int *__restrict__ basin_index,
                                                   const double *__restrict__ pars, const double *__restrict__ pet,
                                                   const double *__restrict__ precip, const double *__restrict__ tmin,
                                                   const double *__restrict__ sm0, const double *__restrict__ gw0,
                                                   double *__restrict__ dec, double *__restrict__ aet,
-                                                  double *__restrict__ q, double *__restrict__ sav) {
+                                                  double *__restrict__ q, double *__restrict__ sav,
+                                                  double *__restrict__ q_staged) {      // [ceil(nmonths / 16)][ncell][16] or NULL
     constexpr int NP = CPW / 8;                          // copy passes per tile (8 rows each)
     __shared__ double T[3][CPW * TLD];
     const int lane = threadIdx.x;
@@ -289,6 +292,12 @@ __global__ void __launch_bounds__(64) k_abcd_tile(int64_t ncell, int nmonths, in
 #pragma unroll
                     for (int a = 0; a < 3; ++a)
                         if (dst[a]) *reinterpret_cast<double2 *>(dst[a] + crow[p] + m) = make_double2(T[a][o], T[a][o + 1]);
+                    // the routing kernel's copy of the runoff when it runs beside this march (xh_fused.hip, mode 1): month m
+                    // of cell c at [m / 16][c][m % 16] -- blocks of months that are multiples of 16 leave every 128-byte
+                    // line of it written whole by one launch
+                    if (q_staged)
+                        *reinterpret_cast<double2 *>(q_staged + ((int64_t)(m >> 4) * ncell + (cell0 + p * 8 + cr)) * 16 + (m & 15)) =
+                            make_double2(T[1][o], T[1][o + 1]);
                 }
             }
             __syncthreads();
@@ -426,12 +435,12 @@ int xh_abcd_enqueue_spinup(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, 
             hipLaunchKernelGGL((k_abcd_tile<true, 32>), dim3(blocks32), dim3(64), 0, st, ncell, s.nmonths, s.spinup, 0,
                                s.spinup, (double *)nullptr, s.d_pidx, s.d_bidx, d_pars, d_pet, d_precip, d_tmin,
                                (const double *)nullptr, (const double *)nullptr, s.d_dec, (double *)nullptr,
-                               (double *)nullptr, (double *)nullptr);
+                               (double *)nullptr, (double *)nullptr, (double *)nullptr);
         else if (mode == 64)
             hipLaunchKernelGGL((k_abcd_tile<true, 64>), dim3(blocks), dim3(64), 0, st, ncell, s.nmonths, s.spinup, 0,
                                s.spinup, (double *)nullptr, s.d_pidx, s.d_bidx, d_pars, d_pet, d_precip, d_tmin,
                                (const double *)nullptr, (const double *)nullptr, s.d_dec, (double *)nullptr,
-                               (double *)nullptr, (double *)nullptr);
+                               (double *)nullptr, (double *)nullptr, (double *)nullptr);
         else
             hipLaunchKernelGGL(k_abcd<true>, dim3(blocks), dim3(64), 0, st, ncell, s.nmonths, s.spinup, s.d_pidx,
                                s.d_bidx, d_pars, d_pet, d_precip, d_tmin, (const double *)nullptr,
@@ -451,24 +460,24 @@ int xh_abcd_enqueue_spinup(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, 
 
 int xh_abcd_enqueue_sim(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, int m_begin, int m_end,
                         const double *d_pars, const double *d_pet, const double *d_precip, const double *d_tmin,
-                        double *d_aet, double *d_q, double *d_sav) {
+                        double *d_aet, double *d_q, double *d_sav, double *d_q_staged) {
     if (s.ncell == 0 || m_end <= m_begin) return XH_OK;
     XH_REQUIRE(ctx, m_begin >= 0 && m_end <= s.nmonths && m_begin % 2 == 0 && m_end % 2 == 0, "xh_abcd: bad month block");
     const int64_t ncell = s.ncell;
     const unsigned blocks = (unsigned)((ncell + 63) / 64), blocks32 = (unsigned)((ncell + 31) / 32);
     const bool whole = m_begin == 0 && m_end == s.nmonths;
     int mode = abcd_env() < 0 ? 32 : abcd_env();
-    if (mode == 0 && !whole) mode = 32;                          // only the tiled kernel marches blocks of months
+    if (mode == 0 && (!whole || d_q_staged)) mode = 32;          // only the tiled kernel marches blocks of months / stages the runoff
     double *state = whole ? nullptr : s.d_state;
     xh_span sp = xh_span_begin_on(ctx, "abcd_sim", st);
     if (mode == 32)
         hipLaunchKernelGGL((k_abcd_tile<false, 32>), dim3(blocks32), dim3(64), 0, st, ncell, s.nmonths, s.nmonths, m_begin,
                            m_end, state, s.d_pidx, s.d_bidx, d_pars, d_pet, d_precip, d_tmin, s.d_sm0, s.d_gw0,
-                           (double *)nullptr, d_aet, d_q, d_sav);
+                           (double *)nullptr, d_aet, d_q, d_sav, d_q_staged);
     else if (mode == 64)
         hipLaunchKernelGGL((k_abcd_tile<false, 64>), dim3(blocks), dim3(64), 0, st, ncell, s.nmonths, s.nmonths, m_begin,
                            m_end, state, s.d_pidx, s.d_bidx, d_pars, d_pet, d_precip, d_tmin, s.d_sm0, s.d_gw0,
-                           (double *)nullptr, d_aet, d_q, d_sav);
+                           (double *)nullptr, d_aet, d_q, d_sav, d_q_staged);
     else
         hipLaunchKernelGGL(k_abcd<false>, dim3(blocks), dim3(64), 0, st, ncell, s.nmonths, s.nmonths, s.d_pidx, s.d_bidx,
                            d_pars, d_pet, d_precip, d_tmin, s.d_sm0, s.d_gw0, (double *)nullptr, d_aet, d_q, d_sav);
@@ -488,7 +497,7 @@ extern "C" int xh_abcd(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spin
     if (rc || ncell == 0) return rc;
     rc = xh_abcd_enqueue_spinup(ctx, ctx->stream, s, d_pars, d_pet, d_precip, d_tmin);
     if (rc) return rc;
-    rc = xh_abcd_enqueue_sim(ctx, ctx->stream, s, 0, nmonths, d_pars, d_pet, d_precip, d_tmin, d_aet, d_q, d_sav);
+    rc = xh_abcd_enqueue_sim(ctx, ctx->stream, s, 0, nmonths, d_pars, d_pet, d_precip, d_tmin, d_aet, d_q, d_sav, nullptr);
     if (rc) return rc;
     if (d_sm0_out) XH_HIP(ctx, hipMemcpyAsync(d_sm0_out, s.d_sm0, sizeof(double) * n_groups, hipMemcpyDeviceToDevice, ctx->stream));
     if (d_gw0_out) XH_HIP(ctx, hipMemcpyAsync(d_gw0_out, s.d_gw0, sizeof(double) * n_groups, hipMemcpyDeviceToDevice, ctx->stream));

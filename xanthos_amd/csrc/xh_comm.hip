@@ -16,6 +16,8 @@
 // runs torch.distributed shares one RCCL): single-GPU users of libxanthos_hip.so do not need it at all.
 #include <dlfcn.h>
 
+#include <cstdlib>
+
 #include <mutex>
 #include <rccl/rccl.h>
 
@@ -46,8 +48,11 @@ RcclApi &rccl() {
 }
 
 void rccl_load(RcclApi &api) {
-    const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    // XH_RCCL_LIBRARY: full path of the RCCL build to bind (a site's own build; the test-only stand-in of tests/fake_rccl in a
+    // process that has PyTorch's bundled copy loaded under the same soname, where the name alone would find that one)
+    const char *names[] = {getenv("XH_RCCL_LIBRARY"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char *n : names) {
+        if (!n || !n[0]) continue;
         api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (api.handle) break;
     }

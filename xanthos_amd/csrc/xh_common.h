@@ -56,6 +56,10 @@ struct xh_ctx {
     // xh_run_fused: side stream and events of the block pipeline
     hipStream_t side_stream[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> side_events;
+    // xh_run_fused mode 1: hand-over words (months ready, placement epoch) + the routing kernel's staged runoff (grow-only)
+    void *d_feed = nullptr;
+    size_t feed_bytes = 0;
+    unsigned feed_epoch = 0;
     // xh_upload_file / xh_download_file: page-locked chunk ring of the file movers (grow-only)
     void *io_ring = nullptr;
     size_t io_ring_bytes = 0;
@@ -104,5 +108,6 @@ struct xh_span {
 xh_span xh_span_begin(xh_ctx *ctx, const char *name);
 xh_span xh_span_begin_on(xh_ctx *ctx, const char *name, hipStream_t stream);   // kernels of a pipelined call on a side stream
 void xh_span_end(xh_span &s);
+void xh_span_cancel(xh_span &s);
 
 static inline int xh_is_leap_gregorian(int y) { return (y % 4 == 0 && y % 100 != 0) || (y % 400 == 0); }

@@ -160,9 +160,15 @@ void xh_span_end(xh_span &s) {
     s.ctx->timers[s.name].pending.emplace_back(s.a, s.b);
 }
 
+void xh_span_cancel(xh_span &s) {      // nothing was launched after all: the span leaves no timing record
+    if (s.a) s.ctx->event_pool.push_back(s.a);
+    if (s.b) s.ctx->event_pool.push_back(s.b);
+    s.a = s.b = nullptr;
+}
+
 extern "C" {
 
-int xh_abi_version(void) { return 3; }
+int xh_abi_version(void) { return 4; }
 
 int xh_device_count(int *n) {
     if (!n) return XH_ERR_ARG;
@@ -220,6 +226,7 @@ void xh_ctx_destroy(xh_ctx *ctx) {
             (void)hipStreamDestroy(ctx->side_stream[i]);
         }
     for (auto e : ctx->side_events) (void)hipEventDestroy(e);
+    if (ctx->d_feed) (void)hipFree(ctx->d_feed);
     if (ctx->d_fault) (void)hipFree(ctx->d_fault);
     if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
     if (ctx->io_ring) (void)hipHostFree(ctx->io_ring);

@@ -18,21 +18,177 @@
 // ABCD's waves taking the register file the routing units were no longer all resident: their bounded waits timed out
 // and the call was re-routed.  The dataflow kernel wants the chip to itself.
 // Results are identical to the three separate calls: the same kernels, the same order of operations.
+//
+// Round 4, mode 1 (XH_FUSED_FEED): the other way round -- the routing kernel gets the chip first and the rest of PM and
+// ABCD runs beside it.  Routing's spin-up pass and the first months of its simulation pass only need the first B0 =
+// max(spin-ups) months of runoff, rounded up to 16; that is 7.9 ms of its 23 at the full grid, and PM + ABCD of the other
+// months is 2.2 ms of work:
+//
+//   stream A   PM [0,B0) | ABCD spin-up, means, sim [0,B0) | routing kernel (all months) ................... | join
+//   stream B                                                  gate | PM [B0,n) | ABCD sim [B0,n) | ready = n
+//
+// What makes this work where round 2's attempt did not: (1) the routing kernel is launched onto an IDLE chip and the side
+// stream's first kernel (k_gate) holds everything else back until the routing kernel reports that each of its workgroups is
+// resident and has claimed its SIMD (place_epoch) -- its units are then never displaced, the others take the wave slots
+// that are left (one PM or ABCD wave fits beside a routing wave's 256 registers); (2) the routing waves raise their issue
+// priority (s_setprio) above the fillers'; (3) the only thing the sub-step loop pays is one scalar comparison per MONTH
+// (month index against the months known to be final), the months-ready word is polled only when that fails; (4) no
+// coherent loads, no invalidates: ABCD writes the routing kernel's runoff a second time in a staged layout
+// [16-month line][cell] whose 128-byte lines are each written whole by one launch and never read before the flag says so
+// (FlowFeed, xh_mrtm_flow.h), so no cache can hold a stale copy.  Same kernels, same arithmetic: bit-identical outputs.
 #include <algorithm>
 #include <string>
 
+#include "xh_mrtm_flow.h"
 #include "xh_stage.h"
 
 namespace {
 
 int fused_resources(xh_ctx *ctx, size_t n_events) {
-    if (!ctx->side_stream[0]) XH_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream[0], hipStreamNonBlocking));
+    if (!ctx->side_stream[0]) {
+        // LOWEST priority, and not only because its kernels are the fillers of mode 1: the runtime multiplexes streams onto
+        // a few hardware queues per priority level, and two streams that share a queue run their kernels in submission
+        // order -- the side stream's kernels would sit behind the routing kernel that is waiting for their months (a
+        // bounded wait, a fault, a re-route: observed).  Streams of different priority never share a queue.
+        int least = 0, greatest = 0;
+        XH_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        // (the context's stream has the default priority 0; a device whose range has nothing below it gets the other end;
+        // XH_FEED_PRIO=high / low: experiments)
+        int prio = least != 0 ? least : greatest;
+        if (const char *env = getenv("XH_FEED_PRIO")) prio = env[0] == 'h' ? greatest : least;
+        XH_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream[0], hipStreamNonBlocking, prio));
+        if (getenv("XH_FLOW_DEBUG")) fprintf(stderr, "[libxanthos_hip] side stream priority %d (range %d .. %d)\n", prio, least, greatest);
+    }
     while (ctx->side_events.size() < n_events) {
         hipEvent_t e = nullptr;
         XH_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->side_events.push_back(e);
     }
     return XH_OK;
+}
+
+__global__ void k_set_word(unsigned *w, unsigned v) {
+    if (threadIdx.x == 0) __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Holds the side stream back until the routing kernel of this call has placed its workgroups (it writes `epoch`), at most
+// `limit_ticks` of the 100 MHz counter: correctness never depends on it (the stream also waits for an event), only who
+// gets the wave slots first.
+__global__ void k_gate(const unsigned *w, unsigned epoch, unsigned long long limit_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// mode 1 of xh_run_fused (see the top of this file).  XH_ERR_LIMIT when the routing cannot be fed: too few months (nothing
+// has been enqueued, *runoff_done false) or a plan / flags the time-skewed dataflow kernel does not take (PM and ABCD have
+// then been enqueued for the whole series on the context's stream, *runoff_done true: the caller routes the ordinary way).
+int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup &ab, bool *runoff_done) {
+    *runoff_done = false;
+    const int nmonths = a->nmonths;
+    // First block: at least the spin-ups (ABCD's needs PET of those months, the routing's pass over them comes first), and
+    // enough months to keep the routing kernel busy until the side stream has delivered the rest: beside the routing waves
+    // PM runs at ~1/6 of its stand-alone speed (one wave per SIMD, below the routing waves' priority), i.e. ~25 us per
+    // month of the full grid against the routing's 33 us per month; 3/8 of the series covers that with margin (measured
+    // at 600 months, profiles/round4/feed_first_block.txt: 192 / 224 months 25.35 ms per step, 128 too few, 320 too many).
+    int b0 = (std::max(a->abcd_spinup, a->routing_spinup) + 15) & ~15;
+    b0 = std::max(b0, (nmonths * 3 / 8 + 15) & ~15);
+    b0 = std::max(b0, 32);
+    if (const char *env = getenv("XH_FEED_FIRST"))      // experiments
+        b0 = std::max((std::max(a->abcd_spinup, a->routing_spinup) + 15) & ~15, atoi(env) & ~15);
+    hipStream_t A = ctx->stream, B = ctx->side_stream[0];
+    auto pm_block = [&](hipStream_t st, int m0, int m1) {
+        return xh_pm_enqueue(ctx, st, pm, m0, m1 - m0, a->d_tas, a->d_tmin, a->d_rhs, a->d_wind, a->d_rsds, a->d_rlds, a->d_tairprev,
+                             a->d_lct, a->d_elev, a->d_pet);
+    };
+    auto sim_block = [&](hipStream_t st, int m0, int m1, double *staged) {
+        return xh_abcd_enqueue_sim(ctx, st, ab, m0, m1, a->d_pars, a->d_pet, a->d_precip, a->d_abcd_tmin, a->d_aet, a->d_q,
+                                   a->d_sav, staged);
+    };
+    if (nmonths - b0 < 64) return XH_ERR_LIMIT;
+    // the routing kernel's copy of the runoff and the two words of the hand-over (each on a line of its own)
+    const size_t lines = (size_t)(nmonths + 15) / 16;
+    const size_t need = lines * (size_t)a->ncell * 128 + 256;
+    if (need > ctx->feed_bytes) {
+        int rc = xh_settle(ctx);
+        if (rc) return rc;
+        if (ctx->d_feed) XH_HIP(ctx, hipFree(ctx->d_feed));
+        ctx->d_feed = nullptr;
+        ctx->feed_bytes = 0;
+        XH_HIP(ctx, hipMalloc(&ctx->d_feed, need));
+        ctx->feed_bytes = need;
+        XH_HIP(ctx, hipMemsetAsync(ctx->d_feed, 0, 256, A));
+    }
+    unsigned *w_ready = static_cast<unsigned *>(ctx->d_feed), *w_epoch = w_ready + 32;
+    double *staged = reinterpret_cast<double *>(static_cast<char *>(ctx->d_feed) + 256);
+    hipEvent_t ev_blk0 = ctx->side_events[0], ev_done = ctx->side_events[1];
+
+    int rc = pm_block(A, 0, b0);
+    if (rc) return rc;
+    rc = xh_abcd_enqueue_spinup(ctx, A, ab, a->d_pars, a->d_pet, a->d_precip, a->d_abcd_tmin);
+    if (rc) return rc;
+    rc = sim_block(A, 0, b0, staged);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(64), 0, A, w_ready, (unsigned)b0);
+    XH_HIP(ctx, hipEventRecord(ev_blk0, A));
+    FlowFeed feed;
+    feed.q_staged = staged;
+    feed.ncell = a->ncell;
+    feed.months_ready = w_ready;
+    feed.ready_at_launch = (unsigned)b0;
+    feed.place_epoch = w_epoch;
+    feed.epoch = ++ctx->feed_epoch;
+    rc = xh_route_series_fed(ctx, a->plan, nmonths, a->routing_spinup, a->h_ndays, a->dt, a->d_flow_dist, a->d_velocity,
+                             a->d_area, a->d_q, a->d_S0, a->d_chstorage, a->d_avgchflow, a->route_flags, &feed);
+    if (rc == XH_ERR_LIMIT) {      // not routed: the rest of the runoff on this stream, then the ordinary call (caller)
+        rc = pm_block(A, b0, nmonths);
+        if (rc) return rc;
+        rc = sim_block(A, b0, nmonths, nullptr);
+        *runoff_done = rc == XH_OK;
+        return rc ? rc : XH_ERR_LIMIT;
+    }
+    if (rc) return rc;
+    // The routing kernel is in stream A's queue.  Everything below goes to stream B: ordered behind the first block by
+    // the event (ABCD's state scratch, the spin-up means), held back by the gate until the routing units are in place.
+    std::string first_error;
+    auto rest = [&]() -> int {
+        XH_HIP(ctx, hipStreamWaitEvent(B, ev_blk0, 0));
+        static const unsigned long long gate_ticks = [] {
+            const char *env = getenv("XH_FEED_GATE_US");
+            return (unsigned long long)(env ? atoll(env) : 20000) * 100ull;
+        }();
+        {   // (its timer also tells callers how many calls were routed this way: xh_timing_get "feed_gate")
+            xh_span sp = xh_span_begin_on(ctx, "feed_gate", B);
+            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, B, w_epoch, feed.epoch, gate_ticks);
+            xh_span_end(sp);
+        }
+        int r = pm_block(B, b0, nmonths);
+        if (r) return r;
+        r = sim_block(B, b0, nmonths, staged);
+        if (r) return r;
+        hipLaunchKernelGGL(k_set_word, dim3(1), dim3(64), 0, B, w_ready, (unsigned)nmonths);
+        XH_HIP(ctx, hipGetLastError());
+        return XH_OK;
+    };
+    rc = rest();
+    if (rc) first_error = ctx->err;
+    // join, whatever happened: later calls on the context's stream (and xh_sync) are ordered behind stream B
+    const hipError_t j1 = hipEventRecord(ev_done, B);
+    const hipError_t j2 = j1 == hipSuccess ? hipStreamWaitEvent(A, ev_done, 0) : j1;
+    if (j2 != hipSuccess) {
+        (void)hipStreamSynchronize(B);
+        if (!rc) rc = xh_fail(ctx, XH_ERR_HIP, "xh_run_fused: joining the side stream failed: %s", hipGetErrorString(j2));
+    }
+    if (rc) {
+        // the routing kernel may be waiting for months that will never come: raise the fault word so that it gives up
+        unsigned *fault = nullptr;
+        if (xh_fault_word(ctx, &fault) == XH_OK) hipLaunchKernelGGL(k_set_word, dim3(1), dim3(64), 0, B, fault, 1u);
+        if (!first_error.empty()) ctx->err = first_error;
+    }
+    return rc;
 }
 
 }  // namespace
@@ -61,6 +217,16 @@ extern "C" int xh_run_fused(xh_ctx *ctx, const xh_fused_args *a) {
     const int nblk = (nmonths + block - 1) / block;
     rc = fused_resources(ctx, (size_t)nblk + 3);
     if (rc) return rc;
+    if (a->mode == 1 && a->plan) {
+        bool runoff_done = false;
+        rc = run_fed(ctx, a, pm, ab, &runoff_done);
+        if (rc != XH_ERR_LIMIT) return rc;
+        if (runoff_done)      // PM and ABCD are complete on the context's stream: the ordinary routing call
+            return xh_route_series(ctx, a->plan, nmonths, a->routing_spinup, a->h_ndays, a->dt, a->d_flow_dist, a->d_velocity,
+                                   a->d_area, a->d_q, a->d_S0, a->d_chstorage, a->d_avgchflow, nullptr, nullptr,
+                                   a->route_flags);
+        // (too few months: nothing has been enqueued, the block pipeline below does the whole series)
+    }
     hipStream_t A = ctx->stream, B = ctx->side_stream[0];
     hipEvent_t ev_start = ctx->side_events[0], ev_done = ctx->side_events[1];
     hipEvent_t *ev_pm = &ctx->side_events[3];
@@ -86,7 +252,7 @@ extern "C" int xh_run_fused(xh_ctx *ctx, const xh_fused_args *a) {
             const int m0 = k * block, m1 = std::min(nmonths, m0 + block);
             XH_HIP(ctx, hipStreamWaitEvent(B, ev_pm[k], 0));
             r = xh_abcd_enqueue_sim(ctx, B, ab, m0, m1, a->d_pars, a->d_pet, a->d_precip, a->d_abcd_tmin, a->d_aet,
-                                    a->d_q, a->d_sav);
+                                    a->d_q, a->d_sav, nullptr);
             if (r) return r;
         }
         XH_HIP(ctx, hipGetLastError());

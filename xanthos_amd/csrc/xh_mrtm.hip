@@ -27,6 +27,8 @@
 #include <thread>
 
 #include "xh_common.h"
+#include <sys/stat.h>
+
 #include "xh_mrtm_flow.h"
 
 namespace {
@@ -378,6 +380,12 @@ struct xh_route_plan {
     // dataflow call confirmed fault-free resets the streak (xh_route_confirm).
     int fault_streak = 0, skip_calls = 0;
     int64_t validated = 0;                       // calls cross-checked against the workgroup-per-network kernel (XH_ROUTE_VALIDATE)
+    // The dataflow kernels' streams rest on an ordering assumption outside the HIP memory model (xh_mrtm_wave.hip, check()).
+    // So that no product run is unverified on a new box, the FIRST dataflow call of a plan is cross-checked like
+    // XH_ROUTE_VALIDATE unless a marker file says this library build already passed on this device with this topology
+    // (route_first_check_*; XH_ROUTE_VALIDATE_FIRST=0 switches it off).
+    bool first_checked = false;
+    uint64_t topo_hash = 0;
     int64_t n_rest_units = 0, n_fb_rest = 0;
     bool fb_rest_single_ds = true;
     DevBuf d_fbr_cells, d_fbr_ptr, d_fbr_col, d_fbr_sgn, d_fbr_ds;
@@ -512,6 +520,17 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
             if (hipMalloc(&plan->d_learn.p, (size_t)n + 256) != hipSuccess || hipMemset(plan->d_learn.p, 0, (size_t)n + 256) != hipSuccess) {
                 route_plan_free(plan, false);
                 return xh_fail(ctx, XH_ERR_HIP, "xh_route_plan_create: device allocation failed");
+            }
+            {
+                uint64_t h = 1469598103934665603ull;      // FNV-1a over the CSR structure
+                auto mix = [&](const void *p, size_t nbytes) {
+                    const unsigned char *b = static_cast<const unsigned char *>(p);
+                    for (size_t i = 0; i < nbytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
+                };
+                mix(h_indptr, sizeof(int64_t) * (size_t)(n + 1));
+                if (nnz) mix(h_indices, sizeof(int32_t) * (size_t)nnz);
+                if (nnz) mix(h_sign, (size_t)nnz);
+                plan->topo_hash = h;
             }
             plan->h_indptr.assign(h_indptr, h_indptr + n + 1);
             plan->h_indices.assign(h_indices, h_indices + nnz);
@@ -779,7 +798,8 @@ extern "C" int xh_route_plan_stats(xh_route_plan *plan, int64_t max_words, uint6
 static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                              const int32_t *h_ndays, double dt, const double *d_flow_dist, const double *d_velocity,
                              const double *d_area, const double *d_runoff, const double *d_S0, double *d_chstorage,
-                             double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow);
+                             double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow,
+                             const FlowFeed *feed = nullptr);
 
 // Bitwise comparison of two arrays (NaN payloads included): XH_ROUTE_VALIDATE
 __global__ void __launch_bounds__(256) k_count_diff(const unsigned long long *a, const unsigned long long *b, int64_t n,
@@ -869,21 +889,102 @@ void xh_route_backoff(xh_route_plan *plan) {      // once per fault event and pl
     plan->skip_calls = 4 << plan->fault_streak;      // 8, 16, ... 256 calls without the dataflow kernels
 }
 
+static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
+                             const int32_t *h_ndays, double dt, const double *d_flow_dist,
+                             const double *d_velocity, const double *d_area, const double *d_runoff,
+                             const double *d_S0, double *d_chstorage, double *d_avgchflow, double *d_S_end,
+                             double *d_F_end, int32_t flags, const FlowFeed *feed);
+
 extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                                const int32_t *h_ndays, double dt, const double *d_flow_dist,
                                const double *d_velocity, const double *d_area, const double *d_runoff,
                                const double *d_S0, double *d_chstorage, double *d_avgchflow, double *d_S_end,
                                double *d_F_end, int32_t flags) {
+    return route_series_call(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
+                             d_chstorage, d_avgchflow, d_S_end, d_F_end, flags, nullptr);
+}
+
+// The runoff source of the routing kernel is the staged copy named by `feed`, filled while the kernel runs; d_runoff is the
+// [ncell, nmonths] array the same months end up in, and what a re-run after a fault reads (complete by then).
+int xh_route_series_fed(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months, const int32_t *h_ndays,
+                        double dt, const double *d_flow_dist, const double *d_velocity, const double *d_area,
+                        const double *d_runoff, const double *d_S0, double *d_chstorage, double *d_avgchflow,
+                        int32_t flags, const FlowFeed *feed) {
+    return route_series_call(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
+                             d_chstorage, d_avgchflow, nullptr, nullptr, flags, feed);
+}
+
+// Marker of a passed first-call check: <dir>/route_ok_<device>_<build>_<topology>; dir = $XH_CACHE_DIR or
+// $HOME/.cache/xanthos_amd.  Failing to read or write it only means the check runs again.
+static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan) {
+    std::string dir;
+    if (const char *d = getenv("XH_CACHE_DIR")) dir = d;
+    else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/xanthos_amd";
+    if (dir.empty()) return std::string();
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const char *t) {
+        for (; *t; ++t) h = (h ^ (unsigned char)*t) * 1099511628211ull;
+    };
+    mix(ctx->prop.name);
+    mix(ctx->prop.gcnArchName);
+    mix(__DATE__ " " __TIME__);      // this translation unit's build: a new library build checks again
+    char name[160];
+    snprintf(name, sizeof(name), "/route_ok_%016llx_%016llx_%lld_%lld", (unsigned long long)h, (unsigned long long)plan->topo_hash,
+             (long long)plan->ncell, (long long)(plan->flow ? plan->flow->n_units : 0));
+    return dir + name;
+}
+
+static bool first_check_needed(xh_ctx *ctx, xh_route_plan *plan) {
+    static const bool enabled = !(getenv("XH_ROUTE_VALIDATE_FIRST") && getenv("XH_ROUTE_VALIDATE_FIRST")[0] == '0');
+    if (!enabled || plan->first_checked || !plan->flow) return false;
+    const std::string path = first_check_path(ctx, plan);
+    if (!path.empty()) {
+        if (FILE *f = fopen(path.c_str(), "r")) {
+            fclose(f);
+            plan->first_checked = true;
+            return false;
+        }
+    }
+    return true;
+}
+
+static void first_check_passed(xh_ctx *ctx, xh_route_plan *plan) {
+    plan->first_checked = true;
+    const std::string path = first_check_path(ctx, plan);
+    if (path.empty()) return;
+    const std::string dir = path.substr(0, path.rfind('/'));
+    for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
+        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
+    if (FILE *f = fopen(path.c_str(), "w")) {
+        fprintf(f, "dataflow routing equal to the workgroup-per-network kernel, bit for bit, on %s\n", ctx->prop.name);
+        fclose(f);
+    }
+}
+
+static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
+                             const int32_t *h_ndays, double dt, const double *d_flow_dist,
+                             const double *d_velocity, const double *d_area, const double *d_runoff,
+                             const double *d_S0, double *d_chstorage, double *d_avgchflow, double *d_S_end,
+                             double *d_F_end, int32_t flags, const FlowFeed *feed) {
     bool used_flow = false;
     if (plan && plan->skip_calls > 0 && (flags & XH_ROUTE_TEST_FAULT) == 0) {      // recently faulted: see xh_route_plan
         plan->skip_calls -= 1;
         flags |= XH_ROUTE_NO_DATAFLOW;
     }
     static const bool validate_env = getenv("XH_ROUTE_VALIDATE") && getenv("XH_ROUTE_VALIDATE")[0] == '1';
-    const bool validate = validate_env || (flags & XH_ROUTE_VALIDATE) != 0;
+    bool validate = validate_env || (flags & XH_ROUTE_VALIDATE) != 0;
     flags &= ~XH_ROUTE_VALIDATE;
+    // first dataflow call of this plan on a box / build that has not passed the cross-check yet: checked like XH_ROUTE_VALIDATE
+    const bool plain_call = plan && (flags & (XH_ROUTE_NO_DATAFLOW | XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_ATOMIC | XH_ROUTE_TEST_FAULT)) == 0;
+    const bool first_check = !validate && plain_call && first_check_needed(ctx, plan);
+    validate = validate || first_check;
+    // a fed call cannot be cross-checked at once (the second routing would read runoff that does not exist yet), nor
+    // routed by anything but the dataflow kernel that knows how to wait for it
+    if (feed && (validate || (flags & (XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_ATOMIC |
+                                       XH_ROUTE_TEST_FAULT)) != 0))
+        return XH_ERR_LIMIT;
     int rc = route_series_impl(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff,
-                               d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end, flags, &used_flow);
+                               d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end, flags, &used_flow, feed);
     if (rc || !used_flow) return rc;
     // remember the call until a synchronisation has confirmed that no bounded wait timed out (xh_fault_check)
     xh_route_record r;
@@ -906,8 +1007,12 @@ extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths
     ctx->pending_routes.push_back(std::move(r));
     rc = xh_fault_collect(ctx);
     if (rc || !validate) return rc;
-    return route_validate(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
-                          d_chstorage, d_avgchflow, d_S_end, d_F_end, flags);
+    const int64_t reroutes_before = ctx->reroutes;
+    rc = route_validate(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
+                        d_chstorage, d_avgchflow, d_S_end, d_F_end, flags);
+    // (a call that had to be re-routed was not routed by the dataflow kernel in the end: nothing was checked)
+    if (rc == XH_OK && ctx->reroutes == reroutes_before && (first_check || !plan->first_checked)) first_check_passed(ctx, plan);
+    return rc;
 }
 
 int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r, bool dataflow_pairs) {
@@ -939,7 +1044,8 @@ extern "C" int xh_route_plan_typed_info(const xh_route_plan *plan, int64_t info[
 static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                              const int32_t *h_ndays, double dt, const double *d_flow_dist, const double *d_velocity,
                              const double *d_area, const double *d_runoff, const double *d_S0, double *d_chstorage,
-                             double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow) {
+                             double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow,
+                             const FlowFeed *feed) {
     if (!ctx || !plan) return XH_ERR_ARG;
     XH_REQUIRE(ctx, plan->ctx == ctx, "xh_route_series: plan belongs to another context");
     XH_REQUIRE(ctx, h_ndays && d_flow_dist && d_velocity && d_area && d_runoff, "xh_route_series: NULL argument");
@@ -1097,6 +1203,8 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     const bool force_fb = (flags & XH_ROUTE_FORCE_FALLBACK) != 0;
     const bool atomic = (flags & XH_ROUTE_ATOMIC) != 0;
     bool use_flow = !force_fb && plan->flow != nullptr && (flags & XH_ROUTE_NO_DATAFLOW) == 0;
+    // fed call: every cell must be routed by k_mrtm_wave (the other kernels read the runoff array itself, at once)
+    if (feed && (!use_flow || plan->n_rest_units > 0 || plan->n_fb_rest > 0 || old_skew_env)) return XH_ERR_LIMIT;
 
     xh_span sp = xh_span_begin(ctx, "mrtm_route");
     XH_HIP(ctx, hipEventRecord(plan->ev_fork, ctx->stream));
@@ -1114,7 +1222,7 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
                            (flags & XH_ROUTE_TEST_FAULT) != 0, nt_even, sm.data(), snt.data(), sg.data(), ssecs.data(),
                            swr.data()};
         const FlowIO fio{d_flow_dist, d_velocity, d_area, d_runoff, d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end,
-                         static_cast<unsigned char *>(plan->d_learn.p)};
+                         static_cast<unsigned char *>(plan->d_learn.p), feed};
         // time-skewed units first; months shorter than the deepest lane lag (long dt) use the monthly-stream kernel
         static const bool skew_env = !(getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] == '0');
         rc = XH_ERR_LIMIT;
@@ -1124,6 +1232,10 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
             rc = old_skew ? skew_launch(ctx, plan->flow, fs, fio, ctx->stream) : wave_launch(ctx, tree_plan, fs, fio, ctx->stream);
         if (rc == XH_ERR_LIMIT && tree_plan != plan->flow && !old_skew) rc = wave_launch(ctx, plan->flow, fs, fio, ctx->stream);
         plan->last_typed = rc == XH_OK && tree_plan != plan->flow && !old_skew;
+        if (feed && rc == XH_ERR_LIMIT) {      // nothing was launched: the caller completes the runoff and calls again
+            xh_span_cancel(sp);
+            return XH_ERR_LIMIT;
+        }
         // what the round-3 kernel cannot take (rows beyond its 32-bit offsets) the round-2 time-skewed kernel may still
         if (rc == XH_ERR_LIMIT && skew_env && !old_skew && (flags & XH_ROUTE_NO_SKEW) == 0) {
             rc = skew_launch(ctx, plan->flow, fs, fio, ctx->stream);

@@ -46,10 +46,24 @@ struct FlowSched {
     const unsigned char *h_wr;
 };
 
+// Routing that starts before the whole runoff series exists (xh_run_fused, mode 1; k_mrtm_wave only).  The runoff is read
+// from a STAGED copy the ABCD kernels write beside the [ncell, nmonths] array: [line v][cell][16 months], one 128-byte line
+// per (16 months, cell), every line written whole by ONE kernel and read only after `months_ready` says so -- a line is
+// never in anybody's cache before it is final, so the hand-over needs no invalidate and no coherent loads, only the flag.
+struct FlowFeed {
+    const double *q_staged = nullptr;     // [ceil(nmonths / 16)][ncell][16]
+    int64_t ncell = 0;                    // cells of the staged array (its line stride is ncell * 128 bytes)
+    const unsigned *months_ready = nullptr;      // device word: months [0, *months_ready) of every cell are final
+    unsigned ready_at_launch = 0;         // its value when the kernel is launched
+    unsigned *place_epoch = nullptr;      // device word the kernel sets to `epoch` once every workgroup is resident and placed
+    unsigned epoch = 0;
+};
+
 struct FlowIO {
     const double *flow_dist, *velocity, *area, *runoff, *S0;
     double *chs, *avg, *S_end, *F_end;
     unsigned char *learn;             // [ncell] cells seen firing unexpectedly (xh_mrtm_wave.hip); never NULL for wave_launch
+    const FlowFeed *feed = nullptr;   // wave_launch only: runoff arrives while the kernel runs (see FlowFeed)
 };
 
 // Partition every tree-shaped river network (each cell drains to at most one cell, no cycle, standard UP - I rows)

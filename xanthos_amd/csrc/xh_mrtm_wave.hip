@@ -51,19 +51,20 @@ constexpr int PLACE_WORDS = 16 + PLACE_KEYS;
 struct MonthRec {                             // one iteration of the schedule (spin-up months, then every month)
     int m, nt, g, write;                      // month index, sub-steps, first global sub-step, 1 = simulation pass
     double secs;
-    int pad[2];
+    long long q_off;                          // byte offset of month m inside a cell's row of the runoff source
 };
 static_assert(sizeof(MonthRec) == 32, "MonthRec is read with one s_load_dwordx8");
 
 // What the month bookkeeping of iteration `it` needs, gathered in one record that is loaded a whole month before it is
 // used (round 3 profile: three dependent loads of month records, each waited for, cost every unit ~30 cycles per sub-step)
 struct FinRec {
-    int m_prev, nt_prev, write_prev;          // month index, sub-steps and write flag of iteration it - 1
+    int m_prev_w, nt_prev;                    // month index (bit 30: write flag) and sub-steps of iteration it - 1
     int m_next2;                              // month index of iteration it + 2 (its runoff is loaded now)
-    double secs_next1;                        // seconds of iteration it + 1
     int g_next1;                              // first global sub-step of iteration it + 1
-    int pad;
+    double secs_next1;                        // seconds of iteration it + 1
+    long long q_off_next2;                    // byte offset of month m_next2 inside a cell's row of the runoff source
 };
+constexpr int FIN_WRITE = 1 << 30;
 static_assert(sizeof(FinRec) == 32, "FinRec is read with one s_load_dwordx8");
 
 struct WaveArgs {
@@ -85,6 +86,15 @@ struct WaveArgs {
     double dt, dtinv;
     const double *flow_dist, *velocity, *area, *runoff, *S0;
     double *chs, *avg, *S_end, *F_end;
+    // runoff source: a cell's row starts at runoff + cell * q_row_stride bytes, month m of it at the record's q_off.  The
+    // [ncell, nmonths] array (stride nmonths * 8, q_off = m * 8), or the staged copy of a fed run (FlowFeed: stride 128,
+    // q_off = (m / 16) * ncell * 128 + (m % 16) * 8) together with the months-ready word and the placement epoch.
+    unsigned q_row_stride;
+    unsigned ready_at_launch;         // months known final at launch (UINT_MAX: all of them, nothing to wait for)
+    const unsigned *months_ready;
+    unsigned *place_epoch;
+    unsigned epoch;
+    int fenced;                       // XH_ROUTE_FENCED=1: agent-scope release / acquire fences around the stream counters (see check())
     char *xbuf;                       // [edges][RS] {F, F2}
     unsigned xbytes;                  // size of the rings
     unsigned ring_mask_b;             // RS * 16 - 1
@@ -184,7 +194,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     // byte offset of this lane's row in the [ncell, nmonths] arrays: a 32-bit register that is never redefined, so that the
     // monthly loads / stores address memory as (uniform base + this) and no address register of an access in flight is ever
     // overwritten (the compiler answers that with s_waitcnt vmcnt(0): ~2 us per month behind the output stores)
-    const unsigned row_off = (unsigned)gc_safe * (unsigned)A(nmonths) * 8u;
+    const unsigned row_off = (unsigned)gc_safe * A(q_row_stride);
     const double tauinv = valid ? A(velocity)[gc] / A(flow_dist)[gc] : 0.0;      // mrtm.py:40
     const double area = valid ? A(area)[gc] : 0.0;
     const double S0v = (valid && A(S0)) ? A(S0)[gc] : 0.0;
@@ -276,13 +286,12 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     FinRecK *p_fin = (FinRecK *)A(fin);
     auto ld_fin = [&](int i) {
         FinRec r;
-        r.m_prev = p_fin[i].m_prev;
+        r.m_prev_w = p_fin[i].m_prev_w;
         r.nt_prev = p_fin[i].nt_prev;
-        r.write_prev = p_fin[i].write_prev;
         r.m_next2 = p_fin[i].m_next2;
-        r.secs_next1 = p_fin[i].secs_next1;
         r.g_next1 = p_fin[i].g_next1;
-        r.pad = 0;
+        r.secs_next1 = p_fin[i].secs_next1;
+        r.q_off_next2 = p_fin[i].q_off_next2;
         return r;
     };
     FinRec fc = ld_fin(0);               // record of the next month bookkeeping, loaded one month ahead
@@ -293,6 +302,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         r.g = p_rec[i].g;
         r.write = p_rec[i].write;
         r.secs = p_rec[i].secs;
+        r.q_off = p_rec[i].q_off;
         return r;
     };
     unsigned *p_trace = A(trace);
@@ -303,8 +313,8 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     // s_waitcnt vmcnt(0) in front of the next sub-step -- behind the month's output stores, ~2 us per month and unit
     // (round 3 profile: ~30 cycles per sub-step of every unit, whatever the order of loads and stores).
     const unsigned q_lds = (unsigned)(size_t)qstage;
-    auto runoff_fetch = [&](int m) {       // asynchronous; complete before the next month bookkeeping (see runoff_take)
-        const char *src = reinterpret_cast<const char *>(p_runoff + m) + (size_t)row_off;
+    auto runoff_fetch = [&](long long q_off) {       // asynchronous; complete before the next month bookkeeping (see runoff_take)
+        const char *src = reinterpret_cast<const char *>(p_runoff) + q_off + (size_t)row_off;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_add_u32 m0, m0, 252\n\t"
                      "global_load_lds_dword %1, off offset:4\n\ts_mov_b32 m0, %0"
@@ -324,12 +334,12 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     double erl_n = 0.0;                                    // lateral inflow of the month to enter
     {
         const MonthRec r0 = ld_rec(0), r1 = ld_rec(1);
-        auto ld_q = [&](int m) {
-            return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(p_runoff + m) + (size_t)row_off);
+        auto ld_q = [&](long long q_off) {
+            return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(p_runoff) + q_off + (size_t)row_off);
         };
-        const double q0 = ld_q(r0.m);
+        const double q0 = ld_q(r0.q_off);
         erl_n = ((valid ? q0 : 0.0) * area) * 1000.0 / r0.secs;                  // mrtm.py:45
-        if (nit > 1) runoff_fetch(r1.m);
+        if (nit > 1) runoff_fetch(r1.q_off);
     }
     // month outputs leave as groups of OB months per cell (32 bytes = one memory sector)
     constexpr int OB = 4;
@@ -337,6 +347,29 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
 #pragma unroll
     for (int j = 0; j < OB; ++j) ob_s[j] = ob_a[j] = 0.0;
     bool alive = true;
+    // Fed run (FlowFeed): months [0, mready) of the runoff source are known to be final.  A month beyond that is waited
+    // for, bounded like every wait here, on the months-ready word (written by a kernel that runs after the one that
+    // produced the months; read like the stream counters).  The staged source is laid out so that no line is ever read
+    // before all of it is final, hence no invalidate between the flag and the data.
+    unsigned mready = A(ready_at_launch);
+    auto wait_months = [&](unsigned need) {
+        const unsigned *p = A(months_ready);
+        if (!p) return true;                             // (cannot happen: ready_at_launch covers the series then)
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_relaxed(p));
+            if (v >= need) {
+                mready = v;
+                return true;
+            }
+            if (ld_relaxed(A(fault)) != 0) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_LIMIT_TICKS) {
+                __hip_atomic_store(A(fault), FAULT_DATA_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    };
     unsigned long long cyc_wait_data = 0, cyc_wait_ring = 0, zone_groups = 0;
     const unsigned long long cyc_begin = __builtin_amdgcn_s_memtime();
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
@@ -378,8 +411,15 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alive = false;
         }
+        const bool fenced = A(fenced) != 0;
         if (any_x) {      // publish what has certainly been stored, then make sure the next CH iterations have ring space
             const int pub = min(max(n - PUBLAG - RING - lmax, 0), total);
+            // XH_ROUTE_FENCED=1: the publication the HIP memory model asks for -- an agent-scope release (buffer_wbl2 sc1 +
+            // s_waitcnt vmcnt(0): every memory operation of the wave drained, the XCD's L2 written back) in front of the
+            // counter store, an agent-scope acquire behind the consumer's counter load.  Measured on MI355X at the full grid
+            // (profiles/round4/fenced_ab.txt); the default keeps the vmcnt(8) form above and the first call of a plan on a
+            // new box / build is cross-checked against the barrier-only kernel instead (xh_mrtm.hip, first_check_*).
+            if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             if (has_x) __hip_atomic_store(A(ready) + xedge, (unsigned)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int need = n + CH - lmax - A(rs);
             seen_done = max(seen_done, pend_done);
@@ -394,6 +434,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             const int need = min(total, n + CH + GROUP - lag_g);
             seen_ready = max(seen_ready, pend_ready);
             alive = wave_wait_ge(has_g && need > 0, ready_p, (unsigned)max(need, 0), seen_ready, A(fault), FAULT_DATA_WAIT);
+            if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("" ::: "memory");      // the stream loads stay behind the poll
         }
         if (any_x) pend_done = load_async(done_p);
@@ -416,7 +457,8 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             erl_n = ((valid ? qn : 0.0) * area) * 1000.0 / f.secs_next1;
         }
         if (it >= 1) {
-            const int m = f.m_prev;
+            const int m = f.m_prev_w & (FIN_WRITE - 1);
+            const bool write_prev = (f.m_prev_w & FIN_WRITE) != 0;
 #pragma unroll
             for (int j = 0; j < OB - 1; ++j) {
                 ob_s[j] = ob_s[j + 1];
@@ -424,7 +466,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             }
             ob_s[OB - 1] = snapS;
             ob_a[OB - 1] = snapA / (double)f.nt_prev;                          // mrtm.py:80
-            if (f.write_prev && valid) {     // whole groups of OB months per cell
+            if (write_prev && valid) {     // whole groups of OB months per cell
                 if ((m & (OB - 1)) == OB - 1) {
                     const int64_t o = (int64_t)gc * nmo + (m - (OB - 1));
 #pragma unroll
@@ -444,7 +486,12 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
                 }
             }
         }
-        if (it + 2 < nit) runoff_fetch(f.m_next2);      // after runoff_take: one staging area
+        if (it + 2 < nit) {                             // after runoff_take: one staging area
+            // Fed run (FlowFeed): the month may not exist yet.  `mready` is the last value of the months-ready word this wave
+            // saw (all ones when the series was complete at launch: the comparison is all an ordinary run pays, once a month).
+            if ((unsigned)f.m_next2 >= mready) alive = wait_months((unsigned)f.m_next2 + 1u);
+            if (alive) runoff_fetch(f.q_off_next2);
+        }
         return f.g_next1;
     };
 
@@ -688,6 +735,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             store_pair(*xsrc[0], PLAIN ? *xsrc0[0] : 0.0, xbyte[0], xpos);
             if (x2) store_pair(*xsrc[1], PLAIN ? *xsrc0[1] : 0.0, xbyte[1], xpos);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // write-through stores acknowledged
+            if (A(fenced)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             if (has_x) __hip_atomic_store(A(ready) + xedge, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (any_g && lane == 0)
@@ -732,8 +780,9 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     //      SIMDs hold two units however the dispatcher spread the workgroups.  The second arrivals that stay take the
     //      cheapest units of the list (units without streams: they delay nobody), their SIMD partners the next ones, with
     //      issue priority, everybody else the rest in list order.
-    __shared__ int unit_sh;
+    __shared__ int unit_sh, prio_sh;
     if (threadIdx.x == 0) {
+        prio_sh = 0;
         unsigned *pl = A(place);
         const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 15u;
@@ -759,7 +808,11 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
         const unsigned rank = __hip_atomic_fetch_add(pl + 16 + key, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;
         if (rank == 0) add(2);
         else if (rank == 1) add(1);
-        __hip_atomic_fetch_add(pl + 0, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned registered = __hip_atomic_fetch_add(pl + 0, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // fed run: the last workgroup to register tells the host's side stream that every unit is resident and placed --
+        // only then may the kernels that produce the rest of the runoff take the free wave slots (xh_fused.hip)
+        if (registered + 1u == n_wg && A(place_epoch))
+            __hip_atomic_store(A(place_epoch), A(epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int idx = -1;                                  // -1: fault, -2: spare workgroup, nothing to do
         if (wait_for(pl + 0, n_wg)) {
             const int firsts = (int)ld_relaxed(pl + 2), seconds = (int)ld_relaxed(pl + 1);
@@ -771,13 +824,14 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
                 if (t < need2) __hip_atomic_fetch_or(pl + 16 + key, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(pl + 4, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 idx = t < need2 ? t : -2;
+                if (t < need2) prio_sh = 1;
             } else if (wait_for(pl + 4, (unsigned)seconds)) {
                 const bool shared = (ld_relaxed(pl + 16 + key) & 0x10000u) != 0;
                 if (firsts > n_units && (int)add(7) >= n_units) {
                     idx = -2;
                 } else if (shared) {
                     idx = need2 + (int)add(5);
-                    __builtin_amdgcn_s_setprio(3);
+                    prio_sh = 3;
                 } else {
                     idx = 2 * need2 + (int)add(6);
                 }
@@ -789,7 +843,17 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     __syncthreads();
     const int unit = unit_sh;
+    const int prio = prio_sh;
     if (unit < 0) return;
+    // Issue priority: a unit that shares its SIMD with a cheaper unit runs ahead of it (3 against the partner's 0); in a fed
+    // run every unit runs ahead of the waves of the kernels that produce its runoff on the same SIMDs (2, partners 3 / 1).
+    if (A(months_ready)) {
+        if (prio == 3) __builtin_amdgcn_s_setprio(3);
+        else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(2);
+    } else if (prio == 3) {
+        __builtin_amdgcn_s_setprio(3);
+    }
     const int p = A(unit_p)[unit];       // uniform per workgroup: terms before | after the diagonal << 4 | chained << 8 | plain << 9
     const bool has_ghost = A(ghost_edge)[(int64_t)unit * LANES + threadIdx.x] >= 0;      // lane k: the unit's k-th import
     const bool g = __any(has_ghost), g2 = __any(has_ghost && threadIdx.x >= 8);
@@ -859,7 +923,8 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     {
         uint64_t limit = (uint64_t)1 << 32;
         if (const char *env = getenv("XH_WAVE_ROW_LIMIT")) limit = std::min<uint64_t>(limit, strtoull(env, nullptr, 10));
-        if ((uint64_t)(fp->max_cell + 1) * (uint64_t)s.nmonths * 8u > limit) {
+        const uint64_t stride = io.feed ? 128u : (uint64_t)s.nmonths * 8u;
+        if ((uint64_t)(fp->max_cell + 1) * stride > limit || (io.feed && (int64_t)fp->max_cell >= io.feed->ncell)) {
             if (getenv("XH_FLOW_DEBUG"))
                 fprintf(stderr, "round-3 time-skewed kernel not used: %d rows x %d months x 8 B exceed its 32-bit row offsets\n",
                         fp->max_cell + 1, s.nmonths);
@@ -896,6 +961,12 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     MonthRec *d_rec = reinterpret_cast<MonthRec *>(static_cast<char *>(fp->d_x) + x_streams + x_cnt);
     FinRec *d_fin = reinterpret_cast<FinRec *>(static_cast<char *>(fp->d_x) + x_streams + x_cnt + x_rec0);
     XH_HIP(ctx, hipMemsetAsync(cnt, 0, x_cnt, st));
+    // where month m of a cell's row lies in the runoff source (WaveArgs::q_row_stride)
+    const FlowFeed *feed = io.feed;
+    auto q_off = [&](int m) -> long long {
+        if (!feed) return (long long)m * 8;
+        return (long long)(m >> 4) * feed->ncell * 128 + (long long)(m & 15) * 8;
+    };
     {   // the schedule as one record per iteration (+ three zero records: the month bookkeeping looks two ahead)
         fp->h_rec.assign((size_t)(s.nit + 3) * sizeof(MonthRec), 0);
         MonthRec *h = reinterpret_cast<MonthRec *>(fp->h_rec.data());
@@ -905,19 +976,20 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
             h[it].g = s.h_g[it];
             h[it].write = s.h_wr[it];
             h[it].secs = s.h_secs[it];
+            h[it].q_off = q_off(s.h_m[it]);
         }
         h[s.nit].g = s.total;
         fp->h_fin.assign((size_t)(s.nit + 2) * sizeof(FinRec), 0);
         FinRec *hf = reinterpret_cast<FinRec *>(fp->h_fin.data());
         for (int it = 0; it <= s.nit; ++it) {
             if (it >= 1) {
-                hf[it].m_prev = h[it - 1].m;
+                hf[it].m_prev_w = h[it - 1].m | (h[it - 1].write ? FIN_WRITE : 0);
                 hf[it].nt_prev = h[it - 1].nt;
-                hf[it].write_prev = h[it - 1].write;
             }
             hf[it].nt_prev = std::max(hf[it].nt_prev, 1);
             hf[it].secs_next1 = it + 1 < s.nit ? h[it + 1].secs : 1.0;
             hf[it].m_next2 = it + 2 < s.nit ? h[it + 2].m : 0;
+            hf[it].q_off_next2 = q_off(hf[it].m_next2);
             hf[it].g_next1 = it + 1 <= s.nit ? h[it + 1].g : s.total;
         }
         hf[s.nit + 1].nt_prev = 1;
@@ -979,7 +1051,13 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.flow_dist = io.flow_dist;
     a.velocity = io.velocity;
     a.area = io.area;
-    a.runoff = io.runoff;
+    a.runoff = feed ? feed->q_staged : io.runoff;
+    a.q_row_stride = feed ? 128u : (unsigned)s.nmonths * 8u;
+    a.ready_at_launch = feed ? feed->ready_at_launch : UINT_MAX;
+    a.months_ready = feed ? feed->months_ready : nullptr;
+    a.place_epoch = feed ? feed->place_epoch : nullptr;
+    a.epoch = feed ? feed->epoch : 0u;
+    a.fenced = (getenv("XH_ROUTE_FENCED") && getenv("XH_ROUTE_FENCED")[0] == '1') ? 1 : 0;
     a.S0 = io.S0;
     a.chs = io.chs;
     a.avg = io.avg;

@@ -36,4 +36,14 @@ int xh_abcd_enqueue_spinup(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, 
 // from the state the previous block left in the setup's scratch)
 int xh_abcd_enqueue_sim(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, int m_begin, int m_end,
                         const double *d_pars, const double *d_pet, const double *d_precip, const double *d_tmin,
-                        double *d_aet, double *d_q, double *d_sav);
+                        double *d_aet, double *d_q, double *d_sav, double *d_q_staged);
+// (d_q_staged: NULL, or the routing kernel's copy of the runoff, [ceil(nmonths / 16)][ncell][16]; FlowFeed in xh_mrtm_flow.h)
+
+// xh_route_series with the runoff arriving while the routing kernel runs (xh_mrtm.hip; xh_run_fused mode 1).  XH_ERR_LIMIT
+// when this plan / schedule cannot be routed that way (nothing has been enqueued then): the caller finishes the runoff
+// first and calls xh_route_series.
+struct FlowFeed;
+int xh_route_series_fed(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months, const int32_t *h_ndays,
+                        double dt, const double *d_flow_dist, const double *d_velocity, const double *d_area,
+                        const double *d_runoff, const double *d_S0, double *d_chstorage, double *d_avgchflow,
+                        int32_t flags, const FlowFeed *feed);

@@ -162,6 +162,7 @@ class OutputGather:
         self.dist, self.torch, self.names, self.root = dist, torch, tuple(names), root
         self.counts = np.array([len(s.cells) for s in shards], dtype=np.int64)
         self.out, self.d_perm, self.comm, self.kind, self.why = None, None, None, 'torch', ''
+        self.exposed_s, self.runs = 0.0, 0      # time a step spends in the gather after the routing has ended
         self.bytes = int(self.counts.sum()) * pipe.nmonths * 8 * len(self.names)
         # The library's own gather (RCCL bound at run time) whatever backend the launcher's process group uses: the group
         # only carries the 128-byte id and the agreement below (with "gloo" on host tensors -- the dry run with every rank
@@ -200,11 +201,16 @@ class OutputGather:
             self.out = {k: ctx.empty((self.ncell, pipe.nmonths)) for k in self.names}
 
     def run(self):
+        import time
         if self.kind == 'rccl':
             self.ctx.sync()       # settles a routing fault (re-route) before the rows leave; ~10 us when there is none
+            t0 = time.perf_counter()
             self.comm.gather_rows([self.pipe.out[k] for k in self.names], self.counts, self.pipe.nmonths,
                                   perm=self.d_perm, out=None if self.out is None else [self.out[k] for k in self.names],
                                   root=self.root)
+            self.ctx.sync()
+            self.exposed_s += time.perf_counter() - t0
+            self.runs += 1
             return None
         world = SimpleNamespace(ncell=self.ncell)
         got = gather_outputs(self.ctx, self.pipe, self.shards[self.rank], self.shards, world, self.dist, self.torch,
@@ -223,6 +229,7 @@ class OutputGather:
 
     def report(self):
         return {'kind': self.kind, 'library': self.library, 'bytes_per_step': self.bytes, 'variables': list(self.names),
+                'exposed_ms': 1e3 * self.exposed_s / self.runs if self.runs else None,
                 'rows_per_rank': self.counts.tolist(), 'fallback_reason': self.why}
 
     def close(self):

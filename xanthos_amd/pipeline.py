@@ -14,6 +14,7 @@ from .pet import penman_monteith as pm_mod
 from .routing import mrtm as mrtm_mod
 from .utils import set_month_arrays
 
+FEED_DEFAULT = '1'      # measured on MI355X: 26.4 -> 25.35 ms per full-grid step (profiles/round4/feed_first_block.txt)
 FORCING = ('tas', 'tmin', 'rhs', 'wind', 'rsds', 'rlds', 'precip', 'abcd_tmin')
 OUTPUTS = ('pet', 'aet', 'q', 'sav', 'chs', 'avg')
 
@@ -145,8 +146,9 @@ class DevicePipeline:
                               self.d_velocity, self.d_area, self.out['q'] if runoff is None else runoff, self.d_S0,
                               self.out['chs'], self.out['avg'], flags=self.route_flags)
 
-    def run_fused(self, with_routing=True, block_months=0):
-        """PM -> ABCD (-> MRTM) as one pipelined call (xh_run_fused): the stages overlap on the device."""
+    def run_fused(self, with_routing=True, block_months=0, mode=0):
+        """PM -> ABCD (-> MRTM) as one pipelined call (xh_run_fused): the stages overlap on the device.  mode 1 ("fed"):
+        the routing kernel starts once the first max(spin-ups) months of runoff exist and the rest of PM and ABCD runs beside it."""
         f = self.forcing
         route = with_routing and self.plan is not None
         self.ctx.run_fused(tables=self.pm_tables, ncell=self.ncell, nmonths=self.nmonths, start_year=self.start_year,
@@ -160,16 +162,24 @@ class DevicePipeline:
                            routing_spinup=self.routing_spinup, ndays=self.ndays, dt=10800.0,
                            flow_dist=self.d_flow_dist, velocity=self.d_velocity, area=self.d_area, S0=self.d_S0,
                            chs=self.out['chs'] if route else None, avg=self.out['avg'] if route else None,
-                           route_flags=self.route_flags, block_months=block_months)
+                           route_flags=self.route_flags, block_months=block_months, mode=mode)
 
-    def run(self, stages=('pm', 'abcd', 'mrtm'), fused=None):
-        """Enqueue the stages one after the other on the context's stream.  ``fused=True`` (or XH_FUSED=1) sends PM +
-        ABCD (+ MRTM) through the pipelined call xh_run_fused instead: identical results; on MI355X the stage-by-stage
-        order is the faster one at the full grid, so it is the default."""
+    def run(self, stages=('pm', 'abcd', 'mrtm'), fused=None, fed=None):
+        """Enqueue the stages on the context's stream.  With all three stages the default is the FED order (xh_run_fused
+        mode 1): the first max(spin-ups) months of PM and ABCD, then the routing kernel, and the remaining
+        months of PM and ABCD beside it on a second stream -- identical results, the 2.8 ms of PM + ABCD mostly hidden
+        under the routing.  ``fed=False`` (or XH_FEED=0) runs the stages strictly one after the other; ``fused=True`` (or
+        XH_FUSED=1) is round 2's block pipeline of PM and ABCD with the routing behind it (slower on MI355X at the full grid)."""
         if fused is None:
             fused = os.environ.get('XH_FUSED') == '1'
-        if fused and 'pm' in stages and 'abcd' in stages and self.nmonths % 12 == 0:
+        if fed is None:
+            fed = os.environ.get('XH_FEED', FEED_DEFAULT) == '1'
+        whole_years = self.nmonths % 12 == 0
+        if fused and 'pm' in stages and 'abcd' in stages and whole_years:
             self.run_fused(with_routing='mrtm' in stages, block_months=int(os.environ.get('XH_FUSED_BLOCK', '0')))
+            return
+        if fed and all(s in stages for s in ('pm', 'abcd', 'mrtm')) and whole_years and self.plan is not None:
+            self.run_fused(with_routing=True, mode=1)
             return
         if 'pm' in stages:
             self.run_pm()
