@@ -504,6 +504,7 @@ def main():
                     help='worker processes of the CPU routing (river networks dealt over them); 0 = min(cores, 16)')
     ap.add_argument('--cpu-mrtm-child', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--no-gate', action='store_true', help='report parity failures in the line but exit 0')
+    ap.add_argument('--launch-echo', type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument('--route-flags', type=int, default=0)
     ap.add_argument('--order', default='auto', choices=['auto', 'fed', 'staged'],
                     help='pm_abcd_mrtm: "staged" = the three stages strictly one after the other; "fed" = the routing kernel '
@@ -514,6 +515,11 @@ def main():
         return cpu_mrtm_child(args.cpu_mrtm_child)
     if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args))                            # before any GPU call in this process
+    if args.launch_echo is not None:                            # (CPU test of the launcher: what a rank was started with)
+        if int(os.environ.get('RANK', '0')) == 0:
+            print(json.dumps({k: os.environ.get(k) for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}),
+                  flush=True)
+        sys.exit(args.launch_echo if os.environ.get('RANK') == str(args.gpus - 1) else 0)
     args.stages = ('pm', 'abcd', 'mrtm') if args.workload == 'pm_abcd_mrtm' else ('pm', 'abcd')
     if args.workload == 'calib' and args.months == 600:
         args.months = 480                                       # BASELINE configs[4]: 480 + 120 spin-up months
@@ -583,19 +589,22 @@ def main():
 
     fed = {'auto': None, 'fed': True, 'staged': False}[args.order]
 
-    def timed(pipe, after_step=None):
+    def timed(pipe, gather=None):
+        # sharded: PET / AET / Q / Sav leave on the gather stream as soon as they are final (beside the routing), ChStorage /
+        # Avg_ChFlow behind the routing; every step ends with the gathered arrays complete on rank 0
+        side = gather.run_side if gather else None
         for _ in range(args.warmup):
-            pipe.run(args.stages, fed=fed)
-            if after_step:
-                after_step()
+            pipe.run(args.stages, fed=fed, after_runoff=side)
+            if gather:
+                gather.run_tail()
         ctx.sync()
         ctx.timing_reset()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            pipe.run(args.stages, fed=fed)
-            if after_step:
-                after_step()
+            pipe.run(args.stages, fed=fed, after_runoff=side)
+            if gather:
+                gather.run_tail()
         ctx.sync()
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
@@ -612,7 +621,7 @@ def main():
         xdist.fill_shard_forcing(ctx, world, shard, pipe, synth.MASTER_SEED + 1, nan_frac=0.001)      # the whole world's rows
         gather = xdist.OutputGather(ctx, pipe, shards, rank, world.ncell, dist, torch,
                                     names=('pet', 'aet', 'q', 'sav') + (('chs', 'avg') if 'mrtm' in args.stages else ()))
-        elapsed = timed(pipe, gather.run)
+        elapsed = timed(pipe, gather)
         units_per_step = NCELL * args.months
         parallelism = '{} basins of one world sharded over {} GPUs ({} cells on rank 0), one gather of {} outputs ' \
                       'per step ({})'.format(NBASINS, world_size, pipe.ncell, len(gather.names), gather.kind)

@@ -86,6 +86,10 @@ int xh_transpose(xh_ctx *ctx, const double *d_src, int64_t rows, int64_t cols, d
  * Names: "pm_pet", "abcd_spinup", "abcd_basin_mean", "abcd_sim", "mrtm_route", "calib_abcd", "calib_kge", "calib_de",
  * "agg_time", "agg_spatial", "drought_thresh", "drought_stats".  xh_timing_get waits for the stream, then returns total milliseconds and launch count. */
 int xh_timing_reset(xh_ctx *ctx);
+/* a caller-named span on the context's stream, read back with xh_timing_get like the library's own timers (one open
+ * at a time): e.g. what a step still spends in the write-out gather after the routing kernel has ended                */
+int xh_mark_begin(xh_ctx *ctx, const char *name);
+int xh_mark_end(xh_ctx *ctx);
 int xh_timing_enable(xh_ctx *ctx, int on);
 int xh_timing_get(xh_ctx *ctx, const char *name, double *total_ms, int64_t *launches);
 
@@ -363,6 +367,17 @@ int xh_comm_create(xh_ctx *ctx, int32_t nranks, int32_t rank, const char *id, si
 void xh_comm_destroy(xh_comm *comm);
 int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *comm, int32_t root, int32_t nvar, const double *const *h_d_local,
                         int64_t ncols, const int64_t *h_counts, const int64_t *d_perm, double *const *h_d_out);
+/*   xh_comm_gather_rows_side : the same gather on the context's gather stream (a hardware queue of its own), ordered behind
+ *                         the kernels that produced the arrays -- everything enqueued on the context so far, or, right after
+ *                         an xh_run_fused in mode 1, the side stream that completed PET / AET / Q / Sav while the routing
+ *                         kernel already runs -- and beside whatever the context does next: the write-out of the four
+ *                         arrays the routing does not touch travels over xGMI while the routing kernel runs.  Give this
+ *                         stream a communicator of its own.
+ *   xh_comm_join        : orders the context's stream behind the side gather (xh_sync and every other synchronising
+ *                         call do so too).                                                                            */
+int xh_comm_gather_rows_side(xh_ctx *ctx, xh_comm *comm, int32_t root, int32_t nvar, const double *const *h_d_local,
+                             int64_t ncols, const int64_t *h_counts, const int64_t *d_perm, double *const *h_d_out);
+int xh_comm_join(xh_ctx *ctx);
 
 /* ------------------------------------------------------------------ bench support (not on the hot path)
  * Fills the eight forcing arrays of the synthetic benchmark world on the device (same distributions as

@@ -588,3 +588,39 @@ def test_fed_routing_equals_stage_by_stage(hip, nm, abcd_spin, route_spin):
     for k in OUTPUTS:
         assert np.array_equal(got[k], ref[k], equal_nan=True), k
     assert ctx.timing('feed_gate')[1] == n0 + 4 and pipe.plan.info()['last_tree_kernel'] == 0
+
+
+def test_first_dataflow_call_of_a_plan_is_cross_checked(hip, tmp_path, monkeypatch):
+    """The dataflow kernels' streams rest on an ordering assumption outside the HIP memory model (xh_mrtm_wave.hip, check();
+    the fenced form costs +86 %, profiles/round4/fenced_ab.txt).  So the FIRST dataflow call of a plan on a device / library
+    build without a pass on record is routed again by the barrier-only kernel and compared on the device; the pass is
+    recorded under XH_CACHE_DIR and later plans of the same topology skip the check."""
+    from xanthos_amd import synth
+    from xanthos_amd.routing import mrtm
+    from oracle import months as o_months, mrtm as o_mrtm
+    monkeypatch.setenv('XH_CACHE_DIR', str(tmp_path / 'cache'))
+    w = synth.make_world(nrow=60, ncol=120, ncell=2500, n_basins=5, seed=77, outlet_frac=0.02)
+    st = SimpleNamespace(ngridrow=w.nrow, ngridcol=w.ncol)
+    ds = mrtm.downstream(w.coords, w.flow_dir, st)
+    rng = np.random.default_rng(5)
+    runoff = rng.gamma(2.0, 30.0, (w.ncell, 12))
+    runoff[rng.random(w.ncell) < 0.01] = np.nan
+    ndays = o_months.set_month_arrays(12, 1975, 1975)[:, 2]
+
+    def fresh():
+        return mrtm.upstream_genmatrix(mrtm.upstream(w.coords, ds, st))      # a new UpstreamMatrix = a new plan
+    um = fresh()
+    ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+    for call, want in ((0, 1), (1, 1), (2, 1)):
+        got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
+        assert um.plan(hip.get_context()).info()['validated'] == want, call
+    marks = [f for f in (tmp_path / 'cache').iterdir() if f.name.startswith('route_ok_')]
+    assert len(marks) == 1
+    um2 = fresh()                                                             # same topology, same box, same build: on record
+    mrtm.route_series(um2, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+    assert um2.plan(hip.get_context()).info()['validated'] == 0
+    monkeypatch.setenv('XH_CACHE_DIR', str(tmp_path / 'elsewhere'))           # no record there: checked again
+    um3 = fresh()
+    mrtm.route_series(um3, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+    assert um3.plan(hip.get_context()).info()['validated'] == 1

@@ -254,3 +254,21 @@ def test_file_range_of_memory_map(tmp_path):
     assert file_range_of(a) is None and file_range_of(np.asarray(mm)) is None
     np.save(str(tmp_path / 'f4.npy'), a.astype(np.float32))
     assert file_range_of(np.load(str(tmp_path / 'f4.npy'), mmap_mode='r')) is None
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """``python bench.py --gpus N`` with no RANK in the environment starts N rank processes itself (before anything touches a
+    GPU: this test has none), gives each RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would, relays
+    rank 0's line as its own stdout and exits with the worst exit code of its ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    for n, code in ((3, 0), (2, 7)):
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--launch-echo', str(code)],
+                             env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        assert out.returncode == code, (out.returncode, out.stderr[-500:])
+        got = json.loads(out.stdout.strip().splitlines()[-1])
+        assert got['RANK'] == '0' and got['LOCAL_RANK'] == '0' and got['WORLD_SIZE'] == str(n)
+        assert got['MASTER_ADDR'] == '127.0.0.1' and int(got['MASTER_PORT']) > 0

@@ -102,6 +102,10 @@ SIGNATURES = {
     'xh_comm_create': (c_int, [_P, c_int32, c_int32, ctypes.c_char_p, c_size_t, POINTER(c_void_p)]),
     'xh_comm_destroy': (None, [_P]),
     'xh_comm_gather_rows': (c_int, [_P, _P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
+    'xh_comm_gather_rows_side': (c_int, [_P, _P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
+    'xh_comm_join': (c_int, [_P]),
+    'xh_mark_begin': (c_int, [_P, c_char_p]),
+    'xh_mark_end': (c_int, [_P]),
     'xh_agg_time': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, _P, _P, _P]),
     'xh_agg_spatial': (c_int, [_P, c_int64, c_int32, c_int32, _P, _P, _P]),
     'xh_nan_to_num': (c_int, [_P, _P, c_int64]),
@@ -323,6 +327,16 @@ class Context:
 
     def timing_reset(self):
         self._check(lib().xh_timing_reset(self.handle))
+
+    def comm_join(self):
+        """Order the context's stream behind the side gather (xh_comm_join)."""
+        self._check(lib().xh_comm_join(self.handle))
+
+    def mark_begin(self, name):
+        self._check(lib().xh_mark_begin(self.handle, name.encode()))
+
+    def mark_end(self):
+        self._check(lib().xh_mark_end(self.handle))
 
     def timing(self, name):
         ms, n = c_double(), c_int64()
@@ -558,15 +572,18 @@ class Comm:
         ctx._check(rc)
         self.handle = h.value
 
-    def gather_rows(self, local, counts, ncols, perm=None, out=None, root=0):
+    def gather_rows(self, local, counts, ncols, perm=None, out=None, root=0, side=False):
         """local: list of DeviceArrays [counts[rank], ncols]; on the root ``perm`` (device int64, rank-major destination
-        rows) and ``out`` (list of DeviceArrays [sum(counts), ncols]). Asynchronous."""
+        rows) and ``out`` (list of DeviceArrays [sum(counts), ncols]). Asynchronous.  ``side``: on the context's gather
+        stream, beside what the context's own stream does next (xh_comm_gather_rows_side; Context.comm_join orders the
+        context's stream behind it)."""
         nvar = len(local)
         cn = np.ascontiguousarray(counts, dtype=np.int64)
         p_local = (c_void_p * nvar)(*[_dptr(x) for x in local])
         p_out = None if out is None else (c_void_p * nvar)(*[_dptr(x) for x in out])
-        self.ctx._check(lib().xh_comm_gather_rows(self.ctx.handle, self.handle, int(root), nvar, p_local, int(ncols),
-                                                  _host_ptr(cn), _dptr(perm), p_out))
+        fn = lib().xh_comm_gather_rows_side if side else lib().xh_comm_gather_rows
+        self.ctx._check(fn(self.ctx.handle, self.handle, int(root), nvar, p_local, int(ncols), _host_ptr(cn), _dptr(perm),
+                           p_out))
 
     def close(self):
         if self.handle is not None:

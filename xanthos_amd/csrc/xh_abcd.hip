@@ -148,7 +148,7 @@ constexpr int TLD = TMS + 1;       // padded row length (doubles)
 // (two waves per SIMD: at most 256 registers, AGPRs included -- CPW = 32 relies on its two waves per SIMD, and in a fed run
 // (xh_fused.hip, mode 1) one of these waves has to fit beside a routing wave's 256)
 template <bool SPINUP, int CPW>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CPW == 32 ? 2 : 1, CPW == 32 ? 2 : 1))) k_abcd_tile(int64_t ncell, int nmonths, int nsteps, int m_begin, int m_end,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CPW < 64 ? 2 : 1, CPW < 64 ? 2 : 1))) k_abcd_tile(int64_t ncell, int nmonths, int nsteps, int m_begin, int m_end,
                                                   double *__restrict__ state,      // [3][ncell] carried between month blocks
                                                   const int *__restrict__ par_index, const int *__restrict__ basin_index,
                                                   const double *__restrict__ pars, const double *__restrict__ pet,
@@ -229,21 +229,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CPW == 
         __syncthreads();
         if (mine) {
             const int mbase = t * TMS - shift;
+            // CB months at a time: their state-independent parts are evaluated together (instruction-level parallelism), then
+            // the recurrence runs through them.  8 for the 32-cell wave; the wider waves hold more prefetch registers and
+            // batch 4 (at 8 they spill 33 - 59 registers per lane, at 4 the 40-cell wave spills none)
+            constexpr int CB = CPW == 32 ? 8 : 4;
 #pragma unroll
-            for (int h = 0; h < TMS; h += 8) {
-                double ipet[8], ipr[8], itn[8];
+            for (int h = 0; h < TMS; h += CB) {
+                double ipet[CB], ipr[CB], itn[CB];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < CB; ++j) {
                     ipet[j] = mypet[h + j];
                     ipr[j] = mypr[h + j];
                     itn[j] = mytn[h + j];
                 }
-                if (mbase + h >= m_begin && mbase + h + 8 <= m_end) {             // all eight months belong to this block
-                    AbcdPre pre[8];
+                if (mbase + h >= m_begin && mbase + h + CB <= m_end) {            // all CB months belong to this block
+                    AbcdPre pre[CB];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pre[j] = abcd_pre(P, K, snow_on, ipet[j], ipr[j], itn[j]);
+                    for (int j = 0; j < CB; ++j) pre[j] = abcd_pre(P, K, snow_on, ipet[j], ipr[j], itn[j]);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < CB; ++j) {
                         const int m = mbase + h + j;
                         double oa, oq;
                         abcd_step(P, s, snow_on, m == 0, pre[j], oa, oq);
@@ -261,7 +265,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CPW == 
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < CB; ++j) {
                         const int m = mbase + h + j;
                         if (m >= m_begin && m < m_end) {
                             double oa, oq;
@@ -464,16 +468,42 @@ int xh_abcd_enqueue_sim(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, int
     if (s.ncell == 0 || m_end <= m_begin) return XH_OK;
     XH_REQUIRE(ctx, m_begin >= 0 && m_end <= s.nmonths && m_begin % 2 == 0 && m_end % 2 == 0, "xh_abcd: bad month block");
     const int64_t ncell = s.ncell;
-    const unsigned blocks = (unsigned)((ncell + 63) / 64), blocks32 = (unsigned)((ncell + 31) / 32);
+    const unsigned blocks = (unsigned)((ncell + 63) / 64);
     const bool whole = m_begin == 0 && m_end == s.nmonths;
     int mode = abcd_env() < 0 ? 32 : abcd_env();
     if (mode == 0 && (!whole || d_q_staged)) mode = 32;          // only the tiled kernel marches blocks of months / stages the runoff
+    // Cells per wave.  Every workgroup marches its cells through the whole block of months, so a grid that does not fit the
+    // chip's wave slots at once (two 256-register waves per SIMD) pays for a whole second round: 2,048 workgroups 0.376 ms,
+    // 2,049 workgroups 0.537 ms at 600 months (tools/abcd_tail_probe.py, profiles/round4/abcd_tail.txt) -- and 67,420 cells
+    // in waves of 32 are 2,107.  The smallest of 32 / 40 / 48 cells per wave that fits in one round is used (40 for the
+    // 0.5-degree grid: 1,686 workgroups); beyond that, rounds cannot be avoided and 32 is the cheapest wave.
+    int cpw = 32;
+    if (mode == 32 && abcd_env() < 0) {
+        const int64_t slots = 2 * 4 * (int64_t)(ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256);
+        for (int c : {32, 40, 48})
+            if ((ncell + c - 1) / c <= slots) {
+                cpw = c;
+                break;
+            }
+        if (const char *env = getenv("XH_ABCD_CPW")) {      // experiments: 32 / 40 / 48
+            const int v = atoi(env);
+            if (v == 32 || v == 40 || v == 48) cpw = v;
+        }
+    }
+    const unsigned blocks_cpw = (unsigned)((ncell + cpw - 1) / cpw);
     double *state = whole ? nullptr : s.d_state;
     xh_span sp = xh_span_begin_on(ctx, "abcd_sim", st);
-    if (mode == 32)
-        hipLaunchKernelGGL((k_abcd_tile<false, 32>), dim3(blocks32), dim3(64), 0, st, ncell, s.nmonths, s.nmonths, m_begin,
-                           m_end, state, s.d_pidx, s.d_bidx, d_pars, d_pet, d_precip, d_tmin, s.d_sm0, s.d_gw0,
-                           (double *)nullptr, d_aet, d_q, d_sav, d_q_staged);
+#define XH_ABCD_TILE_SIM(CPWV)                                                                                                  \
+    hipLaunchKernelGGL((k_abcd_tile<false, CPWV>), dim3(blocks_cpw), dim3(64), 0, st, ncell, s.nmonths, s.nmonths, m_begin, m_end, \
+                       state, s.d_pidx, s.d_bidx, d_pars, d_pet, d_precip, d_tmin, s.d_sm0, s.d_gw0, (double *)nullptr, d_aet,  \
+                       d_q, d_sav, d_q_staged)
+    if (mode == 32 && cpw == 40)
+        XH_ABCD_TILE_SIM(40);
+    else if (mode == 32 && cpw == 48)
+        XH_ABCD_TILE_SIM(48);
+    else if (mode == 32)
+        XH_ABCD_TILE_SIM(32);
+#undef XH_ABCD_TILE_SIM
     else if (mode == 64)
         hipLaunchKernelGGL((k_abcd_tile<false, 64>), dim3(blocks), dim3(64), 0, st, ncell, s.nmonths, s.nmonths, m_begin,
                            m_end, state, s.d_pidx, s.d_bidx, d_pars, d_pet, d_precip, d_tmin, s.d_sm0, s.d_gw0,

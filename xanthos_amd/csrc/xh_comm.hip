@@ -135,9 +135,50 @@ void xh_comm_destroy(xh_comm *c) {
     delete c;
 }
 
+static int gather_rows_on(xh_ctx *ctx, hipStream_t st, xh_comm *c, int32_t root, int32_t nvar, const double *const *h_d_local,
+                          int64_t ncols, const int64_t *h_counts, const int64_t *d_perm, double *const *h_d_out);
+
 int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar, const double *const *h_d_local,
                         int64_t ncols, const int64_t *h_counts, const int64_t *d_perm, double *const *h_d_out) {
     if (!ctx || !c) return XH_ERR_ARG;
+    return gather_rows_on(ctx, ctx->stream, c, root, nvar, h_d_local, ncols, h_counts, d_perm, h_d_out);
+}
+
+// The same gather on the context's GATHER stream (a queue of its own), so that it runs beside whatever the context's stream
+// does next -- the routing kernel, which needs none of PET / AET / Q / Sav's bytes to move.  Ordered behind the kernels that
+// produced the arrays: behind everything enqueued on the context's stream so far, or -- after an xh_run_fused in mode 1,
+// whose runoff is completed by a side stream while the routing kernel already sits in the context's stream -- behind that
+// side stream's last kernel.  xh_comm_join (or any synchronising call) orders the context's stream behind the gather.
+// Use a communicator of its own for this stream (RCCL serialises the operations of one communicator).
+int xh_comm_gather_rows_side(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar, const double *const *h_d_local,
+                             int64_t ncols, const int64_t *h_counts, const int64_t *d_perm, double *const *h_d_out) {
+    if (!ctx || !c) return XH_ERR_ARG;
+    hipStream_t g = nullptr;
+    int rc = xh_gather_stream(ctx, &g);
+    if (rc) return rc;
+    if (ctx->runoff_event_fresh && ctx->runoff_event) {
+        XH_HIP(ctx, hipStreamWaitEvent(g, ctx->runoff_event, 0));
+        ctx->runoff_event_fresh = false;
+    } else {
+        XH_HIP(ctx, hipEventRecord(ctx->gather_event, ctx->stream));
+        XH_HIP(ctx, hipStreamWaitEvent(g, ctx->gather_event, 0));
+    }
+    ctx->gather_pending = true;
+    rc = gather_rows_on(ctx, g, c, root, nvar, h_d_local, ncols, h_counts, d_perm, h_d_out);
+    XH_HIP(ctx, hipEventRecord(ctx->gather_event, g));
+    return rc;
+}
+
+int xh_comm_join(xh_ctx *ctx) {
+    if (!ctx) return XH_ERR_ARG;
+    if (!ctx->gather_pending) return XH_OK;
+    XH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->gather_event, 0));
+    ctx->gather_pending = false;
+    return XH_OK;
+}
+
+static int gather_rows_on(xh_ctx *ctx, hipStream_t st, xh_comm *c, int32_t root, int32_t nvar, const double *const *h_d_local,
+                          int64_t ncols, const int64_t *h_counts, const int64_t *d_perm, double *const *h_d_out) {
     XH_REQUIRE(ctx, root >= 0 && root < c->nranks && nvar > 0 && h_d_local && h_counts && ncols > 0,
                "xh_comm_gather_rows: bad argument");
     RcclApi &api = rccl();
@@ -159,7 +200,7 @@ int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar, con
         if (n_local == 0) return XH_OK;
         XH_NCCL(ctx, api.GroupStart());
         for (int v = 0; v < nvar && first == ncclSuccess; ++v)
-            note(api.Send(h_d_local[v], (size_t)(n_local * ncols), ncclDouble, root, c->comm, ctx->stream), "ncclSend");
+            note(api.Send(h_d_local[v], (size_t)(n_local * ncols), ncclDouble, root, c->comm, st), "ncclSend");
         note(api.GroupEnd(), "ncclGroupEnd");
         if (first != ncclSuccess)
             return xh_fail(ctx, XH_ERR_HIP, "xh_comm_gather_rows: %s failed: %s", what, api.GetErrorString(first));
@@ -193,7 +234,7 @@ int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar, con
             for (int r = 0; r < c->nranks && first == ncclSuccess; ++r) {
                 if (r == root || h_counts[r] == 0) continue;
                 note(api.Recv(stage + ((int64_t)v * remote + off) * ncols, (size_t)(h_counts[r] * ncols), ncclDouble, r,
-                              c->comm, ctx->stream), "ncclRecv");
+                              c->comm, st), "ncclRecv");
                 off += h_counts[r];
             }
         }
@@ -206,16 +247,16 @@ int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar, con
         XH_REQUIRE(ctx, h_d_out[v], "xh_comm_gather_rows: NULL output array");
         int rc;
         if (before_me > 0) {
-            rc = xh_scatter_rows(ctx, stage + (int64_t)v * remote * ncols, d_perm, before_me, ncols, h_d_out[v]);
+            rc = xh_move_rows_on(ctx, st, stage + (int64_t)v * remote * ncols, d_perm, before_me, ncols, h_d_out[v], 1);
             if (rc) return rc;
         }
         if (n_local > 0) {
-            rc = xh_scatter_rows(ctx, h_d_local[v], d_perm + before_me, n_local, ncols, h_d_out[v]);
+            rc = xh_move_rows_on(ctx, st, h_d_local[v], d_perm + before_me, n_local, ncols, h_d_out[v], 1);
             if (rc) return rc;
         }
         if (remote - before_me > 0) {
-            rc = xh_scatter_rows(ctx, stage + ((int64_t)v * remote + before_me) * ncols, d_perm + before_me + n_local,
-                                 remote - before_me, ncols, h_d_out[v]);
+            rc = xh_move_rows_on(ctx, st, stage + ((int64_t)v * remote + before_me) * ncols, d_perm + before_me + n_local,
+                                 remote - before_me, ncols, h_d_out[v], 1);
             if (rc) return rc;
         }
     }

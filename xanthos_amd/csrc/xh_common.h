@@ -53,9 +53,18 @@ struct xh_ctx {
     std::vector<xh_route_record> pending_routes;
     uint64_t work_seq = 0;         // bumped by every entry point that enqueues work on the stream (kernels, copies, row movers)
     int64_t reroutes = 0;          // routing calls re-run after a device fault
-    // xh_run_fused: side stream and events of the block pipeline
+    // xh_run_fused: side stream [0] (lowest priority: the fillers beside the routing kernel) and events of the pipelines;
+    // side stream [1] (highest priority: a queue of its own): the write-out gather of PET / AET / Q / Sav beside the routing
     hipStream_t side_stream[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> side_events;
+    hipEvent_t runoff_event = nullptr;     // xh_run_fused mode 1: recorded on side stream [0] when PET / AET / Q / Sav are final
+    bool runoff_event_fresh = false;       // ... by the last call, and not consumed by a side gather yet
+    hipEvent_t gather_event = nullptr;     // last work of side stream [1]
+    bool gather_pending = false;           // side stream [1] holds work the context's stream has not been joined with
+    // xh_mark_begin / xh_mark_end: one caller-named span on the context's stream
+    hipEvent_t mark_a = nullptr, mark_b = nullptr;
+    bool mark_open = false;
+    std::string mark_name;
     // xh_run_fused mode 1: hand-over words (months ready, placement epoch) + the routing kernel's staged runoff (grow-only)
     void *d_feed = nullptr;
     size_t feed_bytes = 0;
@@ -94,6 +103,12 @@ extern std::string g_xh_create_error;
     do {                                                             \
         if (!(cond)) return xh_fail((ctx), XH_ERR_ARG, __VA_ARGS__); \
     } while (0)
+
+// side stream [1], created on first use (highest priority: never shares a hardware queue with the context's stream)
+int xh_gather_stream(xh_ctx *ctx, hipStream_t *out);
+// row movers on a given stream (xh_gather_rows / xh_scatter_rows are these on the context's stream)
+int xh_move_rows_on(xh_ctx *ctx, hipStream_t st, const double *d_src, const int64_t *d_rows, int64_t nrows, int64_t ncols,
+                    double *d_dst, int scatter);
 
 // scratch slot `which` with at least `bytes` bytes (device memory owned by the context)
 int xh_scratch(xh_ctx *ctx, int which, size_t bytes, void **out);

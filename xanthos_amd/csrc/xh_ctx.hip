@@ -108,6 +108,12 @@ int xh_fault_check(xh_ctx *ctx) {
         fprintf(stderr, "[libxanthos_hip] routing fault %u (a bounded wait between routing units timed out: the device is "
                 "shared and the units were not all resident); re-routing %zu call(s) with one workgroup per network\n",
                 code, pending.size());
+        if (ctx->d_feed) {      // a fed call (xh_run_fused mode 1): how far the side stream had come
+            unsigned w[48] = {0};
+            if (hipMemcpy(w, ctx->d_feed, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[libxanthos_hip]   fed routing: months ready %u, placement epoch %u of %u\n", w[0], w[32],
+                        ctx->feed_epoch);
+        }
         std::vector<xh_route_plan *> plans;
         for (const xh_route_record &r : pending) {
             int rc = xh_route_rerun(ctx, r, false);
@@ -129,8 +135,23 @@ int xh_fault_check(xh_ctx *ctx) {
 }
 
 int xh_settle(xh_ctx *ctx) {
+    if (ctx->gather_pending) {      // a side gather nobody joined: it reads the pipeline's outputs, so it is part of "everything"
+        XH_HIP(ctx, hipStreamSynchronize(ctx->side_stream[1]));
+        ctx->gather_pending = false;
+    }
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return xh_fault_check(ctx);
+}
+
+int xh_gather_stream(xh_ctx *ctx, hipStream_t *out) {
+    if (!ctx->side_stream[1]) {
+        int least = 0, greatest = 0;
+        XH_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        XH_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream[1], hipStreamNonBlocking, greatest != 0 ? greatest : least));
+        XH_HIP(ctx, hipEventCreateWithFlags(&ctx->gather_event, hipEventDisableTiming));
+    }
+    *out = ctx->side_stream[1];
+    return XH_OK;
 }
 
 xh_span xh_span_begin(xh_ctx *ctx, const char *name) { return xh_span_begin_on(ctx, name, ctx->stream); }
@@ -139,6 +160,9 @@ xh_span xh_span_begin_on(xh_ctx *ctx, const char *name, hipStream_t stream) {
     xh_span s{ctx, name};
     s.stream = stream;
     ctx->work_seq += 1;
+    // new work on the context's stream: the "runoff is final" event a fed call left for a side gather is no longer the
+    // thing to wait for (xh_comm_gather_rows_side then orders itself behind the context's stream)
+    if (stream == ctx->stream) ctx->runoff_event_fresh = false;
     if (!ctx->timing) return s;
     auto take = [&](hipEvent_t &e) {
         if (!ctx->event_pool.empty()) {
@@ -226,6 +250,7 @@ void xh_ctx_destroy(xh_ctx *ctx) {
             (void)hipStreamDestroy(ctx->side_stream[i]);
         }
     for (auto e : ctx->side_events) (void)hipEventDestroy(e);
+    if (ctx->gather_event) (void)hipEventDestroy(ctx->gather_event);
     if (ctx->d_feed) (void)hipFree(ctx->d_feed);
     if (ctx->d_fault) (void)hipFree(ctx->d_fault);
     if (ctx->h_fault) (void)hipHostFree(ctx->h_fault);
@@ -409,16 +434,50 @@ __global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ sr
 
 extern "C" {
 
-static int move_rows(xh_ctx *ctx, const double *d_src, const int64_t *d_rows, int64_t nrows, int64_t ncols,
-                     double *d_dst, int scatter) {
+}  // extern "C"
+
+int xh_move_rows_on(xh_ctx *ctx, hipStream_t st, const double *d_src, const int64_t *d_rows, int64_t nrows, int64_t ncols,
+                    double *d_dst, int scatter) {
     if (!ctx) return XH_ERR_ARG;
     XH_REQUIRE(ctx, d_src && d_rows && d_dst && nrows >= 0 && ncols >= 0, "xh_gather/scatter_rows: bad argument");
     if (nrows == 0 || ncols == 0) return XH_OK;
     ctx->work_seq += 1;
     int grid = (int)(nrows < 65536 ? nrows : 65536);
-    hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, ctx->stream, d_src, d_rows, nrows, ncols, d_dst,
-                       scatter);
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, st, d_src, d_rows, nrows, ncols, d_dst, scatter);
     XH_HIP(ctx, hipGetLastError());
+    return XH_OK;
+}
+
+extern "C" {
+
+static int move_rows(xh_ctx *ctx, const double *d_src, const int64_t *d_rows, int64_t nrows, int64_t ncols,
+                     double *d_dst, int scatter) {
+    if (!ctx) return XH_ERR_ARG;
+    return xh_move_rows_on(ctx, ctx->stream, d_src, d_rows, nrows, ncols, d_dst, scatter);
+}
+
+// A named HIP-event span on the context's stream, for callers that want a device time of their own next to the library's
+// kernel timers (xh_timing_get): e.g. what a step spends in the write-out gather after the routing has ended.
+int xh_mark_begin(xh_ctx *ctx, const char *name) {
+    if (!ctx || !name) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, !ctx->mark_open, "xh_mark_begin: a mark is already open");
+    ctx->mark_name = name;
+    xh_span s = xh_span_begin(ctx, ctx->mark_name.c_str());
+    ctx->mark_a = s.a;
+    ctx->mark_b = s.b;
+    ctx->mark_open = true;
+    return XH_OK;
+}
+
+int xh_mark_end(xh_ctx *ctx) {
+    if (!ctx) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, ctx->mark_open, "xh_mark_end: no mark is open");
+    xh_span s{ctx, ctx->mark_name.c_str()};
+    s.a = ctx->mark_a;
+    s.b = ctx->mark_b;
+    s.stream = ctx->stream;
+    xh_span_end(s);
+    ctx->mark_open = false;
     return XH_OK;
 }
 

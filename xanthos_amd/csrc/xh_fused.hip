@@ -182,6 +182,10 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
         (void)hipStreamSynchronize(B);
         if (!rc) rc = xh_fail(ctx, XH_ERR_HIP, "xh_run_fused: joining the side stream failed: %s", hipGetErrorString(j2));
     }
+    if (!rc) {      // PET / AET / Q / Sav are final once ev_done has fired: a side gather of them need not wait for the routing
+        ctx->runoff_event = ev_done;
+        ctx->runoff_event_fresh = true;
+    }
     if (rc) {
         // the routing kernel may be waiting for months that will never come: raise the fault word so that it gives up
         unsigned *fault = nullptr;

@@ -149,33 +149,41 @@ def gather_outputs(ctx, pipe, shard, shards, world, dist, torch, names=('pet', '
 
 
 class OutputGather:
-    """The write-out gather of a sharded run, set up once and run after every pipeline pass.
+    """The write-out gather of a sharded run, set up once and run with every pipeline pass.
 
-    kind "rccl": xh_comm_gather_rows on the library's stream -- no torch tensor, no staging copy on the senders, no
-    padding; rank 0 ends up with ``names`` as device arrays ``[ncell, nmonths]`` in grid order (``self.out``).
-    kind "torch": padded ``torch.distributed.gather`` of a stacked copy (gloo dry runs; RCCL unavailable)."""
+    kind "rccl": xh_comm_gather_rows on the library's streams -- no torch tensor, no staging copy on the senders, no
+    padding; rank 0 ends up with ``names`` as device arrays ``[ncell, nmonths]`` in grid order (``self.out``).  Two phases:
+    ``run_side`` sends PET / AET / Q / Sav on the context's gather stream as soon as they are final (pass it to
+    ``DevicePipeline.run(after_runoff=...)``), i.e. beside the routing kernel, which needs none of them;
+    ``run_tail`` sends ChStorage / Avg_ChFlow behind the routing and joins the two.  What a step still spends in the gather
+    after the routing has ended is timed on the device (``exposed_ms``).  One communicator per stream.
+    kind "torch": padded ``torch.distributed.gather`` of a stacked copy (gloo dry runs; RCCL unavailable), all in ``run_tail``."""
+
+    SIDE = ('pet', 'aet', 'q', 'sav')
 
     def __init__(self, ctx, pipe, shards, rank, ncell, dist, torch, names=('pet', 'aet', 'q', 'sav', 'chs', 'avg'),
                  root=0):
         from . import _hip
         self.ctx, self.pipe, self.shards, self.rank, self.ncell = ctx, pipe, shards, rank, int(ncell)
         self.dist, self.torch, self.names, self.root = dist, torch, tuple(names), root
+        self.side_names = tuple(k for k in self.names if k in self.SIDE)
+        self.tail_names = tuple(k for k in self.names if k not in self.SIDE)
         self.counts = np.array([len(s.cells) for s in shards], dtype=np.int64)
-        self.out, self.d_perm, self.comm, self.kind, self.why = None, None, None, 'torch', ''
-        self.exposed_s, self.runs = 0.0, 0      # time a step spends in the gather after the routing has ended
+        self.out, self.d_perm, self.comm, self.comm_side, self.kind, self.why = None, None, None, None, 'torch', ''
+        self.side_done, self.runs, self._last = False, 0, None
         self.bytes = int(self.counts.sum()) * pipe.nmonths * 8 * len(self.names)
         # The library's own gather (RCCL bound at run time) whatever backend the launcher's process group uses: the group
-        # only carries the 128-byte id and the agreement below (with "gloo" on host tensors -- the dry run with every rank
-        # on one GPU, where a test-only stand-in for librccl.so.1 may be first on the loader path).
+        # only carries the 128-byte ids and the agreement below (with "gloo" on host tensors -- the dry run with every rank
+        # on one GPU, where a test-only stand-in for librccl.so.1 may be named by XH_RCCL_LIBRARY).
         # Agree on RCCL availability BEFORE ncclCommInitRank: the init is itself a collective, so a rank that cannot even
         # load librccl must not leave the others blocked inside it.  comm_unique_id() loads the library and makes an id
-        # (cheap, local); only the root's id is used.
+        # (cheap, local); only the root's ids are used.
         dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-        uid, ok = [None], 1
+        uid, ok = [None, None], 1
         try:
-            mine = _hip.comm_unique_id()
+            mine = [_hip.comm_unique_id(), _hip.comm_unique_id()]
             if rank == root:
-                uid = [mine]
+                uid = mine
         except (_hip.HipError, RuntimeError) as exc:
             self.why, ok = str(exc), 0
         flag = torch.tensor([ok], device=dev)
@@ -184,14 +192,17 @@ class OutputGather:
             dist.broadcast_object_list(uid, src=root)
             try:
                 self.comm = _hip.Comm(ctx, len(shards), rank, uid[0])
+                self.comm_side = _hip.Comm(ctx, len(shards), rank, uid[1])
                 self.kind = 'rccl'
             except (_hip.HipError, RuntimeError) as exc:      # e.g. two ranks on one GPU in a dry run
                 self.why = str(exc)
             flag = torch.tensor([1 if self.kind == 'rccl' else 0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # all ranks take the same path
-            if int(flag.item()) == 0 and self.kind == 'rccl':
-                self.comm.close()
-                self.comm, self.kind = None, 'torch'
+            if int(flag.item()) == 0:
+                for c in (self.comm, self.comm_side):
+                    if c is not None:
+                        c.close()
+                self.comm, self.comm_side, self.kind = None, None, 'torch'
         # which library answered: the test-only stand-in of tests/fake_rccl marks its ids (the report must say so)
         self.library = None
         if self.kind == 'rccl':
@@ -200,16 +211,28 @@ class OutputGather:
             self.d_perm = ctx.upload(np.concatenate([s.cells for s in shards]), dtype=np.int64)
             self.out = {k: ctx.empty((self.ncell, pipe.nmonths)) for k in self.names}
 
-    def run(self):
-        import time
+    def _gather(self, comm, names, side):
+        comm.gather_rows([self.pipe.out[k] for k in names], self.counts, self.pipe.nmonths, perm=self.d_perm,
+                         out=None if self.out is None else [self.out[k] for k in names], root=self.root, side=side)
+
+    def run_side(self):
+        """PET / AET / Q / Sav, on the gather stream, beside the routing (a no-op for kind "torch")."""
+        if self.kind == 'rccl' and self.side_names:
+            self._gather(self.comm_side, self.side_names, True)
+            self.side_done = True
+
+    def run_tail(self):
+        """ChStorage / Avg_ChFlow behind the routing (and whatever run_side did not send), then the join."""
         if self.kind == 'rccl':
-            self.ctx.sync()       # settles a routing fault (re-route) before the rows leave; ~10 us when there is none
-            t0 = time.perf_counter()
-            self.comm.gather_rows([self.pipe.out[k] for k in self.names], self.counts, self.pipe.nmonths,
-                                  perm=self.d_perm, out=None if self.out is None else [self.out[k] for k in self.names],
-                                  root=self.root)
-            self.ctx.sync()
-            self.exposed_s += time.perf_counter() - t0
+            self.ctx.sync()       # settles a routing fault (re-route) before ChStorage / Avg_ChFlow leave (it also waits for
+                                  # the side gather: the two share the links anyway)
+            self.ctx.mark_begin('gather_exposed')
+            rest = self.tail_names if self.side_done else self.names
+            if rest:
+                self._gather(self.comm, rest, False)
+            self.ctx.comm_join()
+            self.ctx.mark_end()
+            self.side_done = False
             self.runs += 1
             return None
         world = SimpleNamespace(ncell=self.ncell)
@@ -218,7 +241,12 @@ class OutputGather:
         if self.torch.cuda.is_available() and self.dist.get_backend() == 'nccl':
             self.torch.cuda.synchronize()
         self._last = got
+        self.runs += 1
         return got
+
+    def run(self):
+        """Everything behind the routing (no overlap): what round 3 did, kept for callers without an after_runoff hook."""
+        return self.run_tail()
 
     def last(self):
         """On the root: the arrays of the last gather as host arrays, by name (grid order)."""
@@ -228,15 +256,23 @@ class OutputGather:
         return {k: self._last[i].cpu().numpy() for i, k in enumerate(self.names)}
 
     def report(self):
+        exposed = None
+        if self.kind == 'rccl':
+            ms, n = self.ctx.timing('gather_exposed')
+            exposed = ms / n if n else None
         return {'kind': self.kind, 'library': self.library, 'bytes_per_step': self.bytes, 'variables': list(self.names),
-                'exposed_ms': 1e3 * self.exposed_s / self.runs if self.runs else None,
+                'beside_the_routing': list(self.side_names) if self.kind == 'rccl' else [],
+                'behind_the_routing': list(self.tail_names) if self.kind == 'rccl' else list(self.names),
+                'exposed_ms': exposed, 'exposed_ms_is': 'device time of a step between the end of the routing kernel and '
+                'the end of the gather (HIP events on the context stream), mean over the timed steps',
                 'rows_per_rank': self.counts.tolist(), 'fallback_reason': self.why}
 
     def close(self):
-        if self.comm is not None:
-            self.ctx.sync()
-            self.comm.close()
-            self.comm = None
+        for c in (self.comm, self.comm_side):
+            if c is not None:
+                self.ctx.sync()
+                c.close()
+        self.comm = self.comm_side = None
         for a in (list(self.out.values()) if self.out else []) + ([self.d_perm] if self.d_perm is not None else []):
             a.free()
         self.out, self.d_perm = None, None

@@ -164,12 +164,14 @@ class DevicePipeline:
                            chs=self.out['chs'] if route else None, avg=self.out['avg'] if route else None,
                            route_flags=self.route_flags, block_months=block_months, mode=mode)
 
-    def run(self, stages=('pm', 'abcd', 'mrtm'), fused=None, fed=None):
+    def run(self, stages=('pm', 'abcd', 'mrtm'), fused=None, fed=None, after_runoff=None):
         """Enqueue the stages on the context's stream.  With all three stages the default is the FED order (xh_run_fused
         mode 1): the first max(spin-ups) months of PM and ABCD, then the routing kernel, and the remaining
         months of PM and ABCD beside it on a second stream -- identical results, the 2.8 ms of PM + ABCD mostly hidden
         under the routing.  ``fed=False`` (or XH_FEED=0) runs the stages strictly one after the other; ``fused=True`` (or
-        XH_FUSED=1) is round 2's block pipeline of PM and ABCD with the routing behind it (slower on MI355X at the full grid)."""
+        XH_FUSED=1) is round 2's block pipeline of PM and ABCD with the routing behind it (slower on MI355X at the full grid).
+        ``after_runoff``: called once PET / AET / Q / Sav have been enqueued and before anything waits for the routing --
+        the place for a side gather of the four arrays (dist.OutputGather.run_side)."""
         if fused is None:
             fused = os.environ.get('XH_FUSED') == '1'
         if fed is None:
@@ -177,14 +179,20 @@ class DevicePipeline:
         whole_years = self.nmonths % 12 == 0
         if fused and 'pm' in stages and 'abcd' in stages and whole_years:
             self.run_fused(with_routing='mrtm' in stages, block_months=int(os.environ.get('XH_FUSED_BLOCK', '0')))
+            if after_runoff:
+                after_runoff()
             return
         if fed and all(s in stages for s in ('pm', 'abcd', 'mrtm')) and whole_years and self.plan is not None:
             self.run_fused(with_routing=True, mode=1)
+            if after_runoff:      # the routing kernel is in the queue; a side gather waits for the runoff's side stream only
+                after_runoff()
             return
         if 'pm' in stages:
             self.run_pm()
         if 'abcd' in stages:
             self.run_abcd()
+        if after_runoff:
+            after_runoff()
         if 'mrtm' in stages:
             self.run_mrtm()
 
