@@ -74,10 +74,11 @@ __global__ void k_set_word(unsigned *w, unsigned v) {
 // Holds the side stream back until the routing kernel of this call has placed its workgroups (it writes `epoch`), at most
 // `limit_ticks` of the 100 MHz counter: correctness never depends on it (the stream also waits for an event), only who
 // gets the wave slots first.
-__global__ void k_gate(const unsigned *w, unsigned epoch, unsigned long long limit_ticks) {
+__global__ void k_gate(unsigned *w, unsigned epoch, unsigned long long limit_ticks) {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+    // (polled with an atomic add of 0: never answered from a cached copy of the line)
+    while ((int)(__hip_atomic_fetch_add(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
         if (__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) break;
         __builtin_amdgcn_s_sleep(32);
     }
@@ -91,11 +92,12 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
     const int nmonths = a->nmonths;
     // First block: at least the spin-ups (ABCD's needs PET of those months, the routing's pass over them comes first), and
     // enough months to keep the routing kernel busy until the side stream has delivered the rest: beside the routing waves
-    // PM runs at ~1/6 of its stand-alone speed (one wave per SIMD, below the routing waves' priority), i.e. ~25 us per
-    // month of the full grid against the routing's 33 us per month; 3/8 of the series covers that with margin (measured
-    // at 600 months, profiles/round4/feed_first_block.txt: 192 / 224 months 25.35 ms per step, 128 too few, 320 too many).
+    // PM runs at 1/3 - 1/4 of its stand-alone speed (one wave per SIMD, below the routing waves' priority; in one-wave
+    // workgroups -- four-wave ones need a free slot on all four SIMDs of a CU at once and ran at 1/6), i.e. ~12 us per month
+    // of the full grid against the routing's 33 us per month; a quarter of the series covers that with margin (measured at
+    // 600 months, profiles/round4/feed_first_block.txt).
     int b0 = (std::max(a->abcd_spinup, a->routing_spinup) + 15) & ~15;
-    b0 = std::max(b0, (nmonths * 3 / 8 + 15) & ~15);
+    b0 = std::max(b0, (nmonths / 4 + 15) & ~15);
     b0 = std::max(b0, 32);
     if (const char *env = getenv("XH_FEED_FIRST"))      // experiments
         b0 = std::max((std::max(a->abcd_spinup, a->routing_spinup) + 15) & ~15, atoi(env) & ~15);
@@ -165,7 +167,13 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
             hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, B, w_epoch, feed.epoch, gate_ticks);
             xh_span_end(sp);
         }
+        // (the paired PM kernel: one wave per SIMD is all that fits beside a routing wave, and it is the variant whose lone
+        // wave has two independent chains to issue from)
+        pm.paired = true;
+        pm.block = 64;
         int r = pm_block(B, b0, nmonths);
+        pm.paired = false;
+        pm.block = 0;
         if (r) return r;
         r = sim_block(B, b0, nmonths, staged);
         if (r) return r;

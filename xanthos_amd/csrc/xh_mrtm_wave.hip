@@ -357,7 +357,13 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         if (!p) return true;                             // (cannot happen: ready_at_launch covers the series then)
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (;;) {
-            const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_relaxed(p));
+            // An atomic read-modify-write (+ 0), not a load: it is carried out where the word lives, so it cannot be answered
+            // from a copy of the line that an earlier poll left in this XCD's L2 (a unit that polls while every other unit is
+            // parked in the same wait has no traffic that would ever evict such a copy).  Rare path: once per call and unit.
+            unsigned v = 0;
+            if (A(fenced) == 2) v = ld_relaxed(p);      // XH_FEED_POLL=load: the plain agent-scope load, for comparison
+            else if (lane == 0) v = __hip_atomic_fetch_add(const_cast<unsigned *>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
             if (v >= need) {
                 mready = v;
                 return true;
@@ -411,7 +417,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alive = false;
         }
-        const bool fenced = A(fenced) != 0;
+        const bool fenced = A(fenced) == 1;
         if (any_x) {      // publish what has certainly been stored, then make sure the next CH iterations have ring space
             const int pub = min(max(n - PUBLAG - RING - lmax, 0), total);
             // XH_ROUTE_FENCED=1: the publication the HIP memory model asks for -- an agent-scope release (buffer_wbl2 sc1 +
@@ -735,7 +741,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             store_pair(*xsrc[0], PLAIN ? *xsrc0[0] : 0.0, xbyte[0], xpos);
             if (x2) store_pair(*xsrc[1], PLAIN ? *xsrc0[1] : 0.0, xbyte[1], xpos);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // write-through stores acknowledged
-            if (A(fenced)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (A(fenced) == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             if (has_x) __hip_atomic_store(A(ready) + xedge, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (any_g && lane == 0)
@@ -1058,6 +1064,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.place_epoch = feed ? feed->place_epoch : nullptr;
     a.epoch = feed ? feed->epoch : 0u;
     a.fenced = (getenv("XH_ROUTE_FENCED") && getenv("XH_ROUTE_FENCED")[0] == '1') ? 1 : 0;
+    if (!a.fenced && getenv("XH_FEED_POLL") && getenv("XH_FEED_POLL")[0] == 'l') a.fenced = 2;      // experiments (wait_months)
     a.S0 = io.S0;
     a.chs = io.chs;
     a.avg = io.avg;

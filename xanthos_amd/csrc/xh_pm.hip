@@ -70,12 +70,15 @@ struct PmCell {          // per-cell quantities shared by the months a thread ha
     double p;            // air pressure (calc_p :185-188)
 };
 
-// One (cell, month): returns PET. lctw[l] = land-cover fraction of class l, totpct = their sum (0 -> 0.01).
-__device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__restrict__ tab, const XhExpConsts &K,
-                                           int nlcs, int water_idx, int snow_idx, double wind_pow,
-                                           double p, double T, double TN, double RH, double W, double RS,
-                                           double RL, double TP, int moy, double dz,
-                                           const double *__restrict__ lct_cell, int lct_stride, double totpct) {
+// The month update in two parts, so that a thread can run the class loop for TWO months at once (k_pm_pet2): everything a
+// month contributes that does not depend on the land class ...
+struct PmMonth {
+    double sx, vpd, rcorr, gcu, fwet, one_m_fwet, inv_fwet, g, rl_term, inv_secs, rho_cp, inv_rr, rs_secs, sig_t4_dz, p_cp, vpd_log, secs_lambda, T, TN, W, dz;
+    int moy;
+};
+
+__device__ __forceinline__ PmMonth pm_prep(const XhExpConsts &K, double p, double T, double TN, double RH, double W, double RS,
+                                           double RL, double TP, int moy, double dz) {
     // ---- terms shared by every land class (SetData :83-99, et_veg :226-282)
     const double esx = 6.10588 * xh_exp(fdiv(17.32491 * T, T + 238.102), K);
     const double vap = esx * (RH * 0.01);                             // constant divisors are multiplied by their reciprocal
@@ -115,11 +118,60 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
     const double vpd_log = vpd * log_r100;                            // exponent of :323 is vpd_log / beta
     const double secs_lambda = secs * (1.0 / LAMBDA1);                // 86400 dz / lambda1 of :306-327
 
-    double acc = 0.0;
-    for (int l = 0; l < nlcs; ++l) {
-        double et;
-        const double oma = (l == water_idx) ? L.one_m_alpha[0][moy]
-                                            : ((l == snow_idx) ? L.one_m_alpha[6][moy] : L.one_m_alpha[l][moy]);
+    PmMonth M;
+    M.sx = sx;
+    M.vpd = vpd;
+    M.rcorr = rcorr;
+    M.gcu = gcu;
+    M.fwet = fwet;
+    M.one_m_fwet = one_m_fwet;
+    M.inv_fwet = inv_fwet;
+    M.g = g;
+    M.rl_term = rl_term;
+    M.inv_secs = inv_secs;
+    M.rho_cp = rho_cp;
+    M.inv_rr = inv_rr;
+    M.rs_secs = rs_secs;
+    M.sig_t4_dz = sig_t4_dz;
+    M.p_cp = p_cp;
+    M.vpd_log = vpd_log;
+    M.secs_lambda = secs_lambda;
+    M.T = T;
+    M.TN = TN;
+    M.W = W;
+    M.dz = dz;
+    M.moy = moy;
+    return M;
+}
+
+// ... and the evapotranspiration of ONE land class in that month (et_veg :223-334, et_water :337-361, et_snow :364-377).
+__device__ __forceinline__ double pm_class(const PmLds &L, const PmTablesDev *__restrict__ tab, const XhExpConsts &K, int l,
+                                           int water_idx, int snow_idx, double wind_pow, const PmMonth &M) {
+    const double sx = M.sx;
+    const double vpd = M.vpd;
+    const double rcorr = M.rcorr;
+    const double gcu = M.gcu;
+    const double fwet = M.fwet;
+    const double one_m_fwet = M.one_m_fwet;
+    const double inv_fwet = M.inv_fwet;
+    const double g = M.g;
+    const double rl_term = M.rl_term;
+    const double inv_secs = M.inv_secs;
+    const double rho_cp = M.rho_cp;
+    const double inv_rr = M.inv_rr;
+    const double rs_secs = M.rs_secs;
+    const double sig_t4_dz = M.sig_t4_dz;
+    const double p_cp = M.p_cp;
+    const double vpd_log = M.vpd_log;
+    const double secs_lambda = M.secs_lambda;
+    const double T = M.T;
+    const double TN = M.TN;
+    const double W = M.W;
+    const double dz = M.dz;
+    const int moy = M.moy;
+    double et;
+    const double oma = (l == water_idx) ? L.one_m_alpha[0][moy]
+                                        : ((l == snow_idx) ? L.one_m_alpha[6][moy] : L.one_m_alpha[l][moy]);
         if (l == snow_idx) {
             // et_snow (:364-377): emissivity 0.85, albedo of land class 6
             const double rnl = sig_t4_dz * 0.85 - rl_term;
@@ -224,6 +276,19 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
             et = secs_lambda * (num * frcp(x_trans * x_as));
             et = fmax(et, 0.0);
         }
+    return et;
+}
+
+// One (cell, month): returns PET. lct_cell[l * lct_stride] = land-cover fraction of class l, totpct = their sum (0 -> 0.01).
+__device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__restrict__ tab, const XhExpConsts &K,
+                                           int nlcs, int water_idx, int snow_idx, double wind_pow,
+                                           double p, double T, double TN, double RH, double W, double RS,
+                                           double RL, double TP, int moy, double dz,
+                                           const double *__restrict__ lct_cell, int lct_stride, double totpct) {
+    const PmMonth M = pm_prep(K, p, T, TN, RH, W, RS, RL, TP, moy, dz);
+    double acc = 0.0;
+    for (int l = 0; l < nlcs; ++l) {
+        const double et = pm_class(L, tab, K, l, water_idx, snow_idx, wind_pow, M);
         const double term = et * lct_cell[l * lct_stride];            // arr *= lct (:467)
         acc += term;                                                  // np.sum over classes, in order (:470); 0 + x is x
     }
@@ -292,6 +357,82 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                          (double)days_in_month(year, moy), lct_cell, n_lc_years, totpct);
         out.y = pm_month(L, tab, K, nlcs, water_idx, snow_idx, wind_pow, p, T.y, TN.y, RH.y, W.y, RS.y, RL.y, TP.y,
                          moy + 1, (double)days_in_month(year, moy + 1), lct_cell, n_lc_years, totpct);
+        *reinterpret_cast<double2 *>(pet + off) = out;
+    }
+}
+
+// The same thread <-> (cell, two months), but BOTH months go through one class loop: two independent dependency chains per
+// wave and the per-class scalars loaded once per pair.  Same functions, same order of operations per month: bit-identical
+// to k_pm_pet.  It needs up to 256 registers (two waves per SIMD instead of three), which is what a lone wave wants: beside
+// a routing wave of a fed run (xh_fused.hip, mode 1) exactly one PM wave fits per SIMD, and one wave of k_pm_pet there runs
+// at ~1/6 of the kernel's own speed for want of independent work (profiles/round4/feed_first_block.txt).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_pm_pet2(const PmTablesDev *__restrict__ tab,
+                                                const int *__restrict__ lc_of_year, int64_t ncell, int nmonths,
+                                                int m_begin, int m_count, const double *__restrict__ tas, const double *__restrict__ tmin,
+                                                const double *__restrict__ rhs, const double *__restrict__ wind,
+                                                const double *__restrict__ rsds, const double *__restrict__ rlds,
+                                                const double *__restrict__ tairprev,
+                                                const double *__restrict__ lct, const double *__restrict__ pressure,
+                                                double *__restrict__ pet) {
+    __shared__ PmLds L;
+    const int nlcs = tab->nlcs;
+    for (int i = threadIdx.x; i < nlcs * 12; i += blockDim.x) {
+        const int l = i / 12, m = i % 12;
+        L.one_m_alpha[l][m] = tab->one_m_alpha[l][m];
+        L.lai[l][m] = tab->lai[l][m];
+        L.fc[l][m] = tab->fc[l][m];
+        L.inv_lai[l][m] = tab->inv_lai[l][m];
+    }
+    __syncthreads();
+    const int water_idx = tab->water_idx, snow_idx = tab->snow_idx, start_year = tab->start_year;
+    const int n_lc_years = tab->n_lc_years;
+    const double wind_pow = tab->wind_pow;
+    const XhExpConsts K = xh_exp_consts();
+    const int half = m_count >> 1;
+    const int64_t total = ncell * (int64_t)half;
+    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < total;
+         item += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = item / half;
+        const int m0 = m_begin + (int)(item - c * half) * 2;
+        const int64_t off = c * nmonths + m0;
+        const double2 T = *reinterpret_cast<const double2 *>(tas + off);
+        const double2 TN = *reinterpret_cast<const double2 *>(tmin + off);
+        const double2 RH = *reinterpret_cast<const double2 *>(rhs + off);
+        const double2 W = *reinterpret_cast<const double2 *>(wind + off);
+        const double2 RS = *reinterpret_cast<const double2 *>(rsds + off);
+        const double2 RL = *reinterpret_cast<const double2 *>(rlds + off);
+        double2 TP;
+        if (tairprev) {
+            TP = *reinterpret_cast<const double2 *>(tairprev + off);
+        } else if (c > 0) {
+            TP = *reinterpret_cast<const double2 *>(tas + off - nmonths);   // previous CELL (data_load.py:128-129)
+        } else {
+            TP = make_double2(0.0, 0.0);
+        }
+        const int yr_i = m0 / 12;
+        const int year = start_year + yr_i;
+        const int moy = m0 - yr_i * 12;
+        const double *lct_cell = lct + c * (int64_t)nlcs * n_lc_years + lc_of_year[yr_i];
+        double totpct = 0.0;
+        for (int l = 0; l < nlcs; ++l) {
+            const double v = lct_cell[l * n_lc_years];
+            totpct = (l == 0) ? v : totpct + v;
+        }
+        totpct = totpct == 0.0 ? 0.01 : totpct;     // :47
+        const double p = pressure[c];
+        const PmMonth A = pm_prep(K, p, T.x, TN.x, RH.x, W.x, RS.x, RL.x, TP.x, moy, (double)days_in_month(year, moy));
+        const PmMonth B = pm_prep(K, p, T.y, TN.y, RH.y, W.y, RS.y, RL.y, TP.y, moy + 1, (double)days_in_month(year, moy + 1));
+        double acc_a = 0.0, acc_b = 0.0;
+        for (int l = 0; l < nlcs; ++l) {
+            const double w = lct_cell[l * n_lc_years];
+            const double et_a = pm_class(L, tab, K, l, water_idx, snow_idx, wind_pow, A);
+            const double et_b = pm_class(L, tab, K, l, water_idx, snow_idx, wind_pow, B);
+            acc_a += et_a * w;                      // arr *= lct (:467); np.sum over classes, in order (:470)
+            acc_b += et_b * w;
+        }
+        double2 out;
+        out.x = fdiv(acc_a, totpct);
+        out.y = fdiv(acc_b, totpct);
         *reinterpret_cast<double2 *>(pet + off) = out;
     }
 }
@@ -401,8 +542,15 @@ int xh_pm_enqueue(xh_ctx *ctx, hipStream_t st, xh_pm_setup &s, int m_begin, int 
     const int64_t items = s.ncell * (int64_t)(m_count / 2);
     // grid-stride loop with a whole number of passes per thread: a block of months (xh_run_fused) is only ~1.5 passes of
     // the capped grid, and a ragged last pass would leave a quarter of the chip idle for it
-    const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 32;
-    const int64_t need = (items + 255) / 256;
+    // XH_PM_BLOCK=64 / 128 / 256: threads per workgroup (experiments: one-wave workgroups fit a SIMD's free registers
+    // whatever the other SIMDs of the CU hold)
+    static const int bsz_env = [] {
+        const int v = getenv("XH_PM_BLOCK") ? atoi(getenv("XH_PM_BLOCK")) : 0;
+        return (v == 64 || v == 128 || v == 256) ? v : 0;
+    }();
+    const int bsz = bsz_env ? bsz_env : ((s.block == 64 || s.block == 128) ? s.block : 256);
+    const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 32 * (256 / bsz);
+    const int64_t need = (items + bsz - 1) / bsz;
     const int64_t passes = (need + cap - 1) / cap;
     int64_t blocks = (need + passes - 1) / passes;
     xh_span sp = xh_span_begin_on(ctx, "pm_pet", st);
@@ -411,9 +559,25 @@ int xh_pm_enqueue(xh_ctx *ctx, hipStream_t st, xh_pm_setup &s, int m_begin, int 
                            s.d_pressure);
         s.pressure_done = true;
     }
-    hipLaunchKernelGGL(k_pm_pet, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const PmTablesDev *>(s.d_tab),
-                       s.d_lcy, s.ncell, s.nmonths, m_begin, m_count, d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds,
-                       d_tairprev, d_lct, s.d_pressure, d_pet);
+    // XH_PM_PAIRED=0 / 1 forces a variant (experiments); otherwise the caller's choice (xh_pm_setup::paired: the fillers
+    // of a fed run), default k_pm_pet
+    static const int paired_env = getenv("XH_PM_PAIRED") ? atoi(getenv("XH_PM_PAIRED")) : -1;
+    const bool paired = paired_env >= 0 ? paired_env != 0 : s.paired;
+    // XH_PM_LDS_PAD=<bytes of dynamic LDS>: experiments on the kernel's speed at reduced occupancy (100000 -> one workgroup
+    // per CU = one wave per SIMD, what a PM wave has beside a routing wave)
+    static const size_t pad = getenv("XH_PM_LDS_PAD") ? (size_t)atoll(getenv("XH_PM_LDS_PAD")) : 0;
+    if (pad) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pm_pet), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pm_pet2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+    }
+    if (paired)
+        hipLaunchKernelGGL(k_pm_pet2, dim3((unsigned)blocks), dim3(bsz), pad, st, static_cast<const PmTablesDev *>(s.d_tab),
+                           s.d_lcy, s.ncell, s.nmonths, m_begin, m_count, d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds,
+                           d_tairprev, d_lct, s.d_pressure, d_pet);
+    else
+        hipLaunchKernelGGL(k_pm_pet, dim3((unsigned)blocks), dim3(bsz), pad, st, static_cast<const PmTablesDev *>(s.d_tab),
+                           s.d_lcy, s.ncell, s.nmonths, m_begin, m_count, d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds,
+                           d_tairprev, d_lct, s.d_pressure, d_pet);
     xh_span_end(sp);
     XH_HIP(ctx, hipGetLastError());
     return XH_OK;

@@ -11,6 +11,9 @@ struct xh_pm_setup {
     int nmonths = 0;
     double *d_pressure = nullptr;     // [ncell] calc_p, filled by the first xh_pm_enqueue
     bool pressure_done = false;
+    bool paired = false;              // k_pm_pet2: both months of a thread in one class loop (256 registers, two chains per wave)
+    int block = 0;                    // threads per workgroup (0 = 256); 64: one-wave workgroups, which fit the registers a SIMD has
+                                      // left beside a routing wave whatever the CU's other SIMDs hold (the fillers of a fed run)
 };
 // Validates, builds the per-class tables and uploads them (waits for the context's stream once).
 int xh_pm_prepare(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int32_t nmonths, int32_t start_year,
