@@ -470,7 +470,9 @@ def launch_ranks(args):
     reader.join()
     for p in procs:
         worst = max(worst, abs(p.returncode) if p.returncode else 0)
-    sys.stdout.write((got[0] if got else b'').decode(errors='replace'))
+    # stdout carries the ONE JSON line; anything else a rank's libraries printed there (gloo's connection banner) goes to stderr
+    for line in (got[0] if got else b'').decode(errors='replace').splitlines():
+        (sys.stdout if line.startswith('{') else sys.stderr).write(line + '\n')
     sys.stdout.flush()
     return worst
 

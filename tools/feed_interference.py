@@ -42,7 +42,10 @@ for name, fed in (('stage by stage', False), ('fed', True), ('stage by stage', F
     linked = (shape & np.uint64(48)) != 0
     total, waits = st[:, 1], st[:, 4] + st[:, 5]
     busy = (total - waits) / nsub
+    clock = total / (st[:, 2] / 100e6) / 1e9                 # shader cycles per second of the 100 MHz real-time counter
+    wall = st[:, 2] / 1e5                                    # ms from a unit's first to its last instruction
     print('{:15s} mrtm_route {:.2f} ms | cycles per sub-step outside waits, stream-linked units: median {:.0f}  p90 {:.0f}  max {:.0f}'
-          ' | all units: median {:.0f}  max {:.0f} | waits per sub-step: median {:.0f}'.format(
+          ' | all units: median {:.0f}  max {:.0f} | waits per sub-step: median {:.0f} | shader clock GHz median {:.3f} min {:.3f}'
+          ' | unit wall ms median {:.2f} max {:.2f}'.format(
               name, ms, np.median(busy[linked]), np.percentile(busy[linked], 90), busy[linked].max(), np.median(busy), busy.max(),
-              np.median(waits[linked] / nsub)), flush=True)
+              np.median(waits[linked] / nsub), np.median(clock), clock.min(), np.median(wall), wall.max()), flush=True)

@@ -11,7 +11,8 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_int, c_int8,
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libxanthos_hip.so')
+# XH_LIBRARY: another build of the library (A/B experiments: `make -C xanthos_amd/csrc exp EXPNAME=... EXPFLAGS=...`)
+LIB_PATH = os.environ.get('XH_LIBRARY') or os.path.join(_HERE, 'libxanthos_hip.so')
 
 XH_ROUTE_DEFAULT, XH_ROUTE_FORCE_FALLBACK, XH_ROUTE_ATOMIC, XH_ROUTE_NO_DATAFLOW, XH_ROUTE_NO_SKEW = 0, 1, 2, 4, 8
 XH_ROUTE_TEST_FAULT, XH_ROUTE_VALIDATE, XH_ROUTE_TYPED = 16, 32, 64

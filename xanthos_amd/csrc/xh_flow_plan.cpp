@@ -799,6 +799,21 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
         std::stable_sort(out.unit_order.begin(), out.unit_order.end(), [&](int x, int y) {
             return coupled(x) != coupled(y) ? !coupled(x) : cost[x] < cost[y];
         });
+        // XH_WAVE_BALANCE=1 (experiment, round 4; off by default): behind the entries that go to the SIMDs with two waves
+        // (2 x (units - SIMDs) of them) the list is ordered by what a unit asks of its CU's LDS per sub-step (values read x
+        // their size), and the kernel hands the k-th quarter of this tail to the workgroups on SIMD k of their CU, so that
+        // every CU holds one unit of each quarter and no CU four heavy ones (a unit loses 10 - 12 % to its CU mates,
+        // profiles/round3/pmc_cu_sharing.txt).  Measured at the full grid, same box, twice: 23.53 / 23.57 ms in arrival
+        // order, 23.64 / 23.65 ms balanced -- no gain: what a unit loses to its mates does not follow their LDS bytes.
+        if (opt.simds > 0 && opt.balance_lds) {
+            const int two = std::min(nunit, 2 * std::max(nunit - opt.simds, 0));
+            auto lds_load = [&](int u) {
+                const int reads = (out.unit_p[u] & 15) + ((out.unit_p[u] >> 4) & 15) + ((out.unit_p[u] & 0x100) ? 1 : 0);
+                return reads * (out.unit_plain[u] ? 8 : 16);
+            };
+            std::stable_sort(out.unit_order.begin() + two, out.unit_order.end(),
+                             [&](int x, int y) { return lds_load(x) < lds_load(y); });
+        }
     }
 
     out.skew_ok = skew_ok;

@@ -30,6 +30,7 @@ struct FlowPlanOptions {
     // The heavy units pace the run (every stream-linked unit follows the slowest one), and they are where one 8-byte
     // read per term instead of a 16-byte pair pays most.
     int plain_min_reads = 0;
+    bool balance_lds = false;    // order the claim list's tail by LDS load (XH_WAVE_BALANCE=1: every CU one unit of each quarter)
     bool debug = false;          // partition statistics on stderr
 };
 

@@ -331,6 +331,7 @@ FlowPlanOptions flow_plan_options(const xh_ctx *ctx) {
     if (const char *e = getenv("XH_FLOW_PAIR_STREAMS")) o.pair_streams = std::min(std::max(atoi(e), 1), G_MAX);
     if (const char *e = getenv("XH_FLOW_PLAIN_MIN_READS")) o.plain_min_reads = atoi(e);
     o.debug = getenv("XH_FLOW_DEBUG") != nullptr;
+    o.balance_lds = getenv("XH_WAVE_BALANCE") && getenv("XH_WAVE_BALANCE")[0] == '1';
     return o;
 }
 

@@ -41,11 +41,15 @@ constexpr int NSLOT = 2 * LANES + 1;          // entries per LDS slot: cells, gh
 constexpr int RING = 8;                       // LDS slots = sub-steps per stream block
 constexpr int GROUP = 16;                     // sub-steps per unrolled group (two blocks)
 constexpr int SK_R = 2;                       // block-transfer rounds: up to 8 * SK_R imports / outlets per unit
-constexpr int CH = 128;                       // iterations between flow-control checks (multiple of GROUP)
+#ifndef XH_WAVE_CH
+#define XH_WAVE_CH 256                        // (128 until round 4: 23.55 -> 23.35 ms at the full grid, same box, two runs each)
+#endif
+constexpr int CH = XH_WAVE_CH;                // iterations between flow-control checks (multiple of GROUP)
 constexpr int PUBLAG = 64;                    // a check publishes the stores older than this many iterations
 constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2, FAULT_PLACE_WAIT = 3, FAULT_GUARD = XH_FAULT_GUARD;
 constexpr unsigned FAULT_TEST = 99;
 constexpr int PLACE_KEYS = 16 * 8 * 2 * 16 * 4;      // (xcc, se, sh, cu, simd) of HW_ID / XCC_ID
+
 constexpr int PLACE_WORDS = 16 + PLACE_KEYS;
 
 struct MonthRec {                             // one iteration of the schedule (spin-up months, then every month)
@@ -94,6 +98,7 @@ struct WaveArgs {
     const unsigned *months_ready;
     unsigned *place_epoch;
     unsigned epoch;
+    int balance;                      // XH_WAVE_BALANCE=1: claim units by LDS-load quarter and SIMD id (placement); default: arrival order
     int fenced;                       // XH_ROUTE_FENCED=1: agent-scope release / acquire fences around the stream counters (see check())
     char *xbuf;                       // [edges][RS] {F, F2}
     unsigned xbytes;                  // size of the rings
@@ -176,7 +181,8 @@ template <> struct Val<true> {
 // round that loads nothing still costs its load, its LDS store and its address arithmetic in every block of 8 sub-steps.
 template <bool PLAIN, int PRE, int POST, int NG, bool CHAIN>
 __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint2 *xtab,
-                                          __attribute__((address_space(3))) unsigned *qstage, const int unit) {
+                                          __attribute__((address_space(3))) unsigned *qstage,
+                                          __attribute__((address_space(3))) double *fend, const int unit) {
     constexpr bool HAS_G = NG > 0;
     typedef Val<PLAIN> V;
     typedef typename V::T val_t;
@@ -186,6 +192,9 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     constexpr unsigned SLOTB = NSLOT * VB;                 // bytes per ring slot
     lds_char *lds0 = (lds_char *)lds_generic;
     const int lane = threadIdx.x;
+#ifdef XH_WAVE_OB_LDS
+    __attribute__((address_space(3))) double *obl = fend + LANES;
+#endif
     const int64_t slot = (int64_t)unit * LANES + lane;
 
     const int gc = A(cell_of_slot)[slot];
@@ -269,7 +278,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
 
     const double dt = A(dt), dtinv = A(dtinv);
     double S = 0.0, F = 0.0, favg = 0.0, erl = 0.0;
-    double snapS = 0.0, snapA = 0.0, snapF = 0.0;
+    double snapS = 0.0, snapA = 0.0;
     int nx = A(lag)[slot];                                  // iteration at which this lane enters its next month
     // Guard / learning.  `fired` becomes 1 when this lane's cell fires although it is not among the cells that can by
     // construction (gval = 0 for those).  In a plain unit that invalidates the run (check()); in a pair unit it is only
@@ -343,9 +352,11 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     }
     // month outputs leave as groups of OB months per cell (32 bytes = one memory sector)
     constexpr int OB = 4;
+#ifndef XH_WAVE_OB_LDS
     double ob_s[OB], ob_a[OB];
 #pragma unroll
     for (int j = 0; j < OB; ++j) ob_s[j] = ob_a[j] = 0.0;
+#endif
     bool alive = true;
     // Fed run (FlowFeed): months [0, mready) of the runoff source are known to be final.  A month beyond that is waited
     // for, bounded like every wait here, on the months-ready word (written by a kernel that runs after the one that
@@ -465,6 +476,21 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         if (it >= 1) {
             const int m = f.m_prev_w & (FIN_WRITE - 1);
             const bool write_prev = (f.m_prev_w & FIN_WRITE) != 0;
+#ifdef XH_WAVE_OB_LDS
+            // the group of OB months waits in LDS (slot = month mod OB), not in 4 OB registers carried through every loop
+            obl[(m & (OB - 1)) * LANES + lane] = snapS;
+            obl[(OB + (m & (OB - 1))) * LANES + lane] = snapA / (double)f.nt_prev;      // mrtm.py:80
+            double ob_s[OB], ob_a[OB];
+            if (write_prev && valid && ((m & (OB - 1)) == OB - 1 || m == nmo - 1)) {
+                const int sh = (m & (OB - 1)) == OB - 1 ? 0 : OB - 1 - (m & (OB - 1));      // partial group: right-aligned as below
+#pragma unroll
+                for (int j = 0; j < OB; ++j) {
+                    const int slot = j - sh;
+                    ob_s[j] = slot >= 0 ? obl[slot * LANES + lane] : 0.0;
+                    ob_a[j] = slot >= 0 ? obl[(OB + slot) * LANES + lane] : 0.0;
+                }
+            }
+#else
 #pragma unroll
             for (int j = 0; j < OB - 1; ++j) {
                 ob_s[j] = ob_s[j + 1];
@@ -472,6 +498,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             }
             ob_s[OB - 1] = snapS;
             ob_a[OB - 1] = snapA / (double)f.nt_prev;                          // mrtm.py:80
+#endif
             if (write_prev && valid) {     // whole groups of OB months per cell
                 if ((m & (OB - 1)) == OB - 1) {
                     const int64_t o = (int64_t)gc * nmo + (m - (OB - 1));
@@ -586,7 +613,10 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     int ntz = nit > 0 ? p_rec[0].nt : 0;
 
     // zone: some lanes cross a month start in this group; first: it is the start of the series (the lanes pick up S0)
-    auto substep = [&](auto zone_c, const int n, const int j, const bool first, const int rel) {
+    // edge: 1 = the start of the series (the lanes pick up S0), 2 = its end (the lanes leave their last outflow for F_end in
+    // LDS: as a register selected at every month start like snapS it cost 0.3 ms of the full grid's 23.4 -- two more live
+    // registers through every loop and two selects per boundary sub-step, for a value only the last month needs)
+    auto substep = [&](auto zone_c, const int n, const int j, const int edge, const int rel) {
         // (a compile-time flag: as a run-time argument the optimiser folded the two variants of the group back into one
         // body with a branch around the boundary code in every sub-step)
         if (decltype(zone_c)::value && ((j & 1) == 0 || odd_ok)) {
@@ -595,10 +625,13 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             const bool c = rel == j;
             snapS = c ? S : snapS;
             snapA = c ? favg : snapA;
-            snapF = c ? F : snapF;
+
             favg = c ? 0.0 : favg;
             erl = c ? erl_n : erl;
-            if (first) S = c ? S0v : S;
+            if (edge == 1) S = c ? S0v : S;
+            if (edge == 2) {
+                if (c) fend[lane] = F;
+            }
         }
         // values for the NEXT sub-step: produced during the previous iteration.  The scheduling barriers keep the reads
         // here, a whole sub-step ahead of the sums that consume them.
@@ -697,14 +730,14 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     int n = 0;
     while (n < N && alive) {
         if (itz <= nit && n + GROUP > gz && n <= gz + lmax) {      // boundary groups of month itz
-            const bool first = itz == 0;
+            const int edge = itz == 0 ? 1 : (itz == nit ? 2 : 0);
             do {
                 housekeeping(n);
                 if (!alive) break;
                 ++zone_groups;
                 const int rel = nx - n;      // the sub-step of this group at which the lane crosses (outside 0..15: not in this group)
 #pragma unroll
-                for (int j = 0; j < GROUP; ++j) substep(std::true_type(), n, j, first, rel);
+                for (int j = 0; j < GROUP; ++j) substep(std::true_type(), n, j, edge, rel);
                 n += GROUP;
                 PROF_MARK(prof_zone)
             } while (n <= gz + lmax && n < N);
@@ -721,7 +754,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
                 housekeeping(n);
                 if (!alive) break;
 #pragma unroll
-                for (int j = 0; j < GROUP; ++j) substep(std::false_type(), n, j, false, 0);
+                for (int j = 0; j < GROUP; ++j) substep(std::false_type(), n, j, 0, 0);
                 n += GROUP;
                 PROF_MARK(prof_plain)
             } while (n < n_end);
@@ -748,7 +781,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             __hip_atomic_store(A(done) + unit, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (valid) {
             if (A(S_end)) A(S_end)[gc] = snapS;
-            if (A(F_end)) A(F_end)[gc] = snapF;
+            if (A(F_end)) A(F_end)[gc] = fend[lane];
         }
     }
     const bool guard_set = __any((fired | gmis) != 0);
@@ -780,6 +813,11 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
     __shared__ uint2 xtab[LANES];
     __shared__ unsigned qstage_sh[2 * LANES];      // runoff of the month after next, low / high words (runoff_fetch)
+#ifdef XH_WAVE_OB_LDS
+    __shared__ double fend_sh[9 * LANES];          // + the month outputs waiting for their group of four (2 x 4 x 64 doubles)
+#else
+    __shared__ double fend_sh[LANES];              // outflow of every lane's last sub-step (F_end)
+#endif
     // ---- which unit this workgroup runs.  The launch has more workgroups than units.  Every workgroup registers on its
     //      SIMD and waits until all have (they are all resident: the launch made sure).  First arrivals run a unit; as
     //      many second arrivals as there are units left over also do, the rest leave -- so exactly (units - SIMDs in use)
@@ -839,7 +877,22 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
                     idx = need2 + (int)add(5);
                     prio_sh = 3;
                 } else {
-                    idx = 2 * need2 + (int)add(6);
+                    // everybody else: the list's tail is ordered by LDS load (xh_flow_plan.cpp); SIMD s of a CU takes from
+                    // its s-th quarter, so the four units of a CU come from the four quarters (a quarter that has run
+                    // out -- the SIMD ids of the shared SIMDs are not spread evenly -- sends the workgroup to the next one)
+                    const int rest = n_units - 2 * need2, q = (rest + 3) >> 2;
+                    const int s0 = (int)((hw >> 4) & 3u);
+                    const bool balance = A(balance) != 0;
+                    if (!balance) {
+                        idx = 2 * need2 + (int)add(6);
+                    } else {
+                        for (int k = 0; k < 4 && idx < 0; ++k) {
+                            const int sq = (s0 + k) & 3, len = min(q, rest - sq * q);
+                            if (len <= 0) continue;
+                            const int t = (int)add(8 + sq);
+                            if (t < len) idx = 2 * need2 + sq * q + t;
+                        }
+                    }
                 }
             }
             if (idx >= n_units) idx = -1;      // cannot happen: the three ranges add up to the units
@@ -865,15 +918,17 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     const bool g = __any(has_ghost), g2 = __any(has_ghost && threadIdx.x >= 8);
     char *l = reinterpret_cast<char *>(lds);
     __attribute__((address_space(3))) unsigned *qst = (__attribute__((address_space(3))) unsigned *)qstage_sh;
+    __attribute__((address_space(3))) double *fnd = (__attribute__((address_space(3))) double *)fend_sh;
+    fend_sh[threadIdx.x] = 0.0;
     // one specialisation per (terms before, terms after, imports?, chained?, plain?): an LDS read costs a lone wave 8-15
     // cycles of issue, so no unit should read padding it does not need
     // NG1 = true compiles the one-round form too (the shapes most units have; each form is ~45 KB of code and ~10 s of
     // compile time, so the rare shapes send every unit with imports through the two-round form)
 #define WAVE_FORM(PLAINF, PRE, POST, CHAINED, NG1)                                                        \
     case (PRE) | ((POST) << 4) | ((CHAINED) ? 0x100 : 0) | ((PLAINF) ? 0x200 : 0):                        \
-        if (g2 || (g && !(NG1))) wave_unit<PLAINF, PRE, POST, 2, CHAINED>(ap, l, xtab, qst, unit);        \
-        else if (g) wave_unit<PLAINF, PRE, POST, (NG1) ? 1 : 2, CHAINED>(ap, l, xtab, qst, unit);         \
-        else wave_unit<PLAINF, PRE, POST, 0, CHAINED>(ap, l, xtab, qst, unit);                            \
+        if (g2 || (g && !(NG1))) wave_unit<PLAINF, PRE, POST, 2, CHAINED>(ap, l, xtab, qst, fnd, unit);        \
+        else if (g) wave_unit<PLAINF, PRE, POST, (NG1) ? 1 : 2, CHAINED>(ap, l, xtab, qst, fnd, unit);         \
+        else wave_unit<PLAINF, PRE, POST, 0, CHAINED>(ap, l, xtab, qst, fnd, unit);                            \
         break;
 #define WAVE_PAIR(PRE, POST, CHAINED) WAVE_FORM(false, PRE, POST, CHAINED, false)
 #define WAVE_PAIR1(PRE, POST, CHAINED) WAVE_FORM(false, PRE, POST, CHAINED, true)
@@ -944,7 +999,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     // nobody deadlocks, but the producer is held at the ring limit, its other consumers starve, and every linked unit ends
     // up waiting a quarter of the time (round 2: 32.7 instead of 26.7 ms with 2,048 sub-steps and a 6-level jump).
     int rs = 2048;
-    while (rs < 8 * CH + 4 * fp->skew_lmax || rs < 1024 + 512 * fp->skew_span) rs *= 2;
+    while (rs < 8 * CH + 4 * fp->skew_lmax || rs < 1024 + (2 * CH + 256) * fp->skew_span) rs *= 2;
     if (const char *env = getenv("XH_FLOW_RS")) {      // experiments: a power of two
         const int v = atoi(env);
         if (v >= 2048 && (v & (v - 1)) == 0) rs = v;
@@ -1019,7 +1074,8 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         const char *env = getenv("XH_FLOW_PER_CU_EXTRA");     // experiments only
         if (env) per_cu += atoi(env);
     }
-    const size_t lds_static = (size_t)RING * NSLOT * sizeof(v2d) + LANES * sizeof(uint2) + 2 * LANES * sizeof(unsigned) + 64;      // + unit_sh, padded
+    const size_t lds_static = (size_t)RING * NSLOT * sizeof(v2d) + LANES * sizeof(uint2) + 2 * LANES * sizeof(unsigned) +
+                              9 * LANES * sizeof(double) + 64;      // + fend_sh (with the month-output slots), unit_sh / prio_sh, padded
     const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
     size_t lds = share > lds_static + 1024 ? share - lds_static : 0;
     XH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mrtm_wave), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1063,6 +1119,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.months_ready = feed ? feed->months_ready : nullptr;
     a.place_epoch = feed ? feed->place_epoch : nullptr;
     a.epoch = feed ? feed->epoch : 0u;
+    a.balance = (getenv("XH_WAVE_BALANCE") && getenv("XH_WAVE_BALANCE")[0] == '1') ? 1 : 0;      // experiment, see xh_flow_plan.cpp
     a.fenced = (getenv("XH_ROUTE_FENCED") && getenv("XH_ROUTE_FENCED")[0] == '1') ? 1 : 0;
     if (!a.fenced && getenv("XH_FEED_POLL") && getenv("XH_FEED_POLL")[0] == 'l') a.fenced = 2;      // experiments (wait_months)
     a.S0 = io.S0;
