@@ -317,6 +317,33 @@ def end_to_end(ctx, pipe, args, log):
             a.free()
     up.close()
     dn.close()
+    # OutputInYear = 1 (out_writer.py:237-248: annual sums of the outputs): the aggregation runs on the device (xh_agg_time)
+    # and only [ncell, years] per output crosses PCIe -- the D2H leg of the serial variant above shrinks 12 x
+    nyr = pipe.nmonths // 12
+    d_ann = {k: ctx.empty((pipe.ncell, nyr)) for k in outs}
+    h_ann = {k: ctx.pinned((pipe.ncell, nyr)) for k in outs}
+    times = []
+    for _ in range(max(args.steps // 2, 3)):
+        t0 = time.perf_counter()
+        for k in names:
+            ctx.h2d_async(pipe.forcing[k], h_in[k])
+            if k != 'precip':
+                ctx.nan_to_num(pipe.forcing[k])
+        pipe.run(args.stages)
+        for k in outs:
+            ctx.agg_time(pipe.ncell, pipe.nmonths, 12, 0, None, pipe.out[k], d_ann[k])
+            ctx.d2h_async(h_ann[k], d_ann[k])
+        ctx.sync()
+        times.append(time.perf_counter() - t0)
+    t_an = float(np.median(times))
+    r['annual_outputs'] = {'value': pipe.ncell * pipe.nmonths / t_an, 'unit': 'cell-months/s', 'ms_per_step': 1e3 * t_an,
+                           'pcie_bytes_per_step': (len(names) * pipe.nmonths + len(outs) * nyr) * pipe.ncell * 8,
+                           'note': 'as the serial variant, but the six outputs leave as annual sums formed on the device '
+                                   '(OutputInYear = 1: xh_agg_time, then {} x [ncell, {}] over PCIe)'.format(len(outs), nyr)}
+    for a in d_ann.values():
+        a.free()
+    for a in h_ann.values():
+        ctx.free_pinned(a)
     r['overlapped'] = {'value': pipe.ncell * pipe.nmonths / t_ov, 'unit': 'cell-months/s', 'ms_per_scenario': 1e3 * t_ov,
                        'note': 'a stream of {} scenarios: upload of the next, compute of the current and download of the '
                                'previous one on three streams, two buffer sets'.format(nscen)}

@@ -192,9 +192,6 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     constexpr unsigned SLOTB = NSLOT * VB;                 // bytes per ring slot
     lds_char *lds0 = (lds_char *)lds_generic;
     const int lane = threadIdx.x;
-#ifdef XH_WAVE_OB_LDS
-    __attribute__((address_space(3))) double *obl = fend + LANES;
-#endif
     const int64_t slot = (int64_t)unit * LANES + lane;
 
     const int gc = A(cell_of_slot)[slot];
@@ -352,11 +349,9 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     }
     // month outputs leave as groups of OB months per cell (32 bytes = one memory sector)
     constexpr int OB = 4;
-#ifndef XH_WAVE_OB_LDS
     double ob_s[OB], ob_a[OB];
 #pragma unroll
     for (int j = 0; j < OB; ++j) ob_s[j] = ob_a[j] = 0.0;
-#endif
     bool alive = true;
     // Fed run (FlowFeed): months [0, mready) of the runoff source are known to be final.  A month beyond that is waited
     // for, bounded like every wait here, on the months-ready word (written by a kernel that runs after the one that
@@ -476,21 +471,6 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         if (it >= 1) {
             const int m = f.m_prev_w & (FIN_WRITE - 1);
             const bool write_prev = (f.m_prev_w & FIN_WRITE) != 0;
-#ifdef XH_WAVE_OB_LDS
-            // the group of OB months waits in LDS (slot = month mod OB), not in 4 OB registers carried through every loop
-            obl[(m & (OB - 1)) * LANES + lane] = snapS;
-            obl[(OB + (m & (OB - 1))) * LANES + lane] = snapA / (double)f.nt_prev;      // mrtm.py:80
-            double ob_s[OB], ob_a[OB];
-            if (write_prev && valid && ((m & (OB - 1)) == OB - 1 || m == nmo - 1)) {
-                const int sh = (m & (OB - 1)) == OB - 1 ? 0 : OB - 1 - (m & (OB - 1));      // partial group: right-aligned as below
-#pragma unroll
-                for (int j = 0; j < OB; ++j) {
-                    const int slot = j - sh;
-                    ob_s[j] = slot >= 0 ? obl[slot * LANES + lane] : 0.0;
-                    ob_a[j] = slot >= 0 ? obl[(OB + slot) * LANES + lane] : 0.0;
-                }
-            }
-#else
 #pragma unroll
             for (int j = 0; j < OB - 1; ++j) {
                 ob_s[j] = ob_s[j + 1];
@@ -498,7 +478,6 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             }
             ob_s[OB - 1] = snapS;
             ob_a[OB - 1] = snapA / (double)f.nt_prev;                          // mrtm.py:80
-#endif
             if (write_prev && valid) {     // whole groups of OB months per cell
                 if ((m & (OB - 1)) == OB - 1) {
                     const int64_t o = (int64_t)gc * nmo + (m - (OB - 1));
@@ -813,11 +792,10 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
     __shared__ uint2 xtab[LANES];
     __shared__ unsigned qstage_sh[2 * LANES];      // runoff of the month after next, low / high words (runoff_fetch)
-#ifdef XH_WAVE_OB_LDS
-    __shared__ double fend_sh[9 * LANES];          // + the month outputs waiting for their group of four (2 x 4 x 64 doubles)
-#else
-    __shared__ double fend_sh[LANES];              // outflow of every lane's last sub-step (F_end)
-#endif
+    // outflow of every lane's last sub-step (F_end): kept here, not in a register selected at every month start.  (Round 4
+    // also tried LDS for the month outputs' group of four -- no gain -- and for cell area / initial storage / next month's
+    // lateral inflow: 23.2 -> 26.9 ms, their reads break the sub-step's counted s_waitcnt lgkmcnt.)
+    __shared__ double fend_sh[LANES];
     // ---- which unit this workgroup runs.  The launch has more workgroups than units.  Every workgroup registers on its
     //      SIMD and waits until all have (they are all resident: the launch made sure).  First arrivals run a unit; as
     //      many second arrivals as there are units left over also do, the rest leave -- so exactly (units - SIMDs in use)
@@ -1075,7 +1053,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         if (env) per_cu += atoi(env);
     }
     const size_t lds_static = (size_t)RING * NSLOT * sizeof(v2d) + LANES * sizeof(uint2) + 2 * LANES * sizeof(unsigned) +
-                              9 * LANES * sizeof(double) + 64;      // + fend_sh (with the month-output slots), unit_sh / prio_sh, padded
+                              LANES * sizeof(double) + 64;      // + fend_sh, unit_sh / prio_sh, padded
     const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
     size_t lds = share > lds_static + 1024 ? share - lds_static : 0;
     XH_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mrtm_wave), hipFuncAttributeMaxDynamicSharedMemorySize,
