@@ -123,6 +123,67 @@ print('COMM_OK')
 '''
 
 
+SIDE_GATHER_CHILD = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from xanthos_amd import _hip as hip, synth
+from xanthos_amd.pipeline import pipeline_from_world
+ctx = hip.get_context(0)
+main, side = hip.Comm(ctx, 1, 0, hip.comm_unique_id()), hip.Comm(ctx, 1, 0, hip.comm_unique_id())
+w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=7, seed=17, outlet_frac=0.02)
+nm = 240
+pipe = pipeline_from_world(ctx, w, nm, 1971, 25, 24)
+ctx.synth_forcing(23, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.004)
+pipe.run(fed=False)
+ref = pipe.download()
+perm_h = np.random.default_rng(1).permutation(w.ncell)
+perm = ctx.upload(perm_h, dtype=np.int64)
+first, second = ('pet', 'aet', 'q', 'sav'), ('chs', 'avg')
+out = {k: ctx.empty((w.ncell, nm)) for k in first + second}
+for fed in (True, False, True, True):
+    for k in out:
+        out[k].zero()
+        pipe.out[k].zero()
+    n0 = ctx.timing('feed_gate')[1]
+    gather_side = lambda: side.gather_rows([pipe.out[k] for k in first], [w.ncell], nm, perm=perm,
+                                           out=[out[k] for k in first], root=0, side=True)
+    pipe.run(fed=fed, after_runoff=gather_side)        # PET / AET / Q / Sav leave beside the routing kernel
+    main.gather_rows([pipe.out[k] for k in second], [w.ncell], nm, perm=perm, out=[out[k] for k in second], root=0)
+    ctx.comm_join()
+    ctx.sync()
+    assert ctx.timing('feed_gate')[1] == n0 + (1 if fed else 0)
+    for k in out:
+        want = np.empty((w.ncell, nm))
+        want[perm_h] = ref[k]
+        assert np.array_equal(out[k].download(), want, equal_nan=True), (k, fed)
+main.close(); side.close()
+print('SIDE_OK')
+'''
+
+
+def test_side_gather_is_ordered_behind_the_runoff(hip, tmp_path):
+    """xh_comm_gather_rows_side in a FED step: the routing kernel already sits in the context's queue when PET / AET / Q / Sav
+    are gathered on the gather stream, so the gather has to order itself behind the side stream that completes the runoff
+    (the event a fed xh_run_fused leaves), not behind the context's stream -- and in a stage-by-stage step behind the
+    context's stream.  One-rank communicators (real RCCL); outputs zeroed before every pass, so a gather that ran early would
+    move zeros."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / 'side_child.py'
+    script.write_text(SIDE_GATHER_CHILD)
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    child = subprocess.Popen([sys.executable, str(script), root], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        out, _ = child.communicate(timeout=240)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        pytest.skip('RCCL communicator bootstrap did not finish within 240 s on this box')
+    assert child.returncode == 0 and 'SIDE_OK' in out, out[-3000:]
+
+
 def test_comm_single_rank_gather(hip, tmp_path):
     """The RCCL write-out gather with one rank: librccl is bound at run time, the communicator initialises, and the
     root's own rows go to their grid positions (the send / receive pairs need several GPUs; tests/test_dist_gloo.py

@@ -1,5 +1,8 @@
 // Context, device memory, row gather/scatter, transpose and HIP-event timing for libxanthos_hip.so.
+#include <dlfcn.h>
+
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 #include "xh_common.h"
@@ -154,11 +157,39 @@ int xh_gather_stream(xh_ctx *ctx, hipStream_t *out) {
     return XH_OK;
 }
 
+// XH_ROCTX=1: every span also opens / closes a roctx range (bound at run time: libroctx64 of the ROCm on the box), so that a
+// rocprofv3 --marker-trace timeline shows the stages by name around their kernels (tracing).
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    bool on = false;
+};
+Roctx &roctx() {
+    static Roctx r = [] {
+        Roctx x;
+        const char *env = getenv("XH_ROCTX");
+        if (!env || env[0] != '1') return x;
+        for (const char *n : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so"}) {
+            if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+                x.push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                x.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                break;
+            }
+        }
+        x.on = x.push && x.pop;
+        return x;
+    }();
+    return r;
+}
+}  // namespace
+
 xh_span xh_span_begin(xh_ctx *ctx, const char *name) { return xh_span_begin_on(ctx, name, ctx->stream); }
 
 xh_span xh_span_begin_on(xh_ctx *ctx, const char *name, hipStream_t stream) {
     xh_span s{ctx, name};
     s.stream = stream;
+    if (roctx().on) (void)roctx().push(name);
     ctx->work_seq += 1;
     // new work on the context's stream: the "runoff is final" event a fed call left for a side gather is no longer the
     // thing to wait for (xh_comm_gather_rows_side then orders itself behind the context's stream)
@@ -179,12 +210,14 @@ xh_span xh_span_begin_on(xh_ctx *ctx, const char *name, hipStream_t stream) {
 }
 
 void xh_span_end(xh_span &s) {
+    if (roctx().on) (void)roctx().pop();
     if (!s.ctx->timing || !s.a || !s.b) return;
     (void)hipEventRecord(s.b, s.stream);
     s.ctx->timers[s.name].pending.emplace_back(s.a, s.b);
 }
 
 void xh_span_cancel(xh_span &s) {      // nothing was launched after all: the span leaves no timing record
+    if (roctx().on) (void)roctx().pop();
     if (s.a) s.ctx->event_pool.push_back(s.a);
     if (s.b) s.ctx->event_pool.push_back(s.b);
     s.a = s.b = nullptr;
