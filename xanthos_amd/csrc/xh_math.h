@@ -64,3 +64,20 @@ __device__ __forceinline__ double xh_exp_nonpos(double x, const XhExpConsts &K) 
     const double e = __builtin_ldexp(p, (int)k);
     return (-1075.0 > x) ? 0.0 : e;               // also x = -inf (rh = 0)
 }
+
+// sqrt for arguments that are zero or of ordinary magnitude (the ABCD month update's rpt^2 - w b / a; Penman-Monteith's
+// temperature ratio).  The library's f64 sqrt is v_rsq_f64 + the Goldschmidt / Newton steps below, wrapped in a
+// rescaling for arguments below 2^-767 and a class test (22 instructions); its argument here, rpt^2 - w b / a, is zero
+// or of ordinary magnitude, so the same steps run bare (10 instructions + the zero / infinity select): identical
+// results, correctly rounded, 9 instructions fewer on the march's dependent chain.  Negative -> NaN like sqrt.
+__device__ __forceinline__ double xh_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y, h0 = 0.5 * y;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0), h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-g1, g1, x);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, x);
+    const double g3 = __builtin_fma(d1, h1, g2);
+    return (x == 0.0 || x == __builtin_inf()) ? x : g3;
+}

@@ -91,8 +91,8 @@ __device__ __forceinline__ PmMonth pm_prep(const XhExpConsts &K, double p, doubl
     const double sx = fdiv(238.1 * 17.325 * esx, tk1 * tk1);
     const double vpd = esx - vap;
     const double xr = (273.15 + T) * (1.0 / 293.15);
-    const double sq = sqrt(xr);
-    const double rcorr = fdiv(p, 101300.0 * (xr * sq * sqrt(sq)));      // pow(x, 1.75) = x * x^(1/2) * x^(1/4)
+    const double sq = xh_sqrt(xr);                                    // (the library's sqrt without its rescaling for tiny arguments:
+    const double rcorr = fdiv(p, 101300.0 * (xr * sq * xh_sqrt(sq)));   //  same bits, 9 instructions fewer each)  pow(x, 1.75) = x * x^(1/2) * x^(1/4)
     const double gcu = 0.00001 * rcorr;
     const double rh = RH > 99.9999 ? 99.9 : RH;                       // calc_rh :205-209
     const double r100 = rh * 0.01;
