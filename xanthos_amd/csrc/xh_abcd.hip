@@ -395,9 +395,32 @@ int xh_abcd_prepare(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spinup,
     const size_t n_int = (size_t)(n_groups + 1) + 3 * (size_t)ncell;
     const size_t int_bytes = (n_int * sizeof(int) + 255) & ~size_t(255);
     const size_t dbl = (9 * (size_t)ncell + 2 * (size_t)n_groups) * sizeof(double);
+    // (as in xh_pm_prepare: the same cell lists as the last call and an untouched scratch slot -> nothing to upload, no
+    //  synchronisation; the double arrays behind the lists are work space every launch rewrites before reading)
+    std::vector<char> key(sizeof(int) * n_int + 4 * sizeof(int64_t));
+    {
+        char *k = key.data();
+        const int64_t meta[4] = {ncell, nmonths, spinup, n_groups};
+        memcpy(k, meta, sizeof(meta));
+        k += sizeof(meta);
+        memcpy(k, ptr.data(), sizeof(int) * (n_groups + 1));
+        k += sizeof(int) * (n_groups + 1);
+        memcpy(k, cells.data(), sizeof(int) * ncell);
+        k += sizeof(int) * ncell;
+        memcpy(k, bidx.data(), sizeof(int) * ncell);
+        k += sizeof(int) * ncell;
+        memcpy(k, pidx.data(), sizeof(int) * ncell);
+    }
+    const bool cached = ctx->scratch[1] && ctx->abcd_cache_gen == ctx->scratch_gen[1] && ctx->abcd_cache == key &&
+                        ctx->scratch_bytes[1] >= int_bytes + dbl;
     void *buf = nullptr;
-    int rc = xh_scratch(ctx, 1, int_bytes + dbl, &buf);
-    if (rc) return rc;
+    int rc = XH_OK;
+    if (cached) {
+        buf = ctx->scratch[1];
+    } else {
+        rc = xh_scratch(ctx, 1, int_bytes + dbl, &buf);
+        if (rc) return rc;
+    }
     out->d_ptr = static_cast<int *>(buf);
     out->d_cells = out->d_ptr + (n_groups + 1);
     out->d_bidx = out->d_cells + ncell;
@@ -406,11 +429,14 @@ int xh_abcd_prepare(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spinup,
     out->d_state = out->d_dec + 6 * ncell;
     out->d_sm0 = out->d_state + 3 * ncell;
     out->d_gw0 = out->d_sm0 + n_groups;
+    if (cached) return XH_OK;
     XH_HIP(ctx, hipMemcpyAsync(out->d_ptr, ptr.data(), sizeof(int) * (n_groups + 1), hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipMemcpyAsync(out->d_cells, cells.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipMemcpyAsync(out->d_bidx, bidx.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipMemcpyAsync(out->d_pidx, pidx.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host vectors die at return
+    ctx->abcd_cache.swap(key);
+    ctx->abcd_cache_gen = ctx->scratch_gen[1];
     return XH_OK;
 }
 

@@ -45,6 +45,11 @@ struct xh_ctx {
     // grow-only scratch buffers (device)
     void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
+    uint64_t scratch_gen[4] = {0, 0, 0, 0};      // bumped by every xh_scratch call on the slot: "did anybody else write there since?"
+    // what xh_pm_prepare / xh_abcd_prepare uploaded last (host copies) and the slot generation right after: a pipeline that
+    // is run again and again with the same tables and cell lists skips the uploads and the stream synchronisation they need
+    std::vector<char> pm_cache, abcd_cache;
+    uint64_t pm_cache_gen = 0, abcd_cache_gen = 0;
     hipDeviceProp_t prop;
     // device-side fault word (bounded spins of the dataflow routing kernel) + pinned host mirror
     unsigned *d_fault = nullptr;

@@ -28,6 +28,7 @@ int xh_fail(xh_ctx *ctx, int code, const char *fmt, ...) {
 
 int xh_scratch(xh_ctx *ctx, int which, size_t bytes, void **out) {
     int rc_device = XH_OK;      // XH_ERR_DEVICE of the settle below: reported after the buffer has been replaced
+    ctx->scratch_gen[which] += 1;
     if (bytes > ctx->scratch_bytes[which]) {
         if (ctx->scratch[which]) {
             // the buffer may be read by a routing call that still has to be confirmed (or re-run): settle before freeing

@@ -523,14 +523,32 @@ int xh_pm_prepare(xh_ctx *ctx, const xh_pm_tables *t, int64_t ncell, int32_t nmo
     void *d_tab = nullptr;
     const size_t tab_bytes = (sizeof(PmTablesDev) + 255) & ~size_t(255);
     const size_t lcy_bytes = (sizeof(int) * nyears + 255) & ~size_t(255);
-    int rc = xh_scratch(ctx, 0, tab_bytes + lcy_bytes + sizeof(double) * ncell, &d_tab);
-    if (rc) return rc;
+    // The same tables, years and cell count as the last call, and nobody has used the scratch slot since: what is on the
+    // device is what would be uploaded again (a pipeline run step after step; each upload needs a stream synchronisation,
+    // i.e. an idle device for a launch latency).  The pressure array is refilled by the first xh_pm_enqueue either way.
+    std::vector<char> key(sizeof(h) + sizeof(int) * nyears + sizeof(int64_t));
+    memcpy(key.data(), &h, sizeof(h));
+    memcpy(key.data() + sizeof(h), lc_of_year.data(), sizeof(int) * nyears);
+    memcpy(key.data() + sizeof(h) + sizeof(int) * nyears, &ncell, sizeof(int64_t));
+    const bool cached = ctx->scratch[0] && ctx->pm_cache_gen == ctx->scratch_gen[0] && ctx->pm_cache == key &&
+                        ctx->scratch_bytes[0] >= tab_bytes + lcy_bytes + sizeof(double) * ncell;
+    int rc = XH_OK;
+    if (cached) {
+        d_tab = ctx->scratch[0];
+    } else {
+        rc = xh_scratch(ctx, 0, tab_bytes + lcy_bytes + sizeof(double) * ncell, &d_tab);
+        if (rc) return rc;
+    }
     int *d_lcy = reinterpret_cast<int *>(static_cast<char *>(d_tab) + tab_bytes);
     out->d_pressure = reinterpret_cast<double *>(static_cast<char *>(d_tab) + tab_bytes + lcy_bytes);
     out->pressure_done = false;
-    XH_HIP(ctx, hipMemcpyAsync(d_tab, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_lcy, lc_of_year.data(), sizeof(int) * nyears, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h / lc_of_year are stack/heap locals
+    if (!cached) {
+        XH_HIP(ctx, hipMemcpyAsync(d_tab, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+        XH_HIP(ctx, hipMemcpyAsync(d_lcy, lc_of_year.data(), sizeof(int) * nyears, hipMemcpyHostToDevice, ctx->stream));
+        XH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // h / lc_of_year are stack/heap locals
+        ctx->pm_cache.swap(key);
+        ctx->pm_cache_gen = ctx->scratch_gen[0];
+    }
 
     out->d_tab = d_tab;
     out->d_lcy = d_lcy;
