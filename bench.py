@@ -622,10 +622,20 @@ def main():
         # sharded: PET / AET / Q / Sav leave on the gather stream as soon as they are final (beside the routing), ChStorage /
         # Avg_ChFlow behind the routing; every step ends with the gathered arrays complete on rank 0
         side = gather.run_side if gather else None
-        for _ in range(args.warmup):
+        for w in range(args.warmup):
+            if w < 2 and 'first_calls' in timed.__dict__:      # what a caller who runs ONE step sees (run_model()): see first_calls
+                ctx.sync()
+                ctx.timing_reset()
+                t1 = time.perf_counter()
             pipe.run(args.stages, fed=fed, after_runoff=side)
             if gather:
                 gather.run_tail()
+            if w < 2 and 'first_calls' in timed.__dict__:
+                ctx.sync()
+                info_w = pipe.plan.info() if pipe.plan is not None else {}
+                timed.first_calls.append({'step_ms': 1e3 * (time.perf_counter() - t1),
+                                          'mrtm_route_ms': ctx.timing('mrtm_route')[0],
+                                          'cross_checked': int(info_w.get('validated', 0)) > 0 and w == 0})
         ctx.sync()
         ctx.timing_reset()
         barrier()
@@ -638,6 +648,7 @@ def main():
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
+    timed.first_calls = []      # the first two steps of the first timed() call, each synchronised and timed on its own
     shard = None
     if sharded:
         # BASELINE configs[3]: the 235 basins of ONE world over the ranks, one gather of the six outputs to rank 0
@@ -799,6 +810,11 @@ def main():
                                                    args.abcd_spinup, args.routing_spinup),
                    'parallelism': parallelism},
         'roofline': roofline, 'kernels': kernels, 'routing_plan': info, 'stage_order': order,
+        # NOT the steady state `value` is about: the first steps of a fresh plan, as run_model()'s single call meets them --
+        # the first dataflow call of a plan on a box without a pass on record is cross-checked against the barrier-only
+        # kernel (cross_checked: its mrtm_route_ms then contains that second routing), and the plan routes in pair form until
+        # the selective plain form has been learnt (routing_plan.form)
+        'first_calls': timed.first_calls[:2],
     }
     gate_failed = False
     if sharded:
