@@ -162,6 +162,13 @@ int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]);
  * partitions built so far, [2] = guard faults so far (-1: more than 8, the plan keeps every unit in pair form),
  * [3] = units of the typed partition.  Selected by the flag XH_ROUTE_TYPED or XH_ROUTE_TYPED=1 in the environment.            */
 int xh_route_plan_typed_info(const xh_route_plan *plan, int64_t info[4]);
+/* Optional, before the first xh_route_series of a plan, with the HOST copies of the arrays the calls will pass on the device:
+ * if this box has routed this grid (same topology, velocity, flow distance and dt) before, the cells it learnt then are read
+ * from $XH_CACHE_DIR or ~/.cache/xanthos_amd and the selective plain tables are built here -- e.g. on the thread that made
+ * the plan, beside the forcing upload -- so that the FIRST call already routes on them instead of in pair form (24.4 ->
+ * 23.3 ms at the full grid).  Either way the plan keeps the file up to date from its confirmed calls.  Results never depend
+ * on it (the guard of the plain units covers what the file does not know).  XH_ROUTE_LEARN_CACHE=0 switches it off.       */
+int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const double *h_flow_dist, const double *h_velocity, double dt);
 
 /* Diagnostics: with XH_FLOW_STATS=1 in the environment the dataflow kernel records, per unit, {shader cycles inside the
  * sub-step loops, shader cycles total, 100 MHz ticks total, shape bits + placement, cycles waiting for data, cycles waiting for ring space}; this call waits for the

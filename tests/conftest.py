@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+# The per-box cache of learnt cells (xh_route_plan_prepare) makes a plan's FIRST call depend on what earlier plans of the same
+# grid did on this machine -- right for a product run, wrong for tests that assert which form a call ran in.  Off unless a test
+# (in a child process) switches it on.
+os.environ.setdefault('XH_ROUTE_LEARN_CACHE', '0')
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

@@ -685,3 +685,65 @@ def test_first_dataflow_call_of_a_plan_is_cross_checked(hip, tmp_path, monkeypat
     um3 = fresh()
     mrtm.route_series(um3, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
     assert um3.plan(hip.get_context()).info()['validated'] == 1
+
+
+LEARN_CHILD = r'''
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from types import SimpleNamespace as NS
+from oracle import months as o_months, mrtm as o_mrtm
+from xanthos_amd import _hip, synth
+from xanthos_amd.routing import mrtm
+ctx = _hip.get_context(0)
+w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=5, seed=3, outlet_frac=0.02)
+st = NS(ngridrow=w.nrow, ngridcol=w.ncol)
+um = mrtm.upstream_genmatrix(mrtm.upstream(w.coords, mrtm.downstream(w.coords, w.flow_dir, st), st))
+rng = np.random.default_rng(11)
+runoff = rng.gamma(2.0, 30.0, (w.ncell, 12))
+ndays = o_months.set_month_arrays(12, 1973, 1973)[:, 2]
+ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+plan = um.plan(ctx)
+plan.prepare(w.flow_dist, w.velocity, 10800.0)
+first = plan.typed_info()
+ok, after = True, []
+for call in range(int(sys.argv[2])):
+    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+    ok = ok and all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
+    after.append(plan.typed_info())
+    time.sleep(0.3)
+print(json.dumps({'ok': bool(ok), 'prepared_builds': int(first['typed_builds']), 'after': after, 'reroutes': int(plan.info()['reroutes']),
+                  'files': sorted(f for f in os.listdir(os.environ['XH_CACHE_DIR']) if f.startswith('learnt_'))}))
+'''
+
+
+def test_learnt_cells_are_kept_per_box_and_the_next_process_starts_plain(tmp_path):
+    """xh_route_plan_prepare (round 4; the review's "call one runs plain"): the set of cells whose neighbours need {F, F2}
+    pairs cannot be fixed from velocity * dt / length alone (profiles/round4/fired_cells.txt), so what a run learns is kept
+    per box.  Process 1 finds nothing, routes in pair form, switches to the selective plain form after a few calls and leaves
+    the file; process 2 builds the selective tables before its FIRST call and routes that call on plain units, without a guard
+    trip -- bit-identical to the oracle either way."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'learn_child.py'
+    script.write_text(LEARN_CHILD)
+    env = dict(os.environ, XH_CACHE_DIR=str(tmp_path / 'cache'), XH_ROUTE_LEARN_CACHE='1')
+    os.makedirs(env['XH_CACHE_DIR'])
+
+    def run(calls):
+        out = subprocess.run([sys.executable, str(script), root, str(calls)], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    one = run(6)
+    assert one['ok'] and one['reroutes'] == 0 and one['prepared_builds'] == 0, one
+    assert one['after'][0]['plain_units'] == 0                       # the first call of a box that knows nothing: pair form
+    assert one['after'][-1]['plain_units'] >= 1 and len(one['files']) == 1, one
+    two = run(2)
+    assert two['ok'] and two['reroutes'] == 0 and two['prepared_builds'] == 1, two
+    assert two['after'][0]['plain_units'] >= 1 and two['after'][0]['guard_trips'] == 0, two      # call one runs plain
+    assert two['after'][0]['typed_builds'] == 1 and set(one['files']) <= set(two['files']), two
+    assert any('.tables_' in f for f in two['files'])                # the selective tables are kept beside the learnt cells

@@ -84,6 +84,7 @@ SIGNATURES = {
     'xh_route_plan_info': (c_int, [_P, POINTER(c_int64)]),
     'xh_route_plan_stats': (c_int, [_P, c_int64, _P, POINTER(c_int64)]),
     'xh_route_plan_typed_info': (c_int, [_P, _P]),
+    'xh_route_plan_prepare': (c_int, [_P, _P, _P, _P, c_double]),
     'xh_mrtm_downstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     'xh_mrtm_upstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     'xh_mrtm_um_csr': (c_int, [c_int64, _P, _P, _P, _P]),
@@ -516,6 +517,15 @@ class RoutePlan:
                 'flow_units', 'flow_edges', 'flow_depth', 'flow_cells', 'flow_max_imports', 'skew_max_lag',
                 'last_tree_kernel', 'reroutes', 'validated')
         return dict(zip(keys, list(arr)))
+
+    def prepare(self, flow_dist, velocity, dt):
+        """xh_route_plan_prepare: host copies of flow distance and velocity [ncell] and dt; builds the selective plain tables
+        ahead of the first call when this box has learnt the grid's firing cells before.  Cheap no-op otherwise."""
+        L = np.ascontiguousarray(flow_dist, dtype=np.float64)
+        v = np.ascontiguousarray(velocity, dtype=np.float64)
+        if L.size != self.ncell or v.size != self.ncell:
+            raise ValueError('flow_dist / velocity must have one value per cell')
+        self.ctx._check(lib().xh_route_plan_prepare(self.ctx.handle, self.handle, _host_ptr(L), _host_ptr(v), float(dt)))
 
     def typed_info(self):
         """Pair / plain units of the dataflow partition (xh_route_plan_typed_info)."""

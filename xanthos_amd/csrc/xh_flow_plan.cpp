@@ -1033,3 +1033,62 @@ std::string flow_tables_check(int n, const int64_t *indptr, const int32_t *indic
         if ((t.unit_p[u] & 0x200) != (t.unit_plain[u] ? 0x200 : 0)) return fail("plain flag of unit " + std::to_string(u));
     return "";
 }
+
+// ---------------------------------------------------------------------------------------------- tables <-> file
+namespace {
+constexpr unsigned long long TABLES_MAGIC = 0x3472546c66485801ull;      // format of flow_tables_save; bump on any change
+
+template <class T>
+bool put_vec(FILE *f, const std::vector<T> &v) {
+    const unsigned long long n = v.size();
+    return fwrite(&n, sizeof(n), 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
+}
+template <class T>
+bool get_vec(FILE *f, std::vector<T> &v) {
+    unsigned long long n = 0;
+    if (fread(&n, sizeof(n), 1, f) != 1 || n > (1ull << 31)) return false;
+    v.resize((size_t)n);
+    return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+template <class F>
+bool tables_io(FILE *f, FlowTables &t, bool write, F &&vec) {
+    int head[11] = {t.n_units, t.n_edges, t.depth, t.n_cells, t.max_imports, t.max_exports, t.n_plain_units, t.skew_ok ? 1 : 0,
+                    t.skew_lmax, t.skew_span, t.typed ? 1 : 0};
+    if (write ? fwrite(head, sizeof(head), 1, f) != 1 : fread(head, sizeof(head), 1, f) != 1) return false;
+    if (!write) {
+        t.n_units = head[0], t.n_edges = head[1], t.depth = head[2], t.n_cells = head[3], t.max_imports = head[4];
+        t.max_exports = head[5], t.n_plain_units = head[6], t.skew_ok = head[7] != 0, t.skew_lmax = head[8];
+        t.skew_span = head[9], t.typed = head[10] != 0;
+    }
+    return vec(t.cell_of_slot) && vec(t.export_edge) && vec(t.ghost_edge) && vec(t.edge_cons_unit) && vec(t.unit_terms) &&
+           vec(t.ent) && vec(t.lag) && vec(t.ghost_lag) && vec(t.unit_p) && vec(t.unit_lmax) && vec(t.unit_glmax) &&
+           vec(t.unit_order) && vec(t.ent2) && vec(t.eprev) && vec(t.edge_prod_cell) && vec(t.edge_cons_cell) &&
+           vec(t.unit_depth) && vec(t.piece_of_cell) && vec(t.unit_of_cell) && vec(t.height_of_cell) && vec(t.ds) &&
+           vec(t.unit_plain) && vec(t.lane_flags) && vec(t.ghost_prod);
+}
+}  // namespace
+
+bool flow_tables_save(const FlowTables &t, const char *path) {
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    FlowTables &m = const_cast<FlowTables &>(t);
+    bool ok = fwrite(&TABLES_MAGIC, sizeof(TABLES_MAGIC), 1, f) == 1 &&
+              tables_io(f, m, true, [&](auto &v) { return put_vec(f, v); });
+    ok = fclose(f) == 0 && ok;
+    if (ok) ok = rename(tmp.c_str(), path) == 0;
+    if (!ok) (void)remove(tmp.c_str());
+    return ok;
+}
+
+bool flow_tables_load(const char *path, FlowTables &t) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    unsigned long long magic = 0;
+    t = FlowTables();
+    const bool ok = fread(&magic, sizeof(magic), 1, f) == 1 && magic == TABLES_MAGIC &&
+                    tables_io(f, t, false, [&](auto &v) { return get_vec(f, v); }) && fgetc(f) == EOF;
+    fclose(f);
+    if (!ok) t = FlowTables();
+    return ok;
+}

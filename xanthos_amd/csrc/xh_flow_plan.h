@@ -63,5 +63,11 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
 std::string flow_tables_check(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
                               const std::vector<char> &handled, const FlowTables &t, const unsigned char *capable);
 
+// Tables to / from a file (the per-box cache of xh_route_plan_prepare: a partition costs tens of milliseconds, reading it
+// back a few).  flow_tables_load returns false on any mismatch of format or size; callers hold what they read to
+// flow_tables_check before using it.
+bool flow_tables_save(const FlowTables &t, const char *path);
+bool flow_tables_load(const char *path, FlowTables &t);
+
 // The (terms before, terms after) shapes compiled for plain units; rounds up.  Returns false if none fits.
 bool flow_plain_class(int pre, int post, bool chained, int &cpre, int &cpost);

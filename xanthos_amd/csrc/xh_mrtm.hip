@@ -386,6 +386,14 @@ struct xh_route_plan {
     // (route_first_check_*; XH_ROUTE_VALIDATE_FIRST=0 switches it off).
     bool first_checked = false;
     uint64_t topo_hash = 0;
+    // xh_route_plan_prepare: what a run LEARNS about a grid -- the cells that fire although velocity * dt / length says they
+    // cannot -- is kept per box (a file beside the first-check marker, keyed by topology, velocity, flow distance and dt), so
+    // that the next process can build the selective plain tables BEFORE its first call (on the thread that makes the plan)
+    // and route its first call on them.  The guard still covers whatever the file does not know.
+    bool prepared = false;
+    std::string learn_path;
+    std::vector<unsigned char> learn_saved;
+    int learn_looks = 0, learn_trips_seen = 0;
     int64_t n_rest_units = 0, n_fb_rest = 0;
     bool fb_rest_single_ds = true;
     DevBuf d_fbr_cells, d_fbr_ptr, d_fbr_col, d_fbr_sgn, d_fbr_ds;
@@ -887,7 +895,130 @@ static int route_validate(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int
     return XH_OK;
 }
 
-void xh_route_confirm(const xh_route_record &r) { r.plan->fault_streak = 0; }
+// After a dataflow call has been confirmed (stream synchronised, no fault): look at what the kernels have learnt so far and
+// keep it for later processes.  The first few confirmed calls of a plan and every call after a guard trip; 1 byte per cell.
+static void learn_save(xh_route_plan *plan) {
+    if (plan->learn_path.empty() || !plan->d_learn.p) return;
+    if (plan->learn_looks >= 4 && plan->learn_trips_seen == plan->guard_trips) return;
+    plan->learn_looks += 1;
+    plan->learn_trips_seen = plan->guard_trips;
+    std::vector<unsigned char> now((size_t)plan->ncell);
+    if (hipMemcpy(now.data(), plan->d_learn.p, now.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    if (now == plan->learn_saved) return;
+    const std::string tmp = plan->learn_path + ".tmp";
+    const std::string dir = plan->learn_path.substr(0, plan->learn_path.rfind('/'));
+    for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
+        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
+    if (FILE *f = fopen(tmp.c_str(), "wb")) {
+        const bool ok = fwrite(now.data(), 1, now.size(), f) == now.size();
+        fclose(f);
+        if (ok && rename(tmp.c_str(), plan->learn_path.c_str()) == 0) plan->learn_saved.swap(now);
+        else (void)remove(tmp.c_str());
+    }
+}
+
+void xh_route_confirm(const xh_route_record &r) {
+    r.plan->fault_streak = 0;
+    learn_save(r.plan);
+}
+
+extern "C" int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const double *h_flow_dist, const double *h_velocity,
+                                     double dt) {
+    if (!ctx || !plan) return XH_ERR_ARG;
+    XH_REQUIRE(ctx, plan->ctx == ctx, "xh_route_plan_prepare: plan belongs to another context");
+    XH_REQUIRE(ctx, h_flow_dist && h_velocity && dt > 0.0, "xh_route_plan_prepare: bad argument");
+    static const bool enabled = !(getenv("XH_ROUTE_LEARN_CACHE") && getenv("XH_ROUTE_LEARN_CACHE")[0] == '0');
+    if (!enabled || plan->prepared || plan->flow_typed || !plan->flow || !plan->flow->skew_ok || plan->h_indptr.empty() ||
+        !plan->d_learn.p)
+        return XH_OK;
+    std::string dir;
+    if (const char *d = getenv("XH_CACHE_DIR")) dir = d;
+    else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/xanthos_amd";
+    if (dir.empty()) return XH_OK;
+    const size_t n = (size_t)plan->ncell;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t nbytes) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < nbytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    mix(h_flow_dist, n * sizeof(double));
+    mix(h_velocity, n * sizeof(double));
+    mix(&dt, sizeof(dt));
+    char name[160];
+    snprintf(name, sizeof(name), "/learnt_%016llx_%016llx_%lld", (unsigned long long)plan->topo_hash, (unsigned long long)h,
+             (long long)plan->ncell);
+    plan->learn_path = dir + name;      // from here on confirmed calls keep the file up to date
+    std::vector<unsigned char> learnt(n, 0);
+    bool have = false;
+    if (FILE *f = fopen(plan->learn_path.c_str(), "rb")) {
+        have = fread(learnt.data(), 1, n, f) == n;
+        fclose(f);
+    }
+    if (!have) return XH_OK;            // nothing known on this box yet: the first calls route in pair form and learn
+    plan->learn_saved = learnt;
+    // the cells that can fire: by construction (the same expression as k_capable), or seen firing in an earlier run
+    std::vector<unsigned char> cap(n);
+    for (size_t c = 0; c < n; ++c) {
+        const double tauinv = h_velocity[c] / h_flow_dist[c];
+        cap[c] = (unsigned char)(((tauinv * dt <= CAPABLE_THRESHOLD) ? 0 : 1) | (learnt[c] ? 1 : 0));
+    }
+    // The selective tables for exactly these cells: read back if this library build has made them on this box before (a
+    // partition is 15-50 ms of host time, the file a few; held to the planner's own invariant checker before use), else made
+    // now and kept.
+    FlowTables t;
+    {
+        uint64_t hc = 1469598103934665603ull;
+        for (size_t c = 0; c < n; ++c) hc = (hc ^ cap[c]) * 1099511628211ull;
+        for (const char *b = __DATE__ " " __TIME__; *b; ++b) hc = (hc ^ (unsigned char)*b) * 1099511628211ull;
+        char tn[64];
+        snprintf(tn, sizeof(tn), ".tables_%016llx", (unsigned long long)hc);
+        const std::string tpath = plan->learn_path + tn;
+        const FlowPlanOptions opt = flow_plan_options(ctx);
+        bool loaded = flow_tables_load(tpath.c_str(), t) && t.n_units > 0 &&
+                      (int64_t)t.cell_of_slot.size() == (int64_t)t.n_units * 64;
+        if (loaded) {
+            std::vector<char> handled(n, 0);
+            for (int c : t.cell_of_slot)
+                if (c >= 0 && (size_t)c < n) handled[c] = 1;
+            loaded = flow_tables_check((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(), plan->h_sign.data(),
+                                       handled, t, cap.data()).empty();
+        }
+        if (!loaded) {
+            std::vector<char> handled;
+            std::string err;
+            if (flow_tables_host(opt, (int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(), plan->h_sign.data(),
+                                 plan->h_comp, plan->h_ncomp, cap.data(), 5, handled, t, err) != 0)
+                return XH_OK;
+            if (t.n_plain_units > 0) (void)flow_tables_save(t, tpath.c_str());
+        }
+    }
+    if (t.n_plain_units == 0) return XH_OK;      // no plain form for this grid: nothing lost
+    const size_t nb = (n + 255) & ~size_t(255);
+    bool ok = hipMalloc(&plan->d_capable.p, 2 * nb) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&plan->d_cap_diff), 64) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void **>(&plan->h_cap_diff), 64, hipHostMallocDefault) == hipSuccess &&
+              hipMemcpy(plan->d_capable.p, cap.data(), n, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(plan->d_learn.p, learnt.data(), n, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok = flow_plan_upload(ctx, t, &plan->flow_typed) == XH_OK && plan->flow_typed != nullptr;
+    if (!ok) {                          // back to the state of an unprepared plan
+        (void)hipGetLastError();
+        free_buf(plan->d_capable);
+        if (plan->d_cap_diff) (void)hipFree(plan->d_cap_diff);
+        if (plan->h_cap_diff) (void)hipHostFree(plan->h_cap_diff);
+        plan->d_cap_diff = plan->h_cap_diff = nullptr;
+        flow_plan_destroy(plan->flow_typed);
+        plan->flow_typed = nullptr;
+        (void)hipMemset(plan->d_learn.p, 0, n);
+        return XH_OK;
+    }
+    plan->typed_builds += 1;
+    plan->typed_sel = 5;
+    plan->prepared = true;
+    return XH_OK;
+}
 
 void xh_route_backoff(xh_route_plan *plan) {      // once per fault event and plan
     plan->fault_streak = std::min(plan->fault_streak + 1, 6);
@@ -1107,7 +1238,8 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     const bool auto_typed = !explicit_typed && auto_env && typed_ok && !old_skew_env && plan->flow->skew_ok &&
                             (flags & (XH_ROUTE_ATOMIC | XH_ROUTE_TEST_FAULT)) == 0 && plan->auto_state.load() != 3;
     if (auto_typed) plan->auto_calls += 1;
-    bool want_typed = explicit_typed || (auto_typed && plan->auto_calls >= 2);
+    // (a plan prepared from the box's cache of learnt cells has its selective tables already: they are tried from call one)
+    bool want_typed = explicit_typed || (auto_typed && (plan->auto_calls >= 2 || plan->prepared));
     const int sel_env = getenv("XH_FLOW_PLAIN_MIN_READS") ? atoi(getenv("XH_FLOW_PLAIN_MIN_READS")) : -1;
     const int sel_want = sel_env >= 0 ? sel_env : (explicit_typed ? 0 : 5);
     unsigned char *d_cap_new = nullptr;

@@ -77,12 +77,14 @@ class DevicePipeline:
             def make():
                 try:
                     self._plan = um.plan(ctx)
+                    self._plan.prepare(flow_dist, velocity, 10800.0)      # selective tables ahead of the first call, if known
                 except BaseException as exc:      # re-raised by `plan`
                     self._plan_error = exc
             self._plan_thread = threading.Thread(target=make, name='xh-route-plan')
             self._plan_thread.start()
         elif um is not None:
             self._plan = um.plan(ctx)
+            self._plan.prepare(flow_dist, velocity, 10800.0)
 
     @property
     def plan(self):
