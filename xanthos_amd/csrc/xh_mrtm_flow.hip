@@ -30,6 +30,8 @@
 //
 // Throughput is then set by the sub-step latency of ONE wave (a few hundred cycles) instead of the instruction
 // issue of the largest network, and the whole chip is busy: 1,121 units over 256 CUs for the 67,420-cell grid.
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -375,8 +377,53 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
     *out = nullptr;
     FlowTables t;
     std::string err;
-    if (flow_tables_host(flow_plan_options(ctx), n, indptr, indices, sign, comp, ncomp, capable, -1, handled, t, err) != 0)
+    const FlowPlanOptions opt = flow_plan_options(ctx);
+    // The all-pairs partition of a grid is the same every time (topology, planner options, library build): 50-70 ms of host
+    // time at the full grid, a few to read back.  Kept in the per-box cache beside the learnt cells (xh_route_plan_prepare;
+    // XH_ROUTE_LEARN_CACHE=0 switches both off) and held to the planner's own invariant checker before it is used.
+    std::string cache;
+    static const bool cache_on = !(getenv("XH_ROUTE_LEARN_CACHE") && getenv("XH_ROUTE_LEARN_CACHE")[0] == '0');
+    if (cache_on && !capable && n > 0 && !opt.debug && !getenv("XH_FLOW_DUMP")) {
+        std::string dir;
+        if (const char *d = getenv("XH_CACHE_DIR")) dir = d;
+        else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/xanthos_amd";
+        if (!dir.empty()) {
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](const void *p, size_t nbytes) {
+                const unsigned char *b = static_cast<const unsigned char *>(p);
+                for (size_t i = 0; i < nbytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
+            };
+            const int64_t nnz = indptr[n];
+            mix(indptr, sizeof(int64_t) * (size_t)(n + 1));
+            if (nnz) mix(indices, sizeof(int32_t) * (size_t)nnz);
+            if (nnz) mix(sign, (size_t)nnz);
+            const int knobs[10] = {opt.simds, opt.piece_cap, opt.chain, opt.cut_rule, opt.tlimit, opt.tlimit_typed, opt.tlimit_plain,
+                                   opt.full_join, opt.pair_streams, (opt.plain_min_reads << 1) | (opt.balance_lds ? 1 : 0)};
+            mix(knobs, sizeof(knobs));
+            const char *stamp = __DATE__ " " __TIME__;
+            mix(stamp, strlen(stamp));
+            char name[96];
+            snprintf(name, sizeof(name), "/pairs_%016llx_%d.tables", (unsigned long long)h, n);
+            cache = dir + name;
+            if (flow_tables_load(cache.c_str(), t) && t.n_units > 0 && (int64_t)t.cell_of_slot.size() == (int64_t)t.n_units * LANES) {
+                handled.assign(n, 0);
+                bool ok = true;
+                for (int c : t.cell_of_slot) {
+                    if (c >= n) ok = false;
+                    else if (c >= 0) handled[c] = 1;
+                }
+                if (ok && flow_tables_check(n, indptr, indices, sign, handled, t, nullptr).empty()) return flow_plan_upload(ctx, t, out);
+            }
+        }
+    }
+    if (flow_tables_host(opt, n, indptr, indices, sign, comp, ncomp, capable, -1, handled, t, err) != 0)
         return xh_fail(ctx, XH_ERR_ARG, "%s", err.c_str());
+    if (!cache.empty() && t.n_units > 0) {
+        const std::string dir = cache.substr(0, cache.rfind('/'));
+        for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
+            if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
+        (void)flow_tables_save(t, cache.c_str());
+    }
     return flow_plan_upload(ctx, t, out);
 }
 
