@@ -9,6 +9,8 @@
 // ever wait on units strictly upstream (data) or downstream (ring space) of themselves.
 #include "xh_flow_plan.h"
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <numeric>
@@ -1069,7 +1071,7 @@ bool tables_io(FILE *f, FlowTables &t, bool write, F &&vec) {
 }  // namespace
 
 bool flow_tables_save(const FlowTables &t, const char *path) {
-    const std::string tmp = std::string(path) + ".tmp";
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)getpid());      // ranks may write the same file
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return false;
     FlowTables &m = const_cast<FlowTables &>(t);

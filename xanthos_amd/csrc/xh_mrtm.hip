@@ -28,6 +28,7 @@
 
 #include "xh_common.h"
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include "xh_mrtm_flow.h"
 
@@ -908,7 +909,7 @@ static void learn_save(xh_route_plan *plan) {
         return;
     }
     if (now == plan->learn_saved) return;
-    const std::string tmp = plan->learn_path + ".tmp";
+    const std::string tmp = plan->learn_path + ".tmp." + std::to_string((long long)getpid());      // ranks may write the same file
     const std::string dir = plan->learn_path.substr(0, plan->learn_path.rfind('/'));
     for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
         if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
