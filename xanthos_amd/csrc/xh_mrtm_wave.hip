@@ -348,7 +348,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         if (nit > 1) runoff_fetch(r1.q_off);
     }
     // month outputs leave as groups of OB months per cell (32 bytes = one memory sector)
-    constexpr int OB = 4;
+    constexpr int OB = 4;               // (groups of 2 free eight registers and cost 1 - 2 %: round 4, same-box A/B)
     double ob_s[OB], ob_a[OB];
 #pragma unroll
     for (int j = 0; j < OB; ++j) ob_s[j] = ob_a[j] = 0.0;
