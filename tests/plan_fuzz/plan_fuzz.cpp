@@ -8,6 +8,8 @@
 // (mrtm.py:50-51), plain units free of cells that need pairs.
 //   usage: plan_fuzz [cases] [seed]
 #include <algorithm>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
@@ -207,6 +209,35 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
         fprintf(stderr, "case %d (kind %d, %d cells, cap %d, chain %d, cut %d, typed %d): %s\n", idx, kind, g.n, opt.piece_cap,
                 (int)opt.chain, (int)opt.cut_rule, (int)(opt.capable != nullptr), bad_msg.c_str());
         return 1;
+    }
+    // The per-box cache (xh_route_plan_prepare, flow_plan_build) keeps tables in a file: what comes back must be what went
+    // in -- and pass the same checker --, and a truncated file must be refused.
+    if (t.n_units > 0 && (idx % 4) == 0) {
+        char path[128];
+        snprintf(path, sizeof(path), "/tmp/plan_fuzz_%d_%d.tables", (int)getpid(), idx);
+        FlowTables u;
+        bool ok = flow_tables_save(t, path) && flow_tables_load(path, u);
+        ok = ok && u.n_units == t.n_units && u.n_edges == t.n_edges && u.depth == t.depth && u.n_plain_units == t.n_plain_units &&
+             u.skew_ok == t.skew_ok && u.skew_lmax == t.skew_lmax && u.skew_span == t.skew_span && u.cell_of_slot == t.cell_of_slot &&
+             u.ent2 == t.ent2 && u.eprev == t.eprev && u.lag == t.lag && u.ghost_lag == t.ghost_lag && u.unit_p == t.unit_p &&
+             u.unit_order == t.unit_order && u.export_edge == t.export_edge && u.ghost_edge == t.ghost_edge &&
+             u.edge_cons_unit == t.edge_cons_unit && u.lane_flags == t.lane_flags && u.ghost_prod == t.ghost_prod &&
+             u.unit_plain == t.unit_plain && u.ent == t.ent;
+        ok = ok && flow_tables_check(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, u, opt.capable).empty();
+        if (ok) {      // cut the file short: the loader has to notice
+            FILE *f = fopen(path, "rb+");
+            if (f) {
+                fseek(f, 0, SEEK_END);
+                const long len = ftell(f);
+                fclose(f);
+                if (len > 16 && truncate(path, len - 7) == 0) ok = !flow_tables_load(path, u);
+            }
+        }
+        remove(path);
+        if (!ok) {
+            fprintf(stderr, "case %d (kind %d, %d cells): tables did not survive the round trip through a file\n", idx, kind, g.n);
+            return 1;
+        }
     }
     if (verbose)
         printf("case %d kind %d: %d cells, %d units (%d plain), %d streams, depth %d, max lag %d\n", idx, kind, g.n, t.n_units,
