@@ -322,6 +322,7 @@ __global__ void __launch_bounds__(256) k_fb_finish(FbArgs a) {
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    bool pooled = false;        // p points into an UploadPool's allocation (freed with the pool, not on its own)
 };
 
 template <typename T>
@@ -410,6 +411,7 @@ struct xh_route_plan {
     hipStream_t streams[N_CLASS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[N_CLASS + 1] = {};
     hipStream_t fb_stream = nullptr;
+    void *d_pool = nullptr;     // the allocation behind the tables uploaded at create (UploadPool)
 };
 
 namespace {
@@ -423,9 +425,35 @@ int find_root(std::vector<int> &parent, int x) {
 }
 
 void free_buf(DevBuf &b) {
-    if (b.p) (void)hipFree(b.p);
+    if (b.p && !b.pooled) (void)hipFree(b.p);
     b.p = nullptr;
+    b.pooled = false;
 }
+
+// The tables of a plan in ONE device allocation and ONE copy: xh_route_plan_create used to make some thirty hipMalloc +
+// hipMemcpy pairs (tens of milliseconds beside run_model()'s forcing upload, which holds the same runtime locks).
+struct UploadPool {
+    struct Item { DevBuf *buf; size_t off, bytes; };
+    std::vector<char> host;
+    std::vector<Item> items;
+    template <typename T>
+    void add(DevBuf &b, const std::vector<T> &v) {
+        const size_t bytes = v.size() * sizeof(T), off = host.size();
+        host.resize(off + ((bytes ? bytes : 16) + 255) / 256 * 256);      // empty tables still get an address of their own
+        if (bytes) memcpy(host.data() + off, v.data(), bytes);
+        items.push_back({&b, off, bytes});
+    }
+    int commit(xh_ctx *ctx, void **base) {
+        XH_HIP(ctx, hipMalloc(base, host.size() ? host.size() : 256));
+        if (!host.empty()) XH_HIP(ctx, hipMemcpy(*base, host.data(), host.size(), hipMemcpyHostToDevice));
+        for (const Item &it : items) {
+            it.buf->p = (char *)*base + it.off;
+            it.buf->bytes = it.bytes;
+            it.buf->pooled = true;
+        }
+        return XH_OK;
+    }
+};
 
 template <int KC, int NTMAX>
 void launch_units(const xh_route_plan *plan, int cls, RouteArgs args, hipStream_t st, bool rest_only) {
@@ -689,43 +717,44 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
         for (size_t i = 0; i < cells.size(); ++i) ds[i] = ds_cell[cells[i]];
     };
     int rc = XH_OK;
+    UploadPool pool;
     {
         std::vector<int> ptr, col, ds;
         std::vector<signed char> sgn;
         build_csr(fb_cells, ptr, col, sgn, ds, plan->fb_single_ds);
         plan->n_fb = (int64_t)fb_cells.size();
-        rc |= upload(ctx, plan->d_fb_cells, fb_cells);
-        rc |= upload(ctx, plan->d_fb_ptr, ptr);
-        rc |= upload(ctx, plan->d_fb_col, col);
-        rc |= upload(ctx, plan->d_fb_sgn, sgn);
-        rc |= upload(ctx, plan->d_fb_ds, ds);
+        pool.add(plan->d_fb_cells, fb_cells);
+        pool.add(plan->d_fb_ptr, ptr);
+        pool.add(plan->d_fb_col, col);
+        pool.add(plan->d_fb_sgn, sgn);
+        pool.add(plan->d_fb_ds, ds);
         build_csr(fb_rest_cells, ptr, col, sgn, ds, plan->fb_rest_single_ds);
         plan->n_fb_rest = (int64_t)fb_rest_cells.size();
-        rc |= upload(ctx, plan->d_fbr_cells, fb_rest_cells);
-        rc |= upload(ctx, plan->d_fbr_ptr, ptr);
-        rc |= upload(ctx, plan->d_fbr_col, col);
-        rc |= upload(ctx, plan->d_fbr_sgn, sgn);
-        rc |= upload(ctx, plan->d_fbr_ds, ds);
+        pool.add(plan->d_fbr_cells, fb_rest_cells);
+        pool.add(plan->d_fbr_ptr, ptr);
+        pool.add(plan->d_fbr_col, col);
+        pool.add(plan->d_fbr_sgn, sgn);
+        pool.add(plan->d_fbr_ds, ds);
         std::vector<int> all(n);
         std::iota(all.begin(), all.end(), 0);
         build_csr(all, ptr, col, sgn, ds, plan->all_single_ds);
         plan->all_nnz = (int64_t)col.size();
-        rc |= upload(ctx, plan->d_all_cells, all);
-        rc |= upload(ctx, plan->d_all_ptr, ptr);
-        rc |= upload(ctx, plan->d_all_col, col);
-        rc |= upload(ctx, plan->d_all_sgn, sgn);
-        rc |= upload(ctx, plan->d_all_ds, ds);
+        pool.add(plan->d_all_cells, all);
+        pool.add(plan->d_all_ptr, ptr);
+        pool.add(plan->d_all_col, col);
+        pool.add(plan->d_all_sgn, sgn);
+        pool.add(plan->d_all_ds, ds);
     }
-    rc |= upload(ctx, plan->d_cell_of_slot, cell_of_slot);
-    rc |= upload(ctx, plan->d_ent, ent);
-    rc |= upload(ctx, plan->d_cnt, cnt);
+    pool.add(plan->d_cell_of_slot, cell_of_slot);
+    pool.add(plan->d_ent, ent);
+    pool.add(plan->d_cnt, cnt);
     for (int k = 0; k < N_CLASS; ++k) {
-        rc |= upload(ctx, plan->d_class_units[k], plan->class_units[k]);
-        rc |= upload(ctx, plan->d_rest_units[k], plan->rest_units[k]);
-        if (!plan->class_units[k].empty() && hipStreamCreateWithFlags(&plan->streams[k], hipStreamNonBlocking) != hipSuccess)
-            rc |= XH_ERR_HIP;
+        pool.add(plan->d_class_units[k], plan->class_units[k]);
+        pool.add(plan->d_rest_units[k], plan->rest_units[k]);
     }
-    if (hipStreamCreateWithFlags(&plan->fb_stream, hipStreamNonBlocking) != hipSuccess) rc |= XH_ERR_HIP;
+    rc |= pool.commit(ctx, &plan->d_pool);
+    // (the streams of the per-class kernels and of the global fallback are made on first use: the dataflow
+    // kernels, which route every tree-shaped grid, never need them)
     if (hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess) rc |= XH_ERR_HIP;
     for (int k = 0; k <= N_CLASS; ++k)
         if (hipEventCreateWithFlags(&plan->ev_join[k], hipEventDisableTiming) != hipSuccess) rc |= XH_ERR_HIP;
@@ -758,6 +787,7 @@ static void route_plan_free(xh_route_plan *plan, bool settle) {
                       &plan->d_all_col, &plan->d_all_sgn, &plan->d_all_ds, &plan->d_fbr_cells, &plan->d_fbr_ptr,
                       &plan->d_fbr_col, &plan->d_fbr_sgn, &plan->d_fbr_ds};
     for (DevBuf *b : bufs) free_buf(*b);
+    if (plan->d_pool) (void)hipFree(plan->d_pool);
     if (plan->auto_thread.joinable()) plan->auto_thread.join();
     flow_plan_destroy(plan->flow);
     flow_plan_destroy(plan->flow_typed);
@@ -1419,7 +1449,9 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         // largest classes first so the long-running workgroups start first
         for (int cls = N_CLASS - 1; cls >= 0; --cls) {
             if ((use_flow ? plan->rest_units[cls] : plan->class_units[cls]).empty()) continue;
-            hipStream_t st = plan->streams[cls];
+            hipStream_t st = nullptr;
+            if (!plan->streams[cls]) XH_HIP(ctx, hipStreamCreateWithFlags(&plan->streams[cls], hipStreamNonBlocking));
+            st = plan->streams[cls];
             XH_HIP(ctx, hipStreamWaitEvent(st, plan->ev_fork, 0));
             switch (cls) {
                 case 0: launch_units<1, 64>(plan, cls, a, st, use_flow); break;
@@ -1479,7 +1511,9 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         f.avg = d_avgchflow;
         f.S_end = d_S_end;
         f.F_end = d_F_end;
-        hipStream_t st = plan->fb_stream;
+        hipStream_t st = nullptr;
+        if (!plan->fb_stream) XH_HIP(ctx, hipStreamCreateWithFlags(&plan->fb_stream, hipStreamNonBlocking));
+        st = plan->fb_stream;
         XH_HIP(ctx, hipStreamWaitEvent(st, plan->ev_fork, 0));
         const dim3 grid((unsigned)((n_fb + 255) / 256)), block(256);
         hipLaunchKernelGGL(k_fb_init, grid, block, 0, st, f);
