@@ -184,6 +184,7 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
     opt.full_join = (int)(rng() % 12);
     opt.pair_streams = 4 + (int)(rng() % 13);
     opt.plain_min_reads = rng() % 2 ? 0 : 2 + (int)(rng() % 6);      // selective plain form in half of the cases
+    opt.lane_trials = idx % 3 == 1 ? 60 : 0;                         // lanes re-assigned against bank conflicts in a third
     std::vector<unsigned char> capable;
     if (rng() % 3 != 0) {
         capable.assign(g.n, 0);
@@ -290,6 +291,7 @@ static int run_file(const char *path, bool typed) {
     if (getenv("TLIMIT_PLAIN")) opt.tlimit_plain = atoi(getenv("TLIMIT_PLAIN"));
     if (getenv("PIECE_CAP")) opt.piece_cap = atoi(getenv("PIECE_CAP"));
     if (getenv("PAIR_STREAMS")) opt.pair_streams = atoi(getenv("PAIR_STREAMS"));
+    if (getenv("LANE_TRIALS")) opt.lane_trials = atoi(getenv("LANE_TRIALS"));
     int ncap = 0;
     for (unsigned char c : capable) ncap += c;
     printf("%d cells, %lld entries, %d cells can fire\n", n, (long long)nnz, ncap);

@@ -332,7 +332,7 @@ ok = True
 # typed: first build, re-build with what was learnt, steady.  XH_TEST_CALLS: repeated plain calls (the adaptive plain form
 # builds its tables on a host thread from the second call on; the pause lets them be ready for the next call)
 for rep in range(3 if os.environ.get('XH_ROUTE_TYPED') else int(os.environ.get('XH_TEST_CALLS', '1'))):
-    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=int(os.environ.get('XH_TEST_FLAGS', '0')))
     ok = ok and all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
     if os.environ.get('XH_TEST_CALLS'):
         time.sleep(0.3)
@@ -349,11 +349,14 @@ print(json.dumps({'ok': bool(ok), 'kernel': int(info['last_tree_kernel']), 'unit
                                  {'XH_ROUTE_TYPED': '1', 'XH_FLOW_PLAIN_MIN_READS': '5'},
                                  {'XH_ROUTE_TYPED': '1', 'XH_FLOW_PLAIN_MIN_READS': '3'}, {'XH_TEST_CALLS': '6'},
                                  {'XH_TEST_CALLS': '6', 'XH_ROUTE_AUTO': '0'},
-                                 {'XH_TEST_CALLS': '6', 'XH_FLOW_PLAIN_MIN_READS': '3'}])
+                                 {'XH_TEST_CALLS': '6', 'XH_FLOW_PLAIN_MIN_READS': '3'},
+                                 {'XH_FLOW_LANE_TRIALS': '300'}, {'XH_FLOW_LANE_TRIALS': '300', 'XH_TEST_CALLS': '6'},
+                                 {'XH_FLOW_LANE_TRIALS': '300', 'XH_TEST_FLAGS': '8'}])
 def test_route_partition_variants_bit_exact(env, tmp_path):
     """The knobs of the dataflow partition (piece capacity, chains, which children become streams, class-aware packing,
     spare workgroups, ring size; typed partition, and its selective form: only the units with the longest rows run in
-    plain form) change which cells share a wave and who waits for whom -- never a bit of the result.  Each
+    plain form; cells moved to other lanes of their unit against LDS bank conflicts, for the time-skewed and -- flags 8 -- the
+    lock-step kernel) change which cells share a wave and who waits for whom -- never a bit of the result.  Each
     variant routes the 3000-cell world in a process of its own (the knobs are read once per process) against the oracle."""
     import json
     import os
@@ -368,7 +371,7 @@ def test_route_partition_variants_bit_exact(env, tmp_path):
                          text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
-    assert res['ok'] and res['kernel'] == 2 and res['reroutes'] == 0, res
+    assert res['ok'] and res['kernel'] == (1 if env.get('XH_TEST_FLAGS') == '8' else 2) and res['reroutes'] == 0, res
     if env.get('XH_FLOW_PIECE_CAP') == '20':
         assert res['edges'] > 150, res          # many more streams than the default cut
     if env.get('XH_ROUTE_TYPED'):

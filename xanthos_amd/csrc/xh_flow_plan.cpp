@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <numeric>
 #include <thread>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -479,6 +481,169 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
 
 }  // namespace
 
+// ---- lanes against LDS bank conflicts ---------------------------------------------------------------------------------
+// A unit's gather is one ds_read_b128 (pair form) or ds_read_b64 (plain form) per row term, each lane addressing the LDS
+// entry of one upstream neighbour.  The LDS serves a wave's read in fixed lane groups -- four of 16 lanes for b128
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32), two of 32 for b64 -- one cycle per group when the lanes of a
+// group address distinct 16-byte (8-byte) columns of the 256-byte bank row; every further distinct address on a busy
+// column costs the whole CU one more LDS cycle (identical addresses are one broadcast).  Cells were laid on the lanes in
+// the order of their ids: neighbours sit near each other and most reads are clean, but a sixth of the LDS cycles of a run
+// were conflicts (SQ_LDS_BANK_CONFLICT).  Which lane holds which cell is free -- every table goes through the
+// slot -- so the cells of a unit (and, among themselves, its imported entries) are moved to lanes on which the unit's
+// reads collide least: a few dozen directed swaps per unit, each kept if the count of extra LDS cycles does not rise.
+struct LaneOpt {
+    const FlowTables &t;
+    int u;
+    int64_t ts;
+    bool plain, chained;
+    int pre, post, ng;
+    int pe[NPAIR];                       // entry (old) -> entry (new); lanes 0..63, imported entries 64..127, zero 128
+    std::vector<int> offenders;          // old entries that sit on a busy column as the second, third .. address
+
+    static int group128(int lane) { return ((lane >> 5) << 1) | (int)((0x0f0ff0f0u >> (lane & 31)) & 1u); }
+
+    LaneOpt(const FlowTables &tt, int unit, int nghost) : t(tt), u(unit), ts((int64_t)tt.n_units * LANES), ng(nghost) {
+        plain = t.unit_plain[u] != 0;
+        chained = (t.unit_p[u] & 0x100) != 0;
+        pre = t.unit_p[u] & 15;
+        post = (t.unit_p[u] >> 4) & 15;
+        std::iota(pe, pe + NPAIR, 0);
+    }
+    // extra LDS cycles per sub-step of the unit's gather under `pe`
+    int cost(bool want_offenders) {
+        if (want_offenders) offenders.clear();
+        const int ngroup = plain ? 2 : 4, ncol = plain ? 32 : 16;
+        int total = 0;
+        int seen[4][32][8], who[4][32][8], nseen[4][32];      // distinct addresses per (group, column) and a lane reading each; 8 hold any realistic pile-up
+        auto column = [&](const unsigned *tab) {
+            for (int g = 0; g < ngroup; ++g)
+                for (int c = 0; c < ncol; ++c) nseen[g][c] = 0;
+            for (int l = 0; l < LANES; ++l) {
+                const int e_old = (int)(tab[(int64_t)u * LANES + l] >> 4), e = pe[e_old];
+                const int lane = pe[l], g = plain ? lane >> 5 : group128(lane), c = e & (ncol - 1);
+                int k = 0, &m = nseen[g][c];
+                while (k < m && k < 8 && seen[g][c][k] != e) ++k;
+                if (k < m || k >= 8) continue;                   // the same address again: a broadcast
+                seen[g][c][m] = e;
+                who[g][c][m++] = l;
+            }
+            for (int g = 0; g < ngroup; ++g) {
+                int worst = 1;
+                for (int c = 0; c < ncol; ++c) worst = std::max(worst, nseen[g][c]);
+                total += worst - 1;
+                if (!want_offenders || worst == 1) continue;
+                for (int c = 0; c < ncol; ++c)                   // everybody on a worst column: the entries read and the reading lanes
+                    if (nseen[g][c] == worst)
+                        for (int k = 0; k < worst; ++k) {
+                            const int e_old = (int)(tab[(int64_t)u * LANES + who[g][c][k]] >> 4);
+                            if (e_old != 2 * LANES) offenders.push_back(e_old);
+                            offenders.push_back(who[g][c][k]);
+                        }
+            }
+        };
+        for (int w = 0; w < pre && w < SK_P; ++w) column(t.ent2.data() + (size_t)w * ts);
+        for (int w = 0; w < post && w < SK_P; ++w) column(t.ent2.data() + (size_t)(SK_P + w) * ts);
+        if (chained) column(t.eprev.data());
+        return total;
+    }
+    // returns (extra cycles before, after)
+    std::pair<int, int> run(int trials) {
+        const int before = cost(true);
+        int cur = before;
+        unsigned long long rng = 0x9e3779b97f4a7c15ull * (unsigned long long)(u + 1);
+        auto next = [&]() {
+            rng ^= rng << 13;
+            rng ^= rng >> 7;
+            rng ^= rng << 17;
+            return (unsigned)(rng >> 11);
+        };
+        for (int it = 0; it < trials && cur > 0 && !offenders.empty(); ++it) {
+            const int a = offenders[next() % offenders.size()];
+            int b;
+            if (a < LANES) b = (int)(next() % LANES);
+            else if (ng > 1) b = LANES + (int)(next() % (unsigned)ng);
+            else continue;
+            if (a == b) continue;
+            std::swap(pe[a], pe[b]);
+            const std::vector<int> keep = offenders;
+            const int c2 = cost(true);
+            if (c2 <= cur) cur = c2;
+            else {
+                std::swap(pe[a], pe[b]);
+                offenders = keep;
+            }
+        }
+        return {before, cur};
+    }
+};
+
+// moves every per-slot table of unit u to the lanes LaneOpt chose
+void lane_apply(FlowTables &t, int u, const int *pe) {
+    const int64_t ts = (int64_t)t.n_units * LANES, base = (int64_t)u * LANES;
+    auto move_rows = [&](auto &vec, int64_t off, int lo, int hi) {        // rows lo..hi-1 of the unit go to pe[row] - lo
+        typename std::remove_reference<decltype(vec)>::type tmp(vec.begin() + off + base, vec.begin() + off + base + LANES);
+        for (int l = lo; l < hi; ++l) vec[off + base + (pe[lo == 0 ? l : LANES + l] - (lo == 0 ? 0 : LANES))] = tmp[l];
+    };
+    auto remap = [&](unsigned &o) {                                      // an entry offset: entry x 16 + low bits
+        const unsigned e = o >> 4;
+        if (e < (unsigned)NPAIR) o = ((unsigned)pe[e] << 4) | (o & 15u);
+    };
+    for (int64_t w = 0; w < W_MAX; ++w)
+        for (int l = 0; l < LANES; ++l) remap(t.ent[(size_t)(w * ts + base + l)]);
+    for (int64_t w = 0; w < 2 * SK_P; ++w)
+        for (int l = 0; l < LANES; ++l) remap(t.ent2[(size_t)(w * ts + base + l)]);
+    for (int l = 0; l < LANES; ++l) remap(t.eprev[(size_t)(base + l)]);
+    move_rows(t.cell_of_slot, 0, 0, LANES);
+    move_rows(t.export_edge, 0, 0, LANES);
+    move_rows(t.lag, 0, 0, LANES);
+    move_rows(t.eprev, 0, 0, LANES);
+    move_rows(t.lane_flags, 0, 0, LANES);
+    for (int64_t w = 0; w < W_MAX; ++w) move_rows(t.ent, w * ts, 0, LANES);
+    for (int64_t w = 0; w < 2 * SK_P; ++w) move_rows(t.ent2, w * ts, 0, LANES);
+    // imported entries: ghost k of the unit is row k of these
+    std::vector<int> ge(t.ghost_edge.begin() + base, t.ghost_edge.begin() + base + LANES),
+        gl(t.ghost_lag.begin() + base, t.ghost_lag.begin() + base + LANES),
+        gp(t.ghost_prod.begin() + base, t.ghost_prod.begin() + base + LANES);
+    for (int k = 0; k < LANES; ++k) {
+        const int k2 = pe[LANES + k] - LANES;
+        t.ghost_edge[base + k2] = ge[k];
+        t.ghost_lag[base + k2] = gl[k];
+        t.ghost_prod[base + k2] = gp[k];
+    }
+}
+
+void lane_optimise(FlowTables &t, int trials, bool debug) {
+    const int nunit = t.n_units;
+    std::vector<int> before(nunit, 0), after(nunit, 0);
+    std::vector<int> perm((size_t)nunit * NPAIR);
+    const int nthread = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+    auto work = [&](int k) {
+        for (int u = k; u < nunit; u += nthread) {
+            int ng = 0;
+            while (ng < LANES && t.ghost_edge[(int64_t)u * LANES + ng] >= 0) ++ng;
+            LaneOpt lo(t, u, ng);
+            const auto r = lo.run(trials);
+            before[u] = r.first;
+            after[u] = r.second;
+            std::copy(lo.pe, lo.pe + NPAIR, perm.begin() + (size_t)u * NPAIR);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < nthread; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto &x : th) x.join();
+    int64_t sb = 0, sa = 0, reads = 0;
+    for (int u = 0; u < nunit; ++u) {
+        if (after[u] < before[u]) lane_apply(t, u, perm.data() + (size_t)u * NPAIR);
+        sb += before[u];
+        sa += std::min(after[u], before[u]);
+        reads += (t.unit_p[u] & 15) + ((t.unit_p[u] >> 4) & 15) + ((t.unit_p[u] & 0x100) ? 1 : 0);
+    }
+    if (debug)
+        fprintf(stderr, "  lanes: %lld extra LDS cycles per sub-step over %d units as laid out by cell id, %lld after %d swaps tried per unit (%lld reads)\n",
+                (long long)sb, nunit, (long long)sa, trials, (long long)reads);
+}
+
 bool flow_plain_class(int pre, int post, bool chained, int &cpre, int &cpost) {
     static const int plain_nc[][2] = {{1, 1}, {1, 2}, {1, 3}, {2, 2}, {2, 3}, {2, 4}, {3, 3}, {4, 2}, {3, 4}, {4, 3}, {4, 4}};
     static const int plain_ch[][2] = {{1, 2}, {1, 3}, {1, 4}, {2, 3}, {2, 4}};
@@ -842,6 +1007,7 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
         if (piece[c] >= 0) out.unit_of_cell[c] = unit_of_piece[piece[c]];
     out.height_of_cell = hgt;
     out.ds = ds;
+    if (opt.lane_trials > 0) lane_optimise(out, opt.lane_trials, opt.debug);
 
     if (opt.debug) {      // partition statistics on stderr
         std::vector<int> hp(8, 0), hi(9, 0), hx(9, 0), hl(10, 0), hpp(25, 0), hpl(25, 0);

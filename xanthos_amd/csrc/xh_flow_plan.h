@@ -31,6 +31,7 @@ struct FlowPlanOptions {
     // read per term instead of a 16-byte pair pays most.
     int plain_min_reads = 0;
     bool balance_lds = false;    // order the claim list's tail by LDS load (XH_WAVE_BALANCE=1: every CU one unit of each quarter)
+    int lane_trials = 0;         // > 0: move the cells of a unit to lanes on which its gather meets fewer LDS bank conflicts (swaps tried per unit)
     bool debug = false;          // partition statistics on stderr
 };
 

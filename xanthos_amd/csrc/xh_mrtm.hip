@@ -1004,10 +1004,11 @@ extern "C" int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const dou
         uint64_t hc = 1469598103934665603ull;
         for (size_t c = 0; c < n; ++c) hc = (hc ^ cap[c]) * 1099511628211ull;
         for (const char *b = __DATE__ " " __TIME__; *b; ++b) hc = (hc ^ (unsigned char)*b) * 1099511628211ull;
+        const FlowPlanOptions opt = flow_plan_options(ctx);
+        hc = (hc ^ (uint64_t)opt.lane_trials) * 1099511628211ull;
         char tn[64];
         snprintf(tn, sizeof(tn), ".tables_%016llx", (unsigned long long)hc);
         const std::string tpath = plan->learn_path + tn;
-        const FlowPlanOptions opt = flow_plan_options(ctx);
         bool loaded = flow_tables_load(tpath.c_str(), t) && t.n_units > 0 &&
                       (int64_t)t.cell_of_slot.size() == (int64_t)t.n_units * 64;
         if (loaded) {

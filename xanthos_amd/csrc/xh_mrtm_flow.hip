@@ -334,6 +334,7 @@ FlowPlanOptions flow_plan_options(const xh_ctx *ctx) {
     if (const char *e = getenv("XH_FLOW_PLAIN_MIN_READS")) o.plain_min_reads = atoi(e);
     o.debug = getenv("XH_FLOW_DEBUG") != nullptr;
     o.balance_lds = getenv("XH_WAVE_BALANCE") && getenv("XH_WAVE_BALANCE")[0] == '1';
+    if (const char *e = getenv("XH_FLOW_LANE_TRIALS")) o.lane_trials = std::max(atoi(e), 0);
     return o;
 }
 
@@ -397,8 +398,8 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
             mix(indptr, sizeof(int64_t) * (size_t)(n + 1));
             if (nnz) mix(indices, sizeof(int32_t) * (size_t)nnz);
             if (nnz) mix(sign, (size_t)nnz);
-            const int knobs[10] = {opt.simds, opt.piece_cap, opt.chain, opt.cut_rule, opt.tlimit, opt.tlimit_typed, opt.tlimit_plain,
-                                   opt.full_join, opt.pair_streams, (opt.plain_min_reads << 1) | (opt.balance_lds ? 1 : 0)};
+            const int knobs[11] = {opt.simds, opt.piece_cap, opt.chain, opt.cut_rule, opt.tlimit, opt.tlimit_typed, opt.tlimit_plain,
+                                   opt.full_join, opt.pair_streams, (opt.plain_min_reads << 1) | (opt.balance_lds ? 1 : 0), opt.lane_trials};
             mix(knobs, sizeof(knobs));
             const char *stamp = __DATE__ " " __TIME__;
             mix(stamp, strlen(stamp));
