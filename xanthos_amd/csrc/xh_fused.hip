@@ -128,7 +128,16 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
     double *staged = reinterpret_cast<double *>(static_cast<char *>(ctx->d_feed) + 256);
     hipEvent_t ev_blk0 = ctx->side_events[0], ev_done = ctx->side_events[1];
 
-    int rc = pm_block(A, 0, b0);
+    // what the routing call will want to know from the device goes first: by the time the call is made the answer is on the
+    // host, and the launch is put together while the first block still runs (xh_route_precheck)
+    static const bool precheck = !(getenv("XH_ROUTE_PRECHECK") && getenv("XH_ROUTE_PRECHECK")[0] == '0');      // 0: A/B runs
+    int rc = precheck ? xh_route_precheck(ctx, a->plan, a->d_flow_dist, a->d_velocity, a->dt) : XH_OK;
+    if (rc) return rc;
+    struct PreGuard {
+        xh_route_plan *plan;
+        ~PreGuard() { xh_route_precheck_cancel(plan); }
+    } pre_guard{a->plan};
+    rc = pm_block(A, 0, b0);
     if (rc) return rc;
     rc = xh_abcd_enqueue_spinup(ctx, A, ab, a->d_pars, a->d_pet, a->d_precip, a->d_abcd_tmin);
     if (rc) return rc;

@@ -412,6 +412,11 @@ struct xh_route_plan {
     hipEvent_t ev_fork = nullptr, ev_join[N_CLASS + 1] = {};
     hipStream_t fb_stream = nullptr;
     void *d_pool = nullptr;     // the allocation behind the tables uploaded at create (UploadPool)
+    // xh_route_precheck: the typed plan's "same cells can fire?" question asked ahead of the call that needs the answer
+    hipEvent_t ev_pre = nullptr;
+    bool pre_armed = false;
+    const double *pre_flow_dist = nullptr, *pre_velocity = nullptr;
+    double pre_dt = 0.0;
 };
 
 namespace {
@@ -780,6 +785,7 @@ static void route_plan_free(xh_route_plan *plan, bool settle) {
     }
     if (plan->fb_stream) (void)hipStreamDestroy(plan->fb_stream);
     if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+    if (plan->ev_pre) (void)hipEventDestroy(plan->ev_pre);
     for (int k = 0; k <= N_CLASS; ++k)
         if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
     DevBuf *bufs[] = {&plan->d_cell_of_slot, &plan->d_ent, &plan->d_cnt, &plan->d_fb_cells, &plan->d_fb_ptr,
@@ -1209,6 +1215,36 @@ extern "C" int xh_route_plan_typed_info(const xh_route_plan *plan, int64_t info[
     return XH_OK;
 }
 
+// Fed order (xh_fused.hip, run_fed): a routing call on a plan that has typed tables asks the device whether the cells that
+// can fire are still the ones the tables were made for (k_capable) and needs the answer on the host before it can launch.
+// Asked inside the call, the host waits for everything in front of it on the stream -- the first block of PM + ABCD -- and the
+// device then idles while the launch is put together (~0.1 ms of a 25 ms step, `tools/step_gaps.py`).  Asked here, in front
+// of that block, the answer is back long before the call: velocity, flow distance, dt and the learnt cells are what they
+// will be then (nothing in between writes them; the pointers and dt are compared, and run_fed cancels what it does not use).
+int xh_route_precheck(xh_ctx *ctx, xh_route_plan *plan, const double *d_flow_dist, const double *d_velocity, double dt) {
+    if (!ctx || !plan || plan->ctx != ctx) return XH_OK;
+    plan->pre_armed = false;
+    if (!plan->flow_typed || !plan->d_capable.p || !plan->d_cap_diff || !plan->h_cap_diff || plan->ncell == 0) return XH_OK;
+    if (!plan->ev_pre) XH_HIP(ctx, hipEventCreateWithFlags(&plan->ev_pre, hipEventDisableTiming));
+    const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
+    unsigned char *d_cap_new = static_cast<unsigned char *>(plan->d_capable.p) + nb;
+    XH_HIP(ctx, hipMemsetAsync(plan->d_cap_diff, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_capable, dim3((unsigned)((plan->ncell + 255) / 256)), dim3(256), 0, ctx->stream, d_velocity, d_flow_dist,
+                       dt, (int)plan->ncell, static_cast<const unsigned char *>(plan->d_learn.p), d_cap_new,
+                       static_cast<const unsigned char *>(plan->d_capable.p), plan->d_cap_diff);
+    XH_HIP(ctx, hipMemcpyAsync(plan->h_cap_diff, plan->d_cap_diff, 4, hipMemcpyDeviceToHost, ctx->stream));
+    XH_HIP(ctx, hipEventRecord(plan->ev_pre, ctx->stream));
+    plan->pre_flow_dist = d_flow_dist;
+    plan->pre_velocity = d_velocity;
+    plan->pre_dt = dt;
+    plan->pre_armed = true;
+    return XH_OK;
+}
+
+void xh_route_precheck_cancel(xh_route_plan *plan) {
+    if (plan) plan->pre_armed = false;
+}
+
 static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                              const int32_t *h_ndays, double dt, const double *d_flow_dist, const double *d_velocity,
                              const double *d_area, const double *d_runoff, const double *d_S0, double *d_chstorage,
@@ -1251,11 +1287,20 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     int *d_nt = d_m + nit;
     int *d_g = d_nt + nit;
     unsigned char *d_wr = reinterpret_cast<unsigned char *>(d_g + nit + 1);
-    XH_HIP(ctx, hipMemcpyAsync(d_secs, ssecs.data(), sizeof(double) * nit, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_m, sm.data(), sizeof(int) * nit, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_nt, snt.data(), sizeof(int) * nit, hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_g, sg.data(), sizeof(int) * (nit + 1), hipMemcpyHostToDevice, ctx->stream));
-    XH_HIP(ctx, hipMemcpyAsync(d_wr, swr.data(), (size_t)nit, hipMemcpyHostToDevice, ctx->stream));
+    // The schedule on the device, for the kernels that read it there -- every one but k_mrtm_wave, whose launch turns the host
+    // arrays into month records: uploaded in front of the first launch that needs it (five small copies that a call routed
+    // by k_mrtm_wave alone, i.e. every tree-shaped grid, no longer pays for).
+    bool sched_on_device = false;
+    auto sched_upload = [&]() -> int {
+        if (sched_on_device) return XH_OK;
+        sched_on_device = true;
+        XH_HIP(ctx, hipMemcpyAsync(d_secs, ssecs.data(), sizeof(double) * nit, hipMemcpyHostToDevice, ctx->stream));
+        XH_HIP(ctx, hipMemcpyAsync(d_m, sm.data(), sizeof(int) * nit, hipMemcpyHostToDevice, ctx->stream));
+        XH_HIP(ctx, hipMemcpyAsync(d_nt, snt.data(), sizeof(int) * nit, hipMemcpyHostToDevice, ctx->stream));
+        XH_HIP(ctx, hipMemcpyAsync(d_g, sg.data(), sizeof(int) * (nit + 1), hipMemcpyHostToDevice, ctx->stream));
+        XH_HIP(ctx, hipMemcpyAsync(d_wr, swr.data(), (size_t)nit, hipMemcpyHostToDevice, ctx->stream));
+        return XH_OK;
+    };
     // typed partition: does the plan at hand fit this call's velocity / flow distance / dt?  (answered by the sync below)
     // Off by default: measured on MI355X (profiles/round3), the typed partition does not beat the all-pair one yet -- its
     // pair units (the cells downstream of cells that can fire, with their imports) pace the run.  XH_ROUTE_TYPED (flag) or
@@ -1295,16 +1340,24 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
             }
         }
     }
+    // (fed order: the question was put to the device in front of the first block of PM + ABCD -- xh_route_precheck -- and the
+    // answer has long arrived: no wait for the stream in the middle of the step)
+    const bool prechecked = plan->pre_armed && want_typed && plan->flow_typed && plan->pre_flow_dist == d_flow_dist &&
+                            plan->pre_velocity == d_velocity && plan->pre_dt == dt;
+    plan->pre_armed = false;
     if (want_typed) {
         const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
         d_cap_new = static_cast<unsigned char *>(plan->d_capable.p) + nb;
-        XH_HIP(ctx, hipMemsetAsync(plan->d_cap_diff, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(k_capable, dim3((unsigned)((plan->ncell + 255) / 256)), dim3(256), 0, ctx->stream, d_velocity,
-                           d_flow_dist, dt, (int)plan->ncell, static_cast<const unsigned char *>(plan->d_learn.p), d_cap_new,
-                           plan->flow_typed ? static_cast<const unsigned char *>(plan->d_capable.p) : nullptr, plan->d_cap_diff);
-        XH_HIP(ctx, hipMemcpyAsync(plan->h_cap_diff, plan->d_cap_diff, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (!prechecked) {
+            XH_HIP(ctx, hipMemsetAsync(plan->d_cap_diff, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_capable, dim3((unsigned)((plan->ncell + 255) / 256)), dim3(256), 0, ctx->stream, d_velocity,
+                               d_flow_dist, dt, (int)plan->ncell, static_cast<const unsigned char *>(plan->d_learn.p), d_cap_new,
+                               plan->flow_typed ? static_cast<const unsigned char *>(plan->d_capable.p) : nullptr, plan->d_cap_diff);
+            XH_HIP(ctx, hipMemcpyAsync(plan->h_cap_diff, plan->d_cap_diff, 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
     }
-    XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (prechecked) XH_HIP(ctx, hipEventSynchronize(plan->ev_pre));
+    else if (want_typed) XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // does the typed plan at hand fit this call (same cells that can fire, same form)?
     const bool typed_fits = want_typed && plan->flow_typed && *plan->h_cap_diff == 0 && plan->typed_sel == sel_want;
     bool use_typed = typed_fits;
@@ -1376,6 +1429,8 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     if (feed && (!use_flow || plan->n_rest_units > 0 || plan->n_fb_rest > 0 || old_skew_env)) return XH_ERR_LIMIT;
 
     xh_span sp = xh_span_begin(ctx, "mrtm_route");
+    // (kernels on the class streams wait for ev_fork: whatever they read must be in the stream before it is recorded)
+    if (!(use_flow && plan->n_rest_units == 0 && plan->n_fb_rest == 0) && (rc = sched_upload()) != XH_OK) return rc;
     XH_HIP(ctx, hipEventRecord(plan->ev_fork, ctx->stream));
     int njoin = 0;
     plan->last_tree_kernel = 0;
@@ -1397,8 +1452,10 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         rc = XH_ERR_LIMIT;
         plan->last_tree_kernel = 2;
         static const bool old_skew = getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] == '2';      // round 2's kernel, for comparison
-        if (skew_env && (flags & XH_ROUTE_NO_SKEW) == 0)
+        if (skew_env && (flags & XH_ROUTE_NO_SKEW) == 0) {
+            if (old_skew && (rc = sched_upload()) != XH_OK) return rc;
             rc = old_skew ? skew_launch(ctx, plan->flow, fs, fio, ctx->stream) : wave_launch(ctx, tree_plan, fs, fio, ctx->stream);
+        }
         if (rc == XH_ERR_LIMIT && tree_plan != plan->flow && !old_skew) rc = wave_launch(ctx, plan->flow, fs, fio, ctx->stream);
         plan->last_typed = rc == XH_OK && tree_plan != plan->flow && !old_skew;
         if (feed && rc == XH_ERR_LIMIT) {      // nothing was launched: the caller completes the runoff and calls again
@@ -1407,11 +1464,13 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         }
         // what the round-3 kernel cannot take (rows beyond its 32-bit offsets) the round-2 time-skewed kernel may still
         if (rc == XH_ERR_LIMIT && skew_env && !old_skew && (flags & XH_ROUTE_NO_SKEW) == 0) {
+            if ((rc = sched_upload()) != XH_OK) return rc;
             rc = skew_launch(ctx, plan->flow, fs, fio, ctx->stream);
             if (rc == XH_OK) plan->last_tree_kernel = 3;
         }
         if (rc == XH_ERR_LIMIT) {
             plan->last_tree_kernel = 1;
+            if ((rc = sched_upload()) != XH_OK) return rc;
             rc = flow_launch(ctx, plan->flow, fs, fio, ctx->stream);
         }
         if (rc == XH_ERR_LIMIT) {
@@ -1423,6 +1482,12 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     }
     const int64_t n_fb = force_fb ? plan->ncell : (use_flow ? plan->n_fb_rest : plan->n_fb);
     const int64_t n_lds_units = use_flow ? plan->n_rest_units : plan->n_units;
+    if (((!force_fb && n_lds_units > 0) || n_fb > 0) && !sched_on_device) {
+        // only after the dataflow kernels turned a tree-only grid down: nothing of this call is running yet
+        rc = sched_upload();
+        if (rc) return rc;
+        XH_HIP(ctx, hipEventRecord(plan->ev_fork, ctx->stream));
+    }
     if (!force_fb && n_lds_units > 0) {
         RouteArgs a;
         a.unit_slot0 = nullptr;

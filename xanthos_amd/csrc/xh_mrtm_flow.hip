@@ -493,6 +493,7 @@ int flow_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     // exchange block: streams, then the counters (zeroed every call)
     const size_t x_streams = (size_t)std::max(fp->n_edges, 1) * RING * (size_t)s.ntmax * sizeof(double2);
     const size_t x_cnt = ((size_t)(fp->n_edges + fp->n_units) * sizeof(unsigned) + 255) & ~size_t(255);
+    fp->rec_key = 0;      // (k_mrtm_wave keeps its month records in this buffer too: this launch lays it out its own way)
     if (x_streams + x_cnt > fp->x_bytes) {
         if (fp->d_x) {
             XH_HIP(ctx, hipStreamSynchronize(st));

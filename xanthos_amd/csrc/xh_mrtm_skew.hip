@@ -631,6 +631,7 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     const size_t x_streams = (size_t)std::max(fp->n_edges, 1) * (size_t)rs * sizeof(v2d);
     if (x_streams >= ((size_t)1 << 32)) return XH_ERR_LIMIT;      // 32-bit ring offsets
     const size_t x_cnt = ((size_t)(fp->n_edges + fp->n_units + PLACE_WORDS) * sizeof(unsigned) + 255) & ~size_t(255);
+    fp->rec_key = 0;      // (k_mrtm_wave keeps its month records in this buffer too: this launch lays it out its own way)
     if (x_streams + x_cnt > fp->x_bytes) {
         if (fp->d_x) {
             XH_HIP(ctx, hipStreamSynchronize(st));
