@@ -654,6 +654,49 @@ def test_fed_routing_equals_stage_by_stage(hip, nm, abcd_spin, route_spin):
     assert ctx.timing('feed_gate')[1] == n0 + 4 and pipe.plan.info()['last_tree_kernel'] == 0
 
 
+def test_fed_routing_notices_new_velocities_in_place(hip):
+    """In the fed order the routing call's question to the device -- do the same cells fire as when the plain-form tables
+    were made? -- is asked in front of the first block of PM + ABCD (xh_route_precheck) and read without a wait when the
+    routing is launched.  Velocities overwritten IN PLACE (same device pointer) between two calls, so that other cells can
+    fire, must be noticed by that early question: the call falls back to the pair form, the tables are made again, and
+    every call equals the stage-by-stage order on the new velocities."""
+    import time
+    from xanthos_amd import synth
+    from xanthos_amd.pipeline import OUTPUTS, pipeline_from_world
+    ctx = hip.get_context()
+    w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=7, seed=29, outlet_frac=0.02)
+    nm = 240
+    pipe = pipeline_from_world(ctx, w, nm, 1971, 25, 24)
+    ctx.synth_forcing(31, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.002)
+
+    def check(tag):
+        pipe.run(fed=False, fused=False)
+        ref = pipe.download()
+        for rep in range(6):            # the adaptive plain form takes over after a few calls (tables made on a host thread)
+            for k in OUTPUTS:
+                pipe.out[k].zero()
+            pipe.run(fed=True, fused=False)
+            got = pipe.download()
+            for k in OUTPUTS:
+                assert np.array_equal(got[k], ref[k], equal_nan=True), (tag, k, rep)
+            time.sleep(0.2)
+        return pipe.plan.typed_info()
+    t0 = check('first velocities')
+    assert t0['plain_units'] >= 1 and t0['typed_builds'] >= 1, t0
+    # other cells can fire now: a fifth of the slow cells get fast, the fast ones slow (velocity * dt / length across 1)
+    rng = np.random.default_rng(3)
+    ratio = w.velocity * 10800.0 / w.flow_dist
+    v2 = w.velocity.copy()
+    flip = rng.random(w.ncell) < 0.2
+    v2[flip & (ratio <= 1.0)] *= 3.0 / np.maximum(ratio[flip & (ratio <= 1.0)], 0.05)
+    v2[ratio > 1.0] *= 0.5 / ratio[ratio > 1.0]
+    assert ((v2 * 10800.0 / w.flow_dist > 1.0) != (ratio > 1.0)).sum() > 50
+    pipe.d_velocity.upload(v2)
+    t1 = check('new velocities, same pointer')
+    assert t1['typed_builds'] > t0['typed_builds'], (t0, t1)
+    assert pipe.plan.info()['reroutes'] == 0
+
+
 def test_first_dataflow_call_of_a_plan_is_cross_checked(hip, tmp_path, monkeypatch):
     """The dataflow kernels' streams rest on an ordering assumption outside the HIP memory model (xh_mrtm_wave.hip, check();
     the fenced form costs +86 %, profiles/round4/fenced_ab.txt).  So the FIRST dataflow call of a plan on a device / library
