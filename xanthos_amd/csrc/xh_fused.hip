@@ -91,13 +91,19 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
     *runoff_done = false;
     const int nmonths = a->nmonths;
     // First block: at least the spin-ups (ABCD's needs PET of those months, the routing's pass over them comes first), and
-    // enough months to keep the routing kernel busy until the side stream has delivered the rest: beside the routing waves
-    // PM runs at 1/3 - 1/4 of its stand-alone speed (one wave per SIMD, below the routing waves' priority; in one-wave
-    // workgroups -- four-wave ones need a free slot on all four SIMDs of a CU at once and ran at 1/6), i.e. ~12 us per month
-    // of the full grid against the routing's 33 us per month; a quarter of the series covers that with margin (measured at
-    // 600 months, profiles/round4/feed_first_block.txt).
+    // enough months to keep the routing kernel busy until the side stream has delivered the rest.  Beside the routing waves
+    // PM + ABCD take ~12 us per month of the full grid (one PM wave per SIMD, below the routing waves' priority, in one-wave
+    // workgroups: four-wave ones need a free slot on all four SIMDs of a CU at once and ran at 1/6 of the stand-alone rate)
+    // and hand everything over at the end; the routing advances one month in ~33 us and asks for month B0 after its spin-up
+    // pass and B0 more months: (spin-up + B0) x 33 >= (months - B0) x 12, plus a quarter as margin.  600 months with 120 months
+    // of spin-up: 90 -> the spin-ups' 128 decide (measured: 24.60 ms per step against 24.70 with 160 months in front, same
+    // box, three alternating runs each; profiles/round4/feed_first_block.txt has the sweep with the slower side kernels of
+    // the round's start, when a quarter of the series was needed).
     int b0 = (std::max(a->abcd_spinup, a->routing_spinup) + 15) & ~15;
-    b0 = std::max(b0, (nmonths / 4 + 15) & ~15);
+    {
+        const long long need = (12ll * nmonths - 33ll * a->routing_spinup) * 5 / (45 * 4);
+        b0 = std::max(b0, (int)((std::max(need, 0ll) + 15) & ~15ll));
+    }
     b0 = std::max(b0, 32);
     if (const char *env = getenv("XH_FEED_FIRST"))      // experiments
         b0 = std::max((std::max(a->abcd_spinup, a->routing_spinup) + 15) & ~15, atoi(env) & ~15);
