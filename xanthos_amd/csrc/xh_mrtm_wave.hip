@@ -786,8 +786,12 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     }
 }
 
-// Two waves per SIMD must fit (more units than SIMDs): at most 256 registers.
-__global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mrtm_wave(const WaveArgs *ap_) {
+// Two waves per SIMD must fit (more units than SIMDs): at most 256 registers.  (XH_WAVE_WPE=3: experiment -- 168 registers,
+// what several worlds per GPU in one launch would need; DESIGN 4.3 "B worlds".)
+#ifndef XH_WAVE_WPE
+#define XH_WAVE_WPE 2
+#endif
+__global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(XH_WAVE_WPE, XH_WAVE_WPE))) k_mrtm_wave(const WaveArgs *ap_) {
     WaveArgsK *ap = (WaveArgsK *)ap_;
     __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
     __shared__ uint2 xtab[LANES];
