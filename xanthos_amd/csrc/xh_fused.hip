@@ -149,7 +149,7 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
     if (rc) return rc;
     rc = sim_block(A, 0, b0, staged);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(64), 0, A, w_ready, (unsigned)b0);
+    // (the months-ready word is set to b0 by the routing launch's own argument kernel: k_mrtm_wave_args)
     XH_HIP(ctx, hipEventRecord(ev_blk0, A));
     FlowFeed feed;
     feed.q_staged = staged;

@@ -37,6 +37,14 @@ namespace {
 
 constexpr int LANES = 64;
 constexpr int SK_P = 4;                       // row terms either side of the diagonal (D8: 4 smaller, 4 larger ids)
+// End of round 4, both on: mrtm_route 23.3 - 23.6 -> 22.5 - 22.6 ms (same box, three alternating pairs; 0 switches either off
+// for an A/B build: make exp EXPFLAGS="-DXH_WAVE_MIDZONE=0 -DXH_WAVE_BMOV=0").
+#ifndef XH_WAVE_MIDZONE
+#define XH_WAVE_MIDZONE 1   // a copy of the boundary loop for the zones that are neither the first nor the last of a run (see substep)
+#endif
+#ifndef XH_WAVE_BMOV
+#define XH_WAVE_BMOV 1      // month-start snapshots as 64-bit moves under the crossing lanes' mask (see substep)
+#endif
 constexpr int NSLOT = 2 * LANES + 1;          // entries per LDS slot: cells, ghosts (imported streams), constant zero
 constexpr int RING = 8;                       // LDS slots = sub-steps per stream block
 constexpr int GROUP = 16;                     // sub-steps per unrolled group (two blocks)
@@ -595,21 +603,41 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     // edge: 1 = the start of the series (the lanes pick up S0), 2 = its end (the lanes leave their last outflow for F_end in
     // LDS: as a register selected at every month start like snapS it cost 0.3 ms of the full grid's 23.4 -- two more live
     // registers through every loop and two selects per boundary sub-step, for a value only the last month needs)
-    auto substep = [&](auto zone_c, const int n, const int j, const int edge, const int rel) {
+    // mid_c: the zone is neither the first nor the last of the series and lags and months are even (dt = 3 h) -- known at
+    // compile time in a copy of the boundary loop of its own, so that all but two zones of a run carry neither the first
+    // zone's pick-up of S0, nor the last zone's store of the outflow (an LDS store under an empty mask in every even
+    // sub-step), nor a branch on odd_ok in every odd one.
+    auto substep = [&](auto zone_c, auto mid_c, const int n, const int j, const int edge, const int rel) {
         // (a compile-time flag: as a run-time argument the optimiser folded the two variants of the group back into one
         // body with a branch around the boundary code in every sub-step)
-        if (decltype(zone_c)::value && ((j & 1) == 0 || odd_ok)) {
+        constexpr bool MID = decltype(mid_c)::value;
+        if (decltype(zone_c)::value && ((j & 1) == 0 || (!MID && odd_ok))) {
             // The lanes whose lag puts them on the month start at this iteration: branch-free (a branch per lane set cost
             // 15 instructions per sub-step of the boundary groups and made the compiler copy the gathered values around)
             const bool c = rel == j;
+#if XH_WAVE_BMOV
+            // four 64-bit moves under the lanes' mask instead of ten 32-bit selects (the compiler prefers the selects)
+            {
+                const unsigned long long cm = __ballot(c);
+                unsigned long long sv;
+                asm volatile("s_and_saveexec_b64 %[sv], %[cm]\n\tv_mov_b64 %[ss], %[s]\n\tv_mov_b64 %[sa], %[fa]\n\t"
+                             "v_mov_b64 %[fa], 0\n\tv_mov_b64 %[e], %[en]\n\ts_mov_b64 exec, %[sv]"
+                             : [ss] "+v"(snapS), [sa] "+v"(snapA), [fa] "+v"(favg), [e] "+v"(erl), [sv] "=&s"(sv)
+                             : [s] "v"(S), [en] "v"(erl_n), [cm] "s"(cm)
+                             : "scc");
+            }
+#else
             snapS = c ? S : snapS;
             snapA = c ? favg : snapA;
 
             favg = c ? 0.0 : favg;
             erl = c ? erl_n : erl;
-            if (edge == 1) S = c ? S0v : S;
-            if (edge == 2) {
-                if (c) fend[lane] = F;
+#endif
+            if (!MID) {
+                if (edge == 1) S = c ? S0v : S;
+                if (edge == 2) {
+                    if (c) fend[lane] = F;
+                }
             }
         }
         // values for the NEXT sub-step: produced during the previous iteration.  The scheduling barriers keep the reads
@@ -710,16 +738,24 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     while (n < N && alive) {
         if (itz <= nit && n + GROUP > gz && n <= gz + lmax) {      // boundary groups of month itz
             const int edge = itz == 0 ? 1 : (itz == nit ? 2 : 0);
-            do {
-                housekeeping(n);
-                if (!alive) break;
-                ++zone_groups;
-                const int rel = nx - n;      // the sub-step of this group at which the lane crosses (outside 0..15: not in this group)
+            auto zone_run = [&](auto mid_c) {
+                do {
+                    housekeeping(n);
+                    if (!alive) break;
+                    ++zone_groups;
+                    const int rel = nx - n;      // the sub-step of this group at which the lane crosses (outside 0..15: not in this group)
 #pragma unroll
-                for (int j = 0; j < GROUP; ++j) substep(std::true_type(), n, j, edge, rel);
-                n += GROUP;
-                PROF_MARK(prof_zone)
-            } while (n <= gz + lmax && n < N);
+                    for (int j = 0; j < GROUP; ++j) substep(std::true_type(), mid_c, n, j, edge, rel);
+                    n += GROUP;
+                    PROF_MARK(prof_zone)
+                } while (n <= gz + lmax && n < N);
+            };
+#if XH_WAVE_MIDZONE
+            if (edge == 0 && !odd_ok) zone_run(std::true_type());
+            else zone_run(std::false_type());
+#else
+            zone_run(std::false_type());
+#endif
             if (alive) {      // every lane has crossed: next boundary
                 nx = itz < nit ? nx + ntz : INT_MAX;
                 ++itz;
@@ -733,7 +769,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
                 housekeeping(n);
                 if (!alive) break;
 #pragma unroll
-                for (int j = 0; j < GROUP; ++j) substep(std::false_type(), n, j, 0, 0);
+                for (int j = 0; j < GROUP; ++j) substep(std::false_type(), std::false_type(), n, j, 0, 0);
                 n += GROUP;
                 PROF_MARK(prof_plain)
             } while (n < n_end);
@@ -949,6 +985,9 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(XH_W
 // small kernel in front of every routing launch (a memset of its own cost the stream another ~5 us of turn-around).
 __global__ void k_mrtm_wave_args(WaveArgs a, WaveArgs *dst, uint4 *cnt, unsigned cnt_vec) {
     if (threadIdx.x == 0) *dst = a;
+    // fed run: the months-ready word still holds the previous call's "all months"; back to what exists at this launch
+    if (threadIdx.x == 0 && a.months_ready)
+        __hip_atomic_store(const_cast<unsigned *>(a.months_ready), a.ready_at_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (unsigned i = threadIdx.x; i < cnt_vec; i += blockDim.x) cnt[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
