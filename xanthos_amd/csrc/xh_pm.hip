@@ -32,6 +32,10 @@ constexpr double GAMMA = 0.67;       // :80
 enum { V_CL = 0, V_BETA, V_RSLIMIT, V_TOPEN, V_TCLOSE, V_TSPAN, V_VCLOSE, V_VOPEN, V_VSPAN, V_RBLMIN, V_RBLMAX,
        V_RBLSPAN, V_RC, V_INVRC, V_EMISS, V_INVTSPAN, V_INVVSPAN, V_INVBETA, V_INVRSLIMIT, PM_NVEC };
 
+#ifndef XH_PM_LCT_AHEAD
+#define XH_PM_LCT_AHEAD 1
+#endif
+
 struct PmTablesDev {
     int nlcs, n_lc_years, water_idx, snow_idx, start_year, nyears;
     double wind_pow;                     // (2/10)^0.11 (:99)
@@ -292,11 +296,24 @@ __device__ __forceinline__ double pm_month(const PmLds &L, const PmTablesDev *__
                                            const double *__restrict__ lct_cell, int lct_stride, double totpct) {
     const PmMonth M = pm_prep(K, p, T, TN, RH, W, RS, RL, TP, moy, dz);
     double acc = 0.0;
+#if XH_PM_LCT_AHEAD
+    // the land-cover fraction of class l + 1 is fetched while class l is computed: as written in the reference's order (the
+    // fraction read where it is used) the load sat at the end of every iteration with s_waitcnt vmcnt(0) right behind it
+    double frac = nlcs > 0 ? lct_cell[0] : 0.0;
+    for (int l = 0; l < nlcs; ++l) {
+        const double frac_next = lct_cell[(l + 1 < nlcs ? l + 1 : l) * lct_stride];
+        const double et = pm_class(L, tab, K, l, water_idx, snow_idx, wind_pow, M);
+        const double term = et * frac;                                // arr *= lct (:467)
+        acc += term;                                                  // np.sum over classes, in order (:470); 0 + x is x
+        frac = frac_next;
+    }
+#else
     for (int l = 0; l < nlcs; ++l) {
         const double et = pm_class(L, tab, K, l, water_idx, snow_idx, wind_pow, M);
         const double term = et * lct_cell[l * lct_stride];            // arr *= lct (:467)
         acc += term;                                                  // np.sum over classes, in order (:470); 0 + x is x
     }
+#endif
     return fdiv(acc, totpct);
 }
 
