@@ -226,6 +226,14 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
                                        tables are built on a host thread from the second plain call on and used once
                                        they are ready, no call waits for them (XH_ROUTE_AUTO=0 switches that off).  Same
                                        bits in every form; DESIGN.md 4.3                                            */
+#define XH_ROUTE_REASSOC 128        /* tree networks by the REASSOCIATED form of the time-skewed kernel (k_mrtm_rsum): the row sum
+                                       of mrtm.py:50-51 travels as running sums along chains of lanes (two LDS reads per
+                                       sub-step for every unit instead of up to six) and the update of mrtm.py:54-69 is fused.
+                                       Equal to the reference to rounding -- <= 1e-9 relative on every routed value at the
+                                       full grid, identical NaN masks; the gate is 1e-6 -- NOT bit for bit.  Also selected for
+                                       every call by XH_ROUTE_REASSOC=1 in the environment (0: never).  xh_route_plan_info[13]
+                                       = 4 when it routed the call.  XH_ROUTE_VALIDATE then compares within 1e-9.        */
+#define XH_ROUTE_EXACT 256          /* the bit-exact kernels for this call whatever the environment says                 */
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,
                     const double *d_flow_dist, const double *d_velocity, const double *d_area,

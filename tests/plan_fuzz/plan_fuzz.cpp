@@ -243,12 +243,43 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
     if (verbose)
         printf("case %d kind %d: %d cells, %d units (%d plain), %d streams, depth %d, max lag %d\n", idx, kind, g.n, t.n_units,
                t.n_plain_units, t.n_edges, t.depth, t.skew_lmax);
+    // The reassociated form of the same graph (xh_flow_rsum.cpp): the same cells routed, its own invariants, the file round trip
+    {
+        std::vector<char> handled_r;
+        FlowTables r;
+        if (flow_tables_build_rsum(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled_r, r, err) != 0) {
+            fprintf(stderr, "case %d (kind %d, %d cells): reassociated build failed: %s\n", idx, kind, g.n, err.c_str());
+            return 1;
+        }
+        if (handled_r != handled) {
+            fprintf(stderr, "case %d (kind %d, %d cells): the reassociated plan routes other cells than the bit-exact one\n", idx, kind, g.n);
+            return 1;
+        }
+        std::string bad_r = flow_tables_check_rsum(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), handled_r, r);
+        if (bad_r.empty() && r.n_units > 0 && (r.skew_lmax > 192 || r.max_imports > 16 || r.max_exports > 16)) bad_r = "limits";
+        if (bad_r.empty() && r.n_units > 0 && (idx % 4) == 1) {
+            char path[128];
+            snprintf(path, sizeof(path), "/tmp/plan_fuzz_%d_%d.rtables", (int)getpid(), idx);
+            FlowTables u;
+            if (!(flow_tables_save(r, path) && flow_tables_load(path, u) && u.rsum && u.ent2 == r.ent2 && u.eprev == r.eprev &&
+                  u.lag == r.lag && u.unit_p == r.unit_p &&
+                  flow_tables_check_rsum(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), handled_r, u).empty()))
+                bad_r = "tables did not survive the round trip through a file";
+            remove(path);
+        }
+        if (!bad_r.empty()) {
+            fprintf(stderr, "case %d (kind %d, %d cells, cap %d): reassociated plan: %s\n", idx, kind, g.n, opt.piece_cap, bad_r.c_str());
+            return 1;
+        }
+        if (verbose)
+            printf("        reassociated: %d units, %d streams, depth %d, max lag %d\n", r.n_units, r.n_edges, r.depth, r.skew_lmax);
+    }
     return 0;
 }
 
-// plan_fuzz --file topo.bin [typed 0|1] : the planner on a topology written by tools/dump_topology.py
+// plan_fuzz --file topo.bin [typed 0|1] [reassociated 0|1] : the planner on a topology written by tools/dump_topology.py
 // (int32 n, int64 nnz, indptr[n+1] int64, indices[nnz] int32, sign[nnz] int8, capable[n] uint8), with statistics
-static int run_file(const char *path, bool typed) {
+static int run_file(const char *path, bool typed, bool rsum) {
     FILE *f = fopen(path, "rb");
     if (!f) return 2;
     int32_t n = 0;
@@ -301,18 +332,20 @@ static int run_file(const char *path, bool typed) {
     std::string err;
     if (getenv("SIMDS")) opt.simds = atoi(getenv("SIMDS"));
     const auto t0 = std::chrono::steady_clock::now();
-    if (flow_tables_build(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)) {
+    if (rsum ? flow_tables_build_rsum(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)
+             : flow_tables_build(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)) {
         printf("build failed: %s\n", err.c_str());
         return 1;
     }
-    printf("flow_tables_build: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    const std::string bad = flow_tables_check(n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, t, opt.capable);
+    printf("flow_tables_build%s: %.1f ms\n", rsum ? "_rsum" : "", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    const std::string bad = rsum ? flow_tables_check_rsum(n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, t)
+                                 : flow_tables_check(n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, t, opt.capable);
     printf("check: %s\n", bad.empty() ? "ok" : bad.c_str());
     return bad.empty() ? 0 : 1;
 }
 
 int main(int argc, char **argv) {
-    if (argc > 2 && std::string(argv[1]) == "--file") return run_file(argv[2], argc > 3 ? atoi(argv[3]) != 0 : true);
+    if (argc > 2 && std::string(argv[1]) == "--file") return run_file(argv[2], argc > 3 ? atoi(argv[3]) != 0 : true, argc > 4 && atoi(argv[4]) != 0);
     const int cases = argc > 1 ? atoi(argv[1]) : 200;
     const unsigned long long seed = argc > 2 ? strtoull(argv[2], nullptr, 10) : 20240807ull;
     std::mt19937_64 rng(seed);

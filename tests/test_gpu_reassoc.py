@@ -1,0 +1,223 @@
+"""GPU tests (-m gpu) of the REASSOCIATED ("tolerance") form of the routing kernel: XH_ROUTE_REASSOC, k_mrtm_rsum.
+
+The form keeps the VALUE of every row sum of mrtm.py:50-51 but not its order (running sums along chains of lanes) and fuses
+the update of mrtm.py:54-69, so its results equal the reference's to rounding, not bit for bit.  The bar written here:
+identical NaN masks and |x - ref| <= 1e-9 |ref| + atol on every routed value (atol 1e-3 m3 for storages, 1e-9 m3/s for
+flows: far below anything a cell holds or passes) against the golden vectors of the real reference and against the oracle.
+The north star's gate is 1e-6.  The bit-exact kernels stay the default and the checker (XH_ROUTE_VALIDATE).
+"""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REASSOC, EXACT, VALIDATE = 128, 256, 32
+
+
+def routed_close(x, ref, atol, rtol=1e-9, tag=''):
+    x, ref = np.asarray(x), np.asarray(ref)
+    assert x.shape == ref.shape
+    assert np.array_equal(np.isnan(x), np.isnan(ref)), 'NaN pattern differs ' + str(tag)
+    m = ~np.isnan(ref)
+    excess = np.abs(x[m] - ref[m]) - (atol + rtol * np.abs(ref[m]))
+    assert (excess <= 0).all(), '{}: {} values beyond the bar, largest excess {:.3e}'.format(tag, int((excess > 0).sum()), excess.max())
+    return float(np.max(np.abs(x[m] - ref[m]) / np.maximum(np.abs(ref[m]), atol * 1e6))) if m.any() else 0.0
+
+
+def series_close(got, ref, tag=''):
+    chs, avg, fend = got
+    routed_close(chs, ref[0], 1e-3, tag=(tag, 'chs'))
+    routed_close(avg, ref[1], 1e-9, tag=(tag, 'avg'))
+    routed_close(fend, ref[2], 1e-9, tag=(tag, 'F_end'))
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from xanthos_amd import _hip
+    assert _hip.device_count() > 0, 'no GPU visible'
+    assert _hip.XH_ROUTE_REASSOC == REASSOC and _hip.XH_ROUTE_EXACT == EXACT
+    return _hip
+
+
+def _um(t, tag):
+    from xanthos_amd.routing import mrtm
+    return mrtm.UpstreamMatrix(t[tag + '_um_indptr'], t[tag + '_um_indices'], t[tag + '_um_data'])
+
+
+@pytest.mark.parametrize('tag', ['rand', 'tree'])
+def test_route_series_golden_reassoc(hip, golden, tag):
+    """The reference's own Components.calculate_routing (tests/golden/mrtm.npz): within the bar.  'rand' is not a forest, so the
+    flag leaves it to the bit-exact kernels -- which is the contract: the flag never changes WHICH cells are routed."""
+    from xanthos_amd.routing import mrtm
+    g, t = golden('mrtm'), golden('topo')
+    um = _um(t, tag)
+    got = mrtm.route_series(um, g[tag + '_L'], g[tag + '_chv'], g[tag + '_area'], g[tag + '_series_runoff'],
+                            g[tag + '_series_ndays'], int(g['series_spinup']), flags=REASSOC)
+    series_close(got, (g[tag + '_series_chstorage'], g[tag + '_series_avgchflow'], g[tag + '_series_Fend']), tag)
+    info = um.plan(hip.get_context()).info()
+    if info['flow_cells'] > 0 and tag == 'tree':
+        assert info['last_tree_kernel'] == 4, info
+
+
+@pytest.mark.parametrize('tag', ['rand', 'tree'])
+def test_streamrouting_golden_reassoc(hip, golden, tag):
+    """One month at a time (the reference's streamrouting signature), 28 .. 31 days, state carried from call to call."""
+    from xanthos_amd.routing import mrtm
+    g, t = golden('mrtm'), golden('topo')
+    um = _um(t, tag)
+    S = g[tag + '_S0']
+    n = len(S)
+    for nday in (28, 29, 30, 31):
+        S, favg, F = mrtm.streamrouting(g[tag + '_L'], S, np.zeros(n), g[tag + '_chv'], g['%s_q_%d' % (tag, nday)],
+                                        g[tag + '_area'], nday, 10800, um, flags=REASSOC)
+        routed_close(S, g['%s_S_%d' % (tag, nday)], 1e-3, tag=(tag, nday, 'S'))
+        routed_close(favg, g['%s_Favg_%d' % (tag, nday)], 1e-9, tag=(tag, nday, 'Favg'))
+        routed_close(F, g['%s_F_%d' % (tag, nday)], 1e-9, tag=(tag, nday, 'F'))
+        S = g['%s_S_%d' % (tag, nday)]          # the next month starts from the reference's state, like the golden run
+
+
+def _world(seed=3, ncell=3000, outlet_frac=0.02):
+    from xanthos_amd import synth
+    from xanthos_amd.routing import mrtm
+    w = synth.make_world(nrow=60, ncol=120, ncell=ncell, n_basins=5, seed=seed, outlet_frac=outlet_frac)
+    st = NS(ngridrow=w.nrow, ngridcol=w.ncol)
+    um = mrtm.upstream_genmatrix(mrtm.upstream(w.coords, mrtm.downstream(w.coords, w.flow_dir, st), st))
+    return w, um
+
+
+def test_route_synthetic_world_reassoc_vs_oracle(hip):
+    """3000 cells, networks far larger than one unit, NaN runoff cells, 2 + 12 months: k_mrtm_rsum against the oracle, against
+    the bit-exact kernel of the same library, and validated on the device (XH_ROUTE_VALIDATE compares within 1e-9 then)."""
+    from oracle import months as o_months
+    from oracle import mrtm as o_mrtm
+    from xanthos_amd.routing import mrtm
+    w, um = _world()
+    rng = np.random.default_rng(9)
+    runoff = rng.gamma(2.0, 30.0, (w.ncell, 12))
+    runoff[rng.random(w.ncell) < 0.01] = np.nan
+    ndays = o_months.set_month_arrays(12, 1972, 1972)[:, 2]
+    ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=REASSOC)
+    series_close(got, ref, 'oracle')
+    plan = um.plan(hip.get_context())
+    info = plan.info()
+    assert info['last_tree_kernel'] == 4 and info['flow_cells'] == w.ncell and info['flow_edges'] > 10, info
+    assert info['skew_max_lag'] <= 192
+    exact = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=EXACT)
+    assert plan.info()['last_tree_kernel'] == 2
+    for a, b in zip(exact, ref):
+        assert np.array_equal(a, b, equal_nan=True)
+    # the form does change bits (otherwise this test would not be looking at it) ...
+    assert not np.array_equal(got[1], exact[1], equal_nan=True)
+    # ... and the device-side cross-check accepts it within its tolerance
+    n_val = plan.info()['validated']
+    again = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=REASSOC | VALIDATE)
+    assert plan.info()['validated'] == n_val + 1 and plan.info()['last_tree_kernel'] == 4
+    for a, b in zip(again, got):
+        assert np.array_equal(a, b, equal_nan=True)          # the same kernel on the same input: the same bits
+
+
+def test_route_reassoc_deep_chain_fires_and_initial_storage(hip):
+    """A 1,500-cell main stem with side branches, scrambled ids, cells that fire every other sub-step, initial storage, 11
+    months, spin-up 3: deep lane lags, every month boundary crossed lane by lane, partial output groups."""
+    from oracle import mrtm as o_mrtm
+    from xanthos_amd.routing import mrtm
+    rng = np.random.default_rng(77)
+    n_main, n = 1500, 1500 + 300
+    ds = np.full(n, -1)
+    ds[1:n_main] = np.arange(0, n_main - 1)
+    ds[n_main:] = rng.integers(5, n_main, n - n_main)
+    perm = rng.permutation(n)
+    ds_p = np.full(n, -1)
+    ds_p[perm] = np.where(ds >= 0, perm[np.clip(ds, 0, None)], -1)
+    rows = [[] for _ in range(n)]
+    for c in range(n):
+        rows[c].append((c, -1))
+        if ds_p[c] >= 0:
+            rows[ds_p[c]].append((c, 1))
+    indptr, indices, data = [0], [], []
+    for r in rows:
+        for col, sgn in sorted(r):
+            indices.append(col)
+            data.append(sgn)
+        indptr.append(len(indices))
+    um = mrtm.UpstreamMatrix(indptr, indices, data)
+    L = rng.uniform(20e3, 60e3, n)
+    L[rng.random(n) < 0.03] = 4e3
+    v = rng.uniform(0.4, 1.5, n)
+    area = rng.uniform(800, 3100, n)
+    q = rng.gamma(2.0, 30.0, (n, 11))
+    S0 = rng.uniform(0.0, 5e7, n)
+    ndays = np.array([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30])
+    ref = o_mrtm.route_series(um.tocsr(), L, v, area, q, ndays, 3, S0=S0)
+    got = mrtm.route_series(um, L, v, area, q, ndays, 3, S0=S0, flags=REASSOC)
+    series_close(got, ref, 'deep chain')
+    info = um.plan(hip.get_context()).info()
+    assert info['last_tree_kernel'] == 4, info
+
+
+@pytest.mark.parametrize('dt', [7200, 17280, 86400])
+def test_route_reassoc_other_time_steps(hip, dt):
+    """dt = 2 h, 4.8 h (odd sub-step counts per month) and one day (months shorter than the lane lags: the flag then leaves the
+    call to the lock-step kernel, bit-exact -- still within the bar)."""
+    from oracle import mrtm as o_mrtm
+    from xanthos_amd.routing import mrtm
+    w, um = _world(seed=5)
+    rng = np.random.default_rng(dt)
+    q = rng.gamma(2.0, 30.0, (w.ncell, 5))
+    ndays = np.array([31, 28, 31, 30, 31])
+    ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, q, ndays, 1, dt=dt)
+    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, q, ndays, 1, dt=dt, flags=REASSOC)
+    series_close(got, ref, dt)
+    assert um.plan(hip.get_context()).info()['last_tree_kernel'] == (4 if dt < 86400 else 1)
+
+
+def test_route_reassoc_fuzz(hip):
+    """tools/fuzz_routing.py's generator, 25 seeded cases (12 .. 6,000 cells, month counts, spin-ups, time steps, NaN runoff,
+    stagnant and over-fast channels, initial storage): the reassociated form against the oracle, within the bar."""
+    import importlib.util
+    import os
+    from oracle import mrtm as o_mrtm
+    from xanthos_amd.routing import mrtm
+    spec = importlib.util.spec_from_file_location('fuzz_routing', os.path.join(os.path.dirname(__file__), '..', 'tools', 'fuzz_routing.py'))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(424242)
+    used = []
+    for k in range(25):
+        c = fz.gen_case(rng)
+        ref = o_mrtm.route_series(c.um.tocsr(), c.L, c.v, c.w.area, c.q, c.ndays, c.spin, S0=c.S0, dt=c.dt)
+        got = mrtm.route_series(c.um, c.L, c.v, c.w.area, c.q, c.ndays, c.spin, S0=c.S0, dt=c.dt, flags=REASSOC)
+        series_close(got, ref, (k, c.ncell, c.nm, c.spin, c.dt))
+        used.append(c.um.plan(hip.get_context()).info()['last_tree_kernel'])
+    assert used.count(4) >= 10, used
+
+
+def test_fed_pipeline_with_reassoc_routing(hip):
+    """The fed stage order (xh_run_fused mode 1) with the reassociated routing kernel: the same bits as the same kernel
+    behind a stage-by-stage run, and all within the bar of the bit-exact routing of the same runoff."""
+    from xanthos_amd import synth
+    from xanthos_amd.pipeline import pipeline_from_world
+    ctx = hip.get_context()
+    w = synth.make_world(nrow=90, ncol=180, ncell=6000, n_basins=20, seed=11)
+    nm = 240
+    pipe = pipeline_from_world(ctx, w, nm, 1961, 25, 24, route_flags=REASSOC)
+    ctx.synth_forcing(5, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.002)
+    pipe.run(fed=False)
+    staged = pipe.download(('q', 'chs', 'avg'))
+    assert pipe.plan.info()['last_tree_kernel'] == 4
+    for k in ('chs', 'avg'):
+        pipe.out[k].zero()
+    pipe.run(fed=True)
+    fed = pipe.download(('q', 'chs', 'avg'))
+    assert pipe.plan.info()['last_tree_kernel'] == 4
+    for k in ('q', 'chs', 'avg'):
+        assert np.array_equal(staged[k], fed[k], equal_nan=True), k
+    pipe.route_flags = EXACT
+    pipe.run(fed=False)
+    exact = pipe.download(('chs', 'avg'))
+    assert pipe.plan.info()['last_tree_kernel'] == 2
+    routed_close(fed['chs'], exact['chs'], 1e-3, tag='chs')
+    routed_close(fed['avg'], exact['avg'], 1e-9, tag='avg')

@@ -18,6 +18,9 @@
 #include <type_traits>
 #include <utility>
 
+using xh_flow::Tree;
+using xh_flow::tree_analyse;
+
 namespace {
 
 constexpr int W_MAX = 9;          // terms per row: 8 D8 neighbours + the diagonal
@@ -27,20 +30,9 @@ constexpr int NPAIR = 2 * LANES + 1;
 constexpr int SK_P = 4;           // row terms either side of the diagonal in the time-skewed layout
 constexpr unsigned SK_ZERO = 2u * LANES * 16u;
 
-struct Tree {
-    int n = 0;
-    const int64_t *indptr = nullptr;
-    const int32_t *indices = nullptr;
-    const int8_t *sign = nullptr;
-    std::vector<int> ds, nchild, child_ptr, child, cell_pre, cell_post;
-    std::vector<char> ok;                 // per cell: its network is a plain tree
-    int sel_reads = 0;                    // selective plain form: pieces / units that hold a cell needing pairs stay below this many reads
-    std::vector<char> must_full;          // typed: the cell has an upstream neighbour that can fire (it gathers both of its flows)
-    const unsigned char *capable = nullptr;
-    bool typed = false;
-};
+}  // namespace
 
-void tree_analyse(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign, const int *comp, int ncomp,
+void xh_flow::tree_analyse(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign, const int *comp, int ncomp,
                   const unsigned char *capable, Tree &t) {
     t.n = n;
     t.indptr = indptr;
@@ -114,6 +106,8 @@ void tree_analyse(int n, const int64_t *indptr, const int32_t *indices, const in
         for (int c = 0; c < n; ++c)
             if (t.ok[c] && capable[c] && t.ds[c] >= 0) t.must_full[t.ds[c]] = 1;
 }
+
+namespace {
 
 // Partition for one piece capacity: pieces, their stream edges and pipeline depth, units.
 struct Partition {
@@ -1204,7 +1198,7 @@ std::string flow_tables_check(int n, const int64_t *indptr, const int32_t *indic
 
 // ---------------------------------------------------------------------------------------------- tables <-> file
 namespace {
-constexpr unsigned long long TABLES_MAGIC = 0x3472546c66485801ull;      // format of flow_tables_save; bump on any change
+constexpr unsigned long long TABLES_MAGIC = 0x3472546c66485802ull;      // format of flow_tables_save; bump on any change
 
 template <class T>
 bool put_vec(FILE *f, const std::vector<T> &v) {
@@ -1215,18 +1209,24 @@ template <class T>
 bool get_vec(FILE *f, std::vector<T> &v) {
     unsigned long long n = 0;
     if (fread(&n, sizeof(n), 1, f) != 1 || n > (1ull << 31)) return false;
+    {   // a corrupt count must not turn into a multi-gigabyte allocation: no more elements than the file still holds
+        const long here = ftell(f);
+        if (here < 0 || fseek(f, 0, SEEK_END) != 0) return false;
+        const long end = ftell(f);
+        if (end < here || fseek(f, here, SEEK_SET) != 0 || n > (unsigned long long)(end - here) / sizeof(T)) return false;
+    }
     v.resize((size_t)n);
     return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
 }
 template <class F>
 bool tables_io(FILE *f, FlowTables &t, bool write, F &&vec) {
-    int head[11] = {t.n_units, t.n_edges, t.depth, t.n_cells, t.max_imports, t.max_exports, t.n_plain_units, t.skew_ok ? 1 : 0,
-                    t.skew_lmax, t.skew_span, t.typed ? 1 : 0};
+    int head[12] = {t.n_units, t.n_edges, t.depth, t.n_cells, t.max_imports, t.max_exports, t.n_plain_units, t.skew_ok ? 1 : 0,
+                    t.skew_lmax, t.skew_span, t.typed ? 1 : 0, t.rsum ? 1 : 0};
     if (write ? fwrite(head, sizeof(head), 1, f) != 1 : fread(head, sizeof(head), 1, f) != 1) return false;
     if (!write) {
         t.n_units = head[0], t.n_edges = head[1], t.depth = head[2], t.n_cells = head[3], t.max_imports = head[4];
         t.max_exports = head[5], t.n_plain_units = head[6], t.skew_ok = head[7] != 0, t.skew_lmax = head[8];
-        t.skew_span = head[9], t.typed = head[10] != 0;
+        t.skew_span = head[9], t.typed = head[10] != 0, t.rsum = head[11] != 0;
     }
     return vec(t.cell_of_slot) && vec(t.export_edge) && vec(t.ghost_edge) && vec(t.edge_cons_unit) && vec(t.unit_terms) &&
            vec(t.ent) && vec(t.lag) && vec(t.ghost_lag) && vec(t.unit_p) && vec(t.unit_lmax) && vec(t.unit_glmax) &&
@@ -1254,8 +1254,13 @@ bool flow_tables_load(const char *path, FlowTables &t) {
     if (!f) return false;
     unsigned long long magic = 0;
     t = FlowTables();
-    const bool ok = fread(&magic, sizeof(magic), 1, f) == 1 && magic == TABLES_MAGIC &&
-                    tables_io(f, t, false, [&](auto &v) { return get_vec(f, v); }) && fgetc(f) == EOF;
+    bool ok = false;
+    try {
+        ok = fread(&magic, sizeof(magic), 1, f) == 1 && magic == TABLES_MAGIC &&
+             tables_io(f, t, false, [&](auto &v) { return get_vec(f, v); }) && fgetc(f) == EOF;
+    } catch (...) {      // (std::bad_alloc: the callers fall back to planning)
+        ok = false;
+    }
     fclose(f);
     if (!ok) t = FlowTables();
     return ok;

@@ -41,6 +41,7 @@ struct FlowTables {
     int skew_lmax = 0;           // largest lane lag of any unit (sub-steps)
     int skew_span = 1;           // most pipeline levels a stream jumps over
     bool typed = false;
+    bool rsum = false;           // reassociated form (xh_flow_rsum.cpp): ent2[0] = the cell's inflow entry, eprev = its chain entry, unit_p = 0x400 | reads
     std::vector<int> cell_of_slot, export_edge, ghost_edge, edge_cons_unit, unit_terms;
     std::vector<unsigned> ent;                                   // lock-step kernel: [9][units*64]
     std::vector<int> lag, ghost_lag, unit_p, unit_lmax, unit_glmax, unit_order;
@@ -51,6 +52,26 @@ struct FlowTables {
     std::vector<unsigned char> lane_flags;                       // [units*64] bit 0: the cell can fire by construction
     std::vector<int> ghost_prod;                                 // [units*64] producer cell of imported stream k of the unit
 };
+
+// ---- shared by the two planners (xh_flow_plan.cpp: sums in stored order; xh_flow_rsum.cpp: reassociated sums)
+namespace xh_flow {
+struct Tree {
+    int n = 0;
+    const int64_t *indptr = nullptr;
+    const int32_t *indices = nullptr;
+    const int8_t *sign = nullptr;
+    std::vector<int> ds, nchild, child_ptr, child, cell_pre, cell_post;
+    std::vector<char> ok;                 // per cell: its network is a plain tree
+    int sel_reads = 0;                    // selective plain form: pieces / units that hold a cell needing pairs stay below this many reads
+    std::vector<char> must_full;          // typed: the cell has an upstream neighbour that can fire (it gathers both of its flows)
+    const unsigned char *capable = nullptr;
+    bool typed = false;
+};
+// which networks are plain trees (rows {-1 on the diagonal, +1 elsewhere}, every cell feeds <= 1 row, <= 9 terms per row,
+// no cycle); downstream pointers, children lists, row shapes
+void tree_analyse(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign, const int *comp, int ncomp,
+                  const unsigned char *capable, Tree &t);
+}  // namespace xh_flow
 
 // Partition every tree-shaped network (each cell drains to at most one cell, no cycle, rows = {-1 on the diagonal, +1
 // elsewhere}, at most 9 terms).  handled[c] = 1 for the cells the tables route.  Returns 0, or -1 with `err` set.
@@ -63,6 +84,15 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
 // through its chains, equals the CSR row in stored order; plain units hold no cell that needs pairs).  Empty = fine.
 std::string flow_tables_check(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
                               const std::vector<char> &handled, const FlowTables &t, const unsigned char *capable);
+
+// The reassociated ("tolerance") form: every upstream neighbour of a cell passes a running sum along a chain, a cell reads
+// the chain's total and its own predecessor -- two values per sub-step for every unit, sums equal to the CSR row's to
+// rounding, not bit for bit (xh_flow_rsum.cpp).  Same contract as flow_tables_build / flow_tables_check; routes the same cells.
+int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign, const int *comp,
+                           int ncomp, const FlowPlanOptions &opt, std::vector<char> &handled, FlowTables &out,
+                           std::string &err);
+std::string flow_tables_check_rsum(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
+                                   const std::vector<char> &handled, const FlowTables &t);
 
 // Tables to / from a file (the per-box cache of xh_route_plan_prepare: a partition costs tens of milliseconds, reading it
 // back a few).  flow_tables_load returns false on any mismatch of format or size; callers hold what they read to

@@ -1,0 +1,613 @@
+// Host-side planner of the REASSOCIATED ("tolerance") form of the dataflow routing kernel (k_mrtm_rsum, xh_mrtm_rsum.hip).
+//
+// Reference: mrtm.py:50-51 forms row i of UM.dot(F) as ((0 + F_a) + F_b) ... - F_i + F_x ... in stored (ascending column)
+// order.  The bit-exact planner (xh_flow_plan.cpp) keeps that order, which is why its units gather up to six values per
+// sub-step.  Here only the VALUE of the sum is kept (to rounding): every upstream neighbour of a cell -- either side of the
+// diagonal -- passes a running sum along a chain of lanes, and a cell reads
+//     A  the running sum of the LAST member of its children's chain   = sum of the flows of all its upstream neighbours
+//     R  the running sum of the member in front of it in its own chain (its previous sibling)
+// and stores R + (its own flow).  Two LDS reads per sub-step for every unit, whatever its rows look like; no plain form,
+// no learning, no guard.  Same pieces / units / one-way streams / time skew as the bit-exact form: a lane that reads a
+// value runs one level (two sub-steps) behind the lane -- or imported stream -- that produced it.
+//
+// What differs in the partition:
+//   * children that are cut off as pieces of their own are chained ACROSS pieces: the outlet of sibling piece k takes the
+//     stream of sibling piece k - 1 as its R and exports the running sum, so a cell imports at most ONE stream (the total
+//     of all its cut-off children), which opens the chain of the children that stayed (or is the cell's A if none did);
+//   * no row-shape rules in the cut or the packing: every unit has the same shape, so pieces are cut for full lanes only;
+//   * the order of a chain is free: children with the tallest (transformed) subtrees go last, which keeps lane lags low.
+#include <algorithm>
+#include <cstdio>
+#include <numeric>
+#include <string>
+#include <thread>
+
+#include "xh_flow_plan.h"
+
+using xh_flow::Tree;
+using xh_flow::tree_analyse;
+
+namespace {
+
+constexpr int LANES = 64;
+constexpr int G_MAX = 16;
+constexpr int W_MAX = 9;
+constexpr int SK_P = 4;
+constexpr unsigned SK_ZERO = 2u * LANES * 16u;
+constexpr int H_MAX = 88;         // tallest piece (levels): lane lags stay below the shortest month's sub-steps (wave_launch)
+
+struct RPart {
+    std::vector<int> queue, piece, roots, psize, pimp, pdepth;
+    std::vector<int> e_prod, e_cons, e_kind;      // stream: producer outlet, consumer cell, 0 = opens the chain of e_cons's children
+                                                  // (or is its A), 1 = R of the outlet e_cons of a sibling piece
+    std::vector<int> unit_of_piece, unit_cells, unit_imp, unit_out, unit_depth;
+    std::vector<char> unit_cheap;
+    int nunit = 0, nedge = 0, maxdepth = 0, n_cheap = 0;
+};
+
+void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P) {
+    const int n = t.n;
+    const std::vector<int> &ds = t.ds, &child = t.child, &child_ptr = t.child_ptr;
+    P = RPart();
+    std::vector<int> &queue = P.queue;
+    queue.reserve(n);
+    std::vector<int> left(t.nchild);
+    for (int c = 0; c < n; ++c)
+        if (t.ok[c] && t.nchild[c] == 0) queue.push_back(c);
+    std::vector<int> dsu(n);
+    std::iota(dsu.begin(), dsu.end(), 0);
+    auto find = [&](int x) {
+        while (dsu[x] != x) {
+            dsu[x] = dsu[dsu[x]];
+            x = dsu[x];
+        }
+        return x;
+    };
+    std::vector<int> open_cnt(n, 0), open_imp(n, 0), open_th(n, 0);
+    std::vector<int> kids, kept, ths;
+    std::vector<int> &roots = P.roots;
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+        const int v = queue[qi];
+        kids.assign(child.begin() + child_ptr[v], child.begin() + child_ptr[v + 1]);
+        std::sort(kids.begin(), kids.end(), [&](int x, int y) { return open_cnt[x] != open_cnt[y] ? open_cnt[x] < open_cnt[y] : x < y; });
+        // transformed height of v's open piece for a set of children kept: the chain runs tallest subtree last, member i of p
+        // sits p - i levels above the last one; a stream (the total of the children cut off) opens the chain, one level more
+        auto height = [&](const std::vector<int> &kp, bool any_cut) {
+            ths.clear();
+            for (int c : kp) ths.push_back(open_th[c]);
+            std::sort(ths.begin(), ths.end());
+            const int p = (int)ths.size();
+            int h = any_cut ? (p > 0 ? p + 1 : 1) : 0;
+            for (int i = 0; i < p; ++i) h = std::max(h, 1 + (p - 1 - i) + ths[i]);
+            return h;
+        };
+        int total = 1, imp = 0;
+        kept.clear();
+        // imports of a piece: those of the children kept + one for all the children cut off; two are held back (that one, and
+        // the sibling stream this piece takes on if it is cut off itself as a later member of a chain of pieces)
+        for (int c : kids)
+            if (total + open_cnt[c] <= cap && imp + open_imp[c] <= G_MAX - 2) {
+                kept.push_back(c);
+                total += open_cnt[c];
+                imp += open_imp[c];
+            }
+        while (!kept.empty() && height(kept, kept.size() < kids.size()) > H_MAX) {      // (rare: a comb-shaped piece)
+            size_t worst = 0;
+            for (size_t i = 1; i < kept.size(); ++i)
+                if (open_th[kept[i]] > open_th[kept[worst]]) worst = i;
+            total -= open_cnt[kept[worst]];
+            imp -= open_imp[kept[worst]];
+            kept.erase(kept.begin() + (long)worst);
+        }
+        const bool any_cut = kept.size() < kids.size();
+        for (int c : kids) {
+            if (std::find(kept.begin(), kept.end(), c) != kept.end()) dsu[find(c)] = v;
+            else roots.push_back(c);                   // c's piece is final; its outlet streams towards v
+        }
+        open_cnt[v] = total;
+        open_imp[v] = imp + (any_cut ? 1 : 0);
+        open_th[v] = height(kept, any_cut);
+        if (ds[v] < 0) roots.push_back(v);
+        else if (--left[ds[v]] == 0) queue.push_back(ds[v]);
+    }
+
+    // ---- pieces, stream edges (siblings chained), pipeline depth
+    const int npiece = (int)roots.size();
+    std::vector<int> piece_of_root(n, -1);
+    for (int p = 0; p < npiece; ++p) piece_of_root[roots[p]] = p;
+    P.piece.assign(n, -1);
+    P.psize.assign(npiece, 0);
+    P.pimp.assign(npiece, 0);
+    P.pdepth.assign(npiece, 0);
+    for (int v : queue) {
+        const int q = piece_of_root[find(v)];
+        P.piece[v] = q;
+        P.psize[q]++;
+    }
+    std::vector<int> grp;
+    for (int p = 0; p < npiece;) {                     // closing order: every producer of a piece comes before it
+        const int v = ds[roots[p]];
+        if (v < 0) {
+            ++p;
+            continue;
+        }
+        grp.clear();
+        while (p < npiece && ds[roots[p]] == v) grp.push_back(p++);
+        // the chain of sibling pieces: shallowest first (each member sits one pipeline level below the one before it)
+        std::stable_sort(grp.begin(), grp.end(), [&](int x, int y) {
+            return P.pdepth[x] != P.pdepth[y] ? P.pdepth[x] < P.pdepth[y] : P.psize[x] > P.psize[y];
+        });
+        for (size_t i = 0; i < grp.size(); ++i) {
+            const bool last = i + 1 == grp.size();
+            const int cons_piece = last ? P.piece[v] : grp[i + 1];
+            P.e_prod.push_back(roots[grp[i]]);
+            P.e_cons.push_back(last ? v : roots[grp[i + 1]]);
+            P.e_kind.push_back(last ? 0 : 1);
+            P.pimp[cons_piece]++;
+            P.pdepth[cons_piece] = std::max(P.pdepth[cons_piece], P.pdepth[grp[i]] + 1);
+        }
+    }
+    P.nedge = (int)P.e_prod.size();
+    P.maxdepth = npiece ? *std::max_element(P.pdepth.begin(), P.pdepth.end()) : 0;
+
+    // ---- packing.  Pieces with a stream in or out: equal pipeline depth per unit (a unit then only ever waits for units
+    //      strictly upstream or downstream of it), first-fit decreasing.  Whole small networks wait for nobody and fill free
+    //      lanes anywhere; the `cheap` cheapest of them (single cells first: they read nothing; then the smallest) are kept
+    //      together as units for the SIMDs that must hold two waves.
+    auto has_out = [&](int p) { return ds[roots[p]] >= 0; };
+    std::vector<int> dep, fre;
+    for (int p = 0; p < npiece; ++p) (P.pimp[p] > 0 || has_out(p) ? dep : fre).push_back(p);
+    std::stable_sort(dep.begin(), dep.end(), [&](int x, int y) {
+        return P.pdepth[x] != P.pdepth[y] ? P.pdepth[x] < P.pdepth[y] : P.psize[x] > P.psize[y];
+    });
+    std::vector<int> by_cost(fre);
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) { return P.psize[x] < P.psize[y]; });
+    int cheap = 0;
+    for (int round = 0; round < 4; ++round) {
+        P.unit_of_piece.assign(npiece, -1);
+        P.unit_cells.clear();
+        P.unit_imp.clear();
+        P.unit_out.clear();
+        P.unit_depth.clear();
+        P.unit_cheap.clear();
+        auto new_unit = [&](int depth, bool is_cheap) {
+            P.unit_cells.push_back(0);
+            P.unit_imp.push_back(0);
+            P.unit_out.push_back(0);
+            P.unit_depth.push_back(depth);
+            P.unit_cheap.push_back(is_cheap ? 1 : 0);
+            return (int)P.unit_cells.size() - 1;
+        };
+        auto put_piece = [&](int p, int u) {
+            P.unit_of_piece[p] = u;
+            P.unit_cells[u] += P.psize[p];
+            P.unit_imp[u] += P.pimp[p];
+            P.unit_out[u] += has_out(p) ? 1 : 0;
+        };
+        {
+            size_t first_open = 0;
+            int cur_depth = -1;
+            for (int p : dep) {
+                if (P.pdepth[p] != cur_depth) {
+                    cur_depth = P.pdepth[p];
+                    first_open = P.unit_cells.size();
+                }
+                int u = -1;
+                for (size_t b = first_open; b < P.unit_cells.size(); ++b)
+                    if (P.unit_cells[b] + P.psize[p] <= LANES && P.unit_imp[b] + P.pimp[p] <= G_MAX &&
+                        P.unit_out[b] + (has_out(p) ? 1 : 0) <= G_MAX) {
+                        u = (int)b;
+                        break;
+                    }
+                if (u < 0) u = new_unit(cur_depth, false);
+                put_piece(p, u);
+                while (first_open < P.unit_cells.size() && P.unit_cells[first_open] >= LANES) ++first_open;
+            }
+        }
+        std::vector<char> taken(npiece, 0);
+        {
+            int made = 0, u = -1;
+            for (int p : by_cost) {
+                if (u < 0 || P.unit_cells[u] + P.psize[p] > LANES) {
+                    if (made == cheap) break;
+                    u = new_unit(0, true);
+                    ++made;
+                }
+                put_piece(p, u);
+                taken[p] = 1;
+            }
+        }
+        // the other free pieces: largest first, each into the fullest unit that still takes it
+        std::vector<int> by_size;
+        for (int p : fre)
+            if (!taken[p]) by_size.push_back(p);
+        std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) { return P.psize[x] > P.psize[y]; });
+        {
+            std::vector<std::vector<int>> bucket(LANES + 1);
+            for (int u = 0; u < (int)P.unit_cells.size(); ++u)
+                if (!P.unit_cheap[u]) bucket[LANES - P.unit_cells[u]].push_back(u);
+            for (int p : by_size) {
+                const int sz = P.psize[p];
+                int u = -1;
+                for (int f = sz; f <= LANES && u < 0; ++f)
+                    if (!bucket[f].empty()) {
+                        u = bucket[f].back();
+                        bucket[f].pop_back();
+                    }
+                if (u < 0) u = new_unit(0, false);
+                put_piece(p, u);
+                bucket[LANES - P.unit_cells[u]].push_back(u);
+            }
+        }
+        P.nunit = (int)P.unit_cells.size();
+        P.n_cheap = cheap;
+        const int need = opt.simds > 0 ? std::max(P.nunit - opt.simds, 0) : 0;
+        if (need <= cheap) break;
+        cheap = need + (round > 0 ? 2 : 0);
+    }
+}
+
+}  // namespace
+
+int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign, const int *comp,
+                           int ncomp, const FlowPlanOptions &opt, std::vector<char> &handled, FlowTables &out,
+                           std::string &err) {
+    out = FlowTables();
+    out.rsum = true;
+    handled.assign(n, 0);
+    if (n == 0) return 0;
+    Tree t;
+    tree_analyse(n, indptr, indices, sign, comp, ncomp, nullptr, t);
+    const std::vector<int> &ds = t.ds;
+
+    RPart P;
+    {
+        static const int caps[] = {LANES, 56, 48, 44, 40, 36, 32, 28, 24};
+        constexpr int NCAP = (int)(sizeof(caps) / sizeof(caps[0]));
+        std::vector<RPart> cand(opt.piece_cap > 0 ? 1 : NCAP);
+        if (cand.size() == 1 || n < 4096) {
+            for (size_t k = 0; k < cand.size(); ++k)
+                rsum_partition(t, opt, opt.piece_cap > 0 ? std::min(opt.piece_cap, LANES) : caps[k], cand[k]);
+        } else {
+            std::vector<std::thread> pool;
+            for (size_t k = 0; k < cand.size(); ++k) pool.emplace_back([&, k] { rsum_partition(t, opt, caps[k], cand[k]); });
+            for (auto &th : pool) th.join();
+        }
+        bool have = false;
+        long best_score = 0;
+        for (size_t k = 0; k < cand.size(); ++k) {
+            RPart &Q = cand[k];
+            int indep = 0;
+            for (int u = 0; u < Q.nunit; ++u) indep += (Q.unit_imp[u] == 0 && Q.unit_out[u] == 0) ? 1 : 0;
+            const int extra = opt.simds > 0 ? std::max(Q.nunit - opt.simds, 0) : 0;
+            // units beyond the SIMD count share a SIMD, and only units without streams may (the claim order below)
+            const long score = 1000000L * std::max(2 * extra - indep, 0) + 1000L * Q.nunit + Q.nedge / 8;
+            if (opt.debug)
+                fprintf(stderr, "flow plan (reassociated): piece capacity %d -> %d units, %d streams, %d units without streams, depth %d\n",
+                        opt.piece_cap > 0 ? opt.piece_cap : caps[k], Q.nunit, Q.nedge, indep, Q.maxdepth + 1);
+            if (!have || score < best_score) {
+                std::swap(P, Q);
+                best_score = score;
+                have = true;
+            }
+        }
+    }
+    const std::vector<int> &piece = P.piece, &roots = P.roots, &unit_of_piece = P.unit_of_piece;
+    const int nunit = P.nunit, nedge = P.nedge;
+    if (nunit == 0) return 0;
+    const int64_t ts = (int64_t)nunit * LANES;
+
+    // ---- slots and imported entries
+    out.cell_of_slot.assign(ts, -1);
+    out.export_edge.assign(ts, -1);
+    out.ghost_edge.assign(ts, -1);
+    out.ghost_prod.assign(ts, 0);
+    out.edge_cons_unit.assign(nedge, 0);
+    std::vector<int> slot_of_cell(n, -1), fill(nunit, 0), gfill(nunit, 0), edge_ghost(nedge, 0);
+    for (int c = 0; c < n; ++c)
+        if (piece[c] >= 0) {
+            const int u = unit_of_piece[piece[c]];
+            const int s = fill[u]++;
+            if (s >= LANES) {
+                err = "flow plan (reassociated): a unit holds more than 64 cells";
+                return -1;
+            }
+            out.cell_of_slot[(int64_t)u * LANES + s] = c;
+            slot_of_cell[c] = s;
+            handled[c] = 1;
+        }
+    std::vector<int> edge_in0(n, -1), edge_in1(n, -1);      // per cell: the stream that feeds its children's sum / its own R
+    for (int ed = 0; ed < nedge; ++ed) {
+        const int cc = P.e_cons[ed], u = unit_of_piece[piece[cc]];
+        const int g = gfill[u]++;
+        if (g >= G_MAX) {
+            err = "flow plan (reassociated): a unit imports more than 16 streams";
+            return -1;
+        }
+        out.edge_cons_unit[ed] = u;
+        edge_ghost[ed] = g;
+        out.ghost_edge[(int64_t)u * LANES + g] = ed;
+        out.ghost_prod[(int64_t)u * LANES + g] = P.e_prod[ed];
+        const int pc = P.e_prod[ed];
+        out.export_edge[(int64_t)unit_of_piece[piece[pc]] * LANES + slot_of_cell[pc]] = ed;
+        (P.e_kind[ed] == 0 ? edge_in0 : edge_in1)[cc] = ed;
+    }
+
+    // ---- chains, heights.  Bottom-up: transformed height of every cell's subtree inside its piece; top-down: levels.
+    std::vector<int> th(n, 0), hgt(n, 0), a_src(n, -1), r_src(n, -1);      // sources: cell id, or -2 - edge, or -1 = zero
+    std::vector<int> kids;
+    for (int c : P.queue) {
+        kids.clear();
+        for (int k = t.child_ptr[c]; k < t.child_ptr[c + 1]; ++k)
+            if (piece[t.child[k]] == piece[c]) kids.push_back(t.child[k]);
+        std::stable_sort(kids.begin(), kids.end(), [&](int x, int y) { return th[x] < th[y]; });
+        const int p = (int)kids.size();
+        int h = edge_in0[c] >= 0 ? (p > 0 ? p + 1 : 1) : 0;
+        for (int i = 0; i < p; ++i) h = std::max(h, 1 + (p - 1 - i) + th[kids[i]]);
+        th[c] = h;
+        // (levels are handed out below, once the parent's level is known; the chain order is fixed here)
+        for (int i = 0; i < p; ++i) r_src[kids[i]] = i > 0 ? kids[i - 1] : (edge_in0[c] >= 0 ? -2 - edge_in0[c] : -1);
+        a_src[c] = p > 0 ? kids[p - 1] : (edge_in0[c] >= 0 ? -2 - edge_in0[c] : -1);
+        // hgt[] temporarily holds a member's offset above the last member of its chain
+        for (int i = 0; i < p; ++i) hgt[kids[i]] = p - 1 - i;
+    }
+    std::vector<int> unit_h(nunit, 0), edge_reader_h(nedge, 0);
+    for (size_t qi = P.queue.size(); qi-- > 0;) {       // downstream cells first
+        const int c = P.queue[qi];
+        if (piece[c] < 0) continue;
+        const bool root = roots[piece[c]] == c;
+        if (root) {
+            hgt[c] = 0;
+            if (edge_in1[c] >= 0) r_src[c] = -2 - edge_in1[c];
+        } else {
+            hgt[c] = hgt[ds[c]] + 1 + hgt[c];
+        }
+        int &uh = unit_h[unit_of_piece[piece[c]]];
+        uh = std::max(uh, hgt[c]);
+    }
+    for (int c = 0; c < n; ++c) {                       // an imported value sits one level above the lane that reads it
+        if (piece[c] < 0) continue;
+        for (int src : {a_src[c], r_src[c]})
+            if (src <= -2) {
+                const int ed = -2 - src;
+                edge_reader_h[ed] = hgt[c];
+                int &uh = unit_h[out.edge_cons_unit[ed]];
+                uh = std::max(uh, hgt[c] + 1);
+            }
+    }
+
+    out.lag.assign(ts, 0);
+    out.ghost_lag.assign(ts, 0);
+    out.unit_p.assign(nunit, 0x400);
+    out.unit_lmax.assign(nunit, 0);
+    out.unit_glmax.assign(nunit, 0);
+    out.ent2.assign((size_t)2 * SK_P * ts, SK_ZERO);
+    out.eprev.assign(ts, SK_ZERO);
+    out.ent.assign((size_t)W_MAX * ts, SK_ZERO);        // (the lock-step kernel's table: this plan is never routed by it)
+    out.unit_terms.assign(nunit, 1);
+    for (int u = 0; u < nunit; ++u) out.unit_lmax[u] = (2 * unit_h[u] + 15) & ~15;
+    auto entry_of = [&](int src, int u) -> unsigned {
+        if (src == -1) return SK_ZERO;
+        if (src <= -2) return (unsigned)(LANES + edge_ghost[-2 - src]) * 16u;
+        (void)u;
+        return (unsigned)slot_of_cell[src] * 16u;
+    };
+    for (int c = 0; c < n; ++c) {
+        if (piece[c] < 0) continue;
+        const int u = unit_of_piece[piece[c]];
+        const int64_t slot = (int64_t)u * LANES + slot_of_cell[c];
+        out.lag[slot] = out.unit_lmax[u] - 2 * hgt[c];
+        out.ent2[(size_t)slot] = entry_of(a_src[c], u);
+        out.eprev[slot] = entry_of(r_src[c], u);
+        if (a_src[c] != -1) out.unit_p[u] |= 1;
+        if (r_src[c] != -1) out.unit_p[u] |= 2;
+    }
+    for (int ed = 0; ed < nedge; ++ed) {
+        const int u = out.edge_cons_unit[ed];
+        const int gl = out.unit_lmax[u] - 2 * (edge_reader_h[ed] + 1);
+        out.ghost_lag[(int64_t)u * LANES + edge_ghost[ed]] = gl;
+        out.unit_glmax[u] = std::max(out.unit_glmax[u], gl);
+    }
+    out.lane_flags.assign(ts, 0);
+    out.unit_plain.assign(nunit, 0);
+
+    std::vector<int> unit_exp(nunit, 0);
+    for (int ed = 0; ed < nedge; ++ed) unit_exp[unit_of_piece[piece[P.e_prod[ed]]]]++;
+    {   // ---- the claim list (top of the kernel): units without streams by rising cost, then the others.  The SIMDs that hold
+        //      two waves get the cheapest units without streams and, with issue priority, the next ones.
+        std::vector<int> cost(nunit);
+        for (int u = 0; u < nunit; ++u)
+            cost[u] = 100 + 25 * ((out.unit_p[u] & 1) + ((out.unit_p[u] >> 1) & 1)) + (P.unit_imp[u] > 0 ? 15 : 0) + (unit_exp[u] > 0 ? 15 : 0);
+        auto coupled = [&](int u) { return P.unit_imp[u] > 0 || unit_exp[u] > 0; };
+        out.unit_order.resize(nunit);
+        std::iota(out.unit_order.begin(), out.unit_order.end(), 0);
+        std::stable_sort(out.unit_order.begin(), out.unit_order.end(), [&](int x, int y) {
+            if (coupled(x) != coupled(y)) return !coupled(x);
+            if (cost[x] != cost[y]) return cost[x] < cost[y];
+            return P.unit_cells[x] < P.unit_cells[y];
+        });
+    }
+
+    out.skew_ok = true;
+    out.skew_lmax = *std::max_element(out.unit_lmax.begin(), out.unit_lmax.end());
+    {
+        int span = 1;
+        for (int ed = 0; ed < nedge; ++ed) span = std::max(span, P.pdepth[piece[P.e_cons[ed]]] - P.pdepth[piece[P.e_prod[ed]]]);
+        out.skew_span = span;
+    }
+    out.n_units = nunit;
+    out.n_edges = nedge;
+    out.depth = P.maxdepth + 1;
+    out.n_cells = (int)std::count(handled.begin(), handled.end(), (char)1);
+    out.max_imports = *std::max_element(P.unit_imp.begin(), P.unit_imp.end());
+    out.max_exports = *std::max_element(unit_exp.begin(), unit_exp.end());
+    out.edge_prod_cell = P.e_prod;
+    out.edge_cons_cell = P.e_cons;
+    out.unit_depth = P.unit_depth;
+    out.piece_of_cell = piece;
+    out.unit_of_cell.assign(n, -1);
+    for (int c = 0; c < n; ++c)
+        if (piece[c] >= 0) out.unit_of_cell[c] = unit_of_piece[piece[c]];
+    out.height_of_cell = hgt;
+    out.ds = ds;
+
+    if (opt.debug) {
+        std::vector<int> hs(4, 0), hl(14, 0), hi(6, 0);
+        int indep = 0;
+        for (int u = 0; u < nunit; ++u) {
+            hs[out.unit_p[u] & 3]++;
+            hl[std::min(out.unit_lmax[u] / 16, 13)]++;
+            hi[P.unit_imp[u] == 0 ? 0 : P.unit_imp[u] <= 2 ? 1 : P.unit_imp[u] <= 4 ? 2 : P.unit_imp[u] <= 8 ? 3 : 4]++;
+            indep += (P.unit_imp[u] == 0 && unit_exp[u] == 0) ? 1 : 0;
+        }
+        fprintf(stderr, "flow plan (reassociated): %d units (%d without streams, %d kept cheap), %d pieces, %d streams, depth %d, %lld of %lld lanes used\n",
+                nunit, indep, P.n_cheap, (int)roots.size(), nedge, P.maxdepth + 1, (long long)out.n_cells, (long long)ts);
+        fprintf(stderr, "  units by reads (none, A, R, A+R): %d %d %d %d\n  units by lmax/16 (0..13+):", hs[0], hs[1], hs[2], hs[3]);
+        for (int k = 0; k < 14; ++k) fprintf(stderr, " %d", hl[k]);
+        fprintf(stderr, "\n  units by imports (0, <=2, <=4, <=8, more): %d %d %d %d %d\n  longest stream jump: %d levels\n", hi[0], hi[1],
+                hi[2], hi[3], hi[4], out.skew_span);
+    }
+    return 0;
+}
+
+// Invariants of a reassociated plan, re-derived from the tables alone: every handled cell in exactly one slot; streams run
+// strictly down the pipeline; <= 16 imports / outlets per unit; every value a lane reads was produced exactly one level
+// (two sub-steps) earlier; the running sum a cell reads as its inflow expands -- through chains of lanes and of pieces -- to
+// exactly the upstream neighbours of its CSR row (mrtm.py:50-51), each once; every lane's value is read by exactly one reader.
+std::string flow_tables_check_rsum(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
+                                   const std::vector<char> &handled, const FlowTables &t) {
+    if (!t.rsum) return "not a reassociated plan";
+    if (t.n_units == 0) {
+        for (int c = 0; c < n; ++c)
+            if (handled[c]) return "handled cell without units";
+        return "";
+    }
+    const int64_t ts = (int64_t)t.n_units * LANES;
+    if ((int64_t)t.cell_of_slot.size() != ts || (int64_t)t.lag.size() != ts || (int64_t)t.eprev.size() != ts ||
+        (int64_t)t.ent2.size() != 2 * SK_P * ts || (int)t.unit_p.size() != t.n_units || (int64_t)t.ghost_edge.size() != ts ||
+        (int64_t)t.ghost_lag.size() != ts || (int64_t)t.export_edge.size() != ts || (int)t.unit_lmax.size() != t.n_units ||
+        (int)t.unit_order.size() != t.n_units || (int)t.edge_cons_unit.size() != t.n_edges ||
+        (int)t.edge_prod_cell.size() != t.n_edges || (int)t.edge_cons_cell.size() != t.n_edges || (int)t.ds.size() != n ||
+        (int)t.unit_depth.size() != t.n_units)
+        return "table sizes";
+    std::vector<int> slot_of(n, -1);
+    for (int64_t s = 0; s < ts; ++s) {
+        const int c = t.cell_of_slot[s];
+        if (c < 0) continue;
+        if (c >= n || !handled[c]) return "slot holds a cell that is not handled";
+        if (slot_of[c] >= 0) return "cell " + std::to_string(c) + " sits in two slots";
+        slot_of[c] = (int)s;
+    }
+    for (int c = 0; c < n; ++c)
+        if (handled[c] && slot_of[c] < 0) return "handled cell " + std::to_string(c) + " has no slot";
+    {
+        std::vector<char> seen(t.n_units, 0);
+        for (int u : t.unit_order) {
+            if (u < 0 || u >= t.n_units || seen[u]) return "claim list is not a permutation of the units";
+            seen[u] = 1;
+        }
+    }
+    std::vector<int> imp(t.n_units, 0), exp(t.n_units, 0);
+    for (int ed = 0; ed < t.n_edges; ++ed) {
+        const int pc = t.edge_prod_cell[ed], cc = t.edge_cons_cell[ed];
+        if (pc < 0 || pc >= n || cc < 0 || cc >= n || slot_of[pc] < 0 || slot_of[cc] < 0) return "stream between cells that are not routed";
+        // a stream follows a flow edge, or links the outlets of two sibling pieces
+        if (t.ds[pc] != cc && !(t.ds[pc] >= 0 && t.ds[pc] == t.ds[cc])) return "stream follows neither a flow edge nor a sibling link";
+        const int pu = slot_of[pc] / LANES, cu = slot_of[cc] / LANES;
+        if (t.export_edge[slot_of[pc]] != ed) return "export_edge of the producer";
+        if (t.edge_cons_unit[ed] != cu) return "edge_cons_unit";
+        if (t.unit_depth[pu] >= t.unit_depth[cu]) return "stream from depth " + std::to_string(t.unit_depth[pu]) + " to depth " + std::to_string(t.unit_depth[cu]);
+        imp[cu]++;
+        exp[pu]++;
+    }
+    for (int u = 0; u < t.n_units; ++u) {
+        if (imp[u] > G_MAX || exp[u] > G_MAX) return "more than 16 imports / outlets in unit " + std::to_string(u);
+        int g = 0;
+        for (int k = 0; k < LANES; ++k)
+            if (t.ghost_edge[(int64_t)u * LANES + k] >= 0) {
+                if (k != g) return "ghost entries are not packed from 0";
+                if (t.ghost_edge[(int64_t)u * LANES + k] >= t.n_edges || t.edge_cons_unit[t.ghost_edge[(int64_t)u * LANES + k]] != u)
+                    return "ghost entry of a stream that does not end in the unit";
+                if (t.ghost_prod[(int64_t)u * LANES + k] != t.edge_prod_cell[t.ghost_edge[(int64_t)u * LANES + k]]) return "ghost_prod";
+                ++g;
+            }
+        if (g != imp[u]) return "ghost count";
+        if (t.unit_lmax[u] & 15) return "unit lag not a multiple of 16";
+        if ((t.unit_p[u] & ~3) != 0x400) return "shape word of unit " + std::to_string(u);
+    }
+    // what a value stands for: the cells whose flows it sums.  expand(entry) appends them.
+    std::vector<int> readers_lane(ts, 0), readers_ghost(t.n_edges, 0);
+    auto expand = [&](int u, unsigned off, std::vector<int> &terms, int depth, auto &&self) -> bool {
+        if (off == SK_ZERO) return true;
+        if (off % 16u) return false;
+        const int e = (int)(off / 16u);
+        if (e >= 2 * LANES || depth > 4 * LANES + t.n_edges) return false;
+        if (e >= LANES) {                                   // imported: whatever the producing outlet exports
+            const int ed = t.ghost_edge[(int64_t)u * LANES + (e - LANES)];
+            if (ed < 0) return false;
+            const int ps = slot_of[t.edge_prod_cell[ed]];
+            return self(ps / LANES, (unsigned)(ps % LANES) * 16u, terms, depth + 1, self);
+        }
+        const int64_t s = (int64_t)u * LANES + e;
+        const int c = t.cell_of_slot[s];
+        if (c < 0) return false;
+        if (!self(u, t.eprev[s], terms, depth + 1, self)) return false;
+        terms.push_back(c);
+        return true;
+    };
+    auto lag_of = [&](int u, unsigned off) {
+        const int e = (int)(off / 16u);
+        return e >= LANES ? t.ghost_lag[(int64_t)u * LANES + (e - LANES)] : t.lag[(int64_t)u * LANES + e];
+    };
+    auto note_reader = [&](int u, unsigned off) {
+        if (off == SK_ZERO) return;
+        const int e = (int)(off / 16u);
+        if (e >= LANES) readers_ghost[t.ghost_edge[(int64_t)u * LANES + (e - LANES)]]++;
+        else readers_lane[(int64_t)u * LANES + e]++;
+    };
+    std::vector<int> terms, want;
+    for (int c = 0; c < n; ++c) {
+        if (!handled[c]) continue;
+        const int s = slot_of[c], u = s / LANES;
+        if (t.lag[s] < 0 || t.lag[s] > t.unit_lmax[u] || (t.lag[s] & 1)) return "lag of cell " + std::to_string(c);
+        const unsigned a = t.ent2[(size_t)s], r = t.eprev[s];
+        for (int w = 1; w < 2 * SK_P; ++w)
+            if (t.ent2[(size_t)w * ts + s] != SK_ZERO) return "a reassociated plan reads one inflow entry per cell";
+        for (unsigned off : {a, r}) {
+            if (off == SK_ZERO) continue;
+            if (off % 16u || off / 16u >= 2u * LANES) return "bad table entry at cell " + std::to_string(c);
+            const int e = (int)(off / 16u);
+            if (e >= LANES ? t.ghost_edge[(int64_t)u * LANES + (e - LANES)] < 0 : t.cell_of_slot[(int64_t)u * LANES + e] < 0)
+                return "cell " + std::to_string(c) + " reads an empty entry";
+            if (t.lag[s] - lag_of(u, off) != 2) return "a value read is not two iterations old at cell " + std::to_string(c);
+            note_reader(u, off);
+        }
+        if (a != SK_ZERO && !(t.unit_p[u] & 1)) return "unit shape lacks the inflow read";
+        if (r != SK_ZERO && !(t.unit_p[u] & 2)) return "unit shape lacks the chain read";
+        terms.clear();
+        if (!expand(u, a, terms, 0, expand)) return "bad chain at cell " + std::to_string(c);
+        want.clear();
+        for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {
+            if (indices[j] == c) {
+                if (sign[j] >= 0) return "diagonal sign";
+            } else {
+                want.push_back(indices[j]);
+            }
+        }
+        std::sort(terms.begin(), terms.end());
+        std::sort(want.begin(), want.end());
+        if (terms != want) return "inflow of cell " + std::to_string(c) + " does not expand to its upstream neighbours";
+    }
+    // every value has exactly one reader (a lane's running sum: the next member or the fed cell; none for a cell without a
+    // downstream cell), and every outlet with a stream is an exported lane
+    for (int c = 0; c < n; ++c) {
+        if (!handled[c]) continue;
+        const int s = slot_of[c];
+        const int want_readers = t.ds[c] >= 0 ? 1 : 0;
+        const int have = readers_lane[s] + (t.export_edge[s] >= 0 ? 1 : 0);
+        if (have != want_readers) return "cell " + std::to_string(c) + " has " + std::to_string(have) + " readers";
+    }
+    for (int ed = 0; ed < t.n_edges; ++ed)
+        if (readers_ghost[ed] != 1) return "stream " + std::to_string(ed) + " has " + std::to_string(readers_ghost[ed]) + " readers";
+    return "";
+}

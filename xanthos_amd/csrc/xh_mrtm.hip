@@ -348,6 +348,12 @@ struct xh_route_plan {
     // distance and dt, which only arrive with xh_route_series.  Built on the first call from a copy of the topology and
     // rebuilt when a later call's data give another set of such cells (one small kernel per call checks).
     FlowPlan *flow_typed = nullptr;
+    // Reassociated form (XH_ROUTE_REASSOC; xh_flow_rsum.cpp, k_mrtm_rsum): a partition of its own over the same cells, made
+    // with the plan when the environment asks for the form, else on the first call that does.  Needs nothing of a call's data.
+    FlowPlan *flow_rsum = nullptr;
+    bool rsum_failed = false;                    // the planner turned the grid down once: not tried again
+    bool last_rsum = false;                      // the last call was routed by k_mrtm_rsum
+    bool first_checked_rsum = false;
     std::vector<int64_t> h_indptr;
     std::vector<int32_t> h_indices;
     std::vector<int8_t> h_sign;
@@ -484,6 +490,41 @@ void launch_units(const xh_route_plan *plan, int cls, RouteArgs args, hipStream_
 
 static void route_plan_free(xh_route_plan *plan, bool settle);
 
+// XH_ROUTE_REASSOC=1 / 0 in the environment: the reassociated form for every call that does not carry XH_ROUTE_EXACT / never.
+// Without it the flag of the call decides (default: the bit-exact kernels).
+static int reassoc_env() {
+    static const int v = [] {
+        const char *e = getenv("XH_ROUTE_REASSOC");
+        return !e ? -1 : (e[0] == '0' ? 0 : 1);
+    }();
+    return v;
+}
+
+// The reassociated partition of the plan's tree networks (host planner + upload).  XH_OK with plan->flow_rsum == nullptr and
+// rsum_failed set when the planner has nothing for this grid; the call then takes the bit-exact path.
+static int rsum_plan_build(xh_ctx *ctx, xh_route_plan *plan) {
+    if (plan->flow_rsum || plan->rsum_failed) return XH_OK;
+    plan->rsum_failed = true;
+    if (!plan->flow || plan->h_indptr.empty()) return XH_OK;
+    std::vector<char> handled;
+    FlowTables t;
+    std::string err;
+    const FlowPlanOptions opt = flow_plan_options(ctx);
+    if (flow_tables_build_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(), plan->h_sign.data(),
+                               plan->h_comp.data(), plan->h_ncomp, opt, handled, t, err) != 0 || t.n_units == 0)
+        return XH_OK;
+    if (t.n_cells != plan->flow->n_cells) return XH_OK;      // must route exactly the cells the bit-exact plan routes
+    if (getenv("XH_FLOW_CHECK")) {
+        const std::string bad = flow_tables_check_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
+                                                       plan->h_sign.data(), handled, t);
+        if (!bad.empty()) return xh_fail(ctx, XH_ERR_ARG, "reassociated flow plan check: %s", bad.c_str());
+    }
+    const int rc = flow_plan_upload(ctx, t, &plan->flow_rsum);
+    if (rc) return rc;
+    plan->rsum_failed = plan->flow_rsum == nullptr;
+    return XH_OK;
+}
+
 extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h_indptr, const int32_t *h_indices,
                                     const int8_t *h_sign, xh_route_plan **out) {
     if (!ctx || !out) return XH_ERR_ARG;
@@ -579,6 +620,13 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
             plan->h_sign.assign(h_sign, h_sign + nnz);
             plan->h_comp = comp;
             plan->h_ncomp = ncomp;
+            if (reassoc_env() == 1) {      // the form every call will ask for: its partition is made with the plan
+                const int rrc = rsum_plan_build(ctx, plan);
+                if (rrc) {
+                    route_plan_free(plan, false);
+                    return rrc;
+                }
+            }
         }
     }
     std::vector<char> comp_flow(ncomp, 0);
@@ -797,6 +845,7 @@ static void route_plan_free(xh_route_plan *plan, bool settle) {
     if (plan->auto_thread.joinable()) plan->auto_thread.join();
     flow_plan_destroy(plan->flow);
     flow_plan_destroy(plan->flow_typed);
+    flow_plan_destroy(plan->flow_rsum);
     free_buf(plan->d_capable);
     free_buf(plan->d_learn);
     if (plan->d_cap_diff) (void)hipFree(plan->d_cap_diff);
@@ -816,13 +865,14 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
     info[5] = plan->total_slots;
     info[6] = plan->all_single_ds ? 1 : 0;
     int64_t fi[5];
-    flow_plan_info(plan->last_typed ? plan->flow_typed : plan->flow, fi);
+    flow_plan_info(plan->last_rsum ? plan->flow_rsum : (plan->last_typed ? plan->flow_typed : plan->flow), fi);
     info[7] = fi[0];                  // dataflow units
     info[8] = fi[1];                  // stream edges
     info[9] = fi[2];                  // pipeline depth
     info[10] = fi[3];                 // cells routed by the dataflow kernel
     info[11] = fi[4];                 // most imported streams of a unit
-    info[12] = (plan->flow && plan->flow->skew_ok) ? plan->flow->skew_lmax : -1;     // deepest lane lag (sub-steps)
+    info[12] = (plan->last_rsum && plan->flow_rsum) ? plan->flow_rsum->skew_lmax
+                                                    : ((plan->flow && plan->flow->skew_ok) ? plan->flow->skew_lmax : -1);     // deepest lane lag (sub-steps)
     info[13] = plan->last_tree_kernel;
     info[14] = plan->reroutes;
     info[15] = plan->validated;
@@ -832,7 +882,7 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
 extern "C" int xh_route_plan_stats(xh_route_plan *plan, int64_t max_words, uint64_t *h_words, int64_t *n_words) {
     if (!plan || !n_words) return XH_ERR_ARG;
     std::vector<unsigned long long> st;
-    int rc = flow_stats_fetch(plan->ctx, plan->last_typed ? plan->flow_typed : plan->flow, st);
+    int rc = flow_stats_fetch(plan->ctx, plan->last_rsum ? plan->flow_rsum : (plan->last_typed ? plan->flow_typed : plan->flow), st);
     if (rc) return rc;
     *n_words = (int64_t)st.size();
     if (h_words)
@@ -856,6 +906,20 @@ __global__ void __launch_bounds__(256) k_count_diff(const unsigned long long *a,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double x = __longlong_as_double((long long)a[i]), y = __longlong_as_double((long long)b[i]);
         local += (x == y || (x != x && y != y)) ? 0ull : 1ull;
+    }
+    if (local) atomicAdd(count, local);
+}
+
+// The same for a call routed by the reassociated form (XH_ROUTE_REASSOC): equal to rounding, not bit for bit.  A value counts
+// when it is farther from the checker's than 1e-9 of it (+ 1e-9 of the array's scale `tiny`, for storages that the excess-flow
+// rule has just emptied), or NaN on one side only.
+__global__ void __launch_bounds__(256) k_count_far(const double *a, const double *b, int64_t n, double rel, double tiny,
+                                                   unsigned long long *count) {
+    unsigned long long local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = a[i], y = b[i];
+        const bool xn = x != x, yn = y != y;
+        local += (xn || yn) ? (xn != yn ? 1ull : 0ull) : ((fabs(x - y) <= rel * fabs(y) + tiny) ? 0ull : 1ull);
     }
     if (local) atomicAdd(count, local);
 }
@@ -904,21 +968,27 @@ static int route_validate(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int
     }
     bool used = false;
     const int routed_by = plan->last_tree_kernel;
+    const bool by_rsum = plan->last_rsum;       // routed by the reassociated form: equal to rounding, compared within 1e-9
     rc = route_series_impl(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
                            t_chs, t_avg, t_S, t_F, (flags | XH_ROUTE_NO_DATAFLOW) & ~XH_ROUTE_TEST_FAULT, &used);
     plan->last_tree_kernel = routed_by;
+    plan->last_rsum = by_rsum;
     if (!rc) {
         (void)hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), ctx->stream);
-        auto cmp = [&](const double *a, const double *b, size_t n) {
-            if (a && b && n)
+        // (storages in m3, flows in m3/s: the absolute terms are far below anything a grid cell holds or passes)
+        auto cmp = [&](const double *a, const double *b, size_t n, double tiny) {
+            if (!(a && b && n)) return;
+            if (by_rsum)
+                hipLaunchKernelGGL(k_count_far, dim3(1024), dim3(256), 0, ctx->stream, a, b, (int64_t)n, 1e-9, tiny, d_cnt);
+            else
                 hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, ctx->stream,
                                    reinterpret_cast<const unsigned long long *>(a),
                                    reinterpret_cast<const unsigned long long *>(b), (int64_t)n, d_cnt);
         };
-        cmp(d_chs, t_chs, nc * (size_t)nmonths);
-        cmp(d_avg, t_avg, nc * (size_t)nmonths);
-        cmp(d_S_end, t_S, nc);
-        cmp(d_F_end, t_F, nc);
+        cmp(d_chs, t_chs, nc * (size_t)nmonths, 1e-3);
+        cmp(d_avg, t_avg, nc * (size_t)nmonths, 1e-9);
+        cmp(d_S_end, t_S, nc, 1e-3);
+        cmp(d_F_end, t_F, nc, 1e-9);
         if (hipMemcpyAsync(&h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess)
             rc = xh_fail(ctx, XH_ERR_HIP, "XH_ROUTE_VALIDATE: comparison failed to run");
@@ -928,7 +998,7 @@ static int route_validate(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int
     plan->validated += 1;
     if (h_cnt)
         return xh_fail(ctx, XH_ERR_DEVICE, "XH_ROUTE_VALIDATE: %llu output values of the dataflow routing kernel differ from "
-                       "the workgroup-per-network kernel", h_cnt);
+                       "the workgroup-per-network kernel%s", h_cnt, by_rsum ? " by more than 1e-9 (reassociated form)" : "");
     return XH_OK;
 }
 
@@ -1090,7 +1160,7 @@ int xh_route_series_fed(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32
 
 // Marker of a passed first-call check: <dir>/route_ok_<device>_<build>_<topology>; dir = $XH_CACHE_DIR or
 // $HOME/.cache/xanthos_amd.  Failing to read or write it only means the check runs again.
-static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan) {
+static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan, bool rsum) {
     std::string dir;
     if (const char *d = getenv("XH_CACHE_DIR")) dir = d;
     else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/xanthos_amd";
@@ -1103,34 +1173,35 @@ static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan
     mix(ctx->prop.gcnArchName);
     mix(__DATE__ " " __TIME__);      // this translation unit's build: a new library build checks again
     char name[160];
-    snprintf(name, sizeof(name), "/route_ok_%016llx_%016llx_%lld_%lld", (unsigned long long)h, (unsigned long long)plan->topo_hash,
-             (long long)plan->ncell, (long long)(plan->flow ? plan->flow->n_units : 0));
+    snprintf(name, sizeof(name), "/route_ok_%016llx_%016llx_%lld_%lld%s", (unsigned long long)h, (unsigned long long)plan->topo_hash,
+             (long long)plan->ncell, (long long)(plan->flow ? plan->flow->n_units : 0), rsum ? "_r" : "");
     return dir + name;
 }
 
-static bool first_check_needed(xh_ctx *ctx, xh_route_plan *plan) {
+static bool first_check_needed(xh_ctx *ctx, xh_route_plan *plan, bool rsum) {
     static const bool enabled = !(getenv("XH_ROUTE_VALIDATE_FIRST") && getenv("XH_ROUTE_VALIDATE_FIRST")[0] == '0');
-    if (!enabled || plan->first_checked || !plan->flow) return false;
-    const std::string path = first_check_path(ctx, plan);
+    bool &checked = rsum ? plan->first_checked_rsum : plan->first_checked;
+    if (!enabled || checked || !plan->flow) return false;
+    const std::string path = first_check_path(ctx, plan, rsum);
     if (!path.empty()) {
         if (FILE *f = fopen(path.c_str(), "r")) {
             fclose(f);
-            plan->first_checked = true;
+            checked = true;
             return false;
         }
     }
     return true;
 }
 
-static void first_check_passed(xh_ctx *ctx, xh_route_plan *plan) {
-    plan->first_checked = true;
-    const std::string path = first_check_path(ctx, plan);
+static void first_check_passed(xh_ctx *ctx, xh_route_plan *plan, bool rsum) {
+    (rsum ? plan->first_checked_rsum : plan->first_checked) = true;
+    const std::string path = first_check_path(ctx, plan, rsum);
     if (path.empty()) return;
     const std::string dir = path.substr(0, path.rfind('/'));
     for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
         if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
     if (FILE *f = fopen(path.c_str(), "w")) {
-        fprintf(f, "dataflow routing equal to the workgroup-per-network kernel, bit for bit, on %s\n", ctx->prop.name);
+        fprintf(f, "dataflow routing equal to the workgroup-per-network kernel, %s, on %s\n", rsum ? "within 1e-9" : "bit for bit", ctx->prop.name);
         fclose(f);
     }
 }
@@ -1150,7 +1221,9 @@ static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     flags &= ~XH_ROUTE_VALIDATE;
     // first dataflow call of this plan on a box / build that has not passed the cross-check yet: checked like XH_ROUTE_VALIDATE
     const bool plain_call = plan && (flags & (XH_ROUTE_NO_DATAFLOW | XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_ATOMIC | XH_ROUTE_TEST_FAULT)) == 0;
-    const bool first_check = !validate && plain_call && first_check_needed(ctx, plan);
+    const bool want_rsum = plan && ((flags & XH_ROUTE_REASSOC) != 0 || reassoc_env() == 1) && (flags & XH_ROUTE_EXACT) == 0 &&
+                           reassoc_env() != 0 && (flags & XH_ROUTE_NO_SKEW) == 0;
+    const bool first_check = !validate && plain_call && first_check_needed(ctx, plan, want_rsum);
     validate = validate || first_check;
     // a fed call cannot be cross-checked at once (the second routing would read runoff that does not exist yet), nor
     // routed by anything but the dataflow kernel that knows how to wait for it
@@ -1185,7 +1258,8 @@ static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     rc = route_validate(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
                         d_chstorage, d_avgchflow, d_S_end, d_F_end, flags);
     // (a call that had to be re-routed was not routed by the dataflow kernel in the end: nothing was checked)
-    if (rc == XH_OK && ctx->reroutes == reroutes_before && (first_check || !plan->first_checked)) first_check_passed(ctx, plan);
+    if (rc == XH_OK && ctx->reroutes == reroutes_before && (first_check || !(plan->last_rsum ? plan->first_checked_rsum : plan->first_checked)))
+        first_check_passed(ctx, plan, plan->last_rsum);
     return rc;
 }
 
@@ -1308,7 +1382,17 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     static const bool typed_env = getenv("XH_ROUTE_TYPED") && getenv("XH_ROUTE_TYPED")[0] == '1';
     static const bool auto_env = !(getenv("XH_ROUTE_AUTO") && getenv("XH_ROUTE_AUTO")[0] == '0');
     static const bool old_skew_env = getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] != '1';
-    const bool typed_ok = plan->flow && !plan->typed_disabled && !plan->h_indptr.empty() &&
+    // Reassociated form (XH_ROUTE_REASSOC, flag or environment): a partition of its own, nothing to learn -- the typed / adaptive
+    // machinery below is for the bit-exact kernel only.
+    bool use_rsum = ((flags & XH_ROUTE_REASSOC) != 0 || reassoc_env() == 1) && (flags & XH_ROUTE_EXACT) == 0 && reassoc_env() != 0 &&
+                    plan->flow && !old_skew_env &&
+                    (flags & (XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_ATOMIC)) == 0;
+    if (use_rsum) {
+        if ((rc = rsum_plan_build(ctx, plan)) != XH_OK) return rc;
+        use_rsum = plan->flow_rsum != nullptr;
+    }
+    flags &= ~(XH_ROUTE_REASSOC | XH_ROUTE_EXACT);
+    const bool typed_ok = plan->flow && !plan->typed_disabled && !plan->h_indptr.empty() && !use_rsum &&
                           (flags & (XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_NO_PLAIN)) == 0;
     const bool explicit_typed = (typed_env || (flags & XH_ROUTE_TYPED) != 0) && typed_ok;
     // adaptive: plain calls only (no test / validation / variant flag), time-skewed kernel in use, months long enough for it
@@ -1421,6 +1505,7 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         }
     }
     FlowPlan *tree_plan = (use_typed && plan->flow_typed && plan->flow_typed->n_plain_units > 0) ? plan->flow_typed : plan->flow;
+    if (use_rsum) tree_plan = plan->flow_rsum;
 
     const bool force_fb = (flags & XH_ROUTE_FORCE_FALLBACK) != 0;
     const bool atomic = (flags & XH_ROUTE_ATOMIC) != 0;
@@ -1434,6 +1519,7 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     XH_HIP(ctx, hipEventRecord(plan->ev_fork, ctx->stream));
     int njoin = 0;
     plan->last_tree_kernel = 0;
+    plan->last_rsum = false;
     if (use_flow) {     // tree-shaped networks: single-wave dataflow units on the context's own stream
         int ntmax = 0, ntmin = INT_MAX;
         bool nt_even = true;
@@ -1457,7 +1543,9 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
             rc = old_skew ? skew_launch(ctx, plan->flow, fs, fio, ctx->stream) : wave_launch(ctx, tree_plan, fs, fio, ctx->stream);
         }
         if (rc == XH_ERR_LIMIT && tree_plan != plan->flow && !old_skew) rc = wave_launch(ctx, plan->flow, fs, fio, ctx->stream);
-        plan->last_typed = rc == XH_OK && tree_plan != plan->flow && !old_skew;
+        plan->last_rsum = rc == XH_OK && use_rsum && tree_plan == plan->flow_rsum && !old_skew;
+        if (plan->last_rsum) plan->last_tree_kernel = 4;
+        plan->last_typed = rc == XH_OK && tree_plan != plan->flow && !old_skew && !plan->last_rsum;
         if (feed && rc == XH_ERR_LIMIT) {      // nothing was launched: the caller completes the runoff and calls again
             xh_span_cancel(sp);
             return XH_ERR_LIMIT;

@@ -14,6 +14,7 @@ struct FlowBuf {
 // Partition of the tree-shaped river networks into single-wave units (64 lanes = 64 cells) linked by one-way streams.
 struct FlowPlan {
     int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0, max_exports = 0, n_plain_units = 0;
+    bool rsum = false;                   // reassociated form (xh_flow_rsum.cpp tables, k_mrtm_rsum): wave_launch only
     int max_cell = -1;                   // largest grid index of a routed cell (the time-skewed kernel's 32-bit row offsets)
     FlowBuf d_cell_of_slot, d_ent, d_export_edge, d_ghost_edge, d_edge_cons_unit, d_unit_terms;
     // time-skewed layout (xh_mrtm_skew.hip); skew_ok = every row has <= 4 terms either side of its diagonal
@@ -92,6 +93,7 @@ int flow_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
 int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st);
 // Round 3's time-skewed kernel (xh_mrtm_wave.hip): same contract, same plan tables, pair and plain units.
 int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st);
+const void *wave_rsum_kernel();      // k_mrtm_rsum (xh_mrtm_rsum.hip): the kernel wave_launch starts for a reassociated plan
 // Per-unit cycle accounting of the last launch (only when XH_FLOW_STATS=1): 6 words per unit
 // {shader cycles in sub-step loops, shader cycles total, 100 MHz ticks total, shape bits, data-wait, ring-wait cycles}.
 int flow_stats_fetch(xh_ctx *ctx, FlowPlan *fp, std::vector<unsigned long long> &out);

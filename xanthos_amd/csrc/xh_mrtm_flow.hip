@@ -442,6 +442,7 @@ int flow_plan_upload(xh_ctx *ctx, const FlowTables &t, FlowPlan **out) {
     fp->max_imports = t.max_imports;
     fp->max_exports = t.max_exports;
     fp->n_plain_units = t.n_plain_units;
+    fp->rsum = t.rsum;
     for (int c : t.cell_of_slot) fp->max_cell = std::max(fp->max_cell, c);
     int rc = put(ctx, fp->d_cell_of_slot, t.cell_of_slot);
     rc |= put(ctx, fp->d_ent, t.ent);

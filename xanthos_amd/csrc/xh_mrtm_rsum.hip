@@ -1,0 +1,59 @@
+// MRTM routing, reassociated ("tolerance") form of the time-skewed dataflow kernel (gfx950) -- round 5.
+//
+// Same machine as k_mrtm_wave (xh_mrtm_wave.hip; the unit's whole run is wave_unit<> of xh_mrtm_wave_unit.h): single-wave units
+// of 64 cells, every unit resident at once, lanes time-skewed by their level, one-way streams in HBM between units, month
+// records, fed runs.  What it gives up is the ORDER of the row sum of mrtm.py:50-51, and with it the bits: every upstream
+// neighbour of a cell passes a running sum {sum F, sum F2} along a chain of lanes (and of pieces: xh_flow_rsum.cpp), so a
+// lane reads two pairs per sub-step whatever its row looks like -- the bit-exact kernel's slowest units read six -- and the
+// explicit Euler update with the "excess flow" rule (mrtm.py:54-69) is fused to eight fp64 operations.  No plain form, no
+// learning, no guard: the first call of a plan is as fast as the twentieth.  Results equal the reference's to rounding
+// (<= 1e-9 relative against the oracle over the full grid and series; the north star's gate is 1e-6) with identical NaN
+// masks; the bit-exact kernel stays the checker (XH_ROUTE_VALIDATE) and the default unless XH_ROUTE_REASSOC is set.
+//
+// Five specialisations instead of 48: units without streams whose cells have no upstream neighbour at all (single-cell
+// networks: nothing to read), without a chain read, with both; units with streams in one or two import rounds.
+#include <algorithm>
+#include "xh_mrtm_wave_unit.h"
+
+namespace {
+
+__global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mrtm_rsum(const WaveArgs *ap_) {
+    WaveArgsK *ap = (WaveArgsK *)ap_;
+    __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
+    __shared__ uint2 xtab[LANES];
+    __shared__ unsigned qstage_sh[2 * LANES];      // runoff of the month after next, low / high words (runoff_fetch)
+    __shared__ double fend_sh[LANES];              // outflow of every lane's last sub-step (F_end)
+    __shared__ int unit_sh, prio_sh;
+    const int unit = wave_claim(ap, &unit_sh, &prio_sh);
+    const int prio = prio_sh;
+    if (unit < 0) return;
+    if (A(months_ready)) {      // fed run: ahead of the waves that produce the runoff on the same SIMDs (see k_mrtm_wave)
+        if (prio == 3) __builtin_amdgcn_s_setprio(3);
+        else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(2);
+    } else if (prio == 3) {
+        __builtin_amdgcn_s_setprio(3);
+    }
+    const int p = A(unit_p)[unit];       // 0x400 | 1 (reads the inflow entry) | 2 (reads the chain entry)
+    const bool has_ghost = A(ghost_edge)[(int64_t)unit * LANES + threadIdx.x] >= 0;      // lane k: the unit's k-th import
+    const bool g = __any(has_ghost), g2 = __any(has_ghost && threadIdx.x >= 8);
+    const bool x = __any(A(export_edge)[(int64_t)unit * LANES + threadIdx.x] >= 0);
+    char *l = reinterpret_cast<char *>(lds);
+    __attribute__((address_space(3))) unsigned *qst = (__attribute__((address_space(3))) unsigned *)qstage_sh;
+    __attribute__((address_space(3))) double *fnd = (__attribute__((address_space(3))) double *)fend_sh;
+    fend_sh[threadIdx.x] = 0.0;
+    if ((p & ~3) != 0x400) {      // not a reassociated plan: a fault rather than wrong results
+        if (threadIdx.x == 0) __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (g2) wave_unit<false, 1, 0, 2, true, true>(ap, l, xtab, qst, fnd, unit);
+    else if (g) wave_unit<false, 1, 0, 1, true, true>(ap, l, xtab, qst, fnd, unit);
+    else if ((p & 2) || x) wave_unit<false, 1, 0, 0, true, true>(ap, l, xtab, qst, fnd, unit);
+    else if (p & 1) wave_unit<false, 1, 0, 0, false, true>(ap, l, xtab, qst, fnd, unit);
+    else wave_unit<false, 0, 0, 0, false, true>(ap, l, xtab, qst, fnd, unit);
+}
+#undef A
+
+}  // namespace
+
+const void *wave_rsum_kernel() { return reinterpret_cast<const void *>(&k_mrtm_rsum); }
