@@ -230,10 +230,13 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
                                        of mrtm.py:50-51 travels as running sums along chains of lanes (two LDS reads per
                                        sub-step for every unit instead of up to six) and the update of mrtm.py:54-69 is fused.
                                        Equal to the reference to rounding -- <= 1e-9 relative on every routed value at the
-                                       full grid, identical NaN masks; the gate is 1e-6 -- NOT bit for bit.  Also selected for
-                                       every call by XH_ROUTE_REASSOC=1 in the environment (0: never).  xh_route_plan_info[13]
-                                       = 4 when it routed the call.  XH_ROUTE_VALIDATE then compares within 1e-9.        */
-#define XH_ROUTE_EXACT 256          /* the bit-exact kernels for this call whatever the environment says                 */
+                                       full grid, identical NaN masks; the gate is 1e-6 -- NOT bit for bit.  THE DEFAULT since
+                                       round 5 for calls that carry neither this flag nor XH_ROUTE_EXACT; XH_ROUTE_REASSOC=0 /
+                                       1 in the environment moves that default.  xh_route_plan_info[13] = 4 when it routed
+                                       the call (months shorter than its lane lags, networks that are not trees: the
+                                       bit-exact kernels).  XH_ROUTE_VALIDATE then compares within 1e-9.               */
+#define XH_ROUTE_EXACT 256          /* the bit-exact kernels for this call (every row sum in scipy's stored order) whatever
+                                       the default says                                                                  */
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,
                     const double *d_flow_dist, const double *d_velocity, const double *d_area,

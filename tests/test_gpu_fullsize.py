@@ -93,6 +93,51 @@ def test_config3_full_length_routing_equals_oracle(full):
     assert 1054 <= info['flow_units'] <= 1075 and info['flow_edges'] > 1200, info
 
 
+def test_config3_reassociated_routing_within_1e9_of_oracle(full):
+    """the REASSOCIATED form (XH_ROUTE_REASSOC, k_mrtm_rsum: running sums along chains of lanes, fused
+    update -- the library's default) over 67,420 cells x (120 + 600) months against the oracle: identical NaN masks and every
+    one of the 80.9 M routed values within 1e-9 |ref| (+ 1e-3 m3 / 1e-9 m3/s); the north star's gate is 1e-6.  Stage by
+    stage, in the fed order (routing fed while PM and ABCD still run), and cross-checked on the device against the
+    barrier-only bit-exact kernel (XH_ROUTE_VALIDATE compares within 1e-9 for this form)."""
+    from xanthos_amd import _hip
+
+    def within(tag):
+        got = full.pipe.download(('chs', 'avg'))
+        worst = 0.0
+        for k, ref, atol in (('chs', full.chs, 1e-3), ('avg', full.avg, 1e-9)):
+            x = got[k]
+            assert np.array_equal(np.isnan(x), np.isnan(ref)), (tag, k, 'NaN masks')
+            m = ~np.isnan(ref)
+            err = np.abs(x[m] - ref[m])
+            assert (err <= 1e-9 * np.abs(ref[m]) + atol).all(), (tag, k, float(err.max()))
+            big = np.abs(ref[m]) > 1e6 * atol
+            worst = max(worst, float((err[big] / np.abs(ref[m][big])).max()))
+        assert full.pipe.plan.info()['last_tree_kernel'] == 4, tag
+        return worst
+    full.pipe.route_flags = _hip.XH_ROUTE_REASSOC
+    for rep in range(3):
+        full.pipe.out['chs'].zero()
+        full.pipe.out['avg'].zero()
+        full.pipe.run_mrtm()
+        worst = within(('staged', rep))
+    assert worst < 1e-10, worst                       # (measured: 3e-12)
+    info = full.pipe.plan.info()
+    assert info['flow_cells'] == 67420 and 1054 <= info['flow_units'] <= 1075 and info['skew_max_lag'] <= 96, info
+    full.pipe.out['chs'].zero()
+    full.pipe.out['avg'].zero()
+    full.pipe.run(fed=True)
+    within('fed')
+    n_val = full.pipe.plan.info()['validated']
+    full.pipe.route_flags = _hip.XH_ROUTE_REASSOC | _hip.XH_ROUTE_VALIDATE
+    full.pipe.out['chs'].zero()
+    full.pipe.run_mrtm()
+    within('validated')
+    assert full.pipe.plan.info()['validated'] == n_val + 1
+    full.pipe.route_flags = 0
+    full.pipe.run_mrtm()                              # (the module's other tests look at the bit-exact kernel again)
+    _check(full, tag='bit-exact again')
+
+
 def test_config3_all_cell_pm_abcd_parity(full):
     """EVERY cell of the full grid, not a sample: PET of 67,420 cells x 60 months against oracle.pm (penman_monteith.py:394-477)
     and AET / Q / Sav of 67,420 cells x (600 + 120 spin-up) months against oracle.abcd (abcd.py:357-391) fed with the run's own

@@ -628,18 +628,29 @@ def test_fed_routing_equals_stage_by_stage(hip, nm, abcd_spin, route_spin):
     ctx = hip.get_context()
     w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=7, seed=17, outlet_frac=0.02)
     pipe = pipeline_from_world(ctx, w, nm, 1971, abcd_spin, route_spin)
-    ctx.synth_forcing(23, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.004)
-    pipe.run(fed=False, fused=False)
-    ref = pipe.download()
-    assert np.isnan(ref['q']).any() and np.isfinite(ref['avg']).any() and np.nanmax(ref['chs']) > 0
+    lat = ctx.upload(w.latitude)
+    # Two forcings, alternating: the staged copy of the runoff, the hand-over words and the stream rings are
+    # reused from call to call, so with ONE forcing a stale staged line -- left in a cache by the previous call -- would hold
+    # the right values and pass.  With two, every call must read what ITS OWN side stream wrote.
+    refs = {}
+    for seed in (23, 57):
+        ctx.synth_forcing(seed, w.ncell, nm, lat, pipe.alloc_forcing(), nan_frac=0.004)
+        pipe.run(fed=False, fused=False)
+        refs[seed] = pipe.download()
+        ref = refs[seed]
+        assert np.isnan(ref['q']).any() and np.isfinite(ref['avg']).any() and np.nanmax(ref['chs']) > 0
+    assert not np.array_equal(refs[23]['q'], refs[57]['q'], equal_nan=True)
     n0 = ctx.timing('feed_gate')[1]
     for rep in range(4):
+        seed = (23, 57)[rep & 1]
+        ctx.synth_forcing(seed, w.ncell, nm, lat, pipe.alloc_forcing(), nan_frac=0.004)
         for k in OUTPUTS:
             pipe.out[k].zero()
         pipe.run(fed=True, fused=False)
         got = pipe.download()
         for k in OUTPUTS:
-            assert np.array_equal(got[k], ref[k], equal_nan=True), (k, rep)
+            assert np.array_equal(got[k], refs[seed][k], equal_nan=True), (k, rep)
+    ref = refs[57]
     # the calls really were routed that way (the gate kernel of the side stream ran once per call), without a re-route
     assert ctx.timing('feed_gate')[1] == n0 + 4
     assert pipe.plan.info()['reroutes'] == 0 and pipe.plan.info()['last_tree_kernel'] == 2
@@ -652,6 +663,47 @@ def test_fed_routing_equals_stage_by_stage(hip, nm, abcd_spin, route_spin):
     for k in OUTPUTS:
         assert np.array_equal(got[k], ref[k], equal_nan=True), k
     assert ctx.timing('feed_gate')[1] == n0 + 4 and pipe.plan.info()['last_tree_kernel'] == 0
+
+
+def test_fault_inside_a_fed_call_is_settled_silently(hip):
+    """a routing fault inside a FED call (XH_ROUTE_TEST_FAULT raises the fault word as a timed-out wait would)
+    is settled like one inside a stage-by-stage call -- the call is routed again from the complete runoff array and the
+    caller hears nothing: what the side stream enqueued behind the routing kernel (the rest of PM and ABCD) reads none of
+    the routing's outputs and must not count as "work that consumed invalid results"."""
+    from xanthos_amd import synth
+    from xanthos_amd.pipeline import OUTPUTS, pipeline_from_world
+    ctx = hip.get_context()
+    w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=7, seed=19, outlet_frac=0.02)
+    nm = 240
+    pipe = pipeline_from_world(ctx, w, nm, 1971, 25, 24)
+    ctx.synth_forcing(41, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.002)
+    pipe.run(fed=False, fused=False)
+    ref = pipe.download()
+    r0, n0 = pipe.plan.info()['reroutes'], ctx.timing('feed_gate')[1]
+    pipe.route_flags = hip.XH_ROUTE_TEST_FAULT
+    for k in OUTPUTS:
+        pipe.out[k].zero()
+    pipe.run(fed=True, fused=False)
+    ctx.sync()                                   # settles the fault: no exception
+    got = pipe.download()
+    for k in OUTPUTS:
+        assert np.array_equal(got[k], ref[k], equal_nan=True), k
+    assert ctx.timing('feed_gate')[1] == n0 + 1                  # the call really ran in the fed order ...
+    assert pipe.plan.info()['reroutes'] == r0 + 1                # ... and its routing was done again after the fault
+    # the same fault followed by work that DOES read the routing's outputs is still reported
+    pipe.route_flags = hip.XH_ROUTE_TEST_FAULT
+    pipe.run(fed=True, fused=False)
+    rows = ctx.upload(np.arange(8, dtype=np.int64), dtype=np.int64)
+    tmp = ctx.empty((8, nm))
+    ctx.gather_rows(pipe.out['chs'], rows, 8, nm, tmp)
+    with pytest.raises(hip.HipError):
+        ctx.sync()
+    pipe.route_flags = 0
+    # (the plan backs off after a fault; the next calls route without the dataflow kernels and still agree)
+    pipe.run(fed=True, fused=False)
+    got = pipe.download()
+    for k in OUTPUTS:
+        assert np.array_equal(got[k], ref[k], equal_nan=True), k
 
 
 def test_fed_routing_notices_new_velocities_in_place(hip):

@@ -17,12 +17,20 @@ calls = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 ctx = _hip.get_context(0)
 w = synth.make_world()
 pipe = pipeline_from_world(ctx, w, 600, 1961, 120, 120)
-ctx.synth_forcing(3, w.ncell, 600, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.001)
-pipe.run(fed=False)
-ctx.sync()
-ref = {k: pipe.out[k].download() for k in ('q', 'chs', 'avg')}
+lat = ctx.upload(w.latitude)
+# two forcings, alternating: a stale staged line left over from the previous call must not be able to pass for the right one
+refs = {}
+for seed in (3, 4):
+    ctx.synth_forcing(seed, w.ncell, 600, lat, pipe.alloc_forcing(), nan_frac=0.001)
+    pipe.run(fed=False)
+    ctx.sync()
+    refs[seed] = {k: pipe.out[k].download() for k in ('q', 'chs', 'avg')}
 bad, faults, times = 0, 0, []
 for i in range(calls):
+    seed = (3, 4)[i & 1]
+    ref = refs[seed]
+    ctx.synth_forcing(seed, w.ncell, 600, lat, pipe.alloc_forcing(), nan_frac=0.001)
+    ctx.sync()
     for k in ('q', 'chs', 'avg'):
         pipe.out[k].zero()
     t = time.perf_counter()

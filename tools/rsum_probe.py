@@ -96,4 +96,11 @@ uniq, cnt = np.unique(key, return_counts=True)
 shared = np.isin(key, uniq[cnt > 1])
 print('SIMDs in use %d, with two units %d; units on shared SIMDs: cycles/sub-step of wall median %.0f max %.0f' % (
     len(uniq), int((cnt > 1).sum()), np.median(total[shared] / nsub) if shared.any() else 0, (total[shared] / nsub).max() if shared.any() else 0))
+zone = (raw3 >> np.uint64(44)).astype(int)
+print('boundary groups per unit: median %d max %d of %d groups' % (np.median(zone), zone.max(), nsub // 16))
+order = np.argsort(-loop)
+print('slowest units (cycles/sub-step outside waits, wall, streams, boundary groups, shared SIMD):')
+for u in order[:10]:
+    print('  unit %4d  %.0f  %.0f  %s  %d  %s' % (u, loop[u] / nsub, total[u] / nsub, {0: '-', 16: 'in', 32: 'out', 48: 'in+out'}[shape[u] & 48],
+                                               zone[u], 'shared' if shared[u] else ''))
 sys.exit(0 if ok else 3)

@@ -136,6 +136,10 @@ class Components:
             self.dsid, self.upid, self.um = hit
         return self.um
 
+    def route_flags(self):
+        """[[mrtm]] routing_form -> flag of xh_route_series (0: the library default)."""
+        return {'reassociated': _hip.XH_ROUTE_REASSOC, 'exact': _hip.XH_ROUTE_EXACT}.get(getattr(self.s, 'routing_form', 'default'), 0)
+
     def calculate_routing(self, runoff):
         """Spin-up + simulation of MRTM over all months (components.py:249-296). Returns Avg_ChFlow."""
         if self.s.routing_module == 'mrtm':
@@ -143,7 +147,7 @@ class Components:
             chs, avg, fend = routing_mod.route_series(um, self.data.flow_dist, self.data.str_velocity, self.data.area,
                                                       runoff, self.yr_imth_dys[:, 2], self.s.routing_spinup,
                                                       S0=self.data.chs_prev, dt=self.routing_timestep_hours,
-                                                      device=self.s.device)
+                                                      device=self.s.device, flags=self.route_flags())
             self.ChStorage, self.Avg_ChFlow, self.instream_flow = chs, avg, fend
             return self.Avg_ChFlow
 
@@ -178,7 +182,7 @@ class Components:
                               velocity=d.str_velocity if um is not None else np.zeros(s.ncell), area=d.area,
                               abcd_spinup=s.runoff_spinup, routing_spinup=getattr(s, 'routing_spinup', 0),
                               water_idx=s.pm_water_idx, snow_idx=s.pm_snow_idx, use_snow=d.tmin is not None,
-                              chs_prev=getattr(d, 'chs_prev', None), plan_async=True)
+                              chs_prev=getattr(d, 'chs_prev', None), plan_async=True, route_flags=self.route_flags())
         ctx.sync()
         self.timings['plan'] = time.time() - t          # static uploads; the routing partition runs on a host thread meanwhile
         t = time.time()

@@ -156,7 +156,9 @@ int xh_comm_gather_rows_side(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar
     hipStream_t g = nullptr;
     int rc = xh_gather_stream(ctx, &g);
     if (rc) return rc;
-    if (ctx->runoff_event_fresh && ctx->runoff_event) {
+    // (the event of a fed call stands for "PET / AET / Q / Sav are final" only while nothing else has been enqueued on the
+    // context since -- kernels, copies, row movers all bump work_seq; otherwise order behind the context's stream)
+    if (ctx->runoff_event_fresh && ctx->runoff_event && ctx->work_seq == ctx->runoff_seq) {
         XH_HIP(ctx, hipStreamWaitEvent(g, ctx->runoff_event, 0));
         ctx->runoff_event_fresh = false;
     } else {
@@ -164,7 +166,19 @@ int xh_comm_gather_rows_side(xh_ctx *ctx, xh_comm *c, int32_t root, int32_t nvar
         XH_HIP(ctx, hipStreamWaitEvent(g, ctx->gather_event, 0));
     }
     ctx->gather_pending = true;
+    // A side gather that moves none of the routing's outputs is not "work behind the routing call" for the settling of a
+    // routing fault (xh_fault_check): the re-routed call leaves what it gathered untouched.
+    const uint64_t seq_before = ctx->work_seq;
+    bool routed_arrays = false;
+    if (!ctx->pending_routes.empty() && h_d_local) {
+        const xh_route_record &pr = ctx->pending_routes.back();
+        for (int v = 0; v < nvar; ++v)
+            routed_arrays = routed_arrays || (h_d_local[v] && (h_d_local[v] == pr.chs || h_d_local[v] == pr.avg ||
+                                                                h_d_local[v] == pr.S_end || h_d_local[v] == pr.F_end));
+    }
     rc = gather_rows_on(ctx, g, c, root, nvar, h_d_local, ncols, h_counts, d_perm, h_d_out);
+    if (!routed_arrays && !ctx->pending_routes.empty() && ctx->pending_routes.back().seq_after == seq_before)
+        ctx->pending_routes.back().seq_after = ctx->work_seq;
     XH_HIP(ctx, hipEventRecord(ctx->gather_event, g));
     return rc;
 }

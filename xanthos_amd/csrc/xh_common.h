@@ -30,6 +30,7 @@ struct xh_route_record {
     const double *flow_dist = nullptr, *velocity = nullptr, *area = nullptr, *runoff = nullptr, *S0 = nullptr;
     double *chs = nullptr, *avg = nullptr, *S_end = nullptr, *F_end = nullptr;
     uint64_t seq_after = 0;        // ctx->work_seq right after the call was enqueued
+    bool fed = false;              // routed while the side stream still produced its runoff (xh_run_fused mode 1)
 };
 int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r, bool dataflow_pairs);      // xh_mrtm.hip: workgroup per network, or the dataflow kernel with every unit in pair form
 void xh_route_confirm(const xh_route_record &r);                // xh_mrtm.hip: the call's dataflow kernel ran fault-free
@@ -77,6 +78,12 @@ struct xh_ctx {
     // xh_upload_file / xh_download_file: page-locked chunk ring of the file movers (grow-only)
     void *io_ring = nullptr;
     size_t io_ring_bytes = 0;
+    // fed order (xh_run_fused mode 1): work_seq at the end of the call that left `runoff_event` (a side gather may use the event
+    // only while nothing else has been enqueued on the context since); whether the side stream has a hardware queue of its own
+    // (a priority level apart from the context's stream -- without one the fed order cannot run); switched off after a fed
+    // call's routing kernel waited in vain for its months (serialised kernels, e.g. under a counter-collecting profiler)
+    uint64_t runoff_seq = 0;
+    bool feed_queue_ok = true, feed_disabled = false;
 };
 
 // Fault code of the routing kernel's plain units: an input outside the argument that lets them gather one value per term

@@ -114,9 +114,19 @@ int xh_fault_check(xh_ctx *ctx) {
                 code, pending.size());
         if (ctx->d_feed) {      // a fed call (xh_run_fused mode 1): how far the side stream had come
             unsigned w[48] = {0};
-            if (hipMemcpy(w, ctx->d_feed, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess)
+            if (hipMemcpy(w, ctx->d_feed, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess) {
                 fprintf(stderr, "[libxanthos_hip]   fed routing: months ready %u, placement epoch %u of %u\n", w[0], w[32],
                         ctx->feed_epoch);
+                // a fed call whose routing kernel gave up waiting for data: most likely the side stream's kernels do not run
+                // beside it here (kernels serialised by a profiler's counter passes or AMD_SERIALIZE_KERNEL) -- stage by
+                // stage from now on instead of one 5 s wait per call after every back-off
+                bool any_fed = false;
+                for (const xh_route_record &r : pending) any_fed = any_fed || r.fed;
+                if (code == 1 && any_fed) {
+                    ctx->feed_disabled = true;
+                    fprintf(stderr, "[libxanthos_hip]   the fed stage order is switched off for this context\n");
+                }
+            }
         }
         std::vector<xh_route_plan *> plans;
         for (const xh_route_record &r : pending) {

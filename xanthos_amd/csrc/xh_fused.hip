@@ -55,6 +55,9 @@ int fused_resources(xh_ctx *ctx, size_t n_events) {
         // (the context's stream has the default priority 0; a device whose range has nothing below it gets the other end;
         // XH_FEED_PRIO=high / low: experiments)
         int prio = least != 0 ? least : greatest;
+        // one priority level only: the side stream would share the context stream's hardware queues and its kernels could sit
+        // behind the routing kernel that waits for them -- no fed order on such a device (run_fed turns the call down)
+        ctx->feed_queue_ok = least != greatest;
         if (const char *env = getenv("XH_FEED_PRIO")) prio = env[0] == 'h' ? greatest : least;
         XH_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream[0], hipStreamNonBlocking, prio));
         if (getenv("XH_FLOW_DEBUG")) fprintf(stderr, "[libxanthos_hip] side stream priority %d (range %d .. %d)\n", prio, least, greatest);
@@ -117,6 +120,10 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
                                    a->d_sav, staged);
     };
     if (nmonths - b0 < 64) return XH_ERR_LIMIT;
+    // nothing has been enqueued yet: a device without a second priority level, or a context on which a fed call has already
+    // waited in vain for its side stream (kernels serialised by a profiler's counter collection, AMD_SERIALIZE_KERNEL), runs
+    // stage by stage
+    if (!ctx->feed_queue_ok || ctx->feed_disabled) return XH_ERR_LIMIT;
     // the routing kernel's copy of the runoff and the two words of the hand-over (each on a line of its own)
     const size_t lines = (size_t)(nmonths + 15) / 16;
     const size_t need = lines * (size_t)a->ncell * 128 + 256;
@@ -198,6 +205,11 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
     };
     rc = rest();
     if (rc) first_error = ctx->err;
+    // What went to stream B reads none of the routing's outputs: it does not count as "work enqueued behind the routing call"
+    // when a fault of this call is settled (xh_fault_check: the call is then routed again from the complete runoff array and
+    // the caller hears nothing, as after a stage-by-stage call).
+    if (!ctx->pending_routes.empty() && ctx->pending_routes.back().plan == a->plan && ctx->pending_routes.back().chs == a->d_chstorage)
+        ctx->pending_routes.back().seq_after = ctx->work_seq;
     // join, whatever happened: later calls on the context's stream (and xh_sync) are ordered behind stream B
     const hipError_t j1 = hipEventRecord(ev_done, B);
     const hipError_t j2 = j1 == hipSuccess ? hipStreamWaitEvent(A, ev_done, 0) : j1;
@@ -208,6 +220,7 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
     if (!rc) {      // PET / AET / Q / Sav are final once ev_done has fired: a side gather of them need not wait for the routing
         ctx->runoff_event = ev_done;
         ctx->runoff_event_fresh = true;
+        ctx->runoff_seq = ctx->work_seq;      // (any later entry point that enqueues work on the context makes the event stale)
     }
     if (rc) {
         // the routing kernel may be waiting for months that will never come: raise the fault word so that it gives up
@@ -241,7 +254,7 @@ extern "C" int xh_run_fused(xh_ctx *ctx, const xh_fused_args *a) {
     rc = xh_abcd_prepare(ctx, a->ncell, nmonths, a->abcd_spinup, a->n_groups, a->h_basin_index, a->h_par_index,
                          a->npar_rows, &ab);
     if (rc || a->ncell == 0) return rc;
-    const int nblk = (nmonths + block - 1) / block;
+    int nblk = (nmonths + block - 1) / block;
     rc = fused_resources(ctx, (size_t)nblk + 3);
     if (rc) return rc;
     if (a->mode == 1 && a->plan) {
@@ -252,7 +265,12 @@ extern "C" int xh_run_fused(xh_ctx *ctx, const xh_fused_args *a) {
             return xh_route_series(ctx, a->plan, nmonths, a->routing_spinup, a->h_ndays, a->dt, a->d_flow_dist, a->d_velocity,
                                    a->d_area, a->d_q, a->d_S0, a->d_chstorage, a->d_avgchflow, nullptr, nullptr,
                                    a->route_flags);
-        // (too few months: nothing has been enqueued, the block pipeline below does the whole series)
+        // (too few months, or no fed order on this context: nothing has been enqueued; the pipeline below does the whole series,
+        // in ONE block when the fed order was refused for the device's sake -- PM, then ABCD, then the routing)
+        if (!ctx->feed_queue_ok || ctx->feed_disabled) {
+            block = (nmonths + 47) / 48 * 48;
+            nblk = 1;
+        }
     }
     hipStream_t A = ctx->stream, B = ctx->side_stream[0];
     hipEvent_t ev_start = ctx->side_events[0], ev_done = ctx->side_events[1];

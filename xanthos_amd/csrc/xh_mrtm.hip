@@ -490,14 +490,23 @@ void launch_units(const xh_route_plan *plan, int cls, RouteArgs args, hipStream_
 
 static void route_plan_free(xh_route_plan *plan, bool settle);
 
-// XH_ROUTE_REASSOC=1 / 0 in the environment: the reassociated form for every call that does not carry XH_ROUTE_EXACT / never.
-// Without it the flag of the call decides (default: the bit-exact kernels).
+// Which form routes the tree networks of a call.  The call's flag decides (XH_ROUTE_EXACT / XH_ROUTE_REASSOC), else
+// XH_ROUTE_REASSOC=1 / 0 in the environment, else the library default: the reassociated form (round 5: <= 3e-12 of the
+// bit-exact kernel on every routed value of the full grid against a gate of 1e-6, 15.3 against 22.6 ms).
+#ifndef XH_REASSOC_DEFAULT
+#define XH_REASSOC_DEFAULT 1
+#endif
 static int reassoc_env() {
     static const int v = [] {
         const char *e = getenv("XH_ROUTE_REASSOC");
         return !e ? -1 : (e[0] == '0' ? 0 : 1);
     }();
     return v;
+}
+static bool reassoc_wanted(int flags) {
+    if (flags & XH_ROUTE_EXACT) return false;
+    if (flags & XH_ROUTE_REASSOC) return true;
+    return reassoc_env() >= 0 ? reassoc_env() == 1 : XH_REASSOC_DEFAULT != 0;
 }
 
 // The reassociated partition of the plan's tree networks (host planner + upload).  XH_OK with plan->flow_rsum == nullptr and
@@ -510,9 +519,47 @@ static int rsum_plan_build(xh_ctx *ctx, xh_route_plan *plan) {
     FlowTables t;
     std::string err;
     const FlowPlanOptions opt = flow_plan_options(ctx);
-    if (flow_tables_build_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(), plan->h_sign.data(),
-                               plan->h_comp.data(), plan->h_ncomp, opt, handled, t, err) != 0 || t.n_units == 0)
-        return XH_OK;
+    // the partition of a grid is the same every time (topology, planner options, library build): kept in the per-box cache
+    // beside the bit-exact one (flow_plan_build) and held to the planner's own invariant checker before it is used
+    std::string cache;
+    static const bool cache_on = !(getenv("XH_ROUTE_LEARN_CACHE") && getenv("XH_ROUTE_LEARN_CACHE")[0] == '0');
+    if (cache_on && !opt.debug) {
+        std::string dir;
+        if (const char *d = getenv("XH_CACHE_DIR")) dir = d;
+        else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/xanthos_amd";
+        if (!dir.empty()) {
+            uint64_t h = plan->topo_hash;
+            const int knobs[2] = {opt.simds, opt.piece_cap};
+            for (size_t i = 0; i < sizeof(knobs); ++i) h = (h ^ reinterpret_cast<const unsigned char *>(knobs)[i]) * 1099511628211ull;
+            for (const char *b = __DATE__ " " __TIME__; *b; ++b) h = (h ^ (unsigned char)*b) * 1099511628211ull;
+            char name[96];
+            snprintf(name, sizeof(name), "/rsum_%016llx_%lld.tables", (unsigned long long)h, (long long)plan->ncell);
+            cache = dir + name;
+        }
+    }
+    bool loaded = false;
+    if (!cache.empty() && flow_tables_load(cache.c_str(), t) && t.rsum && t.n_units > 0 &&
+        (int64_t)t.cell_of_slot.size() == (int64_t)t.n_units * 64) {
+        handled.assign((size_t)plan->ncell, 0);
+        loaded = true;
+        for (int c : t.cell_of_slot) {
+            if (c >= plan->ncell) loaded = false;
+            else if (c >= 0) handled[c] = 1;
+        }
+        loaded = loaded && flow_tables_check_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
+                                                  plan->h_sign.data(), handled, t).empty();
+    }
+    if (!loaded) {
+        if (flow_tables_build_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(), plan->h_sign.data(),
+                                   plan->h_comp.data(), plan->h_ncomp, opt, handled, t, err) != 0 || t.n_units == 0)
+            return XH_OK;
+        if (!cache.empty()) {
+            const std::string dir = cache.substr(0, cache.rfind('/'));
+            for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
+                if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
+            (void)flow_tables_save(t, cache.c_str());
+        }
+    }
     if (t.n_cells != plan->flow->n_cells) return XH_OK;      // must route exactly the cells the bit-exact plan routes
     if (getenv("XH_FLOW_CHECK")) {
         const std::string bad = flow_tables_check_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
@@ -620,7 +667,7 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
             plan->h_sign.assign(h_sign, h_sign + nnz);
             plan->h_comp = comp;
             plan->h_ncomp = ncomp;
-            if (reassoc_env() == 1) {      // the form every call will ask for: its partition is made with the plan
+            if (reassoc_wanted(0)) {       // the form calls without a flag will ask for: its partition is made with the plan
                 const int rrc = rsum_plan_build(ctx, plan);
                 if (rrc) {
                     route_plan_free(plan, false);
@@ -1213,7 +1260,7 @@ static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
                              double *d_F_end, int32_t flags, const FlowFeed *feed) {
     bool used_flow = false;
     if (plan && plan->skip_calls > 0 && (flags & XH_ROUTE_TEST_FAULT) == 0) {      // recently faulted: see xh_route_plan
-        plan->skip_calls -= 1;
+        if (!feed) plan->skip_calls -= 1;      // (a fed call is turned down below and comes back as an ordinary one: counted there)
         flags |= XH_ROUTE_NO_DATAFLOW;
     }
     static const bool validate_env = getenv("XH_ROUTE_VALIDATE") && getenv("XH_ROUTE_VALIDATE")[0] == '1';
@@ -1221,14 +1268,14 @@ static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     flags &= ~XH_ROUTE_VALIDATE;
     // first dataflow call of this plan on a box / build that has not passed the cross-check yet: checked like XH_ROUTE_VALIDATE
     const bool plain_call = plan && (flags & (XH_ROUTE_NO_DATAFLOW | XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_ATOMIC | XH_ROUTE_TEST_FAULT)) == 0;
-    const bool want_rsum = plan && ((flags & XH_ROUTE_REASSOC) != 0 || reassoc_env() == 1) && (flags & XH_ROUTE_EXACT) == 0 &&
-                           reassoc_env() != 0 && (flags & XH_ROUTE_NO_SKEW) == 0;
+    const bool want_rsum = plan && reassoc_wanted(flags) && (flags & XH_ROUTE_NO_SKEW) == 0;
     const bool first_check = !validate && plain_call && first_check_needed(ctx, plan, want_rsum);
     validate = validate || first_check;
     // a fed call cannot be cross-checked at once (the second routing would read runoff that does not exist yet), nor
     // routed by anything but the dataflow kernel that knows how to wait for it
-    if (feed && (validate || (flags & (XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_ATOMIC |
-                                       XH_ROUTE_TEST_FAULT)) != 0))
+    // (XH_ROUTE_TEST_FAULT is taken: the fault word is raised in front of the launch, the units that have to wait give up, and
+    // the call is settled like any faulted one -- routed again from the runoff array, complete by then)
+    if (feed && (validate || (flags & (XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_ATOMIC)) != 0))
         return XH_ERR_LIMIT;
     int rc = route_series_impl(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff,
                                d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end, flags, &used_flow, feed);
@@ -1251,6 +1298,7 @@ static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     r.S_end = d_S_end;
     r.F_end = d_F_end;
     r.seq_after = ctx->work_seq;
+    r.fed = feed != nullptr;
     ctx->pending_routes.push_back(std::move(r));
     rc = xh_fault_collect(ctx);
     if (rc || !validate) return rc;
@@ -1384,8 +1432,7 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     static const bool old_skew_env = getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] != '1';
     // Reassociated form (XH_ROUTE_REASSOC, flag or environment): a partition of its own, nothing to learn -- the typed / adaptive
     // machinery below is for the bit-exact kernel only.
-    bool use_rsum = ((flags & XH_ROUTE_REASSOC) != 0 || reassoc_env() == 1) && (flags & XH_ROUTE_EXACT) == 0 && reassoc_env() != 0 &&
-                    plan->flow && !old_skew_env &&
+    bool use_rsum = reassoc_wanted(flags) && plan->flow && !old_skew_env &&
                     (flags & (XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_ATOMIC)) == 0;
     if (use_rsum) {
         if ((rc = rsum_plan_build(ctx, plan)) != XH_OK) return rc;

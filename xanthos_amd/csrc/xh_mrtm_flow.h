@@ -94,6 +94,7 @@ int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
 // Round 3's time-skewed kernel (xh_mrtm_wave.hip): same contract, same plan tables, pair and plain units.
 int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st);
 const void *wave_rsum_kernel();      // k_mrtm_rsum (xh_mrtm_rsum.hip): the kernel wave_launch starts for a reassociated plan
+const void *wave_exact_kernel();     // k_mrtm_wave (xh_mrtm_wave.hip)
 // Per-unit cycle accounting of the last launch (only when XH_FLOW_STATS=1): 6 words per unit
 // {shader cycles in sub-step loops, shader cycles total, 100 MHz ticks total, shape bits, data-wait, ring-wait cycles}.
 int flow_stats_fetch(xh_ctx *ctx, FlowPlan *fp, std::vector<unsigned long long> &out);

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
         if (prio == 3) __builtin_amdgcn_s_setprio(3);
         else if (prio == 1) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(2);
-    } else if (prio == 3) {
+    } else if (prio == 3 && !(A(balance) & 2)) {
         __builtin_amdgcn_s_setprio(3);
     }
     const int p = A(unit_p)[unit];       // 0x400 | 1 (reads the inflow entry) | 2 (reads the chain entry)

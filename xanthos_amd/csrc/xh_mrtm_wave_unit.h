@@ -87,7 +87,8 @@ struct WaveArgs {
     const unsigned *months_ready;
     unsigned *place_epoch;
     unsigned epoch;
-    int balance;                      // XH_WAVE_BALANCE=1: claim units by LDS-load quarter and SIMD id (placement); default: arrival order
+    int balance;                      // bit 0: XH_WAVE_BALANCE=1: claim units by LDS-load quarter and SIMD id (placement); default: arrival order
+                                      // bit 1 (k_mrtm_rsum only): XH_WAVE_PRIO=0 (experiment): SIMD partners at equal issue priority
     int fenced;                       // XH_ROUTE_FENCED=1: agent-scope release / acquire fences around the stream counters (see check())
     char *xbuf;                       // [edges][RS] {F, F2}
     unsigned xbytes;                  // size of the rings
@@ -659,7 +660,9 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             const double S1 = PRE ? __builtin_fma(ac[0].x, dt, base) : base;  // trial storage: S + dSdt dt (mrtm.py:51, 54)
             const double S2 = PRE ? __builtin_fma(ac[0].y, dt, base) : base;  // the same with the adjusted inflows (mrtm.py:66-69)
             const bool sx = S1 < 0.0;                                          // mrtm.py:54: dSdt dt < -S
-            const double f2 = sx ? __builtin_fma(S1, dtinv, F0) : F0;         // mrtm.py:60
+            // mrtm.py:60 as F + min(S1, 0) / dt: v_min_f64 + v_fma_f64 instead of the fma and two selects (min(NaN, 0) = 0
+            // leaves F2 = F = NaN for a cell whose storage is NaN, as the reference does)
+            const double f2 = __builtin_fma(__builtin_fmin(S1, 0.0), dtinv, F0);
             own[(j & (RING - 1)) * NSLOT] = CHAIN ? v2d{rc.x + F0, rc.y + f2} : v2d{F0, f2};
             double Sn = S2;
             asm volatile("" : "+v"(Sn));
@@ -896,7 +899,7 @@ __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *pr
                     // out -- the SIMD ids of the shared SIMDs are not spread evenly -- sends the workgroup to the next one)
                     const int rest = n_units - 2 * need2, q = (rest + 3) >> 2;
                     const int s0 = (int)((hw >> 4) & 3u);
-                    const bool balance = A(balance) != 0;
+                    const bool balance = (A(balance) & 1) != 0;
                     if (!balance) {
                         idx = 2 * need2 + (int)add(6);
                     } else {
