@@ -38,7 +38,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 SHADER_CLOCK_HZ = 2.4e9        # MI355X peak engine clock (MI355X_MICROARCH.md); s_memtime showed 2.37 GHz under this load
-SUBSTEP_FLOOR_CYCLES = {'pair': 186.0, 'plain': 137.0}      # lone-wave cost of one routing sub-step (tools/micro/substep_plain.hip)
+# lone-wave cost of one routing sub-step, nothing else on the device: a (2,3) row in the bit-exact pair form / a (2,4) row in its
+# plain form (tools/micro/substep_plain.hip, round 3), the reassociated form with both of its reads (tools/micro/substep_rsum.hip,
+# round 5; profiles/round5/substep_rsum.txt)
+SUBSTEP_FLOOR_CYCLES = {'pair': 186.0, 'plain': 137.0, 'reassoc': 104.0}
+LDS_BYTES_PER_CLK = 128.0      # per CU (MI355X_MICROARCH.md, LDS)
+ROUTE_KERNELS = {4: 'k_mrtm_rsum', 2: 'k_mrtm_wave', 3: 'k_mrtm_skew', 1: 'k_mrtm_flow'}
 NCELL, NBASINS = 67420, 235
 
 
@@ -179,18 +184,48 @@ def cpu_baseline(pipe, world, args, log):
                                                   pipe.ndays[:km], 0)
             t_mrtm = time.perf_counter() - t
             res['mrtm'] = world.ncell * km / t_mrtm
+            from xanthos_amd import _hip as _h
             g_chs, g_avg, _ = mrtm.route_series(pipe.um, world.flow_dist, world.velocity, world.area, q_host,
-                                                pipe.ndays[:km], 0)
+                                                pipe.ndays[:km], 0, flags=_h.XH_ROUTE_EXACT)
             parity['routing_months_checked'] = '{} (no spin-up); the default checks the whole run'.format(km)
             mrtm_note = 'MRTM {} months 1 thread = {:.3g} cm/s ({:.1f} s), x{:.2f} for routing spin-up'.format(
                 km, res['mrtm'], t_mrtm, 1.0 + pipe.routing_spinup / nm)
+        from xanthos_amd import _hip
+        reassoc_run = mrtm_full and int(pipe.plan.info()['last_tree_kernel']) == 4
+        parity['routing_form'] = 'reassociated (k_mrtm_rsum)' if reassoc_run else 'bit-exact'
+        if reassoc_run:
+            # The run's own outputs came from the reassociated form (the library default): equal to the oracle to rounding.
+            # The bar is the one the form was accepted on -- identical NaN masks, every value within 1e-9 |ref| (+ 1e-3 m3 /
+            # 1e-9 m3/s) -- far inside the north star's 1e-6; a value beyond it fails the run like a wrong bit did before.
+            rr = {}
+            for name, g, r, atol in (('chs', g_chs, r_chs, 1e-3), ('avg', g_avg, r_avg, 1e-9)):
+                nan_equal = bool(np.array_equal(np.isnan(g), np.isnan(r)))
+                m = ~(np.isnan(g) | np.isnan(r))
+                err, ref = np.abs(g[m] - r[m]), np.abs(r[m])
+                big = ref > 1e6 * atol
+                beyond = int((err > 1e-9 * ref + atol).sum())
+                rr[name] = {'nan_pattern_equal': nan_equal, 'max_rel': float((err[big] / ref[big]).max()) if big.any() else 0.0,
+                            'max_abs': float(err.max()), 'beyond_1e-9': beyond,
+                            'beyond_gate_1e-6': int((err > 1e-6 * ref + atol).sum()), 'values_compared': int(m.sum())}
+                if not nan_equal:
+                    failures.append('routing ({}): NaN pattern differs from the oracle'.format(name))
+                if beyond:
+                    failures.append('routing ({}): {} values beyond 1e-9 |ref| + {:g}'.format(name, beyond, atol))
+            parity['routing_reassociated'] = rr
+            # ... and the checker itself: the same runoff through the bit-exact kernel, every value against the oracle's bits
+            flags0 = pipe.route_flags
+            pipe.route_flags = _hip.XH_ROUTE_EXACT
+            pipe.run_mrtm()
+            g_chs, g_avg = pipe.out['chs'].download(), pipe.out['avg'].download()
+            pipe.route_flags = flags0
+            parity['routing_bit_exact_kernel'] = ROUTE_KERNELS.get(int(pipe.plan.info()['last_tree_kernel']), 'k_mrtm_units')
         parity['routing_bit_exact'] = bool(np.array_equal(g_chs, r_chs, equal_nan=True) and
                                            np.array_equal(g_avg, r_avg, equal_nan=True))
         parity['routing_values_compared'] = int(g_chs.size + g_avg.size)
         if not parity['routing_bit_exact']:
             bad = int((~((g_chs == r_chs) | (np.isnan(g_chs) & np.isnan(r_chs)))).sum() +
                       (~((g_avg == r_avg) | (np.isnan(g_avg) & np.isnan(r_avg)))).sum())
-            failures.append('routing: {} values of ChStorage / Avg_ChFlow differ from the oracle'.format(bad))
+            failures.append('routing: {} values of ChStorage / Avg_ChFlow of the bit-exact kernel differ from the oracle'.format(bad))
     inv = 1.0 / res['pm'] + 1.0 / res['abcd']        # the ABCD rate already includes its spin-up pass
     if 'mrtm' in res:
         # the full-size rate counts the spin-up months as work done; the sampled one is scaled by them
@@ -216,35 +251,76 @@ def cpu_baseline(pipe, world, args, log):
             'full_size_stages': {'pm': bool(k == nm), 'abcd': True, 'mrtm': bool(mrtm_full)}}, parity, failures
 
 
-def routing_selective(ctx, pipe, log):
-    """Secondary measurement, never `value`: the routing alone with the selective plain form asked for explicitly (DESIGN.md
-    4.3: the units that read >= 5 values per sub-step and hold no cell needing both flows gather one 8-byte value per term)
-    -- the form the adaptive default reaches by itself after a few calls on one plan; the steady state is what is timed."""
+def routing_forms(ctx, pipe, log, nsub):
+    """Secondary measurement, never `value`: the routing kernel ALONE in both of its forms on the run's own runoff -- the
+    reassociated form (XH_ROUTE_REASSOC, the default: k_mrtm_rsum) and the bit-exact one (XH_ROUTE_EXACT: k_mrtm_wave in its
+    steady state, i.e. after the adaptive plain form has taken over) -- each with the figures of merit of DESIGN.md section 5:
+    `critical_path` (shader cycles per sub-step of the launch against the lone-wave floor of the form) and, from one more
+    launch with the per-unit accounting switched on (XH_FLOW_STATS=1: st[3] holds each unit's LDS operations per sub-step and
+    the SIMD it ran on), `lds` = LDS bytes a CU moves per sub-step / (128 B/clk x achieved cycles) and the slowest unit."""
     from xanthos_amd import _hip
-    os.environ['XH_FLOW_PLAIN_MIN_READS'] = '5'        # read when the typed plan is built, i.e. at the first flagged call
     flags0 = pipe.route_flags
+    out = {}
     try:
-        pipe.route_flags = flags0 | _hip.XH_ROUTE_TYPED
-        for _ in range(3):                             # plan, guard trip + re-plan with what was learnt, steady
-            pipe.run_mrtm()
-            ctx.sync()                                 # (a guard trip is settled, and learnt from, at a synchronisation)
-        trips0 = int(pipe.plan.typed_info()['guard_trips'])
-        ctx.timing_reset()
-        for _ in range(3):
-            pipe.run_mrtm()
-        ctx.sync()
-        ms, n = ctx.timing('mrtm_route')
-        info = pipe.plan.typed_info()
+        for name, flag, warm in (('reassociated', _hip.XH_ROUTE_REASSOC, 2), ('bit_exact', _hip.XH_ROUTE_EXACT, 6)):
+            pipe.route_flags = flag
+            for _ in range(warm):                          # bit-exact: the selective plain form arrives after a few calls
+                pipe.run_mrtm()
+                ctx.sync()
+                time.sleep(0.05)
+            ctx.timing_reset()
+            for _ in range(3):
+                pipe.run_mrtm()
+            ctx.sync()
+            ms, n = ctx.timing('mrtm_route')
+            ms /= max(n, 1)
+            info = pipe.plan.info()
+            kern = int(info['last_tree_kernel'])
+            ti = pipe.plan.typed_info()
+            floor = SUBSTEP_FLOOR_CYCLES['reassoc' if kern == 4 else ('plain' if ti['plain_units'] > 0 else 'pair')]
+            achieved = ms * 1e-3 / nsub * SHADER_CLOCK_HZ
+            rec = {'mrtm_route_ms': ms, 'device_kernel': ROUTE_KERNELS.get(kern, 'k_mrtm_units'), 'units': int(info['flow_units']),
+                   'streams': int(info['flow_edges']), 'pipeline_depth': int(info['flow_depth']), 'max_lane_lag': int(info['skew_max_lag']),
+                   'plain_units': int(ti['plain_units']) if kern != 4 else 0,
+                   'critical_path': {'substeps': nsub, 'floor_cycles': floor, 'achieved_cycles': achieved, 'frac': floor / achieved,
+                                     'clock_hz': SHADER_CLOCK_HZ}}
+            # per-unit accounting: one launch with the statistics on (costs the units a few cycles per check; not timed above)
+            os.environ['XH_FLOW_STATS'] = '1'
+            try:
+                pipe.run_mrtm()
+                ctx.sync()
+                st = pipe.plan.stats()
+            finally:
+                os.environ.pop('XH_FLOW_STATS', None)
+            if st is not None and len(st):
+                raw3 = st[:, 3]
+                loop = st[:, 0].astype(np.float64) / nsub
+                ops = (raw3 & np.uint64(15)).astype(np.int64)                 # LDS operations per sub-step: reads + the own store
+                plain = ((raw3 >> np.uint64(6)) & np.uint64(1)).astype(np.int64)
+                lds_bytes = ops * 64 * np.where(plain == 1, 8, 16)             # per unit and sub-step (block transfers: +~3 %)
+                hw = (raw3 >> np.uint64(8)) & np.uint64(0xffffffff)
+                cu_key = ((raw3 >> np.uint64(40)) & np.uint64(15)).astype(np.int64) * 4096 + ((hw >> np.uint64(8)) & np.uint64(0xff)).astype(np.int64)
+                per_cu = np.bincount(np.unique(cu_key, return_inverse=True)[1], weights=lds_bytes)
+                slow = int(np.argmax(loop))
+                clock = np.median(st[:, 1].astype(np.float64) / (st[:, 2].astype(np.float64) / 100e6))
+                ach = ms * 1e-3 / nsub * clock                                 # cycles per sub-step at the clock the units saw
+                rec['lds'] = {'bytes_per_cu_per_substep_mean': float(per_cu.mean()), 'bytes_per_cu_per_substep_max': float(per_cu.max()),
+                              'lds_frac': float(per_cu.mean() / (LDS_BYTES_PER_CLK * ach)),
+                              'lds_frac_busiest_cu': float(per_cu.max() / (LDS_BYTES_PER_CLK * ach)),
+                              'bytes_per_clk_peak': LDS_BYTES_PER_CLK, 'cycles_per_substep': float(ach),
+                              'measured_clock_hz': float(clock)}
+                rec['slowest_unit'] = {'cycles_per_substep_outside_waits': float(loop[slow]), 'lds_ops_per_substep': int(ops[slow]),
+                                       'reads_per_substep': int(ops[slow]) - 1, 'plain_form': bool(plain[slow])}
+                rec['unit_cycles_per_substep'] = {'median': float(np.median(loop)), 'p90': float(np.percentile(loop, 90)),
+                                                  'max': float(loop.max())}
+            out[name] = rec
+            log('routing alone, {}: {:.2f} ms ({}; {} units), {:.0f} cycles per sub-step against a floor of {:.0f}'.format(
+                name, ms, rec['device_kernel'], rec['units'], achieved, floor))
     finally:
         pipe.route_flags = flags0
-        os.environ.pop('XH_FLOW_PLAIN_MIN_READS', None)
-    out = {'mrtm_route_ms': ms / max(n, 1), 'plain_units': int(info['plain_units']), 'units': int(info['typed_units']),
-           'guard_trips': int(info['guard_trips']), 'guard_trips_while_timed': int(info['guard_trips']) - trips0,
-           'typed_builds': int(info['typed_builds']),
-           'note': 'XH_ROUTE_TYPED + XH_FLOW_PLAIN_MIN_READS=5 from the first call; bit-exact; the default (adaptive) plan is '
-                   'the one timed in `kernels.mrtm_route`, see routing_plan.form'}
-    log('routing with the selective plain form: {:.2f} ms ({} of {} units plain)'.format(out['mrtm_route_ms'], out['plain_units'],
-                                                                                      out['units']))
+    out['note'] = ('mrtm_route alone on the device, three calls each after warm-up; `reassociated` is the form the timed steps ran in '
+                   'unless routing_plan says otherwise; results of the two forms agree to <= 1e-9 (parity.routing_reassociated), the '
+                   'bit-exact one equals the oracle bit for bit (parity.routing_bit_exact)')
     return out
 
 
@@ -699,6 +775,9 @@ def main():
         ti = pipe.plan.typed_info()
         info['form'] = ('selective plain form ({} of {} units plain; adaptive, tables built on a host thread during the first '
                         'calls)'.format(ti['plain_units'], ti['typed_units']) if ti['plain_units'] > 0 else 'all units in pair form')
+        if int(info.get('last_tree_kernel', 0)) == 4:
+            info['form'] = ('reassociated form (k_mrtm_rsum: row sums as running sums along chains of lanes, two LDS reads per '
+                            'sub-step for every unit, fused update; equal to the reference to rounding, see parity.routing_reassociated)')
         info['guard_trips'] = int(ti['guard_trips'])
     log('routing plan: ' + json.dumps(info))
     value = units_per_step * args.steps / elapsed
@@ -749,8 +828,7 @@ def main():
     # counters cannot be read from inside the run itself.  Each figure carries the device kernel it was taken from and the
     # date of the pass, and is REFUSED (null, with the reason) when that is not the kernel that ran here.
     ran = {'pm_pet': 'k_pm_pet', 'abcd_spinup': 'k_abcd<true>', 'abcd_sim': 'k_abcd_tile<false',
-           'mrtm_route': {2: 'k_mrtm_wave', 3: 'k_mrtm_skew', 1: 'k_mrtm_flow'}.get(int(info.get('last_tree_kernel', 0)),
-                                                                                      'k_mrtm_units')}
+           'mrtm_route': ROUTE_KERNELS.get(int(info.get('last_tree_kernel', 0)), 'k_mrtm_units')}
     if os.environ.get('XH_ABCD_KERNEL') in ('0', '64'):
         ran['abcd_sim'] = 'k_abcd<false>' if os.environ['XH_ABCD_KERNEL'] == '0' else 'k_abcd_tile<false'
     if os.environ.get('XH_MRTM_SKEW') == '2':
@@ -814,12 +892,18 @@ def main():
         # the device (tools/micro/substep_plain.hip, MI355X, round 3: a (2,3)-term unit in pair form / a (2,4)-term unit in
         # plain form); achieved = the launch's time per sub-step in shader cycles.
         achieved = us * 1e-6 * SHADER_CLOCK_HZ
-        roofline['critical_path'] = {'substeps': nsub, 'floor_cycles': SUBSTEP_FLOOR_CYCLES['pair'],
-                                     'floor_cycles_plain_form': SUBSTEP_FLOOR_CYCLES['plain'],
-                                     'achieved_cycles': achieved, 'frac': SUBSTEP_FLOOR_CYCLES['pair'] / achieved,
-                                     'frac_plain_form': SUBSTEP_FLOOR_CYCLES['plain'] / achieved,
-                                     'clock_hz': SHADER_CLOCK_HZ,
-                                     'floor_source': 'tools/micro/substep_plain.hip (lone wave, no neighbours, no streams)'}
+        if ran['mrtm_route'] == 'k_mrtm_rsum':
+            fl = SUBSTEP_FLOOR_CYCLES['reassoc']
+            roofline['critical_path'] = {'substeps': nsub, 'form': 'reassociated', 'floor_cycles': fl, 'achieved_cycles': achieved,
+                                         'frac': fl / achieved, 'clock_hz': SHADER_CLOCK_HZ,
+                                         'floor_source': 'tools/micro/substep_rsum.hip (lone wave, both reads, no streams)'}
+        else:
+            roofline['critical_path'] = {'substeps': nsub, 'form': 'bit-exact', 'floor_cycles': SUBSTEP_FLOOR_CYCLES['pair'],
+                                         'floor_cycles_plain_form': SUBSTEP_FLOOR_CYCLES['plain'],
+                                         'achieved_cycles': achieved, 'frac': SUBSTEP_FLOOR_CYCLES['pair'] / achieved,
+                                         'frac_plain_form': SUBSTEP_FLOOR_CYCLES['plain'] / achieved,
+                                         'clock_hz': SHADER_CLOCK_HZ,
+                                         'floor_source': 'tools/micro/substep_plain.hip (lone wave, no neighbours, no streams)'}
 
     result = {
         'metric': 'cell-months/sec (pm_abcd_mrtm, 67,420 cells)' if args.workload == 'pm_abcd_mrtm'
@@ -872,7 +956,9 @@ def main():
                                   'scaling': 'weak', 'note': '{} independent scenarios, one per GPU'.format(world_size)}
     if rank == 0 and world_size == 1:
         if 'mrtm' in args.stages and not args.no_end_to_end:
-            result['routing_selective_plain'] = routing_selective(ctx, pipe, log)
+            nsub_all = int(sum(int(d * 86400 / 10800) for d in pipe.ndays)) + \
+                int(sum(int(d * 86400 / 10800) for d in pipe.ndays[:args.routing_spinup]))
+            result['routing_forms'] = routing_forms(ctx, pipe, log, nsub_all)
         if not args.no_end_to_end:
             result['end_to_end'] = end_to_end(ctx, pipe, args, log)
             pipe.run(args.stages)                      # outputs of the resident run again, for the parity check below
@@ -886,7 +972,11 @@ def main():
             # not the oracle's bit for bit makes the process exit non-zero (after the line, which says why)
             result['gate'] = {'passed': not failures, 'failures': failures,
                               'checks': 'PET / AET / Q / Sav within 1e-6 |ref| + 1e-9 of the oracle with identical NaN '
-                                        'patterns; ChStorage / Avg_ChFlow bit-identical ({})'.format(
+                                        'patterns; ChStorage / Avg_ChFlow of the run ({}) {}; the bit-exact kernel on the same '
+                                        'runoff bit-identical to the oracle ({})'.format(
+                                            parity.get('routing_form', 'no routing'),
+                                            'within 1e-9 |ref| of the oracle, identical NaN patterns'
+                                            if 'routing_reassociated' in parity else 'bit-identical to the oracle',
                                             parity.get('routing_months_checked', 'no routing'))}
             gate_failed = bool(failures) and not args.no_gate
     if dist is not None:

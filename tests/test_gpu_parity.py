@@ -691,10 +691,10 @@ def test_fault_inside_a_fed_call_is_settled_silently(hip):
     assert ctx.timing('feed_gate')[1] == n0 + 1                  # the call really ran in the fed order ...
     assert pipe.plan.info()['reroutes'] == r0 + 1                # ... and its routing was done again after the fault
     # the same fault followed by work that DOES read the routing's outputs is still reported
+    rows = ctx.upload(np.arange(8, dtype=np.int64), dtype=np.int64)      # (made first: a synchronous upload would settle the fault)
+    tmp = ctx.empty((8, nm))
     pipe.route_flags = hip.XH_ROUTE_TEST_FAULT
     pipe.run(fed=True, fused=False)
-    rows = ctx.upload(np.arange(8, dtype=np.int64), dtype=np.int64)
-    tmp = ctx.empty((8, nm))
     ctx.gather_rows(pipe.out['chs'], rows, 8, nm, tmp)
     with pytest.raises(hip.HipError):
         ctx.sync()
