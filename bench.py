@@ -47,6 +47,37 @@ ROUTE_KERNELS = {4: 'k_mrtm_rsum', 2: 'k_mrtm_wave', 3: 'k_mrtm_skew', 1: 'k_mrt
 NCELL, NBASINS = 67420, 235
 
 
+class TorchGroup:
+    """``torch.distributed`` behind the small process-group interface the package's multi-GPU code asks for (rank, size,
+    bcast, allreduce, gather, barrier: ``xanthos_amd/launch.py``, whose own ``SocketGroup`` is what ``run_model()`` uses).  The
+    bench keeps torch.distributed because the driver starts it under ``torch.distributed.run`` and its timing contract is
+    written in those terms; the group only ever carries ids, flags and -- in the host fall-back of the gather -- rows."""
+
+    def __init__(self, dist, torch, backend):
+        self.dist, self.torch = dist, torch
+        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+        self.dev = 'cuda' if backend == 'nccl' else 'cpu'
+
+    def bcast(self, obj, src=0):
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def allreduce(self, x, op='max'):
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op={'max': self.dist.ReduceOp.MAX, 'min': self.dist.ReduceOp.MIN, 'sum': self.dist.ReduceOp.SUM}[op])
+        v = float(t.item())
+        return int(v) if isinstance(x, int) else v
+
+    def gather(self, obj, root=0, raw=False):
+        got = [None] * self.size if self.rank == root else None
+        self.dist.gather_object(bytes(obj) if raw else obj, got, dst=root)
+        return got
+
+    def barrier(self):
+        self.dist.barrier()
+
+
 def algorithmic_bytes(ncell, nmonths, nlcs, abcd_spinup, routing_spinup):
     """fp64 bytes each kernel must move per launch."""
     cm = ncell * nmonths
@@ -473,7 +504,7 @@ def bench_calib(args, ctx, rank, world_size, dist, torch, backend, log):
     x, fun, nfev, nit, _ = de.result()
     table = np.column_stack([x, fun, nfev, nit])
     if dist is not None:
-        table = gather_results(table, owner, dist)
+        table = gather_results(table, owner, TorchGroup(dist, torch, backend))
     total_mcm = args.members * NCELL * (args.months + args.abcd_spinup)
     value = total_mcm * args.steps / elapsed
     ms = {k: ctx.timing(k) for k in ('calib_abcd', 'calib_kge', 'calib_de')}
@@ -755,7 +786,7 @@ def main():
         pipe = pipeline_from_world(ctx, run_world, args.months, args.start_year, args.abcd_spinup,
                                    args.routing_spinup, um=run_um, route_flags=args.route_flags)
         xdist.fill_shard_forcing(ctx, world, shard, pipe, synth.MASTER_SEED + 1, nan_frac=0.001)      # the whole world's rows
-        gather = xdist.OutputGather(ctx, pipe, shards, rank, world.ncell, dist, torch,
+        gather = xdist.OutputGather(ctx, pipe, shards, TorchGroup(dist, torch, backend), world.ncell,
                                     names=('pet', 'aet', 'q', 'sav') + (('chs', 'avg') if 'mrtm' in args.stages else ()))
         elapsed = timed(pipe, gather)
         units_per_step = NCELL * args.months

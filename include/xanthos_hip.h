@@ -383,6 +383,12 @@ typedef struct xh_comm xh_comm;
 int xh_comm_unique_id(char *id, size_t len);
 int xh_comm_create(xh_ctx *ctx, int32_t nranks, int32_t rank, const char *id, size_t len, xh_comm **out);
 void xh_comm_destroy(xh_comm *comm);
+/*   xh_comm_info        : info[4] = {ranks, this rank, ncclSend calls, ncclRecv calls issued through this communicator so far}.
+ *                         XH_COMM_SELF_LOOP=1 in the environment when a communicator is created (testing on a one-GPU box, with
+ *                         the REAL librccl): the root also sends its OWN rows to itself -- ncclSend and ncclRecv to the own
+ *                         rank inside the group, which RCCL allows -- so they take the whole data path of a remote rank's rows
+ *                         (send kernel, receive into the staging area, row scatter to grid order) instead of the local short cut. */
+int xh_comm_info(const xh_comm *comm, int64_t info[4]);
 int xh_comm_gather_rows(xh_ctx *ctx, xh_comm *comm, int32_t root, int32_t nvar, const double *const *h_d_local,
                         int64_t ncols, const int64_t *h_counts, const int64_t *d_perm, double *const *h_d_out);
 /*   xh_comm_gather_rows_side : the same gather on the context's gather stream (a hardware queue of its own), ordered behind

@@ -1,4 +1,5 @@
-"""Multi-process CPU test (gloo, world_size 2) of the basin sharding and the single output gather."""
+"""Multi-process CPU tests (world_size 2 and 3) of the basin sharding, the launcher, the process group -- the package's own TCP
+rendezvous and torch.distributed's gloo backend behind the same interface -- and the fall-back of the single output gather."""
 import os
 import socket
 import subprocess
@@ -15,29 +16,38 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
-import numpy as np, torch, torch.distributed as dist
+import numpy as np
 from xanthos_amd import synth
-from xanthos_amd.dist import make_shards, gather_to_root
+from xanthos_amd.dist import make_shards, host_gather
 from xanthos_amd.pipeline import topology_from_world
-dist.init_process_group(backend='gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
-rank = dist.get_rank()
+if sys.argv[2] == 'gloo':              # torch.distributed (gloo) behind the same small interface: bench.py's adapter
+    import torch, torch.distributed as dist
+    dist.init_process_group(backend='gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+    import bench
+    group = bench.TorchGroup(dist, torch, 'gloo')
+else:                                  # the package's own TCP rendezvous (no torch anywhere in this process)
+    from xanthos_amd import launch
+    group = launch.current_group()
+    assert 'torch' not in sys.modules
+rank = group.rank
 w = synth.make_world(nrow=36, ncol=72, ncell=900, n_basins=7, seed=33)
 um = topology_from_world(w)
-shards = make_shards(w, um, dist.get_world_size())
+shards = make_shards(w, um, group.size)
 mine = shards[rank].cells
 # "outputs" of this rank: value encodes (variable, global cell, month) so the reassembly can be checked exactly
 nvar, nm = 3, 5
-local = torch.tensor(np.stack([v * 1e6 + mine[:, None] * 10.0 + np.arange(nm)[None, :] for v in range(nvar)]))
-out = gather_to_root(local, shards, w.ncell, dist)
+local = np.stack([v * 1e6 + mine[:, None] * 10.0 + np.arange(nm)[None, :] for v in range(nvar)])
+assert group.allreduce(len(mine), 'sum') == w.ncell and group.allreduce(rank, 'max') == group.size - 1
+assert group.bcast(b'id' * 64 if rank == 0 else None, src=0) == b'id' * 64
+out = host_gather(local, shards, w.ncell, group)
 if rank == 0:
     want = np.stack([v * 1e6 + np.arange(w.ncell)[:, None] * 10.0 + np.arange(nm)[None, :] for v in range(nvar)])
     assert out.shape == (nvar, w.ncell, nm)
-    assert np.array_equal(out.numpy(), want)
+    assert np.array_equal(out, want)
     print('GATHER_OK', [len(s.cells) for s in shards])
 else:
     assert out is None
-dist.barrier()
-dist.destroy_process_group()
+group.barrier()
 '''
 
 
@@ -61,7 +71,14 @@ def test_shards_are_closed_and_balanced():
             assert sub.shape[0] == len(s.cells) and len(sub.indices) == np.diff(um.indptr)[s.cells].sum()
 
 
-def test_gather_to_root_two_ranks_gloo(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize('kind', ['socket', 'gloo'])
+def test_host_gather_two_ranks(tmp_path, kind):
+    """The fall-back of the write-out gather (rows through the process group) and the group's small collectives, with two
+    rank processes on the CPU: through the package's own TCP rendezvous (launch.SocketGroup: what run_model() uses, no
+    torch in the process) and through torch.distributed's gloo backend behind bench.py's adapter."""
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
     with socket.socket() as s:
@@ -70,21 +87,49 @@ def test_gather_to_root_two_ranks_gloo(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, kind], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert 'GATHER_OK' in outs[0]
 
 
+def test_launcher_starts_ranks_and_relays_exit_codes(tmp_path):
+    """launch.spawn: N plain child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, a group
+    that really connects them (three ranks: a max over the ranks, an object from rank 2), the worst exit code returned."""
+    script = tmp_path / 'rank.py'
+    script.write_text("""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+from xanthos_amd import launch
+g = launch.current_group()
+rank, local, world = launch.env_world()
+assert (g.rank, g.size) == (rank, world) == (int(os.environ['RANK']), 3) and local == (0 if sys.argv[2] == '1' else rank)
+assert g.allreduce(rank * 10, 'max') == 20 and g.bcast('x' if rank == 2 else None, src=2) == 'x'
+got = g.gather({'rank': rank}, root=0)
+assert (got == [{'rank': 0}, {'rank': 1}, {'rank': 2}]) if rank == 0 else got is None
+g.barrier()
+print('RANK_OK', rank, flush=True)
+launch.close_group()
+sys.exit(int(sys.argv[3]) if rank == 1 else 0)
+""")
+    code = ("import sys; sys.path.insert(0, %r); from xanthos_amd import launch; "
+            "sys.exit(launch.spawn(3, [%r, %r, sys.argv[1], sys.argv[2]], one_device=sys.argv[1] == '1'))" % (ROOT, str(script), ROOT))
+    for one_device, rc_want in (('0', 0), ('1', 7)):
+        out = subprocess.run([sys.executable, '-c', code, one_device, str(rc_want)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == rc_want, out.stdout + out.stderr
+        assert out.stdout.count('RANK_OK') == 3 and '[rank 2] RANK_OK 2' in out.stdout, out.stdout
+
+
 CALIB_WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
 from types import SimpleNamespace as NS
-import numpy as np, torch.distributed as dist
+import numpy as np
+from xanthos_amd import launch
 from xanthos_amd.calibrate import calibrate_abcd as cal
-dist.init_process_group(backend='gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
-rank = dist.get_rank()
+group = launch.current_group()
+rank = group.rank
 rng = np.random.default_rng(2)
 basin_ids = rng.integers(1, 8, 400)                 # 7 basins of different sizes; basin 8 requested but empty
 nm = 30
@@ -99,7 +144,7 @@ def fake_local(mine, settings, data, pet, seed, popsize, nmembers):     # stands
     rows = np.array([[b + 0.1, b + 0.2, b + 0.3, b + 0.4, b + 0.5, 1.0 / b, 75 * b, b] for b in mine]).reshape(-1, 8)
     return rows, {}
 cal._calibrate_local = fake_local
-res = cal.calibrate_all(settings, data, np.ones((400, nm)), seed=1, dist=dist)
+res = cal.calibrate_all(settings, data, np.ones((400, nm)), seed=1, group=group)
 sizes = np.array([(basin_ids == b).sum() for b in range(1, 8)])
 owner = cal.assign_basins(sizes * nm, 2)
 assert seen == [b for b, r in zip(range(1, 8), owner) if r == rank] and 0 < len(seen) < 7
@@ -112,8 +157,8 @@ if rank == 0:
     print('CALIB_FANOUT_OK', owner.tolist())
 else:
     assert res == {}
-dist.barrier()
-dist.destroy_process_group()
+group.barrier()
+assert 'torch' not in sys.modules
 '''
 
 
@@ -133,7 +178,7 @@ def _run_two_ranks(tmp_path, text, *extra):
     return outs
 
 
-def test_calibration_fanout_two_ranks_gloo(tmp_path):
+def test_calibration_fanout_two_ranks(tmp_path):
     """calibrate_all over 2 ranks: basins dealt by size, each rank searches only its share (the GPU search is
     replaced by a stand-in), ONE collective brings the [n_basins, n_par + 3] table to rank 0, which writes the files."""
     out = tmp_path / 'calib_out'

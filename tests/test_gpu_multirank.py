@@ -190,3 +190,54 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     assert len(g['rows_per_rank']) == 2 and sum(g['rows_per_rank']) == 67420
     assert 'exposed_ms' in g and res['value'] > 0
     assert not [f for f in os.listdir(str(tmp_path)) if f.startswith('xh_fake_rccl_')]      # every message was received
+
+
+# ---- run_model() on N ranks: the product's own multi-GPU path
+RUN_MODEL_PARENT = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+from xanthos_amd import run_model
+assert 'torch' not in sys.modules
+# (this process never touches a GPU: with gpus > 1 it only starts the rank processes and waits for them)
+res = run_model(sys.argv[2], gpus=int(sys.argv[3]))
+assert (res is None) == (int(sys.argv[3]) > 1)
+assert 'torch' not in sys.modules
+print('PARENT_OK')
+'''
+
+
+@pytest.mark.parametrize('nranks', [2, 3])
+def test_run_model_on_n_ranks_writes_the_same_files(tmp_path, nranks):
+    """``run_model(ini, gpus=N)``: the launcher starts N rank processes (all on this box's one GPU: XH_ONE_DEVICE=1), each maps
+    its rows of the forcing files, runs the pipeline on its basins, the six outputs travel to rank 0 through the library's
+    own gather (grouped ncclSend / ncclRecv; the RCCL stand-in of tests/fake_rccl bounces them through files) and rank 0
+    writes -- every .npy / .csv of the output folder byte-identical to the one-rank run's, post-processors and runoff
+    aggregations included.  No torch anywhere: the ranks meet over launch.SocketGroup."""
+    from xanthos_amd import synth
+    w = synth.make_world(nrow=36, ncol=72, ncell=900, n_basins=7, seed=33)
+    f = synth.make_forcing(w, 36)
+    outs = {}
+    for tag, n in (('one', 1), ('many', nranks)):
+        root = str(tmp_path / tag)
+        os.makedirs(root)
+        ini = synth.write_example(root, w, f, 1971, 1973, runoff_spinup=25, routing_spinup=6, post=True, aggregates=True,
+                                  output_vars=('pet', 'aet', 'q', 'soilmoisture', 'avgchflow'),
+                                  output_format=4 if nranks == 2 else 1)          # .npy with two ranks, .csv with three
+        script = tmp_path / (tag + '.py')
+        script.write_text(RUN_MODEL_PARENT)
+        env = dict(os.environ)
+        env.update({'XH_ONE_DEVICE': '1', 'XH_RCCL_LIBRARY': _fake_rccl(), 'XH_FAKE_RCCL_DIR': str(tmp_path),
+                    'XH_ROUTE_REASSOC': '1'})          # (the library default; conftest.py pins the test processes to the other form)
+        env.pop('RANK', None)
+        env.pop('WORLD_SIZE', None)
+        r = subprocess.run([sys.executable, str(script), ROOT, ini, str(n)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and 'PARENT_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+        if n > 1:
+            assert 'gather (rccl)' in r.stdout, r.stdout[-3000:]          # the library's gather, not the host fall-back
+            assert r.stdout.count('of 900 cells on this rank') == n
+        outs[tag] = os.path.join(root, 'output')
+    files = sorted(x for x in os.listdir(outs['one']) if x.endswith(('.npy', '.csv')))
+    assert len(files) >= 6 and files == sorted(x for x in os.listdir(outs['many']) if x.endswith(('.npy', '.csv'))), files
+    for name in files:
+        assert open(os.path.join(outs['one'], name), 'rb').read() == open(os.path.join(outs['many'], name), 'rb').read(), name
+    assert not [x for x in os.listdir(str(tmp_path)) if x.startswith('xh_fake_rccl_')]      # every message was received

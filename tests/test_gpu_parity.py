@@ -118,6 +118,7 @@ for a, b in zip(local, out):
     want = np.empty((n, nm))
     want[perm] = a.download()
     assert np.array_equal(b.download(), want)
+print('INFO', comm.info()['sends'], comm.info()['recvs'])
 comm.close()
 print('COMM_OK')
 '''
@@ -157,6 +158,7 @@ for fed in (True, False, True, True):
         want = np.empty((w.ncell, nm))
         want[perm_h] = ref[k]
         assert np.array_equal(out[k].download(), want, equal_nan=True), (k, fed)
+print('INFO', main.info()['sends'] + side.info()['sends'], main.info()['recvs'] + side.info()['recvs'])
 main.close(); side.close()
 print('SIDE_OK')
 '''
@@ -182,6 +184,35 @@ def test_side_gather_is_ordered_behind_the_runoff(hip, tmp_path):
         child.communicate()
         pytest.skip('RCCL communicator bootstrap did not finish within 240 s on this box')
     assert child.returncode == 0 and 'SIDE_OK' in out, out[-3000:]
+
+
+@pytest.mark.parametrize('child,marker,sends', [('COMM_CHILD', 'COMM_OK', 3), ('SIDE_GATHER_CHILD', 'SIDE_OK', 24)])
+def test_real_rccl_send_recv_through_a_self_loop(hip, tmp_path, child, marker, sends):
+    """the gather's DATA path through the real librccl.so.1 on a one-GPU box.  RCCL refuses two ranks
+    on one device but lets a rank send to itself inside a group; with XH_COMM_SELF_LOOP=1 the root's own rows take the path of
+    a remote rank's -- ncclSend (the pipeline's output buffers as send buffers) -> ncclRecv into the staging area -> row
+    scatter to grid order -- on the context's stream (the first child) and, in fed and staged steps, on the gather stream
+    ordered behind the side stream's runoff event / the context's stream (the second child; outputs zeroed before every
+    pass, so a gather that ran early or lost rows would show).  What is still unexercised afterwards: several PEERS
+    (ncclCommInitRank across processes, xGMI transport)."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / 'child.py'
+    script.write_text(globals()[child])
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    env = dict(os.environ, XH_COMM_SELF_LOOP='1')
+    env.pop('XH_RCCL_LIBRARY', None)                 # the real library, not the test stand-in
+    proc = subprocess.Popen([sys.executable, str(script), root], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        out, _ = proc.communicate(timeout=300)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        pytest.skip('RCCL communicator bootstrap did not finish within 300 s on this box')
+    assert proc.returncode == 0 and marker in out, out[-3000:]
+    info = [ln for ln in out.splitlines() if ln.startswith('INFO ')][-1].split()
+    assert int(info[1]) == sends and int(info[2]) == sends, info          # every array went through ncclSend AND ncclRecv
 
 
 def test_comm_single_rank_gather(hip, tmp_path):

@@ -104,6 +104,7 @@ SIGNATURES = {
     'xh_comm_unique_id': (c_int, [ctypes.c_char_p, c_size_t]),
     'xh_comm_create': (c_int, [_P, c_int32, c_int32, ctypes.c_char_p, c_size_t, POINTER(c_void_p)]),
     'xh_comm_destroy': (None, [_P]),
+    'xh_comm_info': (c_int, [_P, POINTER(c_int64)]),
     'xh_comm_gather_rows': (c_int, [_P, _P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     'xh_comm_gather_rows_side': (c_int, [_P, _P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     'xh_comm_join': (c_int, [_P]),
@@ -583,6 +584,12 @@ class Comm:
             os.close(saved)
         ctx._check(rc)
         self.handle = h.value
+
+    def info(self):
+        """{'ranks', 'rank', 'sends', 'recvs'}: ncclSend / ncclRecv calls issued through this communicator (xh_comm_info)."""
+        arr = (c_int64 * 4)()
+        self.ctx._check(lib().xh_comm_info(self.handle, arr))
+        return dict(zip(('ranks', 'rank', 'sends', 'recvs'), list(arr)))
 
     def gather_rows(self, local, counts, ncols, perm=None, out=None, root=0, side=False):
         """local: list of DeviceArrays [counts[rank], ncols]; on the root ``perm`` (device int64, rank-major destination

@@ -7,7 +7,7 @@ and kept in HBM), and the differential evolution itself runs on the device too (
 with SciPy's defaults (popsize 15 x n_parameters members, Latin-hypercube start, dithered mutation in (0.5, 1),
 recombination 0.7, tol 0.01, maxiter 1000, the two sampled members distinct from the candidate), generation-synchronous
 like SciPy's ``updating='deferred'``, for ALL requested basins at once instead of the reference's serial basin loop
-(:256-262).  With several ranks (``torch.distributed``) the basins are dealt to the ranks largest-first and the
+(:256-262).  With several ranks (``launch.current_group()``) the basins are dealt to the ranks largest-first and the
 ``[n_basins, n_par + 1]`` results gathered on rank 0.  SciPy's driver is unseeded, so the reference's search
 trajectory is not reproducible; the objective is the parity target (tests/golden/kge.npz) and the generation step is
 checked against a numpy restatement of SciPy's (oracle/de.py).
@@ -226,20 +226,20 @@ def assign_basins(sizes, n_ranks):
     return owner
 
 
-def gather_results(local, owner, dist, root=0):
+def gather_results(local, owner, group, root=0):
     """Gather per-basin result rows to ``root``: local [n_local, w] in the rank's basin order -> [n_basins, w].
 
-    ONE collective of ``n_basins x (n_par + 3)`` doubles: every rank contributes a full-size table
-    that is zero outside its own basins, so a sum-reduce to the root IS the gather (x + 0 is exact)."""
-    import torch
-    rank = dist.get_rank()
+    ONE collective of ``n_basins x (n_par + 3)`` doubles in all through the job's process group (``group``:
+    ``launch.SocketGroup`` or anything with ``rank`` and ``gather``): every rank sends its own rows, the root puts them
+    where ``owner`` says."""
     owner = np.asarray(owner)
+    got = group.gather(np.ascontiguousarray(local, dtype=np.float64), root=root)
+    if group.rank != root:
+        return None
     table = np.zeros((len(owner), local.shape[1]))
-    table[np.nonzero(owner == rank)[0]] = local
-    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-    t = torch.from_numpy(table).to(dev)
-    dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
-    return t.cpu().numpy() if rank == root else None
+    for r, rows in enumerate(got):
+        table[np.nonzero(owner == r)[0]] = rows
+    return table
 
 
 def _make_calibrate(b, settings, data, pet):
@@ -263,12 +263,12 @@ def _calibrate_local(mine, settings, data, pet, seed, popsize, nmembers):
     return np.column_stack([x, ed, nfev, nit]), dict(zip(mine, cals))
 
 
-def calibrate_all(settings, data, pet, router_function=None, seed=None, popsize=15, nmembers=None, dist=None):
+def calibrate_all(settings, data, pet, router_function=None, seed=None, popsize=15, nmembers=None, group=None):
     """Calibrate every requested basin (:256-262).
 
-    All basins search in lock-step on the device (differential_evolution_device).  ``dist`` = an initialised
-    ``torch.distributed`` module: the basins are dealt to the ranks by size (every rank needs the same ``seed``), each
-    rank calibrates its share on its own GPU, and rank 0 receives all results in one collective.  Writes the
+    All basins search in lock-step on the device (differential_evolution_device).  ``group`` = the job's process group
+    (``launch.current_group()``; None = one rank): the basins are dealt to the ranks by size (every rank needs the same
+    ``seed``), each rank calibrates its share on its own GPU, and rank 0 receives all results in one collective.  Writes the
     reference's two files per basin (:130-131; on rank 0) and returns {basin: (parameters, kge)} (rank 0; {} elsewhere).
     """
     if settings.set_calibrate != 0:
@@ -280,7 +280,7 @@ def calibrate_all(settings, data, pet, router_function=None, seed=None, popsize=
     sizes = sizes[sizes > 0]
     if not basins:
         return {}
-    rank, n_ranks = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    rank, n_ranks = (group.rank, group.size) if group is not None else (0, 1)
     if n_ranks > 1 and seed is None:
         raise ValueError('a multi-rank calibration needs the same explicit seed on every rank')
     owner = assign_basins(sizes * settings.nmonths, n_ranks)
@@ -288,7 +288,7 @@ def calibrate_all(settings, data, pet, router_function=None, seed=None, popsize=
     st = time.time()
     npar = 5 if data.tmin is not None else 4
     local, cals = _calibrate_local(mine, settings, data, pet, seed, popsize, nmembers)
-    table = gather_results(local, owner, dist) if n_ranks > 1 else local
+    table = gather_results(local, owner, group) if n_ranks > 1 else local
     if rank != 0:
         return {}
     logging.info('\tCalibrated {} basins on {} GPU(s) in {:.1f} s ({} objective evaluations)'.format(

@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-from . import _hip
+from . import _hip, launch
 from .calibrate import calibrate_abcd as calib_mod
 from .data_load import DataLoader
 from .ini_reader import ValidationException
@@ -67,6 +67,12 @@ class Components:
         self.instream_flow = None
         self._writer = None                # OutWriter of output_simulation(): q / ac come from it
         self._q = self._ac = None
+        # several ranks (one process per GPU, started by launch.spawn / any launcher that sets RANK, WORLD_SIZE, ...): the
+        # basins are sharded over them and rank 0 ends up with the gathered outputs, writes the files and runs the
+        # post-processors; the other ranks have nothing to write
+        self.group = launch.current_group()
+        self.is_root = self.group is None or self.group.rank == 0
+        self.gather = None
 
     @property
     def q(self):
@@ -173,6 +179,8 @@ class Components:
         t = time.time()
         um = self.topology() if (run_routing and s.routing_module == 'mrtm') else None
         self.timings['topology'] = time.time() - t
+        if self.group is not None and self.group.size > 1:
+            return self._simulation_sharded(ctx, um, t0, notify)
         t = time.time()
         pipe = DevicePipeline(ctx, ncell=s.ncell, nmonths=s.nmonths, start_year=s.StartYear, basin_ids=d.basin_ids,
                               abcd_pars=np.load(s.calib_file) if not isinstance(s.calib_file, np.ndarray) else s.calib_file,
@@ -210,6 +218,71 @@ class Components:
         self.timings['download'] = 0.0
         logging.info('---{0} has finished successfully: {1} seconds ---'.format(notify, time.time() - t0))
 
+    def _simulation_sharded(self, ctx, um, t0, notify):
+        """The device-resident simulation on this rank's share of the grid (components.py:298-384 for whole basins only; the
+        reference's only parallel seam is the basin chunking of abcd.py:369-389, whose results it re-scatters by membership --
+        the gather below is that step).  ``dist.make_shards`` deals connected components of (same basin) U (flow edge) onto
+        the ranks; every rank maps only ITS rows of the forcing files (memory maps: the rows are read, the rest of the files
+        is never touched), runs the unchanged pipeline, and the six outputs travel to rank 0 in one RCCL gather (PET / AET /
+        Q / Sav beside the routing, ChStorage / Avg_ChFlow behind it), where they sit in HBM in grid order exactly as a
+        one-rank run leaves them.  Every rank computes the same partition without talking."""
+        from types import SimpleNamespace
+        from . import dist
+        s, d, group = self.s, self.data, self.group
+        t = time.time()
+        shards = dist.make_shards(SimpleNamespace(basin_ids=np.asarray(d.basin_ids)), um, group.size)
+        c = shards[group.rank].cells
+        sub_um = dist.sub_matrix(um, c) if um is not None else None
+        pars = np.load(s.calib_file) if not isinstance(s.calib_file, np.ndarray) else s.calib_file
+        chs_prev = getattr(d, 'chs_prev', None)
+        pipe = DevicePipeline(ctx, ncell=len(c), nmonths=s.nmonths, start_year=s.StartYear, basin_ids=np.asarray(d.basin_ids)[c],
+                              abcd_pars=pars, pm_tables=pet_mod.tables_from(d, s.pm_nlcs), lct=np.asarray(d.lct_load)[c],
+                              elev=np.asarray(d.elev)[c], lc_years=s.pm_lc_years, um=sub_um,
+                              flow_dist=np.asarray(d.flow_dist)[c] if um is not None else np.zeros(len(c)),
+                              velocity=np.asarray(d.str_velocity)[c] if um is not None else np.zeros(len(c)),
+                              area=np.asarray(d.area)[c], abcd_spinup=s.runoff_spinup,
+                              routing_spinup=getattr(s, 'routing_spinup', 0), water_idx=s.pm_water_idx,
+                              snow_idx=s.pm_snow_idx, use_snow=d.tmin is not None,
+                              chs_prev=None if chs_prev is None else np.asarray(chs_prev)[c], plan_async=True,
+                              route_flags=self.route_flags())
+        self.timings['plan'] = time.time() - t
+        t = time.time()
+
+        def rows(a):
+            return None if a is None else np.ascontiguousarray(a[c], dtype=np.float64)      # (a memory map: only these rows are read)
+        # the previous CELL's temperature (data_load.py:128-129) of a shard's rows is not the row above: taken from the grid
+        prev = c - 1
+        tairprev = np.ascontiguousarray(d.tair_load[np.maximum(prev, 0)], dtype=np.float64)
+        tairprev[prev < 0] = 0.0
+        pipe.set_forcing({'tas': rows(d.tair_load), 'tmin': rows(d.TMIN_load), 'rhs': rows(d.rhs_load), 'wind': rows(d.wind_load),
+                          'rsds': rows(d.rsds_load), 'rlds': rows(d.rlds_load), 'precip': rows(d.precip),
+                          'abcd_tmin': rows(d.tmin)}, tairprev=tairprev)
+        ctx.sync()
+        self.timings['upload'] = time.time() - t
+        t = time.time()
+        names = ('pet', 'aet', 'q', 'sav') + (('chs', 'avg') if um is not None else ())
+        gather = dist.OutputGather(ctx, pipe, shards, group, s.ncell, names=names)
+        if um is not None:
+            pipe.plan
+        self.timings['plan_wait'] = time.time() - t
+        t = time.time()
+        ctx.timing_reset()
+        pipe.run(('pm', 'abcd', 'mrtm') if um is not None else ('pm', 'abcd'), fed=False, after_runoff=gather.run_side)
+        gather.run_tail()
+        ctx.sync()
+        group.barrier()
+        self.timings['kernels'] = time.time() - t
+        logging.info('\tPET + runoff + routing kernels and the gather ({}), {} of {} cells on this rank: {:.3f} seconds'.format(
+            gather.kind, len(c), s.ncell, time.time() - t))
+        self._log_stage_rates(ctx, pipe, um is not None)
+        self._host = {}
+        self.gather = gather
+        self.shard_pipe = pipe
+        # what the result properties and the writer look at: on the root the gathered arrays, in HBM, in grid order
+        self.pipe = SimpleNamespace(out=gather.out, plan=pipe.plan, ncell=s.ncell, nmonths=s.nmonths) if self.is_root else None
+        self.timings['download'] = 0.0
+        logging.info('---{0} has finished successfully: {1} seconds ---'.format(notify, time.time() - t0))
+
     def _log_stage_rates(self, ctx, pipe, routed):
         """One log line per stage: kernel time (HIP events on the library's stream) and achieved HBM GB/s against the
         algorithmic bytes of the stage (PM 6 reads + 1 write + land cover, ABCD 3 + 3, MRTM 1 + 2)."""
@@ -228,11 +301,14 @@ class Components:
     def calibrate(self):
         """Calibrate the ABCD parameters per basin (components.py:486-497)."""
         pet_out = self.calculate_pet()
-        calib_mod.calibrate_all(settings=self.s, data=self.data, pet=pet_out, router_function=self.calculate_routing)
+        multi = self.group is not None and self.group.size > 1
+        # (several ranks: the basins are dealt over them; the search needs the same explicit seed on every rank)
+        calib_mod.calibrate_all(settings=self.s, data=self.data, pet=pet_out, router_function=self.calculate_routing,
+                                group=self.group if multi else None, seed=20240807 if multi else None)
 
     def drought(self):
         """Drought statistics of runoff or soil moisture (components.py:391-399)."""
-        if self.s.CalculateDroughtStats:
+        if self.s.CalculateDroughtStats and self.is_root:
             from .drought.drought_stats import DroughtStats
             logging.info('---Start Drought Statistics:')
             t0 = time.time()
@@ -241,7 +317,7 @@ class Components:
 
     def accessible_water(self):
         """Accessible water per basin (components.py:401-409)."""
-        if self.s.CalculateAccessibleWater:
+        if self.s.CalculateAccessibleWater and self.is_root:
             from .accessible.accessible import AccessibleWater
             logging.info('---Start Accessible Water:')
             t0 = time.time()
@@ -251,6 +327,8 @@ class Components:
     def output_simulation(self):
         """Aggregate / convert on the device and write the selected variables (components.py:441-474)."""
         from .data_writer.out_writer import OutWriter
+        if not self.is_root:               # (a sharded run: rank 0 holds the gathered outputs and writes)
+            return
         names = {'pet': 'PET', 'aet': 'AET', 'q': 'Q', 'soilmoisture': 'Sav', 'avgchflow': 'Avg_ChFlow'}
         # arrays still in HBM go to the writer as they are (it aggregates / converts / saves from there)
         all_outputs = {k: (self.pipe.out[_RESULTS[a]] if self.pipe is not None and a not in self._host

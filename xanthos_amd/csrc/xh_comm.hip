@@ -82,6 +82,8 @@ struct xh_comm {
     int nranks = 0, rank = 0;
     void *d_stage = nullptr;      // root: received blocks, rank-major
     size_t stage_bytes = 0;
+    bool self_loop = false;       // XH_COMM_SELF_LOOP=1 at creation: the root's own rows travel through ncclSend / ncclRecv too
+    int64_t n_send = 0, n_recv = 0;
 };
 
 #define XH_NCCL(ctx, call)                                                                                     \
@@ -124,7 +126,17 @@ int xh_comm_create(xh_ctx *ctx, int32_t nranks, int32_t rank, const char *id, si
         delete c;
         return xh_fail(ctx, XH_ERR_HIP, "ncclCommInitRank(%d of %d) failed: %s", rank, nranks, api.GetErrorString(r));
     }
+    c->self_loop = getenv("XH_COMM_SELF_LOOP") && getenv("XH_COMM_SELF_LOOP")[0] == '1';
     *out = c;
+    return XH_OK;
+}
+
+int xh_comm_info(const xh_comm *c, int64_t info[4]) {
+    if (!c || !info) return XH_ERR_ARG;
+    info[0] = c->nranks;
+    info[1] = c->rank;
+    info[2] = c->n_send;
+    info[3] = c->n_recv;
     return XH_OK;
 }
 
@@ -213,18 +225,23 @@ static int gather_rows_on(xh_ctx *ctx, hipStream_t st, xh_comm *c, int32_t root,
     if (c->rank != root) {
         if (n_local == 0) return XH_OK;
         XH_NCCL(ctx, api.GroupStart());
-        for (int v = 0; v < nvar && first == ncclSuccess; ++v)
+        for (int v = 0; v < nvar && first == ncclSuccess; ++v) {
             note(api.Send(h_d_local[v], (size_t)(n_local * ncols), ncclDouble, root, c->comm, st), "ncclSend");
+            c->n_send += 1;
+        }
         note(api.GroupEnd(), "ncclGroupEnd");
         if (first != ncclSuccess)
             return xh_fail(ctx, XH_ERR_HIP, "xh_comm_gather_rows: %s failed: %s", what, api.GetErrorString(first));
         return XH_OK;
     }
     XH_REQUIRE(ctx, d_perm && h_d_out, "xh_comm_gather_rows: the root needs d_perm and the output arrays");
+    // self-loop (testing, XH_COMM_SELF_LOOP=1): the root's own rows are sent to and received from its own rank inside the group,
+    // i.e. they count as remote rows and land in the staging area like everybody else's
+    const bool loop = c->self_loop && n_local > 0;
     int64_t remote = 0, before_me = 0;
     for (int r = 0; r < c->nranks; ++r) {
         XH_REQUIRE(ctx, h_counts[r] >= 0, "xh_comm_gather_rows: negative count");
-        if (r != root) remote += h_counts[r];
+        if (r != root || loop) remote += h_counts[r];
         if (r < root) before_me += h_counts[r];
     }
     const size_t need = (size_t)remote * ncols * nvar * sizeof(double);
@@ -246,10 +263,15 @@ static int gather_rows_on(xh_ctx *ctx, hipStream_t st, xh_comm *c, int32_t root,
         for (int v = 0; v < nvar && first == ncclSuccess; ++v) {
             int64_t off = 0;
             for (int r = 0; r < c->nranks && first == ncclSuccess; ++r) {
-                if (r == root || h_counts[r] == 0) continue;
+                if ((r == root && !loop) || h_counts[r] == 0) continue;
                 note(api.Recv(stage + ((int64_t)v * remote + off) * ncols, (size_t)(h_counts[r] * ncols), ncclDouble, r,
                               c->comm, st), "ncclRecv");
+                c->n_recv += 1;
                 off += h_counts[r];
+            }
+            if (loop && first == ncclSuccess) {
+                note(api.Send(h_d_local[v], (size_t)(n_local * ncols), ncclDouble, root, c->comm, st), "ncclSend");
+                c->n_send += 1;
             }
         }
         note(api.GroupEnd(), "ncclGroupEnd");
@@ -260,6 +282,11 @@ static int gather_rows_on(xh_ctx *ctx, hipStream_t st, xh_comm *c, int32_t root,
     for (int v = 0; v < nvar; ++v) {
         XH_REQUIRE(ctx, h_d_out[v], "xh_comm_gather_rows: NULL output array");
         int rc;
+        if (loop) {      // every row, the root's own included, sits in the staging area in rank order = the order of d_perm
+            rc = xh_move_rows_on(ctx, st, stage + (int64_t)v * remote * ncols, d_perm, remote, ncols, h_d_out[v], 1);
+            if (rc) return rc;
+            continue;
+        }
         if (before_me > 0) {
             rc = xh_move_rows_on(ctx, st, stage + (int64_t)v * remote * ncols, d_perm, before_me, ncols, h_d_out[v], 1);
             if (rc) return rc;

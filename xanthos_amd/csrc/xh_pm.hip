@@ -86,8 +86,20 @@ struct PmMonth {
     int moy;
 };
 
+// Floating-point contraction (round 5): inside pm_prep and pm_class -- and only there -- a * b + c within ONE expression is
+// formed as an fma (`#pragma clang fp contract(on)`, decided by the front end per expression), although the library is built
+// with -ffp-contract=off.  Both PM kernels inline these two functions, so they keep producing the same bits as each other
+// (the fed order runs the paired kernel, the stage-by-stage order the other one; the suites compare them bit for bit); the
+// accumulation over the classes outside stays two rounded operations like the reference's `arr *= lct; np.sum`.  Whole-file
+// contraction was measured first (profiles/round5/contract_ab.txt: pm_pet 1.761 -> 1.705 ms) and broke exactly that equality.
+#ifndef XH_PM_CONTRACT
+#define XH_PM_CONTRACT 1
+#endif
 __device__ __forceinline__ PmMonth pm_prep(const XhExpConsts &K, double p, double T, double TN, double RH, double W, double RS,
                                            double RL, double TP, int moy, double dz) {
+#if XH_PM_CONTRACT
+#pragma clang fp contract(on)
+#endif
     // ---- terms shared by every land class (SetData :83-99, et_veg :226-282)
     const double esx = 6.10588 * xh_exp(fdiv(17.32491 * T, T + 238.102), K);
     const double vap = esx * (RH * 0.01);                             // constant divisors are multiplied by their reciprocal
@@ -156,6 +168,9 @@ __device__ __forceinline__ PmMonth pm_prep(const XhExpConsts &K, double p, doubl
 // ... and the evapotranspiration of ONE land class in that month (et_veg :223-334, et_water :337-361, et_snow :364-377).
 __device__ __forceinline__ double pm_class(const PmLds &L, const PmTablesDev *__restrict__ tab, const XhExpConsts &K, int l,
                                            int water_idx, int snow_idx, double wind_pow, const PmMonth &M) {
+#if XH_PM_CONTRACT
+#pragma clang fp contract(on)
+#endif
     const double sx = M.sx;
     const double vpd = M.vpd;
     const double rcorr = M.rcorr;

@@ -12,9 +12,10 @@ the ranks largest-first onto the least-loaded rank (LPT), each rank runs the unc
 cells (no collective on the data path), and the six ``[n_local, nmonths]`` outputs travel to rank 0 in ONE gather over
 RCCL/xGMI, where rows are scattered back to grid order.  The gather is the library's own (``xh_comm_gather_rows``:
 grouped ncclSend / ncclRecv of the exact shard sizes straight from the pipeline's output buffers, csrc/xh_comm.hip);
-``torch.distributed`` is only the launcher and carries the RCCL id.  ``gather_to_root`` (a padded
-``torch.distributed.gather``) remains for the gloo CPU tests and as the fallback when RCCL cannot be initialised
-(e.g. the dry run with every rank on one GPU).
+the process group -- any object with ``rank``, ``size``, ``bcast``, ``allreduce`` and ``gather`` like
+``launch.SocketGroup``, this package's own TCP rendezvous; ``bench.py`` wraps ``torch.distributed`` the same way -- only
+carries the RCCL ids and a flag.  ``host_gather`` (the rows through the group itself) is the fall-back when RCCL cannot make
+a communicator, e.g. a dry run with every rank on one GPU.  No PyTorch in this package.
 """
 from types import SimpleNamespace
 
@@ -42,12 +43,13 @@ def shard_components(basin_ids, um):
                 parent[max(ra, rb)] = min(ra, rb)
         else:
             first[b] = c
-    rows = np.repeat(np.arange(n), np.diff(um.indptr))
-    for r, c in zip(rows, um.indices):
-        if r != c:
-            ra, rb = find(int(r)), find(int(c))
-            if ra != rb:
-                parent[max(ra, rb)] = min(ra, rb)
+    if um is not None:                       # (no routing selected: whole basins are all the ranks need)
+        rows = np.repeat(np.arange(n), np.diff(um.indptr))
+        for r, c in zip(rows, um.indices):
+            if r != c:
+                ra, rb = find(int(r)), find(int(c))
+                if ra != rb:
+                    parent[max(ra, rb)] = min(ra, rb)
     roots = np.array([find(c) for c in range(n)])
     _, labels = np.unique(roots, return_inverse=True)
     return labels
@@ -110,42 +112,27 @@ def fill_shard_forcing(ctx, world, shard, pipe, seed, nan_frac=0.0):
         b.free()
 
 
-def gather_to_root(local, shards, ncell, dist, root=0):
-    """ONE gather of a stacked ``[nvar, n_local, ncols]`` tensor to ``root``; returns ``[nvar, ncell, ncols]`` there.
-
-    ``local`` is a torch tensor on the rank's device (CUDA with the "nccl" backend = RCCL, CPU with "gloo").
-    Shards differ in size, so every rank pads to the largest shard (RCCL has no gather-v).
-    """
-    import torch
-    rank, world_size = dist.get_rank(), dist.get_world_size()
-    nvar, n_local, ncols = local.shape
-    n_max = max(len(s.cells) for s in shards)
-    send = local
-    if n_local != n_max:
-        send = torch.zeros((nvar, n_max, ncols), dtype=local.dtype, device=local.device)
-        send[:, :n_local] = local
-    recv = [torch.empty_like(send) for _ in range(world_size)] if rank == root else None
-    dist.gather(send.contiguous(), gather_list=recv, dst=root)
-    if rank != root:
-        return None
-    out = torch.empty((nvar, ncell, ncols), dtype=local.dtype, device=local.device)
-    for s, buf in zip(shards, recv):
-        idx = torch.as_tensor(s.cells, device=local.device)
-        out.index_copy_(1, idx, buf[:, :len(s.cells)])
+def assemble_rows(parts, shards, ncell):
+    """Rank-major blocks ``[nvar, n_local(rank), ncols]`` -> ``[nvar, ncell, ncols]`` in grid order (rows of rank r are the
+    cells ``shards[r].cells``)."""
+    nvar, ncols = parts[0].shape[0], parts[0].shape[2]
+    out = np.empty((nvar, ncell, ncols))
+    for part, sh in zip(parts, shards):
+        out[:, sh.cells, :] = part
     return out
 
 
-def gather_outputs(ctx, pipe, shard, shards, world, dist, torch, names=('pet', 'aet', 'q', 'sav', 'chs', 'avg')):
-    """Copy the pipeline's outputs into one torch CUDA tensor and gather them on rank 0 (grid order)."""
-    from . import _hip
-    n, nm = pipe.ncell, pipe.nmonths
-    local = torch.empty((len(names), n, nm), dtype=torch.float64, device='cuda')
-    for i, k in enumerate(names):
-        ctx._check(_hip.lib().xh_memcpy_d2d(ctx.handle, local[i].data_ptr(), pipe.out[k].ptr, n * nm * 8))
-    ctx.sync()                       # our stream -> torch's stream hand-off
-    if dist.get_backend() != 'nccl':
-        local = local.cpu()          # gloo dry runs gather on the host
-    return gather_to_root(local, shards, world.ncell, dist)
+def host_gather(arrays, shards, ncell, group, root=0):
+    """Fall-back of the write-out gather when RCCL is not available (two test ranks on one GPU, CPU dry runs): every rank's
+    ``[nvar, n_local, ncols]`` host block travels through the process group (``group.gather(..., raw=True)``: one message
+    per rank) and the root reorders the rows.  Returns ``[nvar, ncell, ncols]`` on ``root``, None elsewhere."""
+    local = np.ascontiguousarray(arrays, dtype=np.float64)
+    got = group.gather(memoryview(local).cast('B'), root=root, raw=True)
+    if group.rank != root:
+        return None
+    nvar, ncols = local.shape[0], local.shape[2]
+    parts = [np.frombuffer(b, dtype=np.float64).reshape(nvar, len(sh.cells), ncols) for b, sh in zip(got, shards)]
+    return assemble_rows(parts, shards, ncell)
 
 
 class OutputGather:
@@ -157,19 +144,20 @@ class OutputGather:
     ``DevicePipeline.run(after_runoff=...)``), i.e. beside the routing kernel, which needs none of them;
     ``run_tail`` sends ChStorage / Avg_ChFlow behind the routing and joins the two.  What a step still spends in the gather
     after the routing has ended is timed on the device (``exposed_ms``).  One communicator per stream.
-    kind "torch": padded ``torch.distributed.gather`` of a stacked copy (gloo dry runs; RCCL unavailable), all in ``run_tail``."""
+    kind "host": the rows through the process group (``host_gather``; dry runs, RCCL unavailable), all in ``run_tail``; the root
+    uploads the assembled arrays, so ``self.out`` holds device arrays in grid order either way."""
 
     SIDE = ('pet', 'aet', 'q', 'sav')
 
-    def __init__(self, ctx, pipe, shards, rank, ncell, dist, torch, names=('pet', 'aet', 'q', 'sav', 'chs', 'avg'),
-                 root=0):
+    def __init__(self, ctx, pipe, shards, group, ncell, names=('pet', 'aet', 'q', 'sav', 'chs', 'avg'), root=0):
         from . import _hip
+        rank = group.rank
         self.ctx, self.pipe, self.shards, self.rank, self.ncell = ctx, pipe, shards, rank, int(ncell)
-        self.dist, self.torch, self.names, self.root = dist, torch, tuple(names), root
+        self.group, self.names, self.root = group, tuple(names), root
         self.side_names = tuple(k for k in self.names if k in self.SIDE)
         self.tail_names = tuple(k for k in self.names if k not in self.SIDE)
         self.counts = np.array([len(s.cells) for s in shards], dtype=np.int64)
-        self.out, self.d_perm, self.comm, self.comm_side, self.kind, self.why = None, None, None, None, 'torch', ''
+        self.out, self.d_perm, self.comm, self.comm_side, self.kind, self.why = None, None, None, None, 'host', ''
         self.side_done, self.runs, self._last = False, 0, None
         self.bytes = int(self.counts.sum()) * pipe.nmonths * 8 * len(self.names)
         # The library's own gather (RCCL bound at run time) whatever backend the launcher's process group uses: the group
@@ -178,7 +166,6 @@ class OutputGather:
         # Agree on RCCL availability BEFORE ncclCommInitRank: the init is itself a collective, so a rank that cannot even
         # load librccl must not leave the others blocked inside it.  comm_unique_id() loads the library and makes an id
         # (cheap, local); only the root's ids are used.
-        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
         uid, ok = [None, None], 1
         try:
             mine = [_hip.comm_unique_id(), _hip.comm_unique_id()]
@@ -186,29 +173,26 @@ class OutputGather:
                 uid = mine
         except (_hip.HipError, RuntimeError) as exc:
             self.why, ok = str(exc), 0
-        flag = torch.tensor([ok], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            dist.broadcast_object_list(uid, src=root)
+        if int(group.allreduce(ok, 'min')) == 1:
+            uid = group.bcast([bytes(u) for u in uid] if rank == root else None, src=root)
             try:
                 self.comm = _hip.Comm(ctx, len(shards), rank, uid[0])
                 self.comm_side = _hip.Comm(ctx, len(shards), rank, uid[1])
                 self.kind = 'rccl'
             except (_hip.HipError, RuntimeError) as exc:      # e.g. two ranks on one GPU in a dry run
                 self.why = str(exc)
-            flag = torch.tensor([1 if self.kind == 'rccl' else 0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # all ranks take the same path
-            if int(flag.item()) == 0:
+            if int(group.allreduce(1 if self.kind == 'rccl' else 0, 'min')) == 0:      # all ranks take the same path
                 for c in (self.comm, self.comm_side):
                     if c is not None:
                         c.close()
-                self.comm, self.comm_side, self.kind = None, None, 'torch'
+                self.comm, self.comm_side, self.kind = None, None, 'host'
         # which library answered: the test-only stand-in of tests/fake_rccl marks its ids (the report must say so)
         self.library = None
         if self.kind == 'rccl':
             self.library = 'test stand-in (tests/fake_rccl)' if bytes(uid[0][:4]) == b'FAKE' else 'librccl.so.1'
-        if self.kind == 'rccl' and rank == root:
-            self.d_perm = ctx.upload(np.concatenate([s.cells for s in shards]), dtype=np.int64)
+        if rank == root:
+            if self.kind == 'rccl':
+                self.d_perm = ctx.upload(np.concatenate([s.cells for s in shards]), dtype=np.int64)
             self.out = {k: ctx.empty((self.ncell, pipe.nmonths)) for k in self.names}
 
     def _gather(self, comm, names, side):
@@ -216,7 +200,7 @@ class OutputGather:
                          out=None if self.out is None else [self.out[k] for k in names], root=self.root, side=side)
 
     def run_side(self):
-        """PET / AET / Q / Sav, on the gather stream, beside the routing (a no-op for kind "torch")."""
+        """PET / AET / Q / Sav, on the gather stream, beside the routing (a no-op for kind "host")."""
         if self.kind == 'rccl' and self.side_names:
             self._gather(self.comm_side, self.side_names, True)
             self.side_done = True
@@ -235,14 +219,13 @@ class OutputGather:
             self.side_done = False
             self.runs += 1
             return None
-        world = SimpleNamespace(ncell=self.ncell)
-        got = gather_outputs(self.ctx, self.pipe, self.shards[self.rank], self.shards, world, self.dist, self.torch,
-                             names=self.names)
-        if self.torch.cuda.is_available() and self.dist.get_backend() == 'nccl':
-            self.torch.cuda.synchronize()
-        self._last = got
+        local = np.stack([self.pipe.out[k].download() for k in self.names])      # (the download settles a routing fault first)
+        got = host_gather(local, self.shards, self.ncell, self.group, root=self.root)
+        if got is not None:
+            for i, k in enumerate(self.names):
+                self.out[k].upload(got[i])
         self.runs += 1
-        return got
+        return None
 
     def run(self):
         """Everything behind the routing (no overlap): what round 3 did, kept for callers without an after_runoff hook."""
@@ -250,10 +233,8 @@ class OutputGather:
 
     def last(self):
         """On the root: the arrays of the last gather as host arrays, by name (grid order)."""
-        if self.kind == 'rccl':
-            self.ctx.sync()
-            return {k: self.out[k].download() for k in self.names}
-        return {k: self._last[i].cpu().numpy() for i, k in enumerate(self.names)}
+        self.ctx.sync()
+        return {k: self.out[k].download() for k in self.names}
 
     def report(self):
         exposed = None
@@ -263,6 +244,7 @@ class OutputGather:
         return {'kind': self.kind, 'library': self.library, 'bytes_per_step': self.bytes, 'variables': list(self.names),
                 'beside_the_routing': list(self.side_names) if self.kind == 'rccl' else [],
                 'behind_the_routing': list(self.tail_names) if self.kind == 'rccl' else list(self.names),
+                'process_group': type(self.group).__name__,
                 'exposed_ms': exposed, 'exposed_ms_is': 'device time of a step between the end of the routing kernel and '
                 'the end of the gather (HIP events on the context stream), mean over the timed steps',
                 'rows_per_rank': self.counts.tolist(), 'fallback_reason': self.why}
