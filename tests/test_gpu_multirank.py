@@ -235,7 +235,7 @@ def test_run_model_on_n_ranks_writes_the_same_files(tmp_path, nranks):
         if n > 1:
             assert 'gather (rccl)' in r.stdout, r.stdout[-3000:]          # the library's gather, not the host fall-back
             assert r.stdout.count('of 900 cells on this rank') == n
-        outs[tag] = os.path.join(root, 'output')
+        outs[tag] = os.path.join(root, 'output', 'pm_abcd_mrtm_synth')
     files = sorted(x for x in os.listdir(outs['one']) if x.endswith(('.npy', '.csv')))
     assert len(files) >= 6 and files == sorted(x for x in os.listdir(outs['many']) if x.endswith(('.npy', '.csv'))), files
     for name in files:

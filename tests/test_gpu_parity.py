@@ -814,6 +814,23 @@ def test_first_dataflow_call_of_a_plan_is_cross_checked(hip, tmp_path, monkeypat
     um3 = fresh()
     mrtm.route_series(um3, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
     assert um3.plan(hip.get_context()).info()['validated'] == 1
+    # round 5: the record is also keyed on the HIP runtime and driver versions (the ordering assumption is theirs as much as
+    # the silicon's): a pass recorded under another runtime does not count
+    monkeypatch.setenv('XH_CACHE_DIR', str(tmp_path / 'cache'))
+    monkeypatch.setenv('XH_TEST_RUNTIME_TAG', 'another runtime')
+    um4 = fresh()
+    mrtm.route_series(um4, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+    assert um4.plan(hip.get_context()).info()['validated'] == 1
+    monkeypatch.delenv('XH_TEST_RUNTIME_TAG')
+    # ... and a long-lived plan is cross-checked again every XH_ROUTE_VALIDATE_EVERY-th dataflow call (default 1,000)
+    monkeypatch.setenv('XH_ROUTE_VALIDATE_EVERY', '3')
+    um5 = fresh()
+    seen = []
+    for call in range(7):
+        got = mrtm.route_series(um5, w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
+        seen.append(um5.plan(hip.get_context()).info()['validated'])
+    assert seen == [0, 0, 1, 1, 1, 2, 2], seen
 
 
 LEARN_CHILD = r'''

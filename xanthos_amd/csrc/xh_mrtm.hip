@@ -393,6 +393,10 @@ struct xh_route_plan {
     // XH_ROUTE_VALIDATE unless a marker file says this library build already passed on this device with this topology
     // (route_first_check_*; XH_ROUTE_VALIDATE_FIRST=0 switches it off).
     bool first_checked = false;
+    // ... and every XH_ROUTE_VALIDATE_EVERY-th dataflow call of a long-lived plan is cross-checked again (default 1,000; 0 =
+    // never): one clean pass says little about call 10^4 of a server that routes scenarios all day (~0.25 s each time)
+    int64_t dataflow_calls = 0;
+    bool validate_due = false;
     uint64_t topo_hash = 0;
     // xh_route_plan_prepare: what a run LEARNS about a grid -- the cells that fire although velocity * dt / length says they
     // cannot -- is kept per box (a file beside the first-check marker, keyed by topology, velocity, flow distance and dt), so
@@ -1219,6 +1223,15 @@ static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan
     mix(ctx->prop.name);
     mix(ctx->prop.gcnArchName);
     mix(__DATE__ " " __TIME__);      // this translation unit's build: a new library build checks again
+    {   // the HIP runtime and the driver the pass was recorded under: the ordering the streams rely on is theirs as much as
+        // the silicon's (XH_TEST_RUNTIME_TAG: appended, so that a test can stand in for "another runtime")
+        int rt = 0, drv = 0;
+        (void)hipRuntimeGetVersion(&rt);
+        (void)hipDriverGetVersion(&drv);
+        char ver[96];
+        snprintf(ver, sizeof(ver), "rt%d drv%d %s", rt, drv, getenv("XH_TEST_RUNTIME_TAG") ? getenv("XH_TEST_RUNTIME_TAG") : "");
+        mix(ver);
+    }
     char name[160];
     snprintf(name, sizeof(name), "/route_ok_%016llx_%016llx_%lld_%lld%s", (unsigned long long)h, (unsigned long long)plan->topo_hash,
              (long long)plan->ncell, (long long)(plan->flow ? plan->flow->n_units : 0), rsum ? "_r" : "");
@@ -1269,7 +1282,21 @@ static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     // first dataflow call of this plan on a box / build that has not passed the cross-check yet: checked like XH_ROUTE_VALIDATE
     const bool plain_call = plan && (flags & (XH_ROUTE_NO_DATAFLOW | XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_ATOMIC | XH_ROUTE_TEST_FAULT)) == 0;
     const bool want_rsum = plan && reassoc_wanted(flags) && (flags & XH_ROUTE_NO_SKEW) == 0;
-    const bool first_check = !validate && plain_call && first_check_needed(ctx, plan, want_rsum);
+    bool first_check = !validate && plain_call && first_check_needed(ctx, plan, want_rsum);
+    if (plain_call && plan->flow) {
+        const char *ev = getenv("XH_ROUTE_VALIDATE_EVERY");      // (read per call: a long-lived caller may change its mind)
+        const int64_t every = ev ? (int64_t)atoll(ev) : (int64_t)1000;
+        if (plan->validate_due && !feed) {      // the fed call that was due came back as an ordinary one: checked now
+            first_check = first_check || !validate;
+            plan->validate_due = false;
+        } else {
+            plan->dataflow_calls += 1;
+            if (!validate && !first_check && every > 0 && plan->dataflow_calls % every == 0) {      // handled like the first one
+                first_check = true;
+                plan->validate_due = feed != nullptr;      // (a fed call cannot be checked at once: turned down below)
+            }
+        }
+    }
     validate = validate || first_check;
     // a fed call cannot be cross-checked at once (the second routing would read runoff that does not exist yet), nor
     // routed by anything but the dataflow kernel that knows how to wait for it
