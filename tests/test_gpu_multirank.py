@@ -206,13 +206,16 @@ print('PARENT_OK')
 '''
 
 
-@pytest.mark.parametrize('nranks', [2, 3])
-def test_run_model_on_n_ranks_writes_the_same_files(tmp_path, nranks):
+@pytest.mark.parametrize('nranks,form', [(2, 'exact'), (3, 'default')])
+def test_run_model_on_n_ranks_writes_the_same_files(tmp_path, nranks, form):
     """``run_model(ini, gpus=N)``: the launcher starts N rank processes (all on this box's one GPU: XH_ONE_DEVICE=1), each maps
     its rows of the forcing files, runs the pipeline on its basins, the six outputs travel to rank 0 through the library's
     own gather (grouped ncclSend / ncclRecv; the RCCL stand-in of tests/fake_rccl bounces them through files) and rank 0
-    writes -- every .npy / .csv of the output folder byte-identical to the one-rank run's, post-processors and runoff
-    aggregations included.  No torch anywhere: the ranks meet over launch.SocketGroup."""
+    writes -- post-processors and runoff aggregations included.  With the bit-exact routing kernels (``routing_form = exact``
+    in the ini) every .npy / .csv of the output folder is byte-identical to the one-rank run's.  With the library's default
+    (the reassociated form, whose sums follow the chains of the partition -- and a shard's partition is not the whole
+    world's) every file but the channel flow is byte-identical and the channel flow agrees within 1e-9.  No torch anywhere:
+    the ranks meet over launch.SocketGroup."""
     from xanthos_amd import synth
     w = synth.make_world(nrow=36, ncol=72, ncell=900, n_basins=7, seed=33)
     f = synth.make_forcing(w, 36)
@@ -223,13 +226,16 @@ def test_run_model_on_n_ranks_writes_the_same_files(tmp_path, nranks):
         ini = synth.write_example(root, w, f, 1971, 1973, runoff_spinup=25, routing_spinup=6, post=True, aggregates=True,
                                   output_vars=('pet', 'aet', 'q', 'soilmoisture', 'avgchflow'),
                                   output_format=4 if nranks == 2 else 1)          # .npy with two ranks, .csv with three
+        if form == 'exact':
+            text = open(ini).read()
+            assert 'routing_spinup' in text
+            open(ini, 'w').write(text.replace('routing_spinup', 'routing_form = exact\n    routing_spinup', 1))
         script = tmp_path / (tag + '.py')
         script.write_text(RUN_MODEL_PARENT)
         env = dict(os.environ)
-        env.update({'XH_ONE_DEVICE': '1', 'XH_RCCL_LIBRARY': _fake_rccl(), 'XH_FAKE_RCCL_DIR': str(tmp_path),
-                    'XH_ROUTE_REASSOC': '1'})          # (the library default; conftest.py pins the test processes to the other form)
-        env.pop('RANK', None)
-        env.pop('WORLD_SIZE', None)
+        env.update({'XH_ONE_DEVICE': '1', 'XH_RCCL_LIBRARY': _fake_rccl(), 'XH_FAKE_RCCL_DIR': str(tmp_path)})
+        for k in ('RANK', 'WORLD_SIZE', 'XH_ROUTE_REASSOC'):      # (conftest.py pins the TEST processes to the bit-exact form;
+            env.pop(k, None)                                      #  these run the library's default unless the ini says otherwise)
         r = subprocess.run([sys.executable, str(script), ROOT, ini, str(n)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and 'PARENT_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
         if n > 1:
@@ -238,6 +244,16 @@ def test_run_model_on_n_ranks_writes_the_same_files(tmp_path, nranks):
         outs[tag] = os.path.join(root, 'output', 'pm_abcd_mrtm_synth')
     files = sorted(x for x in os.listdir(outs['one']) if x.endswith(('.npy', '.csv')))
     assert len(files) >= 6 and files == sorted(x for x in os.listdir(outs['many']) if x.endswith(('.npy', '.csv'))), files
+    n_close = 0
     for name in files:
-        assert open(os.path.join(outs['one'], name), 'rb').read() == open(os.path.join(outs['many'], name), 'rb').read(), name
+        one, many = (open(os.path.join(outs[t], name), 'rb').read() for t in ('one', 'many'))
+        if one == many:
+            continue
+        assert form == 'default' and 'avgchflow' in name, name          # only the routed variable, only in the reassociated form
+        a, b = (np.genfromtxt(os.path.join(outs[t], name), delimiter=',', skip_header=1) for t in ('one', 'many'))
+        assert a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)), name
+        m = ~np.isnan(a)
+        assert (np.abs(a[m] - b[m]) <= 1e-9 * np.abs(a[m]) + 1e-9).all(), (name, float(np.abs(a[m] - b[m]).max()))
+        n_close += 1
+    assert n_close <= 1
     assert not [x for x in os.listdir(str(tmp_path)) if x.startswith('xh_fake_rccl_')]      # every message was received

@@ -12,6 +12,7 @@ from types import SimpleNamespace as NS
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+os.environ.setdefault('XH_ROUTE_REASSOC', '0')      # this tool holds the BIT-EXACT kernels to the oracle's bits (the default form is tested to 1e-9 elsewhere)
 from oracle import mrtm as o_mrtm            # noqa: E402
 from xanthos_amd import _hip, synth           # noqa: E402
 from xanthos_amd.routing import mrtm          # noqa: E402

@@ -12,7 +12,7 @@ import json
 import sys
 
 KEYS = ('k_pm_pet', 'k_pm_pressure', 'k_abcd_tile<false', 'k_abcd_tile<true', 'k_abcd<true>', 'k_abcd<false>',
-        'k_abcd_basin_mean', 'k_mrtm_wave_args', 'k_mrtm_wave', 'k_mrtm_skew', 'k_mrtm_flow', 'k_mrtm_units')
+        'k_abcd_basin_mean', 'k_mrtm_wave_args', 'k_mrtm_rsum', 'k_mrtm_wave', 'k_mrtm_skew', 'k_mrtm_flow', 'k_mrtm_units')
 out, dirs = sys.argv[1], sys.argv[2:]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in dirs:

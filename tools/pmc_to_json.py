@@ -13,7 +13,7 @@ import collections, csv, glob, json, sys
 fetch_dir, write_dir, out = sys.argv[1:4]
 WIDE = {'k_pm_pet': 2.0, 'k_synth': 2.0, 'k_abcd_tile<false': 2.0, 'k_abcd_tile<true': 2.0}      # whole-line streams
 KEYS = ('k_pm_pet', 'k_abcd_tile<false', 'k_abcd_tile<true', 'k_abcd<true>', 'k_abcd<false>', 'k_abcd_basin_mean',
-        'k_mrtm_wave_args', 'k_mrtm_wave', 'k_mrtm_skew', 'k_mrtm_flow', 'k_mrtm_units', 'k_synth', 'k_sc1_store',
+        'k_mrtm_wave_args', 'k_mrtm_rsum', 'k_mrtm_wave', 'k_mrtm_skew', 'k_mrtm_flow', 'k_mrtm_units', 'k_synth', 'k_sc1_store',
         'k_sc1_load', 'k_plain_store', 'k_plain_load')
 
 
@@ -47,7 +47,7 @@ for k in sorted(set(f) | set(w)):
     kr, kw, note = WIDE.get(k, 1.0), 1.0, None
     if k in WIDE:
         note = 'reads are wide coalesced streams: FETCH_SIZE doubled'
-    elif k in ('k_mrtm_wave', 'k_mrtm_skew') and calib and calib['fetch_factor_sc1'] and calib['write_factor_sc1']:
+    elif k in ('k_mrtm_rsum', 'k_mrtm_wave', 'k_mrtm_skew') and calib and calib['fetch_factor_sc1'] and calib['write_factor_sc1']:
         kr, kw = calib['fetch_factor_sc1'], calib['write_factor_sc1']
         note = ('stream traffic dominates: factors measured with tools/micro/sc1_traffic.hip on the same access shapes '
                 '(16-byte sc1 raw-buffer loads / stores, whole lines)')

@@ -25,7 +25,7 @@ cp gpurun_out/prof_trace/*/*kernel_stats.csv gpurun_out/kernel_stats.csv
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d gpurun_out/prof_insts -- python3 bench.py --steps 2 --warmup 1 --order staged --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/prof_cyc -- python3 bench.py --steps 2 --warmup 1 --order staged --no-cpu-baseline --no-end-to-end > /dev/null 2>&1
 python3 tools/pmc_insts_json.py gpurun_out/pmc_insts.json gpurun_out/prof_insts gpurun_out/prof_cyc > /dev/null
-(python3 tools/pmc_summary.py gpurun_out/prof_insts; python3 tools/pmc_summary.py gpurun_out/prof_cyc) | grep -E "k_pm_pet|k_abcd|k_mrtm_wave" > gpurun_out/pmc_insts.txt
+(python3 tools/pmc_summary.py gpurun_out/prof_insts; python3 tools/pmc_summary.py gpurun_out/prof_cyc) | grep -E "k_pm_pet|k_abcd|k_mrtm_wave|k_mrtm_rsum" > gpurun_out/pmc_insts.txt
 timeout 900 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.log
 timeout 300 python3 bench.py --workload pm_abcd --steps 10 --warmup 2 > gpurun_out/bench_pm_abcd.json 2> gpurun_out/bench_pm_abcd.log
 timeout 600 python3 bench.py --workload calib --steps 5 --warmup 1 > gpurun_out/bench_calib.json 2> gpurun_out/bench_calib.log

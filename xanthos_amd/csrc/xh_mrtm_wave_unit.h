@@ -424,8 +424,11 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         // before the counter store -- the guide's measured `sc1` hand-off form (vmcnt(0) in front of the flag), without the L2
         // write-back of a release fence; the import loads two blocks ahead are simply waited for.  Priced against the default
         // in profiles/round5/fence_mid_ab.txt.
-        if (A(fenced) == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pend_ready), "+v"(pend_done) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(pend_ready), "+v"(pend_done) : : "memory");   // older stores acknowledged, pend_* in
+        // (a statement of its own BEHIND the counted wait, without register operands: pend_* are registers of loads in
+        // flight until that wait, and anything that makes the compiler copy them first -- a branch around the wait did --
+        // reads them before they have arrived)
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(pend_ready), "+v"(pend_done) : : "memory");   // older stores acknowledged, pend_* in
+        if (A(fenced) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (PLAIN && __any((fired | gmis) != 0)) {       // the plain form does not hold for this input: give up, the host re-routes
             learn_now();
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
