@@ -393,10 +393,12 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     //      stream access, so "all but the 8 youngest memory operations have completed" covers every store older than
     //      PUBLAG iterations without draining the loads that are two blocks ahead.
     //      MEMORY-ORDERING ASSUMPTION (outside the HIP memory model, stated here because everything rests on it): the
-    //      stream stores are write-through `sc1` buffer stores; vmcnt retires this wave's memory operations in issue
-    //      order and a write-through store retires only when the memory side has acknowledged it, so after
-    //      `s_waitcnt vmcnt(8)` every store older than PUBLAG iterations is visible at agent scope; only then is the
-    //      counter advanced (relaxed agent-scope store, itself ordered behind the waitcnt by the "memory" clobber).  A
+    //      stream stores are write-through `sc1` buffer stores, and a write-through store retires (leaves vmcnt) only
+    //      when the memory side has acknowledged it; since round 5 the publication waits for `s_waitcnt vmcnt(0)` -- ALL
+    //      of the wave's memory operations, the form the guide measured for `sc1` hand-offs -- so every stream store
+    //      issued so far is visible at agent scope; only then is the
+    //      counter advanced (relaxed agent-scope store, itself ordered behind the waitcnt by the "memory" clobber).  (Until
+    //      round 4: vmcnt(8) + the in-order retirement of vmcnt + a publication lag of PUBLAG iterations; XH_ROUTE_FENCED=lag.)  A
     //      consumer reads the counter with an agent-scope load and the data with `sc1` loads, which re-fetch past its
     //      XCD's L2.  No release / acquire fences.  Evidence: every full-size launch of the test suite bit-identical to
     //      the oracle, XH_ROUTE_VALIDATE (the same call routed by the barrier-only kernel and compared on the device),
@@ -420,15 +422,18 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     };
     auto check = [&](int n) {
         const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-        // XH_ROUTE_FENCED=mid (fenced == 3; round 5): EVERY memory operation of the wave has been acknowledged
-        // before the counter store -- the guide's measured `sc1` hand-off form (vmcnt(0) in front of the flag), without the L2
-        // write-back of a release fence; the import loads two blocks ahead are simply waited for.  Priced against the default
-        // in profiles/round5/fence_mid_ab.txt.
-        // (a statement of its own BEHIND the counted wait, without register operands: pend_* are registers of loads in
-        // flight until that wait, and anything that makes the compiler copy them first -- a branch around the wait did --
-        // reads them before they have arrived)
+        // Round 5, the default since: EVERY memory operation of the wave has been acknowledged before the counter
+        // store -- `s_waitcnt vmcnt(0)` in front of the flag, the guide's measured `sc1` hand-off form, without the L2 write-back
+        // of a release fence; the import loads two blocks ahead are simply waited for.  Priced on both kernels, same box,
+        // alternating (profiles/round5/fence_mid_ab.txt): 15.08 - 15.38 against 15.16 - 15.36 ms (reassociated), 22.0 - 22.9
+        // against 22.3 - 23.0 (bit-exact) -- nothing; the full release / acquire pair costs +76 % / +40 %.  XH_ROUTE_FENCED=lag
+        // (fenced == 4) is round 4's form for comparison: all but the 8 youngest operations + a publication lag of PUBLAG.
+        // (The second wait is a statement of its own BEHIND the counted one, without register operands: pend_* are registers
+        // of loads in flight until that wait, and anything that makes the compiler copy them first -- a branch around the wait
+        // did, and every stream-linked unit then read counters that had not arrived -- reads garbage.)
         asm volatile("s_waitcnt vmcnt(8)" : "+v"(pend_ready), "+v"(pend_done) : : "memory");   // older stores acknowledged, pend_* in
-        if (A(fenced) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool lagged = A(fenced) == 4;
+        if (!lagged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (PLAIN && __any((fired | gmis) != 0)) {       // the plain form does not hold for this input: give up, the host re-routes
             learn_now();
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -436,7 +441,8 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         }
         const bool fenced = A(fenced) == 1;
         if (any_x) {      // publish what has certainly been stored, then make sure the next CH iterations have ring space
-            const int pub = min(max(n - PUBLAG - RING - lmax, 0), total);
+            // (everything stored so far is acknowledged: publish it all; the lagged form holds back PUBLAG sub-steps)
+            const int pub = min(max(n - (lagged ? PUBLAG : 0) - RING - lmax, 0), total);
             // XH_ROUTE_FENCED=1: the publication the HIP memory model asks for -- an agent-scope release (buffer_wbl2 sc1 +
             // s_waitcnt vmcnt(0): every memory operation of the wave drained, the XCD's L2 written back) in front of the
             // counter store, an agent-scope acquire behind the consumer's counter load.  Measured on MI355X at the full grid
