@@ -125,6 +125,43 @@ def streamrouting(L, S0, F0, ChV, q, area, nday, dt, UM):
     return S, favg, F
 
 
+def streamrouting_fused(L, S0, F0, ChV, q, area, nday, dt, UM):
+    """One month in the arithmetic of the REASSOCIATED kernel form (k_mrtm_rsum, csrc/xh_mrtm_wave_unit.h RSUM; test
+    infrastructure like the rest of this package): the same explicit Euler step and "excess flow" rule as ``streamrouting``
+    (mrtm.py:50-69), restated so that a cell needs only the SUM of its upstream neighbours' flows -- in any order -- and
+    eight operations:
+
+        base = S a + erl dt                    a = 1 - (ChV / L) dt
+        S1   = base + (sum F) dt               the trial storage; Sx of mrtm.py:54 (dSdt dt < -S) is S1 < 0
+        F2   = F + min(S1, 0) / dt             mrtm.py:60: inbound + lateral + S / dt = F + S1 / dt
+        S    = Sx ? 0 : base + (sum F2) dt     mrtm.py:63, 69
+
+    numpy has no fma, so this differs from the kernel by roundings of its own; both are held to 1e-9 of ``streamrouting``
+    (tests/test_oracle_golden.py here, tests/test_gpu_reassoc.py on the device; measured ~1e-12)."""
+    nt = int(nday * 24 * 3600 / dt)
+    n = L.shape[0]
+    up = (UM + sparse.eye(n, dtype=int)).tocsr().astype(float)          # UP = UM + I: inflow only
+    tauinv = ChV / L
+    a = 1.0 - tauinv * dt
+    dtinv = 1.0 / dt
+    erldt = ((q * area) * (1e6 / 1e3) / (nday * 24 * 3600)) * dt
+    S = np.copy(S0)
+    F = np.copy(F0)
+    favg = np.zeros(n, dtype=float)
+    with np.errstate(invalid='ignore'):
+        for _ in range(nt):
+            F0_ = S * tauinv
+            base = S * a + erldt
+            S1 = up.dot(F0_) * dt + base
+            sx = S1 < 0.0
+            F = F0_ + np.where(sx, S1, 0.0) * dtinv
+            S2 = up.dot(F) * dt + base
+            S = np.where(sx, 0.0, S2)
+            favg += F
+    favg /= nt
+    return S, favg, F
+
+
 def route_series(UM, flow_dist, velocity, area, runoff, ndays, spinup_months, S0=None, dt=10800):
     """Month loops of Components.calculate_routing (components.py:273-294).
 

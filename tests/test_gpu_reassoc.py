@@ -221,3 +221,57 @@ def test_fed_pipeline_with_reassoc_routing(hip):
     assert pipe.plan.info()['last_tree_kernel'] == 2
     routed_close(fed['chs'], exact['chs'], 1e-3, tag='chs')
     routed_close(fed['avg'], exact['avg'], 1e-9, tag='avg')
+
+
+def test_run_model_default_routing_form_against_the_oracle_chain(tmp_path):
+    """run_model() as a user meets it since round 5 -- no flag, no environment switch, so the reassociated routing form (a child
+    process: conftest.py pins the test processes themselves to the bit-exact form) -- against the oracle chain PM -> ABCD ->
+    MRTM: PET / AET / Q / Sav as before, ChStorage / Avg_ChFlow within the form's bar; and ``routing_form = exact`` in the ini
+    gives the bit-exact kernels back."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from oracle import abcd as o_abcd, months as o_months, mrtm as o_mrtm, pm as o_pm
+    from xanthos_amd import synth
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    w = synth.make_world(nrow=36, ncol=72, ncell=900, n_basins=7, seed=33)
+    f = synth.make_forcing(w, 36)
+    child = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from xanthos_amd import Xanthos
+res = Xanthos(sys.argv[2]).execute()
+np.savez(sys.argv[3], q=res.Q, chs=res.ChStorage, avg=res.Avg_ChFlow, area=res.data.area, L=res.data.flow_dist, v=res.data.str_velocity)
+print(json.dumps({'kernel': int(res.pipe.plan.info()['last_tree_kernel'])}))
+"""
+    script = tmp_path / 'child.py'
+    script.write_text(child)
+    got = {}
+    for form in ('default', 'exact'):
+        d = str(tmp_path / form)
+        os.makedirs(d)
+        ini = synth.write_example(d, w, f, 1971, 1973, runoff_spinup=25, routing_spinup=6)
+        if form == 'exact':
+            text = open(ini).read()
+            open(ini, 'w').write(text.replace('routing_spinup', 'routing_form = exact\nrouting_spinup', 1))
+        env = dict(os.environ)
+        env.pop('XH_ROUTE_REASSOC', None)
+        r = subprocess.run([sys.executable, str(script), root, ini, os.path.join(d, 'out.npz')], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        kernel = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])['kernel']
+        assert kernel == (4 if form == 'default' else 2), (form, kernel)
+        got[form] = np.load(os.path.join(d, 'out.npz'))
+    st = NS(ngridrow=w.nrow, ngridcol=w.ncol)
+    um = o_mrtm.upstream_genmatrix(o_mrtm.upstream(w.coords, o_mrtm.downstream(w.coords, w.flow_dir, st), st))
+    ndays = o_months.set_month_arrays(36, 1971, 1973)[:, 2]
+    g = got['exact']
+    chs, avg, _ = o_mrtm.route_series(um, g['L'], g['v'], g['area'], g['q'], ndays, 6)
+    assert np.array_equal(g['chs'], chs, equal_nan=True) and np.array_equal(g['avg'], avg, equal_nan=True)
+    d_ = got['default']
+    assert np.array_equal(d_['q'], g['q'], equal_nan=True)                       # the stages in front are the same kernels
+    routed_close(d_['chs'], chs, 1e-3, tag='ChStorage')
+    routed_close(d_['avg'], avg, 1e-9, tag='Avg_ChFlow')
+    assert not np.array_equal(d_['avg'], avg, equal_nan=True)

@@ -121,6 +121,33 @@ def test_route_series_bit_exact(golden, tag):
     assert np.array_equal(ndays, g[tag + '_series_ndays'])
 
 
+@pytest.mark.parametrize('tag', ['rand', 'tree'])
+def test_fused_routing_form_matches_reference_within_1e9(golden, tag):
+    """The arithmetic of the reassociated kernel form (oracle.mrtm.streamrouting_fused: inflow as a plain sum, the update of
+    mrtm.py:50-69 fused to eight operations) against the REFERENCE's own streamrouting outputs (tests/golden/mrtm.npz, 28-31
+    day months, firing cells included): identical NaN masks, every value within 1e-9 |ref| (+ 1e-3 m3 / 1e-9 m3/s) -- the bar
+    the device kernel of that form is held to on the GPU."""
+    g, t = golden('mrtm'), golden('topo')
+    um = _um(g, t, tag)
+    S = g[tag + '_S0']
+    n = len(S)
+    worst = 0.0
+    for nday in (28, 29, 30, 31):
+        S1, favg, F = o_mrtm.streamrouting_fused(g[tag + '_L'], S, np.zeros(n), g[tag + '_chv'], g['%s_q_%d' % (tag, nday)],
+                                                 g[tag + '_area'], nday, 10800, um)
+        for x, name, atol in ((S1, 'S', 1e-3), (favg, 'Favg', 1e-9), (F, 'F', 1e-9)):
+            ref = g['%s_%s_%d' % (tag, name, nday)]
+            assert np.array_equal(np.isnan(x), np.isnan(ref))
+            m = ~np.isnan(ref)
+            err = np.abs(x[m] - ref[m])
+            assert (err <= 1e-9 * np.abs(ref[m]) + atol).all(), (tag, nday, name, float(err.max()))
+            big = np.abs(ref[m]) > 1e6 * atol
+            if big.any():
+                worst = max(worst, float((err[big] / np.abs(ref[m][big])).max()))
+        S = g['%s_S_%d' % (tag, nday)]
+    assert worst < 1e-11, worst
+
+
 @pytest.mark.parametrize('basin', [0, 1])
 @pytest.mark.parametrize('unit', ['km3_per_mth', 'mm_per_mth'])
 @pytest.mark.parametrize('tag', ['snow', 'nosnow'])

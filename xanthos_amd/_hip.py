@@ -121,7 +121,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 4        # xh_abi_version() of the library these signatures describe
+ABI_VERSION = 5        # xh_abi_version() of the library these signatures describe
 
 
 def lib():

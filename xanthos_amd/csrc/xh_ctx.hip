@@ -236,7 +236,7 @@ void xh_span_cancel(xh_span &s) {      // nothing was launched after all: the sp
 
 extern "C" {
 
-int xh_abi_version(void) { return 4; }
+int xh_abi_version(void) { return 5; }
 
 int xh_device_count(int *n) {
     if (!n) return XH_ERR_ARG;
