@@ -1089,6 +1089,9 @@ extern "C" int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const dou
     XH_REQUIRE(ctx, plan->ctx == ctx, "xh_route_plan_prepare: plan belongs to another context");
     XH_REQUIRE(ctx, h_flow_dist && h_velocity && dt > 0.0, "xh_route_plan_prepare: bad argument");
     static const bool enabled = !(getenv("XH_ROUTE_LEARN_CACHE") && getenv("XH_ROUTE_LEARN_CACHE")[0] == '0');
+    // (what is prepared here -- the selective plain tables of the BIT-EXACT kernel -- is of no use to a process whose calls
+    // route in the reassociated form by default; a call that asks for XH_ROUTE_EXACT later learns the way it always did)
+    if (reassoc_wanted(0)) return XH_OK;
     if (!enabled || plan->prepared || plan->flow_typed || !plan->flow || !plan->flow->skew_ok || plan->h_indptr.empty() ||
         !plan->d_learn.p)
         return XH_OK;
