@@ -275,3 +275,88 @@ print(json.dumps({'kernel': int(res.pipe.plan.info()['last_tree_kernel'])}))
     routed_close(d_['chs'], chs, 1e-3, tag='ChStorage')
     routed_close(d_['avg'], avg, 1e-9, tag='Avg_ChFlow')
     assert not np.array_equal(d_['avg'], avg, equal_nan=True)
+
+
+def test_route_reassoc_edge_sizes_and_forced_fault(hip):
+    """Smallest legal problems in the reassociated form -- a two-cell network (cell 1 drains into cell 0, a reach shorter than
+    velocity x dt: it fires), 13 months (a partial group of output months), with and without spin-up; a single cell -- and the
+    fault path: XH_ROUTE_TEST_FAULT raises the fault word in front of the launch, the units that wait give up, the call is
+    routed again by the workgroup-per-network kernel at the next synchronisation (bit-exact then, hence inside the bar)."""
+    from oracle import mrtm as o_mrtm
+    from xanthos_amd.routing import mrtm
+    um = mrtm.UpstreamMatrix([0, 2, 3], [0, 1, 1], [-1, 1, -1])
+    L, v, area = np.array([30e3, 1000.0]), np.array([1.0, 2.0]), np.array([2500.0, 2400.0])
+    q = np.random.default_rng(2).gamma(2.0, 30.0, (2, 13))
+    ndays = np.array([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31, 31])
+    for spin in (0, 5):
+        ref = o_mrtm.route_series(um.tocsr(), L, v, area, q, ndays, spin)
+        series_close(mrtm.route_series(um, L, v, area, q, ndays, spin, flags=REASSOC), ref, ('two cells', spin))
+        assert um.plan(hip.get_context()).info()['last_tree_kernel'] == 4
+    um1 = mrtm.UpstreamMatrix([0, 1], [0], [-1])
+    ref = o_mrtm.route_series(um1.tocsr(), L[:1], v[:1], area[:1], q[:1], ndays, 2)
+    series_close(mrtm.route_series(um1, L[:1], v[:1], area[:1], q[:1], ndays, 2, flags=REASSOC), ref, 'one cell')
+    w, umw = _world(seed=8)
+    rng = np.random.default_rng(4)
+    runoff = rng.gamma(2.0, 30.0, (w.ncell, 8))
+    nd = ndays[:8]
+    ref = o_mrtm.route_series(umw.tocsr(), w.flow_dist, w.velocity, w.area, runoff, nd, 2)
+    plan = umw.plan(hip.get_context())
+    r0 = plan.info()['reroutes']
+    got = mrtm.route_series(umw, w.flow_dist, w.velocity, w.area, runoff, nd, 2, flags=REASSOC | hip.XH_ROUTE_TEST_FAULT)
+    series_close(got, ref, 'forced fault')
+    assert plan.info()['reroutes'] == r0 + 1
+    got = mrtm.route_series(umw, w.flow_dist, w.velocity, w.area, runoff, nd, 2, flags=REASSOC)      # (backs off: no dataflow kernel)
+    series_close(got, ref, 'after the fault')
+
+
+_REASSOC_PARTITION_CHILD = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from types import SimpleNamespace as NS
+from oracle import months as o_months
+from oracle import mrtm as o_mrtm
+from xanthos_amd import _hip, synth
+from xanthos_amd.routing import mrtm
+w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=5, seed=3, outlet_frac=0.02)
+st = NS(ngridrow=w.nrow, ngridcol=w.ncol)
+um = mrtm.upstream_genmatrix(mrtm.upstream(w.coords, mrtm.downstream(w.coords, w.flow_dir, st), st))
+rng = np.random.default_rng(11)
+runoff = rng.gamma(2.0, 30.0, (w.ncell, 12))
+ndays = o_months.set_month_arrays(12, 1973, 1973)[:, 2]
+ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
+got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=_hip.XH_ROUTE_REASSOC)
+worst = 0.0
+for x, r, atol in zip(got, ref, (1e-3, 1e-9, 1e-9)):
+    err = np.abs(x - r)
+    assert (err <= 1e-9 * np.abs(r) + atol).all()
+    worst = max(worst, float((err / np.maximum(np.abs(r), 1e6 * atol)).max()))
+info = um.plan(_hip.get_context()).info()
+print(json.dumps({'kernel': int(info['last_tree_kernel']), 'units': int(info['flow_units']), 'edges': int(info['flow_edges']),
+                  'lag': int(info['skew_max_lag']), 'worst': worst}))
+"""
+
+
+@pytest.mark.parametrize('env', [{}, {'XH_FLOW_PIECE_CAP': '64'}, {'XH_FLOW_PIECE_CAP': '20'}, {'XH_FLOW_PIECE_CAP': '5'},
+                                 {'XH_FLOW_RS': '2048', 'XH_FLOW_SPARE': '3'}, {'XH_ROUTE_FENCED': 'lag'}, {'XH_ROUTE_FENCED': '1'},
+                                 {'XH_FLOW_CHECK': '1', 'XH_FLOW_PIECE_CAP': '12'}])
+def test_route_reassoc_partition_variants(env, tmp_path):
+    """The reassociated planner under other piece capacities (64: few streams, long chains; 5: a stream per handful of cells,
+    chains of pieces everywhere), ring sizes and spare workgroups, the lagged and the fully fenced publication, and the
+    planner's invariant checker inside the library: every variant within the bar of the oracle (a child process each: the
+    switches are read when the library builds its plan)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / 'child.py'
+    script.write_text(_REASSOC_PARTITION_CHILD)
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, str(script), root], env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    info = json.loads(out.stdout.strip().splitlines()[-1])
+    assert info['kernel'] == 4 and info['worst'] < 1e-10, info
+    if env.get('XH_FLOW_PIECE_CAP') == '5':
+        assert info['edges'] > 300, info
