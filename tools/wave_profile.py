@@ -11,7 +11,7 @@ from xanthos_amd.pipeline import pipeline_from_world
 months = int(sys.argv[1]) if len(sys.argv) > 1 else 240
 ctx = _hip.get_context(0)
 w = synth.make_world()
-pipe = pipeline_from_world(ctx, w, months, 1961, 60, 0)
+pipe = pipeline_from_world(ctx, w, months, 1961, 60, 0, route_flags=int(os.environ.get('XH_PROFILE_ROUTE_FLAGS', '0')))
 ctx.synth_forcing(1, pipe.ncell, pipe.nmonths, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.0)
 pipe.run(('pm', 'abcd'))
 for rep in range(2):
