@@ -54,6 +54,16 @@ def test_ini_defaults_and_selector_validation(example, tmp_path):
         ConfigReader(variant('runoff_module = abcd', 'runoff_module = gwam'))
     with pytest.raises(ValidationException):
         ConfigReader(variant('routing_module = mrtm', 'routing_module = rtm'))
+    # round 5: which form of the routing kernel ([[mrtm]] routing_form; not a key of the reference)
+    assert ConfigReader(ini).routing_form == 'default'
+    for value, flag in (('reassociated', 128), ('Exact', 256), ('default', 0)):
+        cfg = ConfigReader(variant('routing_spinup = 6', 'routing_form = {}\nrouting_spinup = 6'.format(value)))
+        assert cfg.routing_form == value.lower()
+        from xanthos_amd.components import Components
+        from types import SimpleNamespace as NS
+        assert Components.route_flags(NS(s=cfg)) == flag
+    with pytest.raises(ValidationException):
+        ConfigReader(variant('routing_spinup = 6', 'routing_form = fast\nrouting_spinup = 6'))
 
 
 def test_data_loader_transforms(example):
