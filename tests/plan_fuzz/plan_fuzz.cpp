@@ -247,7 +247,17 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
     {
         std::vector<char> handled_r;
         FlowTables r;
-        if (flow_tables_build_rsum(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled_r, r, err) != 0) {
+        // leaves that may be carried by their downstream cell's lane (half of the cases): cells without upstream neighbours that
+        // cannot fire
+        std::vector<unsigned char> foldable;
+        FlowPlanOptions opt_r = opt;
+        if (idx % 2 == 0) {
+            foldable.assign(g.n, 0);
+            for (int c = 0; c < g.n; ++c)
+                foldable[c] = (g.indptr[c + 1] - g.indptr[c] == 1) && (capable.empty() || !capable[c]) && (rng() % 8 != 0);
+            opt_r.foldable = foldable.data();
+        }
+        if (flow_tables_build_rsum(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt_r, handled_r, r, err) != 0) {
             fprintf(stderr, "case %d (kind %d, %d cells): reassociated build failed: %s\n", idx, kind, g.n, err.c_str());
             return 1;
         }
@@ -262,7 +272,7 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
             snprintf(path, sizeof(path), "/tmp/plan_fuzz_%d_%d.rtables", (int)getpid(), idx);
             FlowTables u;
             if (!(flow_tables_save(r, path) && flow_tables_load(path, u) && u.rsum && u.ent2 == r.ent2 && u.eprev == r.eprev &&
-                  u.lag == r.lag && u.unit_p == r.unit_p &&
+                  u.lag == r.lag && u.unit_p == r.unit_p && u.fold_of_slot == r.fold_of_slot && u.n_folded == r.n_folded &&
                   flow_tables_check_rsum(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), handled_r, u).empty()))
                 bad_r = "tables did not survive the round trip through a file";
             remove(path);
@@ -272,7 +282,7 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
             return 1;
         }
         if (verbose)
-            printf("        reassociated: %d units, %d streams, depth %d, max lag %d\n", r.n_units, r.n_edges, r.depth, r.skew_lmax);
+            printf("        reassociated: %d units, %d streams, depth %d, max lag %d, %d leaves folded\n", r.n_units, r.n_edges, r.depth, r.skew_lmax, r.n_folded);
     }
     return 0;
 }
@@ -331,6 +341,12 @@ static int run_file(const char *path, bool typed, bool rsum) {
     FlowTables t;
     std::string err;
     if (getenv("SIMDS")) opt.simds = atoi(getenv("SIMDS"));
+    std::vector<unsigned char> foldable;
+    if (rsum && getenv("FOLD")) {
+        foldable.assign(n, 0);
+        for (int c = 0; c < n; ++c) foldable[c] = (g.indptr[c + 1] - g.indptr[c] == 1) && !capable[c];
+        opt.foldable = foldable.data();
+    }
     const auto t0 = std::chrono::steady_clock::now();
     if (rsum ? flow_tables_build_rsum(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)
              : flow_tables_build(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)) {

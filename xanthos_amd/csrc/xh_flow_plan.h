@@ -33,6 +33,10 @@ struct FlowPlanOptions {
     bool balance_lds = false;    // order the claim list's tail by LDS load (XH_WAVE_BALANCE=1: every CU one unit of each quarter)
     int lane_trials = 0;         // > 0: move the cells of a unit to lanes on which its gather meets fewer LDS bank conflicts (swaps tried per unit)
     bool debug = false;          // partition statistics on stderr
+    // Reassociated planner only (xh_flow_rsum.cpp): foldable[c] != 0 for LEAF cells (no upstream neighbour) that cannot fire
+    // (velocity * dt / length below 1) -- such a cell's outflow is a one-fma recurrence that the lane of its downstream cell can
+    // carry in registers, so it needs no lane, no LDS slot and no level of lag of its own.  nullptr: nothing is folded.
+    const unsigned char *foldable = nullptr;
 };
 
 struct FlowTables {
@@ -51,6 +55,8 @@ struct FlowTables {
     std::vector<char> unit_plain;
     std::vector<unsigned char> lane_flags;                       // [units*64] bit 0: the cell can fire by construction
     std::vector<int> ghost_prod;                                 // [units*64] producer cell of imported stream k of the unit
+    std::vector<int> fold_of_slot;                               // reassociated form: [units*64] the leaf cell folded into the lane's cell, or -1 (empty: none)
+    int n_folded = 0;
 };
 
 // ---- shared by the two planners (xh_flow_plan.cpp: sums in stored order; xh_flow_rsum.cpp: reassociated sums)

@@ -45,7 +45,7 @@ struct RPart {
     int nunit = 0, nedge = 0, maxdepth = 0, n_cheap = 0;
 };
 
-void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P) {
+void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P, std::vector<int> &fold_leaf) {
     const int n = t.n;
     const std::vector<int> &ds = t.ds, &child = t.child, &child_ptr = t.child_ptr;
     P = RPart();
@@ -150,6 +150,39 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
     P.nedge = (int)P.e_prod.size();
     P.maxdepth = npiece ? *std::max_element(P.pdepth.begin(), P.pdepth.end()) : 0;
 
+    // ---- folded leaves (opt.foldable).  A leaf that cannot fire is a one-fma recurrence, which the lane of its downstream cell
+    //      can carry in registers (xh_mrtm_wave_unit.h, FOLD): no lane, no LDS slot, no level of lag -- at ~4 more fp64
+    //      operations per sub-step for the whole unit of that lane.  Only units that nobody waits for and that wait for nobody
+    //      can afford that for free, so only pieces WITHOUT STREAMS (whole small networks) fold: every cell of such a piece takes
+    //      ONE of its foldable leaf children into its lane.  The pieces shrink; what this buys is units: 67,420 cells are 2.9 %
+    //      more than the chip's lanes, and the ~40 SIMDs that had to hold two units each ended the kernel.
+    fold_leaf.assign(n, -1);
+    if (opt.foldable) {
+        auto free_piece = [&](int p) { return P.pimp[p] == 0 && ds[roots[p]] < 0; };
+        for (int c : queue) {
+            const int q = P.piece[c];
+            if (q < 0 || !free_piece(q)) continue;
+            for (int k = child_ptr[c]; k < child_ptr[c + 1]; ++k) {
+                const int l = child[k];
+                if (opt.foldable[l] && t.nchild[l] == 0 && P.piece[l] == q) {
+                    fold_leaf[c] = l;
+                    break;
+                }
+            }
+        }
+        for (int c = 0; c < n; ++c)
+            if (fold_leaf[c] >= 0) {
+                P.psize[P.piece[fold_leaf[c]]]--;
+                P.piece[fold_leaf[c]] = -1;
+            }
+        queue.erase(std::remove_if(queue.begin(), queue.end(), [&](int c) { return P.piece[c] < 0; }), queue.end());
+    }
+    // pieces that carry folded leaves may only sit in units WITHOUT streams (they must not fill the free lanes of a unit that
+    // others wait for: the whole unit pays for the folded lanes)
+    std::vector<char> has_fold(npiece, 0);
+    for (int c = 0; c < n; ++c)
+        if (fold_leaf[c] >= 0) has_fold[P.piece[c]] = 1;
+
     // ---- packing.  Pieces with a stream in or out: equal pipeline depth per unit (a unit then only ever waits for units
     //      strictly upstream or downstream of it), first-fit decreasing.  Whole small networks wait for nobody and fill free
     //      lanes anywhere; the `cheap` cheapest of them (single cells first: they read nothing; then the smallest) are kept
@@ -230,9 +263,12 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
                 const int sz = P.psize[p];
                 int u = -1;
                 for (int f = sz; f <= LANES && u < 0; ++f)
-                    if (!bucket[f].empty()) {
-                        u = bucket[f].back();
-                        bucket[f].pop_back();
+                    for (size_t i = bucket[f].size(); i-- > 0;) {
+                        const int b = bucket[f][i];
+                        if (has_fold[p] && (P.unit_imp[b] > 0 || P.unit_out[b] > 0)) continue;
+                        u = b;
+                        bucket[f].erase(bucket[f].begin() + (long)i);
+                        break;
                     }
                 if (u < 0) u = new_unit(0, false);
                 put_piece(p, u);
@@ -261,16 +297,18 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
     const std::vector<int> &ds = t.ds;
 
     RPart P;
+    std::vector<int> fold_leaf;                        // cell -> the leaf its lane carries, or -1
     {
         static const int caps[] = {LANES, 56, 48, 44, 40, 36, 32, 28, 24};
         constexpr int NCAP = (int)(sizeof(caps) / sizeof(caps[0]));
         std::vector<RPart> cand(opt.piece_cap > 0 ? 1 : NCAP);
+        std::vector<std::vector<int>> cand_fold(cand.size());
         if (cand.size() == 1 || n < 4096) {
             for (size_t k = 0; k < cand.size(); ++k)
-                rsum_partition(t, opt, opt.piece_cap > 0 ? std::min(opt.piece_cap, LANES) : caps[k], cand[k]);
+                rsum_partition(t, opt, opt.piece_cap > 0 ? std::min(opt.piece_cap, LANES) : caps[k], cand[k], cand_fold[k]);
         } else {
             std::vector<std::thread> pool;
-            for (size_t k = 0; k < cand.size(); ++k) pool.emplace_back([&, k] { rsum_partition(t, opt, caps[k], cand[k]); });
+            for (size_t k = 0; k < cand.size(); ++k) pool.emplace_back([&, k] { rsum_partition(t, opt, caps[k], cand[k], cand_fold[k]); });
             for (auto &th : pool) th.join();
         }
         bool have = false;
@@ -287,6 +325,7 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
                         opt.piece_cap > 0 ? opt.piece_cap : caps[k], Q.nunit, Q.nedge, indep, Q.maxdepth + 1);
             if (!have || score < best_score) {
                 std::swap(P, Q);
+                std::swap(fold_leaf, cand_fold[k]);
                 best_score = score;
                 have = true;
             }
@@ -316,6 +355,17 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
             slot_of_cell[c] = s;
             handled[c] = 1;
         }
+    for (int c = 0; c < n; ++c)
+        if (fold_leaf[c] >= 0) {
+            if (piece[c] < 0) {
+                err = "flow plan (reassociated): a folded leaf lost its carrier";
+                return -1;
+            }
+            if (out.fold_of_slot.empty()) out.fold_of_slot.assign(ts, -1);
+            out.fold_of_slot[(int64_t)unit_of_piece[piece[c]] * LANES + slot_of_cell[c]] = fold_leaf[c];
+            handled[fold_leaf[c]] = 1;
+            out.n_folded++;
+        }
     std::vector<int> edge_in0(n, -1), edge_in1(n, -1);      // per cell: the stream that feeds its children's sum / its own R
     for (int ed = 0; ed < nedge; ++ed) {
         const int cc = P.e_cons[ed], u = unit_of_piece[piece[cc]];
@@ -339,7 +389,7 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
     for (int c : P.queue) {
         kids.clear();
         for (int k = t.child_ptr[c]; k < t.child_ptr[c + 1]; ++k)
-            if (piece[t.child[k]] == piece[c]) kids.push_back(t.child[k]);
+            if (piece[t.child[k]] >= 0 && piece[t.child[k]] == piece[c]) kids.push_back(t.child[k]);      // (a folded leaf has no piece)
         std::stable_sort(kids.begin(), kids.end(), [&](int x, int y) { return th[x] < th[y]; });
         const int p = (int)kids.size();
         int h = edge_in0[c] >= 0 ? (p > 0 ? p + 1 : 1) : 0;
@@ -401,6 +451,7 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
         out.eprev[slot] = entry_of(r_src[c], u);
         if (a_src[c] != -1) out.unit_p[u] |= 1;
         if (r_src[c] != -1) out.unit_p[u] |= 2;
+        if (fold_leaf[c] >= 0) out.unit_p[u] |= 4;                  // the unit carries folded leaves: the FOLD variant of the kernel
     }
     for (int ed = 0; ed < nedge; ++ed) {
         const int u = out.edge_cons_unit[ed];
@@ -462,6 +513,14 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
         }
         fprintf(stderr, "flow plan (reassociated): %d units (%d without streams, %d kept cheap), %d pieces, %d streams, depth %d, %lld of %lld lanes used\n",
                 nunit, indep, P.n_cheap, (int)roots.size(), nedge, P.maxdepth + 1, (long long)out.n_cells, (long long)ts);
+        {
+            int nfu = 0, nfi = 0;
+            for (int u = 0; u < nunit; ++u) {
+                nfu += (out.unit_p[u] & 4) ? 1 : 0;
+                nfi += ((out.unit_p[u] & 4) && (P.unit_imp[u] > 0 || unit_exp[u] > 0)) ? 1 : 0;
+            }
+            fprintf(stderr, "  folded leaves: %d, in %d units (of them with streams: %d)\n", out.n_folded, nfu, nfi);
+        }
         fprintf(stderr, "  units by reads (none, A, R, A+R): %d %d %d %d\n  units by lmax/16 (0..13+):", hs[0], hs[1], hs[2], hs[3]);
         for (int k = 0; k < 14; ++k) fprintf(stderr, " %d", hl[k]);
         fprintf(stderr, "\n  units by imports (0, <=2, <=4, <=8, more): %d %d %d %d %d\n  longest stream jump: %d levels\n", hi[0], hi[1],
@@ -498,8 +557,23 @@ std::string flow_tables_check_rsum(int n, const int64_t *indptr, const int32_t *
         if (slot_of[c] >= 0) return "cell " + std::to_string(c) + " sits in two slots";
         slot_of[c] = (int)s;
     }
+    // folded leaves: carried by the lane of their downstream cell, no slot of their own, no upstream neighbours
+    std::vector<int> carrier(n, -1);
+    if (!t.fold_of_slot.empty()) {
+        if ((int64_t)t.fold_of_slot.size() != ts) return "fold table size";
+        for (int64_t s = 0; s < ts; ++s) {
+            const int l = t.fold_of_slot[s];
+            if (l < 0) continue;
+            const int c = t.cell_of_slot[s];
+            if (c < 0 || l >= n || !handled[l] || slot_of[l] >= 0 || carrier[l] >= 0) return "folded leaf " + std::to_string(l);
+            if (t.ds[l] != c) return "folded leaf " + std::to_string(l) + " is not carried by its downstream cell";
+            if (indptr[l + 1] - indptr[l] != 1) return "folded cell " + std::to_string(l) + " is not a leaf";
+            if (!(t.unit_p[s / LANES] & 4)) return "unit shape lacks the fold flag";
+            carrier[l] = c;
+        }
+    }
     for (int c = 0; c < n; ++c)
-        if (handled[c] && slot_of[c] < 0) return "handled cell " + std::to_string(c) + " has no slot";
+        if (handled[c] && slot_of[c] < 0 && carrier[c] < 0) return "handled cell " + std::to_string(c) + " has no slot";
     {
         std::vector<char> seen(t.n_units, 0);
         for (int u : t.unit_order) {
@@ -533,7 +607,7 @@ std::string flow_tables_check_rsum(int n, const int64_t *indptr, const int32_t *
             }
         if (g != imp[u]) return "ghost count";
         if (t.unit_lmax[u] & 15) return "unit lag not a multiple of 16";
-        if ((t.unit_p[u] & ~3) != 0x400) return "shape word of unit " + std::to_string(u);
+        if ((t.unit_p[u] & ~7) != 0x400) return "shape word of unit " + std::to_string(u);
     }
     // what a value stands for: the cells whose flows it sums.  expand(entry) appends them.
     std::vector<int> readers_lane(ts, 0), readers_ghost(t.n_edges, 0);
@@ -567,7 +641,7 @@ std::string flow_tables_check_rsum(int n, const int64_t *indptr, const int32_t *
     };
     std::vector<int> terms, want;
     for (int c = 0; c < n; ++c) {
-        if (!handled[c]) continue;
+        if (!handled[c] || slot_of[c] < 0) continue;
         const int s = slot_of[c], u = s / LANES;
         if (t.lag[s] < 0 || t.lag[s] > t.unit_lmax[u] || (t.lag[s] & 1)) return "lag of cell " + std::to_string(c);
         const unsigned a = t.ent2[(size_t)s], r = t.eprev[s];
@@ -586,6 +660,7 @@ std::string flow_tables_check_rsum(int n, const int64_t *indptr, const int32_t *
         if (r != SK_ZERO && !(t.unit_p[u] & 2)) return "unit shape lacks the chain read";
         terms.clear();
         if (!expand(u, a, terms, 0, expand)) return "bad chain at cell " + std::to_string(c);
+        if (!t.fold_of_slot.empty() && t.fold_of_slot[s] >= 0) terms.push_back(t.fold_of_slot[s]);      // the leaf the lane carries itself
         want.clear();
         for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {
             if (indices[j] == c) {
@@ -601,7 +676,7 @@ std::string flow_tables_check_rsum(int n, const int64_t *indptr, const int32_t *
     // every value has exactly one reader (a lane's running sum: the next member or the fed cell; none for a cell without a
     // downstream cell), and every outlet with a stream is an exported lane
     for (int c = 0; c < n; ++c) {
-        if (!handled[c]) continue;
+        if (!handled[c] || slot_of[c] < 0) continue;
         const int s = slot_of[c];
         const int want_readers = t.ds[c] >= 0 ? 1 : 0;
         const int have = readers_lane[s] + (t.export_edge[s] >= 0 ? 1 : 0);
