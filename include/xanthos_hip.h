@@ -237,6 +237,11 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
                                        bit-exact kernels).  XH_ROUTE_VALIDATE then compares within 1e-9.               */
 #define XH_ROUTE_EXACT 256          /* the bit-exact kernels for this call (every row sum in scipy's stored order) whatever
                                        the default says                                                                  */
+/* The reassociated plan the last call ran on: info[4] = {its units, the leaves it folded into their downstream cells' lanes,
+ * 1 if a guard trip has switched the plan with folded leaves off, folded leaves of the prepared plan (xh_route_plan_prepare
+ * with XH_FLOW_FOLD=1: leaves that cannot fire -- velocity * dt / length < 1 -- of river networks small enough to have no
+ * streams are carried by their parents' lanes, which frees enough lanes for every unit to have a SIMD of its own)}.        */
+int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[4]);
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,
                     const double *d_flow_dist, const double *d_velocity, const double *d_area,

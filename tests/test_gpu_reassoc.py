@@ -360,3 +360,76 @@ def test_route_reassoc_partition_variants(env, tmp_path):
     assert info['kernel'] == 4 and info['worst'] < 1e-10, info
     if env.get('XH_FLOW_PIECE_CAP') == '5':
         assert info['edges'] > 300, info
+
+
+_FOLD_CHILD = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import mrtm as o_mrtm
+from xanthos_amd import _hip, synth
+from xanthos_amd.pipeline import pipeline_from_world
+ctx = _hip.get_context(0)
+w = synth.make_world(nrow=60, ncol=120, ncell=4000, n_basins=9, seed=21, outlet_frac=0.12)      # many small river networks
+nm = 36
+pipe = pipeline_from_world(ctx, w, nm, 1971, 25, 12)           # (makes the plan and hands it velocity / flow distance / dt)
+ctx.synth_forcing(7, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.003)
+pipe.run(('pm', 'abcd'), fed=False)
+q = pipe.out['q'].download()
+ref = o_mrtm.route_series(pipe.um.tocsr(), w.flow_dist, w.velocity, w.area, q, pipe.ndays, 12)
+
+def close(tag):
+    worst = 0.0
+    for k, r, atol in (('chs', ref[0], 1e-3), ('avg', ref[1], 1e-9)):
+        x = pipe.out[k].download()
+        assert np.array_equal(np.isnan(x), np.isnan(r)), (tag, k)
+        m = ~np.isnan(r)
+        err = np.abs(x[m] - r[m])
+        assert (err <= 1e-9 * np.abs(r[m]) + atol).all(), (tag, k, float(err.max()))
+        worst = max(worst, float((err / np.maximum(np.abs(r[m]), 1e6 * atol)).max()))
+    return worst
+out = {}
+for k in ('chs', 'avg'):
+    pipe.out[k].zero()
+pipe.run_mrtm()
+out['worst'] = close('folded')
+out['info'] = pipe.plan.rsum_info()
+out['kernel'] = int(pipe.plan.info()['last_tree_kernel'])
+pipe.run(fed=True)                                              # the fed order on the folded plan
+out['worst_fed'] = close('fed')
+out['info_fed'] = pipe.plan.rsum_info()
+# the guard: NEGATIVE runoff in the row of a folded leaf is outside the argument that lets its parent's lane carry it (it
+# could fire) -- the unit gives up, the call is routed again on the plan without folded leaves, the result is still right
+leaves = np.nonzero(np.diff(pipe.um.indptr) == 1)[0]
+q2 = q.copy()
+q2[leaves, 5] = -3.0
+d_q2 = ctx.upload(q2)
+ref = o_mrtm.route_series(pipe.um.tocsr(), w.flow_dist, w.velocity, w.area, q2, pipe.ndays, 12)
+pipe.run_mrtm(runoff=d_q2)
+ctx.sync()
+out['worst_guard'] = close('guard')
+out['info_guard'] = pipe.plan.rsum_info()
+print(json.dumps(out))
+"""
+
+
+def test_folded_leaves_in_the_reassociated_form(tmp_path):
+    """XH_FLOW_FOLD=1: leaves that cannot fire, in river networks small enough to have no streams, are carried by the lanes of
+    their downstream cells (one fma recurrence each) -- fewer units, every value still within the bar of the oracle, staged
+    and fed; and the guard: negative runoff in a folded leaf's row makes the unit give up, the call is routed again on the
+    plan without folded leaves (which is then the one in use)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / 'fold_child.py'
+    script.write_text(_FOLD_CHILD)
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    env = dict(os.environ, XH_FLOW_FOLD='1', XH_FLOW_CHECK='1')
+    env.pop('XH_ROUTE_REASSOC', None)
+    r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out['kernel'] == 4 and out['worst'] < 1e-10 and out['worst_fed'] < 1e-10 and out['worst_guard'] < 1e-10, out
+    assert out['info']['folded'] > 50 and out['info_fed']['folded'] == out['info']['folded'], out
+    assert out['info_guard']['fold_disabled'] == 1 and out['info_guard']['folded'] == 0, out

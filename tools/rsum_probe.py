@@ -45,6 +45,7 @@ for name, flags in (('exact', _hip.XH_ROUTE_EXACT), ('reassoc', _hip.XH_ROUTE_RE
     res[name] = {k: pipe.out[k].download().copy() for k in ('chs', 'avg')}
     print('%-8s first call %.2f ms; routed by kernel %d; units %d, streams %d, depth %d, max lag %d' % (
         name, ms, info['last_tree_kernel'], info['flow_units'], info['flow_edges'], info['flow_depth'], info['skew_max_lag']), flush=True)
+print('reassociated plan:', pipe.plan.rsum_info(), flush=True)
 ok = True
 for k in ('chs', 'avg'):
     a, b = res['reassoc'][k], res['exact'][k]

@@ -85,6 +85,7 @@ SIGNATURES = {
     'xh_route_plan_info': (c_int, [_P, POINTER(c_int64)]),
     'xh_route_plan_stats': (c_int, [_P, c_int64, _P, POINTER(c_int64)]),
     'xh_route_plan_typed_info': (c_int, [_P, _P]),
+    'xh_route_plan_rsum_info': (c_int, [_P, POINTER(c_int64)]),
     'xh_route_plan_prepare': (c_int, [_P, _P, _P, _P, c_double]),
     'xh_mrtm_downstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     'xh_mrtm_upstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
@@ -528,6 +529,12 @@ class RoutePlan:
         if L.size != self.ncell or v.size != self.ncell:
             raise ValueError('flow_dist / velocity must have one value per cell')
         self.ctx._check(lib().xh_route_plan_prepare(self.ctx.handle, self.handle, _host_ptr(L), _host_ptr(v), float(dt)))
+
+    def rsum_info(self):
+        """The reassociated plan the last call ran on (xh_route_plan_rsum_info)."""
+        arr = (c_int64 * 4)()
+        self.ctx._check(lib().xh_route_plan_rsum_info(self.handle, arr))
+        return dict(zip(('units', 'folded', 'fold_disabled', 'prepared_folded'), list(arr)))
 
     def typed_info(self):
         """Pair / plain units of the dataflow partition (xh_route_plan_typed_info)."""

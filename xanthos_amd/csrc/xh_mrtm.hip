@@ -351,6 +351,15 @@ struct xh_route_plan {
     // Reassociated form (XH_ROUTE_REASSOC; xh_flow_rsum.cpp, k_mrtm_rsum): a partition of its own over the same cells, made
     // with the plan when the environment asks for the form, else on the first call that does.  Needs nothing of a call's data.
     FlowPlan *flow_rsum = nullptr;
+    // ... and the same with FOLDED LEAVES (xh_flow_rsum.cpp, FlowPlanOptions::foldable): which leaves cannot fire depends on
+    // velocity, flow distance and dt, so this one is made by xh_route_plan_prepare from the host copies (XH_FLOW_FOLD=1); the
+    // kernel guards the assumption and a trip routes the call again on flow_rsum and switches the folded plan off
+    FlowPlan *flow_rsum_fold = nullptr;
+    double fold_dt = 0.0;
+    bool fold_disabled = false;
+    bool fold_tried = false;      // prepare() has asked the planner once (it may have had nothing to fold)
+    bool first_checked_fold = false;
+    FlowPlan *last_rsum_plan = nullptr;          // the plan the last reassociated call ran on
     bool rsum_failed = false;                    // the planner turned the grid down once: not tried again
     bool last_rsum = false;                      // the last call was routed by k_mrtm_rsum
     bool first_checked_rsum = false;
@@ -513,18 +522,16 @@ static bool reassoc_wanted(int flags) {
     return reassoc_env() >= 0 ? reassoc_env() == 1 : XH_REASSOC_DEFAULT != 0;
 }
 
-// The reassociated partition of the plan's tree networks (host planner + upload).  XH_OK with plan->flow_rsum == nullptr and
-// rsum_failed set when the planner has nothing for this grid; the call then takes the bit-exact path.
-static int rsum_plan_build(xh_ctx *ctx, xh_route_plan *plan) {
-    if (plan->flow_rsum || plan->rsum_failed) return XH_OK;
-    plan->rsum_failed = true;
-    if (!plan->flow || plan->h_indptr.empty()) return XH_OK;
-    std::vector<char> handled;
-    FlowTables t;
+// The reassociated partition of the plan's tree networks, from the per-box cache or from the host planner
+// (xh_flow_rsum.cpp).  `foldable` (or nullptr): the leaves the parents' lanes may carry (FlowPlanOptions::foldable).  The
+// partition of a grid is the same every time (topology, planner options, foldable set, library build): it is kept in the
+// cache beside the bit-exact one (flow_plan_build) and held to the planner's own invariant checker before it is used.
+// False: the planner has nothing for this grid.
+static bool rsum_tables_get(xh_ctx *ctx, xh_route_plan *plan, const unsigned char *foldable, FlowTables &t,
+                            std::vector<char> &handled) {
     std::string err;
-    const FlowPlanOptions opt = flow_plan_options(ctx);
-    // the partition of a grid is the same every time (topology, planner options, library build): kept in the per-box cache
-    // beside the bit-exact one (flow_plan_build) and held to the planner's own invariant checker before it is used
+    FlowPlanOptions opt = flow_plan_options(ctx);
+    opt.foldable = foldable;
     std::string cache;
     static const bool cache_on = !(getenv("XH_ROUTE_LEARN_CACHE") && getenv("XH_ROUTE_LEARN_CACHE")[0] == '0');
     if (cache_on && !opt.debug) {
@@ -536,34 +543,49 @@ static int rsum_plan_build(xh_ctx *ctx, xh_route_plan *plan) {
             const int knobs[2] = {opt.simds, opt.piece_cap};
             for (size_t i = 0; i < sizeof(knobs); ++i) h = (h ^ reinterpret_cast<const unsigned char *>(knobs)[i]) * 1099511628211ull;
             for (const char *b = __DATE__ " " __TIME__; *b; ++b) h = (h ^ (unsigned char)*b) * 1099511628211ull;
+            if (foldable)
+                for (int64_t c = 0; c < plan->ncell; ++c) h = (h ^ foldable[c]) * 1099511628211ull;
             char name[96];
-            snprintf(name, sizeof(name), "/rsum_%016llx_%lld.tables", (unsigned long long)h, (long long)plan->ncell);
+            snprintf(name, sizeof(name), "/rsum%s_%016llx_%lld.tables", foldable ? "f" : "", (unsigned long long)h, (long long)plan->ncell);
             cache = dir + name;
         }
     }
-    bool loaded = false;
     if (!cache.empty() && flow_tables_load(cache.c_str(), t) && t.rsum && t.n_units > 0 &&
-        (int64_t)t.cell_of_slot.size() == (int64_t)t.n_units * 64) {
+        (int64_t)t.cell_of_slot.size() == (int64_t)t.n_units * 64 && (foldable != nullptr) == (t.n_folded > 0)) {
         handled.assign((size_t)plan->ncell, 0);
-        loaded = true;
-        for (int c : t.cell_of_slot) {
-            if (c >= plan->ncell) loaded = false;
+        bool ok = true;
+        auto take = [&](int c) {
+            if (c >= plan->ncell) ok = false;
             else if (c >= 0) handled[c] = 1;
-        }
-        loaded = loaded && flow_tables_check_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
-                                                  plan->h_sign.data(), handled, t).empty();
+        };
+        for (int c : t.cell_of_slot) take(c);
+        for (int c : t.fold_of_slot) take(c);
+        if (ok && flow_tables_check_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(), plan->h_sign.data(),
+                                         handled, t).empty())
+            return true;
+        t = FlowTables();
     }
-    if (!loaded) {
-        if (flow_tables_build_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(), plan->h_sign.data(),
-                                   plan->h_comp.data(), plan->h_ncomp, opt, handled, t, err) != 0 || t.n_units == 0)
-            return XH_OK;
-        if (!cache.empty()) {
-            const std::string dir = cache.substr(0, cache.rfind('/'));
-            for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
-                if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
-            (void)flow_tables_save(t, cache.c_str());
-        }
+    if (flow_tables_build_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(), plan->h_sign.data(),
+                               plan->h_comp.data(), plan->h_ncomp, opt, handled, t, err) != 0 || t.n_units == 0)
+        return false;
+    if (!cache.empty() && (foldable == nullptr || t.n_folded > 0)) {
+        const std::string dir = cache.substr(0, cache.rfind('/'));
+        for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
+            if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
+        (void)flow_tables_save(t, cache.c_str());
     }
+    return true;
+}
+
+// The reassociated plan (host planner + upload).  XH_OK with plan->flow_rsum == nullptr and rsum_failed set when the planner
+// has nothing for this grid; the call then takes the bit-exact path.
+static int rsum_plan_build(xh_ctx *ctx, xh_route_plan *plan) {
+    if (plan->flow_rsum || plan->rsum_failed) return XH_OK;
+    plan->rsum_failed = true;
+    if (!plan->flow || plan->h_indptr.empty()) return XH_OK;
+    std::vector<char> handled;
+    FlowTables t;
+    if (!rsum_tables_get(ctx, plan, nullptr, t, handled)) return XH_OK;
     if (t.n_cells != plan->flow->n_cells) return XH_OK;      // must route exactly the cells the bit-exact plan routes
     if (getenv("XH_FLOW_CHECK")) {
         const std::string bad = flow_tables_check_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
@@ -897,6 +919,7 @@ static void route_plan_free(xh_route_plan *plan, bool settle) {
     flow_plan_destroy(plan->flow);
     flow_plan_destroy(plan->flow_typed);
     flow_plan_destroy(plan->flow_rsum);
+    flow_plan_destroy(plan->flow_rsum_fold);
     free_buf(plan->d_capable);
     free_buf(plan->d_learn);
     if (plan->d_cap_diff) (void)hipFree(plan->d_cap_diff);
@@ -916,13 +939,13 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
     info[5] = plan->total_slots;
     info[6] = plan->all_single_ds ? 1 : 0;
     int64_t fi[5];
-    flow_plan_info(plan->last_rsum ? plan->flow_rsum : (plan->last_typed ? plan->flow_typed : plan->flow), fi);
+    flow_plan_info(plan->last_rsum ? plan->last_rsum_plan : (plan->last_typed ? plan->flow_typed : plan->flow), fi);
     info[7] = fi[0];                  // dataflow units
     info[8] = fi[1];                  // stream edges
     info[9] = fi[2];                  // pipeline depth
     info[10] = fi[3];                 // cells routed by the dataflow kernel
     info[11] = fi[4];                 // most imported streams of a unit
-    info[12] = (plan->last_rsum && plan->flow_rsum) ? plan->flow_rsum->skew_lmax
+    info[12] = (plan->last_rsum && plan->last_rsum_plan) ? plan->last_rsum_plan->skew_lmax
                                                     : ((plan->flow && plan->flow->skew_ok) ? plan->flow->skew_lmax : -1);     // deepest lane lag (sub-steps)
     info[13] = plan->last_tree_kernel;
     info[14] = plan->reroutes;
@@ -933,7 +956,7 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
 extern "C" int xh_route_plan_stats(xh_route_plan *plan, int64_t max_words, uint64_t *h_words, int64_t *n_words) {
     if (!plan || !n_words) return XH_ERR_ARG;
     std::vector<unsigned long long> st;
-    int rc = flow_stats_fetch(plan->ctx, plan->last_rsum ? plan->flow_rsum : (plan->last_typed ? plan->flow_typed : plan->flow), st);
+    int rc = flow_stats_fetch(plan->ctx, plan->last_rsum ? plan->last_rsum_plan : (plan->last_typed ? plan->flow_typed : plan->flow), st);
     if (rc) return rc;
     *n_words = (int64_t)st.size();
     if (h_words)
@@ -1088,10 +1111,41 @@ extern "C" int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const dou
     if (!ctx || !plan) return XH_ERR_ARG;
     XH_REQUIRE(ctx, plan->ctx == ctx, "xh_route_plan_prepare: plan belongs to another context");
     XH_REQUIRE(ctx, h_flow_dist && h_velocity && dt > 0.0, "xh_route_plan_prepare: bad argument");
+    XH_HIP(ctx, hipSetDevice(ctx->device));                      // may be called from a host thread of its own (run_model())
     static const bool enabled = !(getenv("XH_ROUTE_LEARN_CACHE") && getenv("XH_ROUTE_LEARN_CACHE")[0] == '0');
-    // (what is prepared here -- the selective plain tables of the BIT-EXACT kernel -- is of no use to a process whose calls
+    // (what is prepared below -- the selective plain tables of the BIT-EXACT kernel -- is of no use to a process whose calls
     // route in the reassociated form by default; a call that asks for XH_ROUTE_EXACT later learns the way it always did)
-    if (reassoc_wanted(0)) return XH_OK;
+    if (reassoc_wanted(0)) {
+        // ... but the reassociated plan with FOLDED LEAVES needs exactly what this call brings: which leaves cannot fire
+        // (XH_FLOW_FOLD=0: never folded)
+        static const bool fold_on = !(getenv("XH_FLOW_FOLD") && getenv("XH_FLOW_FOLD")[0] == '0');
+        if (!fold_on || plan->flow_rsum_fold || plan->fold_disabled || plan->fold_tried || !plan->flow || plan->h_indptr.empty())
+            return XH_OK;
+        plan->fold_tried = true;
+        const size_t n = (size_t)plan->ncell;
+        std::vector<unsigned char> foldable(n, 0);
+        size_t nfold = 0;
+        for (size_t c = 0; c < n; ++c) {
+            const double tauinv = h_velocity[c] / h_flow_dist[c];
+            const bool leaf = plan->h_indptr[c + 1] - plan->h_indptr[c] == 1;
+            foldable[c] = (leaf && tauinv >= 0.0 && tauinv * dt <= CAPABLE_THRESHOLD) ? 1 : 0;      // (NaN: not foldable)
+            nfold += foldable[c];
+        }
+        if (nfold == 0) return XH_OK;
+        std::vector<char> handled;
+        FlowTables t;
+        if (!rsum_tables_get(ctx, plan, foldable.data(), t, handled) || t.n_folded == 0) return XH_OK;
+        if (t.n_cells != plan->flow->n_cells) return XH_OK;
+        if (getenv("XH_FLOW_CHECK")) {
+            const std::string bad = flow_tables_check_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
+                                                           plan->h_sign.data(), handled, t);
+            if (!bad.empty()) return xh_fail(ctx, XH_ERR_ARG, "reassociated flow plan check (folded leaves): %s", bad.c_str());
+        }
+        const int rcu = flow_plan_upload(ctx, t, &plan->flow_rsum_fold);
+        if (rcu) return rcu;
+        plan->fold_dt = dt;
+        return XH_OK;
+    }
     if (!enabled || plan->prepared || plan->flow_typed || !plan->flow || !plan->flow->skew_ok || plan->h_indptr.empty() ||
         !plan->d_learn.p)
         return XH_OK;
@@ -1214,7 +1268,8 @@ int xh_route_series_fed(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32
 
 // Marker of a passed first-call check: <dir>/route_ok_<device>_<build>_<topology>; dir = $XH_CACHE_DIR or
 // $HOME/.cache/xanthos_amd.  Failing to read or write it only means the check runs again.
-static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan, bool rsum) {
+// (form: 0 the bit-exact kernels, 1 the reassociated form, 2 the reassociated form with folded leaves)
+static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan, int form) {
     std::string dir;
     if (const char *d = getenv("XH_CACHE_DIR")) dir = d;
     else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/xanthos_amd";
@@ -1237,15 +1292,23 @@ static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan
     }
     char name[160];
     snprintf(name, sizeof(name), "/route_ok_%016llx_%016llx_%lld_%lld%s", (unsigned long long)h, (unsigned long long)plan->topo_hash,
-             (long long)plan->ncell, (long long)(plan->flow ? plan->flow->n_units : 0), rsum ? "_r" : "");
+             (long long)plan->ncell, (long long)(plan->flow ? plan->flow->n_units : 0), form == 2 ? "_rf" : form == 1 ? "_r" : "");
     return dir + name;
 }
 
-static bool first_check_needed(xh_ctx *ctx, xh_route_plan *plan, bool rsum) {
+static bool &first_checked_of(xh_route_plan *plan, int form) {
+    return form == 2 ? plan->first_checked_fold : form == 1 ? plan->first_checked_rsum : plan->first_checked;
+}
+
+static int last_form(const xh_route_plan *plan) {
+    return !plan->last_rsum ? 0 : (plan->flow_rsum_fold && plan->last_rsum_plan == plan->flow_rsum_fold) ? 2 : 1;
+}
+
+static bool first_check_needed(xh_ctx *ctx, xh_route_plan *plan, int form) {
     static const bool enabled = !(getenv("XH_ROUTE_VALIDATE_FIRST") && getenv("XH_ROUTE_VALIDATE_FIRST")[0] == '0');
-    bool &checked = rsum ? plan->first_checked_rsum : plan->first_checked;
+    bool &checked = first_checked_of(plan, form);
     if (!enabled || checked || !plan->flow) return false;
-    const std::string path = first_check_path(ctx, plan, rsum);
+    const std::string path = first_check_path(ctx, plan, form);
     if (!path.empty()) {
         if (FILE *f = fopen(path.c_str(), "r")) {
             fclose(f);
@@ -1256,15 +1319,15 @@ static bool first_check_needed(xh_ctx *ctx, xh_route_plan *plan, bool rsum) {
     return true;
 }
 
-static void first_check_passed(xh_ctx *ctx, xh_route_plan *plan, bool rsum) {
-    (rsum ? plan->first_checked_rsum : plan->first_checked) = true;
-    const std::string path = first_check_path(ctx, plan, rsum);
+static void first_check_passed(xh_ctx *ctx, xh_route_plan *plan, int form) {
+    first_checked_of(plan, form) = true;
+    const std::string path = first_check_path(ctx, plan, form);
     if (path.empty()) return;
     const std::string dir = path.substr(0, path.rfind('/'));
     for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
         if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
     if (FILE *f = fopen(path.c_str(), "w")) {
-        fprintf(f, "dataflow routing equal to the workgroup-per-network kernel, %s, on %s\n", rsum ? "within 1e-9" : "bit for bit", ctx->prop.name);
+        fprintf(f, "dataflow routing equal to the workgroup-per-network kernel, %s, on %s\n", form ? "within 1e-9" : "bit for bit", ctx->prop.name);
         fclose(f);
     }
 }
@@ -1285,7 +1348,8 @@ static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     // first dataflow call of this plan on a box / build that has not passed the cross-check yet: checked like XH_ROUTE_VALIDATE
     const bool plain_call = plan && (flags & (XH_ROUTE_NO_DATAFLOW | XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_ATOMIC | XH_ROUTE_TEST_FAULT)) == 0;
     const bool want_rsum = plan && reassoc_wanted(flags) && (flags & XH_ROUTE_NO_SKEW) == 0;
-    bool first_check = !validate && plain_call && first_check_needed(ctx, plan, want_rsum);
+    const int want_form = !want_rsum ? 0 : (plan->flow_rsum_fold && !plan->fold_disabled && dt == plan->fold_dt) ? 2 : 1;
+    bool first_check = !validate && plain_call && first_check_needed(ctx, plan, want_form);
     if (plain_call && plan->flow) {
         const char *ev = getenv("XH_ROUTE_VALIDATE_EVERY");      // (read per call: a long-lived caller may change its mind)
         const int64_t every = ev ? (int64_t)atoll(ev) : (int64_t)1000;
@@ -1336,8 +1400,8 @@ static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     rc = route_validate(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
                         d_chstorage, d_avgchflow, d_S_end, d_F_end, flags);
     // (a call that had to be re-routed was not routed by the dataflow kernel in the end: nothing was checked)
-    if (rc == XH_OK && ctx->reroutes == reroutes_before && (first_check || !(plan->last_rsum ? plan->first_checked_rsum : plan->first_checked)))
-        first_check_passed(ctx, plan, plan->last_rsum);
+    if (rc == XH_OK && ctx->reroutes == reroutes_before && (first_check || !first_checked_of(plan, last_form(plan))))
+        first_check_passed(ctx, plan, last_form(plan));
     return rc;
 }
 
@@ -1350,12 +1414,25 @@ int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r, bool dataflow_pairs) {
         // series, so the next call's partition knows them.  If the guard keeps tripping all the same, the plain form is
         // given up for this plan.
         if (++r.plan->guard_trips > 8) r.plan->typed_disabled = true;
+        // (a reassociated call: the guard was that of the folded leaves -- one of them can fire with this call's data; the
+        // plan with folded leaves is given up, XH_ROUTE_NO_PLAIN below routes on the one without)
+        if (r.plan->last_rsum && r.plan->last_rsum_plan == r.plan->flow_rsum_fold) r.plan->fold_disabled = true;
         flags |= XH_ROUTE_NO_PLAIN;
     } else {
         flags |= XH_ROUTE_NO_DATAFLOW;
     }
     return route_series_impl(ctx, r.plan, r.nmonths, r.spinup_months, r.ndays.data(), r.dt, r.flow_dist, r.velocity,
                              r.area, r.runoff, r.S0, r.chs, r.avg, r.S_end, r.F_end, flags, &used_flow);
+}
+
+extern "C" int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[4]) {
+    if (!plan || !info) return XH_ERR_ARG;
+    const FlowPlan *fp = plan->last_rsum ? plan->last_rsum_plan : nullptr;
+    info[0] = fp ? fp->n_units : 0;
+    info[1] = fp ? fp->n_folded : 0;
+    info[2] = plan->fold_disabled ? 1 : 0;
+    info[3] = plan->flow_rsum_fold ? plan->flow_rsum_fold->n_folded : 0;
+    return XH_OK;
 }
 
 extern "C" int xh_route_plan_typed_info(const xh_route_plan *plan, int64_t info[4]) {
@@ -1582,7 +1659,10 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         }
     }
     FlowPlan *tree_plan = (use_typed && plan->flow_typed && plan->flow_typed->n_plain_units > 0) ? plan->flow_typed : plan->flow;
-    if (use_rsum) tree_plan = plan->flow_rsum;
+    FlowPlan *rsum_plan = plan->flow_rsum;
+    if (use_rsum && plan->flow_rsum_fold && !plan->fold_disabled && dt == plan->fold_dt && (flags & XH_ROUTE_NO_PLAIN) == 0)
+        rsum_plan = plan->flow_rsum_fold;      // leaves that cannot fire carried by their parents' lanes (guarded in the kernel)
+    if (use_rsum) tree_plan = rsum_plan;
 
     const bool force_fb = (flags & XH_ROUTE_FORCE_FALLBACK) != 0;
     const bool atomic = (flags & XH_ROUTE_ATOMIC) != 0;
@@ -1620,7 +1700,8 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
             rc = old_skew ? skew_launch(ctx, plan->flow, fs, fio, ctx->stream) : wave_launch(ctx, tree_plan, fs, fio, ctx->stream);
         }
         if (rc == XH_ERR_LIMIT && tree_plan != plan->flow && !old_skew) rc = wave_launch(ctx, plan->flow, fs, fio, ctx->stream);
-        plan->last_rsum = rc == XH_OK && use_rsum && tree_plan == plan->flow_rsum && !old_skew;
+        plan->last_rsum = rc == XH_OK && use_rsum && tree_plan == rsum_plan && !old_skew;
+        if (plan->last_rsum) plan->last_rsum_plan = rsum_plan;
         if (plan->last_rsum) plan->last_tree_kernel = 4;
         plan->last_typed = rc == XH_OK && tree_plan != plan->flow && !old_skew && !plan->last_rsum;
         if (feed && rc == XH_ERR_LIMIT) {      // nothing was launched: the caller completes the runoff and calls again

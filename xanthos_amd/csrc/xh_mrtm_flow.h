@@ -31,6 +31,8 @@ struct FlowPlan {
     void *d_skew_args = nullptr;         // argument block of the time-skewed kernel (rewritten, stream-ordered, by every launch)
     std::vector<char> h_rec, h_fin;      // host copies of the month records of the last launch (sources of asynchronous copies)
     uint64_t rec_key = 0;                // hash of the schedule / runoff layout the records on the device were made for (0: none)
+    FlowBuf d_fold_cell;                 // reassociated form with folded leaves: [units*64] the leaf a lane carries, or -1 (NULL: none)
+    int n_folded = 0;
     FlowBuf d_lane_flags, d_ghost_prod;  // typed partition: cells that can fire by construction; producer cell of every imported stream
 };
 

@@ -301,7 +301,7 @@ void flow_plan_destroy(FlowPlan *fp) {
     FlowBuf *bufs[] = {&fp->d_cell_of_slot, &fp->d_ent,      &fp->d_export_edge, &fp->d_ghost_edge,
                        &fp->d_edge_cons_unit, &fp->d_unit_terms, &fp->d_lag,        &fp->d_ghost_lag,
                        &fp->d_ent2,         &fp->d_eprev,       &fp->d_unit_order,  &fp->d_unit_p,     &fp->d_unit_lmax,   &fp->d_unit_glmax,
-                       &fp->d_lane_flags,   &fp->d_ghost_prod};
+                       &fp->d_lane_flags,   &fp->d_ghost_prod,   &fp->d_fold_cell};
     for (FlowBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (fp->d_x) (void)hipFree(fp->d_x);
@@ -444,6 +444,7 @@ int flow_plan_upload(xh_ctx *ctx, const FlowTables &t, FlowPlan **out) {
     fp->n_plain_units = t.n_plain_units;
     fp->rsum = t.rsum;
     for (int c : t.cell_of_slot) fp->max_cell = std::max(fp->max_cell, c);
+    for (int c : t.fold_of_slot) fp->max_cell = std::max(fp->max_cell, c);
     int rc = put(ctx, fp->d_cell_of_slot, t.cell_of_slot);
     rc |= put(ctx, fp->d_ent, t.ent);
     rc |= put(ctx, fp->d_export_edge, t.export_edge);
@@ -460,6 +461,8 @@ int flow_plan_upload(xh_ctx *ctx, const FlowTables &t, FlowPlan **out) {
     rc |= put(ctx, fp->d_unit_glmax, t.unit_glmax);
     rc |= put(ctx, fp->d_lane_flags, t.lane_flags);
     rc |= put(ctx, fp->d_ghost_prod, t.ghost_prod);
+    if (!t.fold_of_slot.empty()) rc |= put(ctx, fp->d_fold_cell, t.fold_of_slot);
+    fp->n_folded = t.n_folded;
     if (rc) {
         flow_plan_destroy(fp);
         return XH_ERR_HIP;

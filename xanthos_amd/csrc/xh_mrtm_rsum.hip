@@ -21,8 +21,8 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     WaveArgsK *ap = (WaveArgsK *)ap_;
     __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
     __shared__ uint2 xtab[LANES];
-    __shared__ unsigned qstage_sh[2 * LANES];      // runoff of the month after next, low / high words (runoff_fetch)
-    __shared__ double fend_sh[LANES];              // outflow of every lane's last sub-step (F_end)
+    __shared__ unsigned qstage_sh[4 * LANES];      // runoff of the month after next, low / high words (runoff_fetch); second half: folded leaves
+    __shared__ double fend_sh[2 * LANES];          // outflow of every lane's last sub-step (F_end); second half: folded leaves
     __shared__ int unit_sh, prio_sh;
     const int unit = wave_claim(ap, &unit_sh, &prio_sh);
     const int prio = prio_sh;
@@ -42,11 +42,16 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     __attribute__((address_space(3))) unsigned *qst = (__attribute__((address_space(3))) unsigned *)qstage_sh;
     __attribute__((address_space(3))) double *fnd = (__attribute__((address_space(3))) double *)fend_sh;
     fend_sh[threadIdx.x] = 0.0;
-    if ((p & ~3) != 0x400) {      // not a reassociated plan: a fault rather than wrong results
+    fend_sh[LANES + threadIdx.x] = 0.0;
+    if ((p & ~7) != 0x400) {      // not a reassociated plan: a fault rather than wrong results
         if (threadIdx.x == 0) __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (g2) wave_unit<false, 1, 0, 2, true, true>(ap, l, xtab, qst, fnd, unit);
+    // (a unit that carries folded leaves has no streams: xh_flow_rsum.cpp)
+    if ((p & 4) && !g && !x && A(fold_cell)) wave_unit<false, 1, 0, 0, true, true, true>(ap, l, xtab, qst, fnd, unit);
+    else if (p & 4) {      // not produced by the plan; a fault rather than wrong results
+        if (threadIdx.x == 0) __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (g2) wave_unit<false, 1, 0, 2, true, true>(ap, l, xtab, qst, fnd, unit);
     else if (g) wave_unit<false, 1, 0, 1, true, true>(ap, l, xtab, qst, fnd, unit);
     else if ((p & 2) || x) wave_unit<false, 1, 0, 0, true, true>(ap, l, xtab, qst, fnd, unit);
     else if (p & 1) wave_unit<false, 1, 0, 0, false, true>(ap, l, xtab, qst, fnd, unit);

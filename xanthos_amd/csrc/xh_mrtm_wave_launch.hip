@@ -145,7 +145,8 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         if (env) per_cu += atoi(env);
     }
     const size_t lds_static = (size_t)RING * NSLOT * sizeof(v2d) + LANES * sizeof(uint2) + 2 * LANES * sizeof(unsigned) +
-                              LANES * sizeof(double) + 64;      // + fend_sh, unit_sh / prio_sh, padded
+                              LANES * sizeof(double) + 64 +     // + fend_sh, unit_sh / prio_sh, padded
+                              (fp->rsum ? 2 * LANES * sizeof(unsigned) + LANES * sizeof(double) : 0);      // (k_mrtm_rsum: the folded leaves' halves)
     const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
     size_t lds = share > lds_static + 1024 ? share - lds_static : 0;
     // the reassociated plan (xh_flow_rsum.cpp) has a kernel of its own: same argument block, same protocol (xh_mrtm_rsum.hip)
@@ -229,6 +230,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         }
     }
     a.trace = fp->d_trace;
+    a.fold_cell = static_cast<const int *>(fp->d_fold_cell.p);
     if (!fp->d_skew_args) XH_HIP(ctx, hipMalloc(&fp->d_skew_args, sizeof(WaveArgs) + 256));
     // stream-ordered: the previous launch has finished reading the block before this one rewrites it
     hipLaunchKernelGGL(k_mrtm_wave_args, dim3(1), dim3(256), 0, st, a, static_cast<WaveArgs *>(fp->d_skew_args),

@@ -99,6 +99,7 @@ struct WaveArgs {
     unsigned *fault;
     unsigned long long *stats;
     unsigned *trace;                  // [units][nit + 1] 100 MHz ticks at which each unit finished each month (XH_FLOW_TRACE, with stats)
+    const int *fold_cell;             // (at the end: k_mrtm_rsum only) [units*64] the leaf cell a lane carries besides its own, or -1; NULL: none
 };
 
 __device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
@@ -178,7 +179,22 @@ template <> struct Val<true> {
 //     S    = sx ? 0 : base + (sum F2) dt                        (mrtm.py:63, 69)
 // -- 8 fp64 operations, one compare, four selects instead of ~20 + 2 per row term; equal to the reference's sequence to
 // rounding (tested to 1e-9 of every routed value against the oracle at the full grid; the gate is 1e-6), not bit for bit.
-template <bool PLAIN, int PRE, int POST, int NG, bool CHAIN, bool RSUM = false>
+// FOLD (with RSUM, units without streams only): a lane also carries ONE leaf child of its cell that does not fire
+// (velocity * dt / length < 1 and a storage that never turns negative: guarded) -- for such a cell the step of mrtm.py:50-69
+// is the linear recurrence S <- S a + erl dt with outflow S / tau, which costs the lane four fp64 operations per sub-step
+// (outflow, recurrence, the month's flow sum, one fma into the carrier's `base`) instead of a lane, an LDS slot and a level
+// of lag of its own.  The leaf runs at the carrier's own sub-step; its month bookkeeping rides on the carrier's.
+//
+// The guard.  Within a month erl is constant and x -> fma(x, a, erl dt) is non-decreasing in x, so the storages of a month
+// form a monotone sequence (in floating point too): if the month starts and ends at S >= 0 no sub-step in between had S < 0,
+// and the reference's branch mrtm.py:54 was never taken -- the recurrence IS the reference's step.  The kernel therefore
+// looks at the storage once per month (FOLD_EPS below); a month that ends lower makes the unit give up (FAULT_GUARD: the
+// host routes the call again on the plan without folded leaves and stays on it).  Runoff that is negative by a rounding
+// error of the runoff model (-1e-17 mm on a dry cell) takes the storage of an empty leaf to about -1e-11 m3: the reference
+// passes that volume on at once (mrtm.py:60, a flow of -1e-15 m3/s), the recurrence over 1 / (tau^-1 dt) sub-steps; both
+// conserve it, and the difference is nine orders below this form's bar (1e-9 m3/s, 1e-3 m3: xh_mrtm.hip k_count_far).
+// FOLD_EPS = 1e-6 m3 keeps the guard from tripping on that while bounding what it lets through to 1e-10 m3/s.
+template <bool PLAIN, int PRE, int POST, int NG, bool CHAIN, bool RSUM = false, bool FOLD = false>
 __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint2 *xtab,
                                           __attribute__((address_space(3))) unsigned *qstage,
                                           __attribute__((address_space(3))) double *fend, const int unit) {
@@ -207,6 +223,20 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     // table offsets are entry x 16 (the pair layout); a plain unit's entries are 8 bytes
     auto ent_off = [](unsigned o) { return PLAIN ? o >> 1 : o; };
     static_assert(!RSUM || (!PLAIN && PRE <= 1 && POST == 0), "reassociated form: one inflow entry, pair values");
+    static_assert(!FOLD || (RSUM && NG == 0), "folded leaves: reassociated form, units without imports");
+    // the folded leaf of this lane
+    const int gcL = FOLD ? A(fold_cell)[slot] : -1;
+    const bool validL = FOLD && valid && gcL >= 0;
+    const unsigned row_offL = (unsigned)(validL ? gcL : 0) * A(q_row_stride);
+    const double tauL = validL ? A(velocity)[gcL] / A(flow_dist)[gcL] : 0.0;
+    const double acoefL = 1.0 - tauL * A(dt);
+    const double areaL = validL ? A(area)[gcL] : 0.0;
+    const double S0L = (validL && A(S0)) ? A(S0)[gcL] : 0.0;
+    double SL = 0.0, favgL = 0.0, erlL = 0.0, erlL_n = 0.0, snapSL = 0.0, snapAL = 0.0, FL = 0.0;
+    // guard of the folded leaves (above): velocity * dt / length not below 1 (the plan was made for other data), a negative
+    // or NaN ratio, a negative initial storage -- and, month by month in finalize(), a storage below -FOLD_EPS
+    constexpr double FOLD_EPS = 1e-6;
+    unsigned gfold = (validL && !(tauL * A(dt) <= 1.0 - 1.0 / 1048576.0 && tauL >= 0.0 && S0L >= 0.0)) ? 1u : 0u;
     constexpr int PRE_N = PRE > 0 ? PRE : 1, POST_N = POST > 0 ? POST : 1;      // (array extents: a side may be empty)
     lds_cchar *epre[PRE_N], *epost[POST_N];
 #pragma unroll
@@ -329,6 +359,14 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
                      : "=&s"(keep)
                      : "v"(src), "s"(q_lds)
                      : "memory");
+        if (FOLD) {      // the folded leaves' rows: a second staging area of 2 x 64 dwords behind the first
+            const char *srcL = reinterpret_cast<const char *>(p_runoff) + q_off + (size_t)row_offL;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_add_u32 m0, m0, 252\n\t"
+                         "global_load_lds_dword %1, off offset:4\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(srcL), "s"(q_lds + 2u * LANES * 4u)
+                         : "memory");
+        }
     };
     auto runoff_take = [&]() {
         // vmcnt retires in order.  A unit with streams has issued at least one stream access per block of 8 sub-steps since
@@ -348,13 +386,20 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         const double q0 = ld_q(r0.q_off);
         erl_n = ((valid ? q0 : 0.0) * area) * 1000.0 / r0.secs;                  // mrtm.py:45
         if (RSUM) erl_n *= A(dt);
+        if (FOLD) {
+            const double q0L = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(p_runoff) + r0.q_off + (size_t)row_offL);
+            erlL_n = (((validL ? q0L : 0.0) * areaL) * 1000.0 / r0.secs) * A(dt);
+        }
         if (nit > 1) runoff_fetch(r1.q_off);
     }
     // month outputs leave as groups of OB months per cell (32 bytes = one memory sector)
     constexpr int OB = 4;               // (groups of 2 free eight registers and cost 1 - 2 %: round 4, same-box A/B)
     double ob_s[OB], ob_a[OB];
+    double ob_sL[FOLD ? OB : 1], ob_aL[FOLD ? OB : 1];      // the folded leaf's months
 #pragma unroll
     for (int j = 0; j < OB; ++j) ob_s[j] = ob_a[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < (FOLD ? OB : 1); ++j) ob_sL[j] = ob_aL[j] = 0.0;
     bool alive = true;
     // Fed run (FlowFeed): months [0, mready) of the runoff source are known to be final.  A month beyond that is waited
     // for, bounded like every wait here, on the months-ready word (written by a kernel that runs after the one that
@@ -439,6 +484,10 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alive = false;
         }
+        if (FOLD && __any(gfold != 0)) {                 // a folded leaf that can fire after all: the host routes again without folding
+            __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            alive = false;
+        }
         const bool fenced = A(fenced) == 1;
         if (any_x) {      // publish what has certainly been stored, then make sure the next CH iterations have ring space
             // (everything stored so far is acknowledged: publish it all; the lagged form holds back PUBLAG sub-steps)
@@ -485,6 +534,11 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             const double qn = runoff_take();
             erl_n = ((valid ? qn : 0.0) * area) * 1000.0 / f.secs_next1;
             if (RSUM) erl_n *= dt;
+            if (FOLD) {      // (runoff_take has waited for the loads of both staging areas: a unit without streams waits vmcnt(0))
+                const unsigned lo = qstage[2 * LANES + lane], hi = qstage[3 * LANES + lane];
+                const double qnL = __hiloint2double((int)hi, (int)lo);
+                erlL_n = (((validL ? qnL : 0.0) * areaL) * 1000.0 / f.secs_next1) * dt;
+            }
         }
         if (it >= 1) {
             const int m = f.m_prev_w & (FIN_WRITE - 1);
@@ -496,6 +550,35 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             }
             ob_s[OB - 1] = snapS;
             ob_a[OB - 1] = snapA / (double)f.nt_prev;                          // mrtm.py:80
+            if (FOLD) {
+#pragma unroll
+                for (int j = 0; j < OB - 1; ++j) {
+                    ob_sL[j] = ob_sL[j + 1];
+                    ob_aL[j] = ob_aL[j + 1];
+                }
+                ob_sL[OB - 1] = snapSL;
+                ob_aL[OB - 1] = snapAL / (double)f.nt_prev;
+                gfold |= (snapSL < -FOLD_EPS) ? 2u : 0u;                       // (NaN storage: as the reference, not a firing)
+                if (write_prev && validL) {
+                    if ((m & (OB - 1)) == OB - 1) {
+                        const int64_t o = (int64_t)gcL * nmo + (m - (OB - 1));
+#pragma unroll
+                        for (int j = 0; j < OB; j += 2) {
+                            if (p_chs) *reinterpret_cast<v2d *>(p_chs + o + j) = v2d{ob_sL[j], ob_sL[j + 1]};
+                            if (p_avg) *reinterpret_cast<v2d *>(p_avg + o + j) = v2d{ob_aL[j], ob_aL[j + 1]};
+                        }
+                    } else if (m == nmo - 1) {
+                        const int r = (m & (OB - 1)) + 1;
+                        const int64_t o = (int64_t)gcL * nmo + (m + 1 - r);
+#pragma unroll
+                        for (int j = 0; j < OB; ++j)
+                            if (j >= OB - r) {
+                                if (p_chs) p_chs[o + j - (OB - r)] = ob_sL[j];
+                                if (p_avg) p_avg[o + j - (OB - r)] = ob_aL[j];
+                            }
+                    }
+                }
+            }
             if (write_prev && valid) {     // whole groups of OB months per cell
                 if ((m & (OB - 1)) == OB - 1) {
                     const int64_t o = (int64_t)gc * nmo + (m - (OB - 1));
@@ -643,10 +726,18 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             favg = c ? 0.0 : favg;
             erl = c ? erl_n : erl;
 #endif
+            if (FOLD) {      // the folded leaf crosses the month with its carrier
+                snapSL = c ? SL : snapSL;
+                snapAL = c ? favgL : snapAL;
+                favgL = c ? 0.0 : favgL;
+                erlL = c ? erlL_n : erlL;
+            }
             if (!MID) {
                 if (edge == 1) S = c ? S0v : S;
+                if (FOLD && edge == 1) SL = c ? S0L : SL;
                 if (edge == 2) {
                     if (c) fend[lane] = F;
+                    if (FOLD && c) fend[LANES + lane] = FL;
                 }
             }
         }
@@ -670,7 +761,13 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         if ((j & (RING - 1)) == 1) block_store(n + j - 1);
         const double F0 = S * tauinv;                                          // mrtm.py:50
         if constexpr (RSUM) {
-            const double base = __builtin_fma(S, acoef, erl);                 // (erl: lateral inflow x dt in this form)
+            double base = __builtin_fma(S, acoef, erl);                       // (erl: lateral inflow x dt in this form)
+            if (FOLD) {      // the folded leaf's step: its outflow joins the cell's inflow of this very sub-step
+                FL = SL * tauL;                                                // mrtm.py:50
+                SL = __builtin_fma(SL, acoefL, erlL);                          // mrtm.py:51, 69 for a cell without inflow that cannot fire
+                favgL += FL;                                                   // mrtm.py:78
+                base = __builtin_fma(FL, dt, base);
+            }
             const double S1 = PRE ? __builtin_fma(ac[0].x, dt, base) : base;  // trial storage: S + dSdt dt (mrtm.py:51, 54)
             const double S2 = PRE ? __builtin_fma(ac[0].y, dt, base) : base;  // the same with the adjusted inflows (mrtm.py:66-69)
             const bool sx = S1 < 0.0;                                          // mrtm.py:54: dSdt dt < -S
@@ -802,7 +899,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     if (alive) {
         while (itf <= nit) finalize(itf++);
         learn_now();
-        if (PLAIN && __any((fired | gmis) != 0)) {
+        if ((PLAIN && __any((fired | gmis) != 0)) || (FOLD && __any(gfold != 0))) {
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alive = false;
         }
@@ -821,6 +918,10 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         if (valid) {
             if (A(S_end)) A(S_end)[gc] = snapS;
             if (A(F_end)) A(F_end)[gc] = fend[lane];
+        }
+        if (validL) {
+            if (A(S_end)) A(S_end)[gcL] = snapSL;
+            if (A(F_end)) A(F_end)[gcL] = fend[LANES + lane];
         }
     }
     const bool guard_set = __any((fired | gmis) != 0);
