@@ -138,6 +138,76 @@ def test_config3_reassociated_routing_within_1e9_of_oracle(full):
     _check(full, tag='bit-exact again')
 
 
+_PREPARED_CHILD = r"""
+import json, os, sys
+import numpy as np
+root, ref_dir = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root)
+from xanthos_amd import _hip, synth
+from xanthos_amd.pipeline import pipeline_from_world
+ctx = _hip.get_context(0)
+w = synth.make_world()
+nm = 600
+pipe = pipeline_from_world(ctx, w, nm, 1961, 120, 120)
+ctx.synth_forcing(3, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.001)
+pipe.run(('pm', 'abcd'), fused=False)
+q_ref = np.load(os.path.join(ref_dir, 'q.npy'))
+refs = {'chs': (np.load(os.path.join(ref_dir, 'chs.npy')), 1e-3), 'avg': (np.load(os.path.join(ref_dir, 'avg.npy')), 1e-9)}
+out = {'same_runoff': bool(np.array_equal(pipe.out['q'].download(), q_ref, equal_nan=True))}
+def worst(tag):
+    got = pipe.download(('chs', 'avg'))
+    wr = 0.0
+    for k, (ref, atol) in refs.items():
+        x = got[k]
+        assert np.array_equal(np.isnan(x), np.isnan(ref)), (tag, k, 'NaN masks')
+        m = ~np.isnan(ref)
+        err = np.abs(x[m] - ref[m])
+        assert (err <= 1e-9 * np.abs(ref[m]) + atol).all(), (tag, k, float(err.max()))
+        big = np.abs(ref[m]) > 1e6 * atol
+        wr = max(wr, float((err[big] / np.abs(ref[m][big])).max()))
+    return wr
+pipe.out['chs'].zero(); pipe.out['avg'].zero()
+pipe.run_mrtm()
+ctx.sync()
+out['staged'] = worst('staged')
+out['info'] = pipe.plan.rsum_info()
+out['kernel'] = int(pipe.plan.info()['last_tree_kernel'])
+pipe.out['chs'].zero(); pipe.out['avg'].zero()
+pipe.run(fed=True)
+ctx.sync()
+out['fed'] = worst('fed')
+out['info_fed'] = pipe.plan.rsum_info()
+print(json.dumps(out))
+"""
+
+
+def test_config3_prepared_plan_with_folded_leaves_within_1e9_of_oracle(full, tmp_path):
+    """The plan a default process routes on -- reassociated form, PREPARED (leaves that do not fire folded into their downstream
+    cells' lanes: 1,012 units, every one alone on its SIMD) -- at the full grid and length against the oracle: identical NaN
+    masks, every routed value within 1e-9 |ref|, stage by stage and in the fed order, the guard quiet.  In a process of its own:
+    this module runs with XH_ROUTE_REASSOC=0 (conftest), which a library reads once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    np.save(tmp_path / 'q.npy', full.pipe.out['q'].download())
+    np.save(tmp_path / 'chs.npy', full.chs)
+    np.save(tmp_path / 'avg.npy', full.avg)
+    script = tmp_path / 'prepared_child.py'
+    script.write_text(_PREPARED_CHILD)
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    env = dict(os.environ, XH_FLOW_CHECK='1')
+    for k in ('XH_ROUTE_REASSOC', 'XH_FLOW_FOLD'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script), root, str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out['same_runoff'] and out['kernel'] == 4, out
+    assert out['staged'] < 1e-10 and out['fed'] < 1e-10, out                    # (measured: 3e-12)
+    for info in (out['info'], out['info_fed']):
+        assert info['folded'] > 2500 and info['fold_disabled'] == 0 and info['units'] <= 1024, out
+
+
 def test_config3_all_cell_pm_abcd_parity(full):
     """EVERY cell of the full grid, not a sample: PET of 67,420 cells x 60 months against oracle.pm (penman_monteith.py:394-477)
     and AET / Q / Sav of 67,420 cells x (600 + 120 spin-up) months against oracle.abcd (abcd.py:357-391) fed with the run's own
