@@ -18,6 +18,7 @@ constexpr int RING = 8;
 // MODE 0: reassociated form, reads A and R.  MODE 1: reads A only (no chain read).  MODE 2: no reads at all (single-cell networks).
 // MODE 3: MODE 0 without the LDS (arithmetic only: what the VALU work alone costs a lone wave).
 // MODE 4: the bit-exact pair form of a (2,3) row (5 ds_read_b128, two sums in stored order) -- round 3's reference point.
+// MODE 5: MODE 0 with the reads issued TWO sub-steps ahead of their use (a lane lag of three iterations per level instead of two).
 template <int MODE>
 __global__ void __launch_bounds__(256) k(double *out, unsigned long long *cyc, double tauinv, double dt, double dtinv, double erl,
                                          const int *perm, int iters) {
@@ -30,18 +31,20 @@ __global__ void __launch_bounds__(256) k(double *out, unsigned long long *cyc, d
     lds_d2 *own = (lds_d2 *)lds + lane;
     lds_d2 *e[5];
     for (int w = 0; w < 5; ++w) e[w] = (lds_d2 *)lds + perm[w * 64 + lane];
-    v2d v[5], vn[5];
+    v2d v[5], vn[5], vnn[2];
     for (int w = 0; w < 5; ++w) v[w] = vn[w] = v2d{0.001, 0.001};
+    vnn[0] = vnn[1] = v2d{0.001, 0.001};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            constexpr int NR = MODE == 0 ? 2 : MODE == 1 ? 1 : MODE == 4 ? 5 : 0;
+            constexpr int NR = (MODE == 0 || MODE == 5) ? 2 : MODE == 1 ? 1 : MODE == 4 ? 5 : 0;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int w = 0; w < NR; ++w) vn[w] = e[w][((j + 7) & 7) * SLOT_PAIRS];
+            for (int w = 0; w < NR; ++w) (MODE == 5 ? vnn[w & 1] : vn[w]) = e[w][((j + 7) & 7) * SLOT_PAIRS];
             __builtin_amdgcn_sched_barrier(0);
-            if (MODE != 3) __builtin_amdgcn_s_waitcnt(0xC07F | ((NR + 1) << 8));
+            if (MODE == 5) __builtin_amdgcn_s_waitcnt(0xC07F | ((2 * NR + 2) << 8));
+            else if (MODE != 3) __builtin_amdgcn_s_waitcnt(0xC07F | ((NR + 1) << 8));
             __builtin_amdgcn_sched_barrier(0);
             const double F0 = S * tauinv;
             if (MODE == 4) {
@@ -65,7 +68,7 @@ __global__ void __launch_bounds__(256) k(double *out, unsigned long long *cyc, d
                 const double S2 = MODE == 2 ? base : __builtin_fma(v[0].y, dt, base);
                 const bool sx = S1 < 0.0;
                 const double f2 = __builtin_fma(__builtin_fmin(S1, 0.0), dtinv, F0);
-                const v2d o = (MODE == 0 || MODE == 3) ? v2d{v[1].x + F0, v[1].y + f2} : v2d{F0, f2};
+                const v2d o = (MODE == 0 || MODE == 3 || MODE == 5) ? v2d{v[1].x + F0, v[1].y + f2} : v2d{F0, f2};
                 if (MODE != 3) own[(j & 7) * SLOT_PAIRS] = o;
                 else asm volatile("" ::"v"(o));
                 double Sn = S2;
@@ -75,6 +78,10 @@ __global__ void __launch_bounds__(256) k(double *out, unsigned long long *cyc, d
             }
 #pragma unroll
             for (int w = 0; w < NR; ++w) v[w] = vn[w];
+            if (MODE == 5) {
+                vn[0] = vnn[0];
+                vn[1] = vnn[1];
+            }
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -106,5 +113,6 @@ int main() {
     RUN(2, "reassociated: no read (single-cell networks)")
     RUN(3, "reassociated: the arithmetic alone (no LDS)")
     RUN(4, "bit-exact pairs (2,3): 5 ds_read_b128, two sums in stored order")
+    RUN(5, "reassociated, reads two sub-steps ahead of their use")
     return 0;
 }
