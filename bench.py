@@ -315,6 +315,11 @@ def routing_forms(ctx, pipe, log, nsub):
                    'plain_units': int(ti['plain_units']) if kern != 4 else 0,
                    'critical_path': {'substeps': nsub, 'floor_cycles': floor, 'achieved_cycles': achieved, 'frac': floor / achieved,
                                      'clock_hz': SHADER_CLOCK_HZ}}
+            if kern == 4:      # which reassociated plan: leaves folded into their downstream cells' lanes (the prepared plan)
+                ri = pipe.plan.rsum_info()
+                rec['units'] = int(ri['units'])
+                rec['folded_leaves'] = int(ri['folded'])
+                rec['fold_guard_tripped'] = bool(ri['fold_disabled'])
             # per-unit accounting: one launch with the statistics on (costs the units a few cycles per check; not timed above)
             os.environ['XH_FLOW_STATS'] = '1'
             try:
