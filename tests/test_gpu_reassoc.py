@@ -398,6 +398,16 @@ out['kernel'] = int(pipe.plan.info()['last_tree_kernel'])
 pipe.run(fed=True)                                              # the fed order on the folded plan
 out['worst_fed'] = close('fed')
 out['info_fed'] = pipe.plan.rsum_info()
+# the end state of the run (future mode's hand-over: S_end / F_end per cell) of folded leaves comes from their carriers' lanes
+d_S, d_F = ctx.empty(w.ncell), ctx.empty(w.ncell)
+ctx.route_series(pipe.plan, nm, 12, pipe.ndays, 10800.0, pipe.d_flow_dist, pipe.d_velocity, pipe.d_area, pipe.out['q'], None,
+                 pipe.out['chs'], pipe.out['avg'], d_S, d_F, 0)
+ctx.sync()
+out['info_end'] = pipe.plan.rsum_info()
+for name, x, r, atol in (('S_end', d_S.download(), ref[0][:, -1], 1e-3), ('F_end', d_F.download(), ref[2], 1e-9)):
+    assert np.array_equal(np.isnan(x), np.isnan(r)), name
+    m = ~np.isnan(r)
+    assert (np.abs(x[m] - r[m]) <= 1e-9 * np.abs(r[m]) + atol).all(), (name, float(np.abs(x[m] - r[m]).max()))
 # the guard: NEGATIVE runoff in the row of a folded leaf is outside the argument that lets its parent's lane carry it (it
 # could fire) -- the unit gives up, the call is routed again on the plan without folded leaves, the result is still right
 leaves = np.nonzero(np.diff(pipe.um.indptr) == 1)[0]
@@ -431,5 +441,5 @@ def test_folded_leaves_in_the_reassociated_form(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out['kernel'] == 4 and out['worst'] < 1e-10 and out['worst_fed'] < 1e-10 and out['worst_guard'] < 1e-10, out
-    assert out['info']['folded'] > 50 and out['info_fed']['folded'] == out['info']['folded'], out
+    assert out['info']['folded'] > 50 and out['info_fed']['folded'] == out['info']['folded'] == out['info_end']['folded'], out
     assert out['info_guard']['fold_disabled'] == 1 and out['info_guard']['folded'] == 0, out
