@@ -237,11 +237,17 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
                                        bit-exact kernels).  XH_ROUTE_VALIDATE then compares within 1e-9.               */
 #define XH_ROUTE_EXACT 256          /* the bit-exact kernels for this call (every row sum in scipy's stored order) whatever
                                        the default says                                                                  */
-/* The reassociated plan the last call ran on: info[4] = {its units, the leaves it folded into their downstream cells' lanes,
- * 1 if a guard trip has switched the plan with folded leaves off, folded leaves of the prepared plan (xh_route_plan_prepare
- * with XH_FLOW_FOLD=1: leaves that cannot fire -- velocity * dt / length < 1 -- of river networks small enough to have no
- * streams are carried by their parents' lanes, which frees enough lanes for every unit to have a SIMD of its own)}.        */
-int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[4]);
+/* The reassociated plan the last call ran on: info[6] = {its units; the leaves it folded into their downstream cells' lanes;
+ * 1 if a guard trip has switched the prepared plan off; folded leaves of the prepared plan; special cells of the plan the
+ * last call ran on, -1 if its lanes pass pairs of sums; special cells of the prepared plan (-1: pairs, or none prepared)}.
+ * The PREPARED plan is the one xh_route_plan_prepare makes from the call's velocities, lengths and dt (reassociated form
+ * only; XH_FLOW_FOLD=0 / XH_RSUM_SINGLE=0 switch its two parts off):
+ *  - leaves that cannot fire (velocity * dt / length < 1) of river networks small enough to have no streams are carried by
+ *    their parents' lanes, which frees enough lanes for every unit to have a SIMD of its own;
+ *  - the lanes pass ONE running sum instead of the pair {sum F, sum F2}: only a cell that can fire AND has an upstream
+ *    neighbour that can needs both, and those few sit in units of their own.
+ * Both rest on which cells can fire; the kernel guards the assumption and a trip routes the call again on the plain plan. */
+int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[6]);
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,
                     const double *d_flow_dist, const double *d_velocity, const double *d_area,

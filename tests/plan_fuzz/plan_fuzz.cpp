@@ -257,6 +257,14 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
                 foldable[c] = (g.indptr[c + 1] - g.indptr[c] == 1) && (capable.empty() || !capable[c]) && (rng() % 8 != 0);
             opt_r.foldable = foldable.data();
         }
+        // single-sum plans: the cells that can fire given (as the typed cases have them), or drawn here at 2 / 10 / 40 %
+        std::vector<unsigned char> capable_r;
+        if (opt_r.capable == nullptr && idx % 3 != 2) {
+            const unsigned dens = (idx % 3 == 0) ? 2u : ((idx / 3) % 2 ? 10u : 40u);
+            capable_r.assign(g.n, 0);
+            for (int c = 0; c < g.n; ++c) capable_r[c] = (rng() % 100u < dens) && !(opt_r.foldable && foldable[c]);
+            opt_r.capable = capable_r.data();
+        }
         if (flow_tables_build_rsum(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt_r, handled_r, r, err) != 0) {
             fprintf(stderr, "case %d (kind %d, %d cells): reassociated build failed: %s\n", idx, kind, g.n, err.c_str());
             return 1;
@@ -272,7 +280,7 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
             snprintf(path, sizeof(path), "/tmp/plan_fuzz_%d_%d.rtables", (int)getpid(), idx);
             FlowTables u;
             if (!(flow_tables_save(r, path) && flow_tables_load(path, u) && u.rsum && u.ent2 == r.ent2 && u.eprev == r.eprev &&
-                  u.lag == r.lag && u.unit_p == r.unit_p && u.fold_of_slot == r.fold_of_slot && u.n_folded == r.n_folded &&
+                  u.lag == r.lag && u.unit_p == r.unit_p && u.fold_of_slot == r.fold_of_slot && u.n_folded == r.n_folded && u.n_special == r.n_special && u.lane_flags == r.lane_flags &&
                   flow_tables_check_rsum(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), handled_r, u).empty()))
                 bad_r = "tables did not survive the round trip through a file";
             remove(path);
@@ -282,7 +290,7 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
             return 1;
         }
         if (verbose)
-            printf("        reassociated: %d units, %d streams, depth %d, max lag %d, %d leaves folded\n", r.n_units, r.n_edges, r.depth, r.skew_lmax, r.n_folded);
+            printf("        reassociated: %d units, %d streams, depth %d, max lag %d, %d leaves folded, %d special cells\n", r.n_units, r.n_edges, r.depth, r.skew_lmax, r.n_folded, r.n_special);
     }
     return 0;
 }
@@ -347,6 +355,7 @@ static int run_file(const char *path, bool typed, bool rsum) {
         for (int c = 0; c < n; ++c) foldable[c] = (g.indptr[c + 1] - g.indptr[c] == 1) && !capable[c];
         opt.foldable = foldable.data();
     }
+    if (rsum) opt.capable = getenv("SINGLE") ? capable.data() : nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     if (rsum ? flow_tables_build_rsum(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)
              : flow_tables_build(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)) {
@@ -357,6 +366,37 @@ static int run_file(const char *path, bool typed, bool rsum) {
     const std::string bad = rsum ? flow_tables_check_rsum(n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, t)
                                  : flow_tables_check(n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, t, opt.capable);
     printf("check: %s\n", bad.empty() ? "ok" : bad.c_str());
+    if (const char *dc = getenv("DUMP_CELLS")) {      // DUMP_CELLS=a,b,c: where the planner put these cells
+        std::vector<int> slot_of(n, -1);
+        for (size_t sl = 0; sl < t.cell_of_slot.size(); ++sl)
+            if (t.cell_of_slot[sl] >= 0) slot_of[t.cell_of_slot[sl]] = (int)sl;
+        const int64_t ts = (int64_t)t.n_units * 64;
+        auto ent_name = [&](int u, unsigned off) {
+            char buf[96];
+            const int e = (int)(off / 16u);
+            if (e == 128) snprintf(buf, sizeof(buf), "zero");
+            else if (e >= 64) snprintf(buf, sizeof(buf), "import %d (stream %d from cell %d)", e - 64, t.ghost_edge[(int64_t)u * 64 + e - 64], t.ghost_prod[(int64_t)u * 64 + e - 64]);
+            else snprintf(buf, sizeof(buf), "lane %d (cell %d)", e, t.cell_of_slot[(int64_t)u * 64 + e]);
+            return std::string(buf);
+        };
+        for (const char *q = dc; *q;) {
+            const int c = atoi(q);
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+            if (c < 0 || c >= n || slot_of[c] < 0) { printf("cell %d: no slot\n", c); continue; }
+            const int sl = slot_of[c], u = sl / 64;
+            int ncell = 0, nimp = 0, nexp = 0;
+            for (int k = 0; k < 64; ++k) {
+                ncell += t.cell_of_slot[(int64_t)u * 64 + k] >= 0;
+                nimp += t.ghost_edge[(int64_t)u * 64 + k] >= 0;
+                nexp += t.export_edge[(int64_t)u * 64 + k] >= 0;
+            }
+            printf("cell %d: unit %d lane %d shape 0x%x (cells %d imports %d outlets %d depth %d lmax %d) lag %d flag %d A = %s, R = %s, export %d\n", c, u, sl % 64,
+                   t.unit_p[u], ncell, nimp, nexp, t.unit_depth[u], t.unit_lmax[u], t.lag[sl], (int)t.lane_flags[sl], ent_name(u, t.ent2[(size_t)sl]).c_str(),
+                   ent_name(u, t.eprev[sl]).c_str(), t.export_edge[sl]);
+            (void)ts;
+        }
+    }
     return bad.empty() ? 0 : 1;
 }
 

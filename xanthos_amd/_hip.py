@@ -532,9 +532,9 @@ class RoutePlan:
 
     def rsum_info(self):
         """The reassociated plan the last call ran on (xh_route_plan_rsum_info)."""
-        arr = (c_int64 * 4)()
+        arr = (c_int64 * 6)()
         self.ctx._check(lib().xh_route_plan_rsum_info(self.handle, arr))
-        return dict(zip(('units', 'folded', 'fold_disabled', 'prepared_folded'), list(arr)))
+        return dict(zip(('units', 'folded', 'fold_disabled', 'prepared_folded', 'special', 'prepared_special'), list(arr)))
 
     def typed_info(self):
         """Pair / plain units of the dataflow partition (xh_route_plan_typed_info)."""

@@ -37,6 +37,8 @@ struct FlowPlanOptions {
     // (velocity * dt / length below 1) -- such a cell's outflow is a one-fma recurrence that the lane of its downstream cell can
     // carry in registers, so it needs no lane, no LDS slot and no level of lag of its own.  nullptr: nothing is folded.
     const unsigned char *foldable = nullptr;
+    // Reassociated planner: with `capable` given it makes the SINGLE-SUM partition (xh_flow_rsum.cpp): lanes pass one running
+    // sum instead of a pair, and the cells that can fire AND have an upstream neighbour that can sit alone in `special` units.
 };
 
 struct FlowTables {
@@ -57,6 +59,7 @@ struct FlowTables {
     std::vector<int> ghost_prod;                                 // [units*64] producer cell of imported stream k of the unit
     std::vector<int> fold_of_slot;                               // reassociated form: [units*64] the leaf cell folded into the lane's cell, or -1 (empty: none)
     int n_folded = 0;
+    int n_special = 0;                                           // reassociated form: -1 = pair-sum plan; >= 0 = single-sum plan with that many special cells
 };
 
 // ---- shared by the two planners (xh_flow_plan.cpp: sums in stored order; xh_flow_rsum.cpp: reassociated sums)

@@ -16,6 +16,16 @@
 //     of all its cut-off children), which opens the chain of the children that stayed (or is the cell's A if none did);
 //   * no row-shape rules in the cut or the packing: every unit has the same shape, so pieces are cut for full lanes only;
 //   * the order of a chain is free: children with the tallest (transformed) subtrees go last, which keeps lane lags low.
+//
+// SINGLE-SUM plans (FlowPlanOptions::capable given; kernel side: xh_mrtm_wave_unit.h, SGL).  The pair {sum F, sum F2} is only
+// ever needed by a cell that can fire itself AND has an upstream neighbour that can (a neighbour that cannot fire has
+// F2 = F; a cell that cannot fire has S1 >= S2 >= 0 and uses the adjusted sum only): 8 of the 67,420 cells of the synthetic
+// world.  Everywhere else the lanes pass ONE running sum, that of the adjusted flows, and every lane leaves its own deficit
+// m = min(S1, 0) of the sub-step in the other half of its entry.  A `special` cell reads both halves of its inflow entry:
+// sum F = sum F2 - m_k / dt, where k is its one upstream neighbour that can fire, made the LAST member of the chain.  The
+// partition makes that possible without charging anybody else: a special cell is a piece of its own (every neighbour cut off,
+// the capable one last in the chain of sibling pieces, the cell itself first in its own), and special pieces share units only
+// with each other.  A cell that can fire with TWO upstream neighbours that can is not handled: the plan falls back to pairs.
 #include <algorithm>
 #include <cstdio>
 #include <numeric>
@@ -41,8 +51,9 @@ struct RPart {
     std::vector<int> e_prod, e_cons, e_kind;      // stream: producer outlet, consumer cell, 0 = opens the chain of e_cons's children
                                                   // (or is its A), 1 = R of the outlet e_cons of a sibling piece
     std::vector<int> unit_of_piece, unit_cells, unit_imp, unit_out, unit_depth;
-    std::vector<char> unit_cheap;
+    std::vector<char> unit_cheap, unit_special, special;
     int nunit = 0, nedge = 0, maxdepth = 0, n_cheap = 0;
+    int n_special = -1;               // -1: pair-sum plan (no `capable`, or a cell the single-sum form does not handle)
 };
 
 void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P, std::vector<int> &fold_leaf) {
@@ -63,6 +74,24 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         }
         return x;
     };
+    // single-sum plan: the cells that need both sums
+    std::vector<char> &special = P.special;
+    special.assign(n, 0);
+    if (opt.capable) {
+        P.n_special = 0;
+        for (int v = 0; v < n && P.n_special >= 0; ++v) {
+            if (!t.ok[v] || !opt.capable[v]) continue;
+            int nc = 0;
+            for (int k = child_ptr[v]; k < child_ptr[v + 1]; ++k) nc += opt.capable[child[k]] ? 1 : 0;
+            if (nc == 1) {
+                special[v] = 1;
+                P.n_special++;
+            } else if (nc > 1) {
+                P.n_special = -1;      // not handled: pairs for this grid
+            }
+        }
+        if (P.n_special < 0) special.assign(n, 0);
+    }
     std::vector<int> open_cnt(n, 0), open_imp(n, 0), open_th(n, 0);
     std::vector<int> kids, kept, ths;
     std::vector<int> &roots = P.roots;
@@ -86,7 +115,7 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         // imports of a piece: those of the children kept + one for all the children cut off; two are held back (that one, and
         // the sibling stream this piece takes on if it is cut off itself as a later member of a chain of pieces)
         for (int c : kids)
-            if (total + open_cnt[c] <= cap && imp + open_imp[c] <= G_MAX - 2) {
+            if (!special[v] && !special[c] && total + open_cnt[c] <= cap && imp + open_imp[c] <= G_MAX - 2) {
                 kept.push_back(c);
                 total += open_cnt[c];
                 imp += open_imp[c];
@@ -134,7 +163,15 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         grp.clear();
         while (p < npiece && ds[roots[p]] == v) grp.push_back(p++);
         // the chain of sibling pieces: shallowest first (each member sits one pipeline level below the one before it)
+        // (single-sum plans: under a special cell the neighbour that can fire goes last -- its entry carries the deficit the
+        // cell needs --; a special cell goes first in its own chain and needs no chain read then)
+        const bool v_special = special[v] != 0;
+        auto rank = [&](int x) {
+            if (v_special && opt.capable[roots[x]]) return 2;
+            return special[roots[x]] ? 0 : 1;
+        };
         std::stable_sort(grp.begin(), grp.end(), [&](int x, int y) {
+            if (rank(x) != rank(y)) return rank(x) < rank(y);
             return P.pdepth[x] != P.pdepth[y] ? P.pdepth[x] < P.pdepth[y] : P.psize[x] > P.psize[y];
         });
         for (size_t i = 0; i < grp.size(); ++i) {
@@ -203,7 +240,9 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         P.unit_out.clear();
         P.unit_depth.clear();
         P.unit_cheap.clear();
+        P.unit_special.clear();
         auto new_unit = [&](int depth, bool is_cheap) {
+            P.unit_special.push_back(0);
             P.unit_cells.push_back(0);
             P.unit_imp.push_back(0);
             P.unit_out.push_back(0);
@@ -226,13 +265,17 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
                     first_open = P.unit_cells.size();
                 }
                 int u = -1;
+                const char sp = special[roots[p]];      // special pieces (one cell each) only share units with each other
                 for (size_t b = first_open; b < P.unit_cells.size(); ++b)
-                    if (P.unit_cells[b] + P.psize[p] <= LANES && P.unit_imp[b] + P.pimp[p] <= G_MAX &&
-                        P.unit_out[b] + (has_out(p) ? 1 : 0) <= G_MAX) {
+                    if (P.unit_special[b] == sp && P.unit_cells[b] + P.psize[p] <= LANES && P.unit_imp[b] + P.pimp[p] <= (sp ? 8 : G_MAX) &&
+                        P.unit_out[b] + (has_out(p) ? 1 : 0) <= (sp ? 8 : G_MAX)) {
                         u = (int)b;
                         break;
                     }
-                if (u < 0) u = new_unit(cur_depth, false);
+                if (u < 0) {
+                    u = new_unit(cur_depth, false);
+                    P.unit_special[u] = sp;
+                }
                 put_piece(p, u);
                 while (first_open < P.unit_cells.size() && P.unit_cells[first_open] >= LANES) ++first_open;
             }
@@ -258,7 +301,7 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         {
             std::vector<std::vector<int>> bucket(LANES + 1);
             for (int u = 0; u < (int)P.unit_cells.size(); ++u)
-                if (!P.unit_cheap[u]) bucket[LANES - P.unit_cells[u]].push_back(u);
+                if (!P.unit_cheap[u] && !P.unit_special[u]) bucket[LANES - P.unit_cells[u]].push_back(u);
             for (int p : by_size) {
                 const int sz = P.psize[p];
                 int u = -1;
@@ -453,6 +496,9 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
         if (r_src[c] != -1) out.unit_p[u] |= 2;
         if (fold_leaf[c] >= 0) out.unit_p[u] |= 4;                  // the unit carries folded leaves: the FOLD variant of the kernel
     }
+    out.n_special = P.n_special;
+    if (P.n_special >= 0)                                           // single-sum plan: 8 = one running sum, 16 = special unit
+        for (int u = 0; u < nunit; ++u) out.unit_p[u] |= P.unit_special[u] ? 24 : 8;
     for (int ed = 0; ed < nedge; ++ed) {
         const int u = out.edge_cons_unit[ed];
         const int gl = out.unit_lmax[u] - 2 * (edge_reader_h[ed] + 1);
@@ -460,6 +506,9 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
         out.unit_glmax[u] = std::max(out.unit_glmax[u], gl);
     }
     out.lane_flags.assign(ts, 0);
+    if (P.n_special >= 0)
+        for (int64_t sl = 0; sl < ts; ++sl)
+            if (out.cell_of_slot[sl] >= 0 && opt.capable[out.cell_of_slot[sl]]) out.lane_flags[sl] = 1;
     out.unit_plain.assign(nunit, 0);
 
     std::vector<int> unit_exp(nunit, 0);
@@ -520,6 +569,11 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
                 nfi += ((out.unit_p[u] & 4) && (P.unit_imp[u] > 0 || unit_exp[u] > 0)) ? 1 : 0;
             }
             fprintf(stderr, "  folded leaves: %d, in %d units (of them with streams: %d)\n", out.n_folded, nfu, nfi);
+        }
+        {
+            int nsu = 0;
+            for (int u = 0; u < nunit; ++u) nsu += (out.unit_p[u] & 16) ? 1 : 0;
+            fprintf(stderr, "  single-sum plan: %s, %d special cells in %d units\n", P.n_special >= 0 ? "yes" : "no", std::max(P.n_special, 0), nsu);
         }
         fprintf(stderr, "  units by reads (none, A, R, A+R): %d %d %d %d\n  units by lmax/16 (0..13+):", hs[0], hs[1], hs[2], hs[3]);
         for (int k = 0; k < 14; ++k) fprintf(stderr, " %d", hl[k]);
@@ -607,7 +661,8 @@ std::string flow_tables_check_rsum(int n, const int64_t *indptr, const int32_t *
             }
         if (g != imp[u]) return "ghost count";
         if (t.unit_lmax[u] & 15) return "unit lag not a multiple of 16";
-        if ((t.unit_p[u] & ~7) != 0x400) return "shape word of unit " + std::to_string(u);
+        if ((t.unit_p[u] & ~31) != 0x400) return "shape word of unit " + std::to_string(u);
+        if (t.n_special >= 0 ? !(t.unit_p[u] & 8) : (t.unit_p[u] & 24) != 0) return "single-sum flags of unit " + std::to_string(u);
     }
     // what a value stands for: the cells whose flows it sums.  expand(entry) appends them.
     std::vector<int> readers_lane(ts, 0), readers_ghost(t.n_edges, 0);
@@ -660,6 +715,18 @@ std::string flow_tables_check_rsum(int n, const int64_t *indptr, const int32_t *
         if (r != SK_ZERO && !(t.unit_p[u] & 2)) return "unit shape lacks the chain read";
         terms.clear();
         if (!expand(u, a, terms, 0, expand)) return "bad chain at cell " + std::to_string(c);
+        if (t.n_special >= 0) {
+            // single-sum plan (lane_flags bit 0: the cell can fire): a cell that can fire with an upstream neighbour that can
+            // reads that neighbour's entry -- the LAST member of the chain, whose first half is its deficit -- in a special unit
+            if ((int64_t)t.lane_flags.size() != ts) return "lane flags";
+            int ncap = 0;
+            for (int x : terms) ncap += (t.lane_flags[slot_of[x]] & 1) ? 1 : 0;
+            if ((t.lane_flags[s] & 1) && ncap > 0) {
+                if (ncap != 1) return "cell " + std::to_string(c) + " can fire and has two upstream neighbours that can";
+                if (!(t.unit_p[u] & 16)) return "special cell " + std::to_string(c) + " in an ordinary unit";
+                if (!(t.lane_flags[slot_of[terms.back()]] & 1)) return "the neighbour of cell " + std::to_string(c) + " that can fire is not the last member of its chain";
+            }
+        }
         if (!t.fold_of_slot.empty() && t.fold_of_slot[s] >= 0) terms.push_back(t.fold_of_slot[s]);      // the leaf the lane carries itself
         want.clear();
         for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j) {

@@ -527,11 +527,12 @@ static bool reassoc_wanted(int flags) {
 // partition of a grid is the same every time (topology, planner options, foldable set, library build): it is kept in the
 // cache beside the bit-exact one (flow_plan_build) and held to the planner's own invariant checker before it is used.
 // False: the planner has nothing for this grid.
-static bool rsum_tables_get(xh_ctx *ctx, xh_route_plan *plan, const unsigned char *foldable, FlowTables &t,
-                            std::vector<char> &handled) {
+static bool rsum_tables_get(xh_ctx *ctx, xh_route_plan *plan, const unsigned char *foldable, const unsigned char *capable,
+                            FlowTables &t, std::vector<char> &handled) {
     std::string err;
     FlowPlanOptions opt = flow_plan_options(ctx);
     opt.foldable = foldable;
+    opt.capable = capable;
     std::string cache;
     static const bool cache_on = !(getenv("XH_ROUTE_LEARN_CACHE") && getenv("XH_ROUTE_LEARN_CACHE")[0] == '0');
     if (cache_on && !opt.debug) {
@@ -543,15 +544,19 @@ static bool rsum_tables_get(xh_ctx *ctx, xh_route_plan *plan, const unsigned cha
             const int knobs[2] = {opt.simds, opt.piece_cap};
             for (size_t i = 0; i < sizeof(knobs); ++i) h = (h ^ reinterpret_cast<const unsigned char *>(knobs)[i]) * 1099511628211ull;
             for (const char *b = __DATE__ " " __TIME__; *b; ++b) h = (h ^ (unsigned char)*b) * 1099511628211ull;
-            if (foldable)
-                for (int64_t c = 0; c < plan->ncell; ++c) h = (h ^ foldable[c]) * 1099511628211ull;
+            for (const unsigned char *set : {foldable, capable}) {
+                h = (h ^ (set ? 1u : 0u)) * 1099511628211ull;
+                if (set)
+                    for (int64_t c = 0; c < plan->ncell; ++c) h = (h ^ set[c]) * 1099511628211ull;
+            }
             char name[96];
-            snprintf(name, sizeof(name), "/rsum%s_%016llx_%lld.tables", foldable ? "f" : "", (unsigned long long)h, (long long)plan->ncell);
+            snprintf(name, sizeof(name), "/rsum%s%s_%016llx_%lld.tables", foldable ? "f" : "", capable ? "s" : "", (unsigned long long)h,
+                     (long long)plan->ncell);
             cache = dir + name;
         }
     }
     if (!cache.empty() && flow_tables_load(cache.c_str(), t) && t.rsum && t.n_units > 0 &&
-        (int64_t)t.cell_of_slot.size() == (int64_t)t.n_units * 64 && (foldable != nullptr) == (t.n_folded > 0)) {
+        (int64_t)t.cell_of_slot.size() == (int64_t)t.n_units * 64 && (foldable || t.n_folded == 0) && (capable || t.n_special < 0)) {
         handled.assign((size_t)plan->ncell, 0);
         bool ok = true;
         auto take = [&](int c) {
@@ -568,7 +573,7 @@ static bool rsum_tables_get(xh_ctx *ctx, xh_route_plan *plan, const unsigned cha
     if (flow_tables_build_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(), plan->h_sign.data(),
                                plan->h_comp.data(), plan->h_ncomp, opt, handled, t, err) != 0 || t.n_units == 0)
         return false;
-    if (!cache.empty() && (foldable == nullptr || t.n_folded > 0)) {
+    if (!cache.empty()) {
         const std::string dir = cache.substr(0, cache.rfind('/'));
         for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
             if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
@@ -585,7 +590,7 @@ static int rsum_plan_build(xh_ctx *ctx, xh_route_plan *plan) {
     if (!plan->flow || plan->h_indptr.empty()) return XH_OK;
     std::vector<char> handled;
     FlowTables t;
-    if (!rsum_tables_get(ctx, plan, nullptr, t, handled)) return XH_OK;
+    if (!rsum_tables_get(ctx, plan, nullptr, nullptr, t, handled)) return XH_OK;
     if (t.n_cells != plan->flow->n_cells) return XH_OK;      // must route exactly the cells the bit-exact plan routes
     if (getenv("XH_FLOW_CHECK")) {
         const std::string bad = flow_tables_check_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
@@ -1116,30 +1121,35 @@ extern "C" int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const dou
     // (what is prepared below -- the selective plain tables of the BIT-EXACT kernel -- is of no use to a process whose calls
     // route in the reassociated form by default; a call that asks for XH_ROUTE_EXACT later learns the way it always did)
     if (reassoc_wanted(0)) {
-        // ... but the reassociated plan with FOLDED LEAVES needs exactly what this call brings: which leaves cannot fire
-        // (XH_FLOW_FOLD=0: never folded)
+        // ... but the PREPARED reassociated plan (xanthos_hip.h, xh_route_plan_rsum_info: folded leaves, single sums) needs
+        // exactly what this call brings: which cells can fire.  XH_FLOW_FOLD=0 / XH_RSUM_SINGLE=0: without the one / the other.
         static const bool fold_on = !(getenv("XH_FLOW_FOLD") && getenv("XH_FLOW_FOLD")[0] == '0');
-        if (!fold_on || plan->flow_rsum_fold || plan->fold_disabled || plan->fold_tried || !plan->flow || plan->h_indptr.empty())
+        static const bool single_on = !(getenv("XH_RSUM_SINGLE") && getenv("XH_RSUM_SINGLE")[0] == '0');
+        if ((!fold_on && !single_on) || plan->flow_rsum_fold || plan->fold_disabled || plan->fold_tried || !plan->flow || plan->h_indptr.empty())
             return XH_OK;
         plan->fold_tried = true;
         const size_t n = (size_t)plan->ncell;
-        std::vector<unsigned char> foldable(n, 0);
+        std::vector<unsigned char> foldable(n, 0), capable(n, 0);
         size_t nfold = 0;
         for (size_t c = 0; c < n; ++c) {
             const double tauinv = h_velocity[c] / h_flow_dist[c];
             const bool leaf = plan->h_indptr[c + 1] - plan->h_indptr[c] == 1;
-            foldable[c] = (leaf && tauinv >= 0.0 && tauinv * dt <= CAPABLE_THRESHOLD) ? 1 : 0;      // (NaN: not foldable)
+            capable[c] = (tauinv * dt <= CAPABLE_THRESHOLD) ? 0 : 1;                                    // (NaN: can fire)
+            foldable[c] = (leaf && tauinv >= 0.0 && tauinv * dt <= CAPABLE_THRESHOLD) ? 1 : 0;          // (NaN: not foldable)
             nfold += foldable[c];
         }
-        if (nfold == 0) return XH_OK;
+        const bool fold = fold_on && nfold > 0;
+        if (!fold && !single_on) return XH_OK;
         std::vector<char> handled;
         FlowTables t;
-        if (!rsum_tables_get(ctx, plan, foldable.data(), t, handled) || t.n_folded == 0) return XH_OK;
+        if (!rsum_tables_get(ctx, plan, fold ? foldable.data() : nullptr, single_on ? capable.data() : nullptr, t, handled) ||
+            (t.n_folded == 0 && t.n_special < 0))
+            return XH_OK;
         if (t.n_cells != plan->flow->n_cells) return XH_OK;
         if (getenv("XH_FLOW_CHECK")) {
             const std::string bad = flow_tables_check_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
                                                            plan->h_sign.data(), handled, t);
-            if (!bad.empty()) return xh_fail(ctx, XH_ERR_ARG, "reassociated flow plan check (folded leaves): %s", bad.c_str());
+            if (!bad.empty()) return xh_fail(ctx, XH_ERR_ARG, "reassociated flow plan check (prepared plan): %s", bad.c_str());
         }
         const int rcu = flow_plan_upload(ctx, t, &plan->flow_rsum_fold);
         if (rcu) return rcu;
@@ -1425,13 +1435,15 @@ int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r, bool dataflow_pairs) {
                              r.area, r.runoff, r.S0, r.chs, r.avg, r.S_end, r.F_end, flags, &used_flow);
 }
 
-extern "C" int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[4]) {
+extern "C" int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[6]) {
     if (!plan || !info) return XH_ERR_ARG;
     const FlowPlan *fp = plan->last_rsum ? plan->last_rsum_plan : nullptr;
     info[0] = fp ? fp->n_units : 0;
     info[1] = fp ? fp->n_folded : 0;
     info[2] = plan->fold_disabled ? 1 : 0;
     info[3] = plan->flow_rsum_fold ? plan->flow_rsum_fold->n_folded : 0;
+    info[4] = fp ? fp->n_special : -1;
+    info[5] = plan->flow_rsum_fold ? plan->flow_rsum_fold->n_special : -1;
     return XH_OK;
 }
 

@@ -463,6 +463,7 @@ int flow_plan_upload(xh_ctx *ctx, const FlowTables &t, FlowPlan **out) {
     rc |= put(ctx, fp->d_ghost_prod, t.ghost_prod);
     if (!t.fold_of_slot.empty()) rc |= put(ctx, fp->d_fold_cell, t.fold_of_slot);
     fp->n_folded = t.n_folded;
+    fp->n_special = t.n_special;
     if (rc) {
         flow_plan_destroy(fp);
         return XH_ERR_HIP;

@@ -43,19 +43,38 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     __attribute__((address_space(3))) double *fnd = (__attribute__((address_space(3))) double *)fend_sh;
     fend_sh[threadIdx.x] = 0.0;
     fend_sh[LANES + threadIdx.x] = 0.0;
-    if ((p & ~7) != 0x400) {      // not a reassociated plan: a fault rather than wrong results
+    if ((p & ~31) != 0x400) {      // not a reassociated plan: a fault rather than wrong results
         if (threadIdx.x == 0) __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    // (a unit that carries folded leaves has no streams: xh_flow_rsum.cpp)
-    if ((p & 4) && !g && !x && A(fold_cell)) wave_unit<false, 1, 0, 0, true, true, true>(ap, l, xtab, qst, fnd, unit);
-    else if (p & 4) {      // not produced by the plan; a fault rather than wrong results
-        if (threadIdx.x == 0) __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool bad = false;
+    if ((p & 8) && (A(balance) & 4) && (unit % 100) == 7 && !(p & 20)) {      // EXPERIMENT (timing only): one unit in a hundred in the pair form
+        if (g2) wave_unit<false, 1, 0, 2, true, true>(ap, l, xtab, qst, fnd, unit);
+        else if (g) wave_unit<false, 1, 0, 1, true, true>(ap, l, xtab, qst, fnd, unit);
+        else wave_unit<false, 1, 0, 0, true, true>(ap, l, xtab, qst, fnd, unit);
+    } else if (p & 8) {      // single-sum plan (xh_flow_rsum.cpp): one running sum per entry; 16: a unit of special cells
+        if (p & 16) {
+            if ((p & 4) || g2 || !g) bad = true;
+            else if (p & 2) wave_unit<false, 1, 0, 1, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
+            else wave_unit<false, 1, 0, 1, false, true, false, 2>(ap, l, xtab, qst, fnd, unit);
+        } else if (p & 4) {      // (a unit that carries folded leaves has no streams)
+            if (g || x || !A(fold_cell)) bad = true;
+            else wave_unit<false, 1, 0, 0, true, true, true, 1>(ap, l, xtab, qst, fnd, unit);
+        } else if (g2) wave_unit<false, 1, 0, 2, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);
+        else if (g) wave_unit<false, 1, 0, 1, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);
+        else if ((p & 2) || x) wave_unit<false, 1, 0, 0, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);
+        else if (p & 1) wave_unit<false, 1, 0, 0, false, true, false, 1>(ap, l, xtab, qst, fnd, unit);
+        else wave_unit<false, 0, 0, 0, false, true, false, 1>(ap, l, xtab, qst, fnd, unit);
+    } else if (p & 4) {
+        if (g || x || !A(fold_cell)) bad = true;
+        else wave_unit<false, 1, 0, 0, true, true, true>(ap, l, xtab, qst, fnd, unit);
     } else if (g2) wave_unit<false, 1, 0, 2, true, true>(ap, l, xtab, qst, fnd, unit);
     else if (g) wave_unit<false, 1, 0, 1, true, true>(ap, l, xtab, qst, fnd, unit);
     else if ((p & 2) || x) wave_unit<false, 1, 0, 0, true, true>(ap, l, xtab, qst, fnd, unit);
     else if (p & 1) wave_unit<false, 1, 0, 0, false, true>(ap, l, xtab, qst, fnd, unit);
     else wave_unit<false, 0, 0, 0, false, true>(ap, l, xtab, qst, fnd, unit);
+    if (bad && threadIdx.x == 0)      // a shape the planner does not produce: a fault rather than wrong results
+        __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #undef A
 

@@ -194,7 +194,7 @@ template <> struct Val<true> {
 // passes that volume on at once (mrtm.py:60, a flow of -1e-15 m3/s), the recurrence over 1 / (tau^-1 dt) sub-steps; both
 // conserve it, and the difference is nine orders below this form's bar (1e-9 m3/s, 1e-3 m3: xh_mrtm.hip k_count_far).
 // FOLD_EPS = 1e-6 m3 keeps the guard from tripping on that while bounding what it lets through to 1e-10 m3/s.
-template <bool PLAIN, int PRE, int POST, int NG, bool CHAIN, bool RSUM = false, bool FOLD = false>
+template <bool PLAIN, int PRE, int POST, int NG, bool CHAIN, bool RSUM = false, bool FOLD = false, int SGL = 0>
 __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint2 *xtab,
                                           __attribute__((address_space(3))) unsigned *qstage,
                                           __attribute__((address_space(3))) double *fend, const int unit) {
@@ -224,6 +224,8 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     auto ent_off = [](unsigned o) { return PLAIN ? o >> 1 : o; };
     static_assert(!RSUM || (!PLAIN && PRE <= 1 && POST == 0), "reassociated form: one inflow entry, pair values");
     static_assert(!FOLD || (RSUM && NG == 0), "folded leaves: reassociated form, units without imports");
+    static_assert(SGL == 0 || RSUM, "single-sum units: reassociated form");
+    static_assert(SGL != 2 || PRE == 1, "special units read their inflow entry");
     // the folded leaf of this lane
     const int gcL = FOLD ? A(fold_cell)[slot] : -1;
     const bool validL = FOLD && valid && gcL >= 0;
@@ -237,6 +239,12 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     // or NaN ratio, a negative initial storage -- and, month by month in finalize(), a storage below -FOLD_EPS
     constexpr double FOLD_EPS = 1e-6;
     unsigned gfold = (validL && !(tauL * A(dt) <= 1.0 - 1.0 / 1048576.0 && tauL >= 0.0 && S0L >= 0.0)) ? 1u : 0u;
+    // guard of the single-sum form (SGL; the argument is at the sub-step): its plan was made for the cells that can fire at
+    // THIS velocity, length and dt -- a cell that can but is not marked, a negative initial storage or (month by month,
+    // below) runoff negative beyond a rounding error of the runoff model make the unit give up like the folded leaves' guard
+    constexpr double SGL_EPS = 1e-6;      // m3 per sub-step
+    unsigned gsgl = 0;
+    if (SGL != 0) gsgl = (valid && ((!(tauinv * A(dt) <= 1.0 - 1.0 / 1048576.0) && !(A(lane_flags)[slot] & 1u)) || S0v < 0.0)) ? 1u : 0u;
     constexpr int PRE_N = PRE > 0 ? PRE : 1, POST_N = POST > 0 ? POST : 1;      // (array extents: a side may be empty)
     lds_cchar *epre[PRE_N], *epost[POST_N];
 #pragma unroll
@@ -386,6 +394,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         const double q0 = ld_q(r0.q_off);
         erl_n = ((valid ? q0 : 0.0) * area) * 1000.0 / r0.secs;                  // mrtm.py:45
         if (RSUM) erl_n *= A(dt);
+        if (SGL != 0) gsgl |= (erl_n < -SGL_EPS) ? 2u : 0u;
         if (FOLD) {
             const double q0L = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(p_runoff) + r0.q_off + (size_t)row_offL);
             erlL_n = (((validL ? q0L : 0.0) * areaL) * 1000.0 / r0.secs) * A(dt);
@@ -484,7 +493,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alive = false;
         }
-        if (FOLD && __any(gfold != 0)) {                 // a folded leaf that can fire after all: the host routes again without folding
+        if ((FOLD && __any(gfold != 0)) || (SGL != 0 && __any(gsgl != 0))) {      // a folded leaf that can fire after all, a single-sum plan made for other data: the host routes again on the plain reassociated plan
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alive = false;
         }
@@ -534,6 +543,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             const double qn = runoff_take();
             erl_n = ((valid ? qn : 0.0) * area) * 1000.0 / f.secs_next1;
             if (RSUM) erl_n *= dt;
+            if (SGL != 0) gsgl |= (erl_n < -SGL_EPS) ? 2u : 0u;
             if (FOLD) {      // (runoff_take has waited for the loads of both staging areas: a unit without streams waits vmcnt(0))
                 const unsigned lo = qstage[2 * LANES + lane], hi = qstage[3 * LANES + lane];
                 const double qnL = __hiloint2double((int)hi, (int)lo);
@@ -747,9 +757,18 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         val_t(&ac)[PRE_N] = va[j & 1], (&bc)[POST_N] = vb[j & 1], (&an)[PRE_N] = va[(j & 1) ^ 1], (&bn)[POST_N] = vb[(j & 1) ^ 1];
         const val_t rc = vr[j & 1];
         const unsigned so = (unsigned)((j + RING - 1) & (RING - 1)) * SLOTB;
-        if (CHAIN) vr[(j & 1) ^ 1] = *(lds_cv *)(eprv + so);
+        if constexpr (SGL != 0) {      // single-sum units read the one running sum (the second half of an entry): 8-byte reads
+            typedef __attribute__((address_space(3))) const double lds_c1;
+            if (CHAIN) vr[(j & 1) ^ 1].y = *(lds_c1 *)(eprv + so + 8u);
+            if (PRE) {
+                if (SGL == 2) an[0] = *(lds_cv *)(epre[0] + so);
+                else an[0].y = *(lds_c1 *)(epre[0] + so + 8u);
+            }
+        } else {
+            if (CHAIN) vr[(j & 1) ^ 1] = *(lds_cv *)(eprv + so);
 #pragma unroll
-        for (int w = 0; w < PRE; ++w) an[w] = *(lds_cv *)(epre[w] + so);
+            for (int w = 0; w < PRE; ++w) an[w] = *(lds_cv *)(epre[w] + so);
+        }
 #pragma unroll
         for (int w = 0; w < POST; ++w) bn[w] = *(lds_cv *)(epost[w] + so);
         __builtin_amdgcn_sched_barrier(0);
@@ -768,6 +787,37 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
                 favgL += FL;                                                   // mrtm.py:78
                 base = __builtin_fma(FL, dt, base);
             }
+            if constexpr (SGL == 2) {
+                // Special unit of a single-sum plan: its cells can fire and have ONE upstream neighbour k that can, the last
+                // member of the chain they read -- whose entry is {m_k, sum F2}: sum F = sum F2 - m_k / dt, so the trial
+                // storage of mrtm.py:51-54 is S2 - m_k (to rounding) and the step is the pair form's.
+                const double S2 = __builtin_fma(ac[0].y, dt, base);            // mrtm.py:66-69
+                const double S1 = S2 - ac[0].x;                                // mrtm.py:51, 54
+                const bool sx = S1 < 0.0;
+                const double m = __builtin_fmin(S1, 0.0);
+                const double f2 = __builtin_fma(m, dtinv, F0);                 // mrtm.py:60
+                own[(j & (RING - 1)) * NSLOT] = v2d{m, CHAIN ? rc.y + f2 : f2};
+                double Sn = S2;
+                asm volatile("" : "+v"(Sn));
+                S = sx ? 0.0 : Sn;                                             // mrtm.py:63, 69
+                F = f2;
+                favg += f2;
+            } else if constexpr (SGL == 1) {
+                // Single-sum unit: none of its cells is one that can fire AND has an upstream neighbour that can.  For every
+                // other cell the two sums of mrtm.py:51 and :66 are the same number whenever they matter -- a neighbour that
+                // cannot fire has F2 = F; a cell that cannot fire itself has S1 >= S2 >= 0 and uses the adjusted sum only --
+                // so the lanes pass ONE running sum (of the adjusted flows F2) and the step is
+                //     S1 = base + (sum F2) dt,  m = min(S1, 0),  F2 = F + m / dt,  S = S1 - m
+                // (S = 0 exactly where the cell fires, S1 where it does not, NaN where S1 is NaN: min returns the 0).
+                // The entry's first half carries m, the cell's deficit of this sub-step, for the lanes of `special` units.
+                const double S1 = PRE ? __builtin_fma(ac[0].y, dt, base) : base;
+                const double m = __builtin_fmin(S1, 0.0);
+                const double f2 = __builtin_fma(m, dtinv, F0);
+                own[(j & (RING - 1)) * NSLOT] = v2d{m, CHAIN ? rc.y + f2 : f2};
+                S = S1 - m;
+                F = f2;
+                favg += f2;
+            } else {
             const double S1 = PRE ? __builtin_fma(ac[0].x, dt, base) : base;  // trial storage: S + dSdt dt (mrtm.py:51, 54)
             const double S2 = PRE ? __builtin_fma(ac[0].y, dt, base) : base;  // the same with the adjusted inflows (mrtm.py:66-69)
             const bool sx = S1 < 0.0;                                          // mrtm.py:54: dSdt dt < -S
@@ -780,6 +830,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             S = sx ? 0.0 : Sn;                                                 // mrtm.py:63, 69
             F = f2;
             favg += f2;                                                        // mrtm.py:78
+            }
         } else if constexpr (PLAIN) {
             double s1 = 0.0;                                                   // UM.dot(F), stored order (mrtm.py:51)
 #pragma unroll
@@ -899,7 +950,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     if (alive) {
         while (itf <= nit) finalize(itf++);
         learn_now();
-        if ((PLAIN && __any((fired | gmis) != 0)) || (FOLD && __any(gfold != 0))) {
+        if ((PLAIN && __any((fired | gmis) != 0)) || (FOLD && __any(gfold != 0)) || (SGL != 0 && __any(gsgl != 0))) {
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alive = false;
         }
