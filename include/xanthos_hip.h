@@ -238,15 +238,18 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
 #define XH_ROUTE_EXACT 256          /* the bit-exact kernels for this call (every row sum in scipy's stored order) whatever
                                        the default says                                                                  */
 /* The reassociated plan the last call ran on: info[6] = {its units; the leaves it folded into their downstream cells' lanes;
- * 1 if a guard trip has switched the prepared plan off; folded leaves of the prepared plan; special cells of the plan the
- * last call ran on, -1 if its lanes pass pairs of sums; special cells of the prepared plan (-1: pairs, or none prepared)}.
+ * 1 if a guard trip has switched the prepared plan off; folded leaves of the prepared plan; cells in pair form of the plan
+ * the last call ran on, -1 if ALL its lanes pass pairs of sums; the same for the prepared plan (-1: pairs, or none prepared)}.
  * The PREPARED plan is the one xh_route_plan_prepare makes from the call's velocities, lengths and dt (reassociated form
  * only; XH_FLOW_FOLD=0 / XH_RSUM_SINGLE=0 switch its two parts off):
  *  - leaves that cannot fire (velocity * dt / length < 1) of river networks small enough to have no streams are carried by
  *    their parents' lanes, which frees enough lanes for every unit to have a SIMD of its own;
- *  - the lanes pass ONE running sum instead of the pair {sum F, sum F2}: only a cell that can fire AND has an upstream
- *    neighbour that can needs both, and those few sit in units of their own.
- * Both rest on which cells can fire; the kernel guards the assumption and a trip routes the call again on the plain plan. */
+ *  - the lanes pass ONE running sum (of the adjusted flows) instead of the pair {sum F, sum F2}: only a cell that may fire
+ *    AND has an upstream neighbour that may needs both -- the cells that can fire by construction with such a neighbour and
+ *    a halo of XH_RSUM_HALO (8) cells downstream of them, where the reference's corner S1 >= 0 > S2 (mrtm.py:54, :66-69)
+ *    sends negative flows -- and those few sit in pair units of their own.
+ * Both rest on which cells can fire; the kernel guards the assumptions (folded leaves' storage, lateral inflow and initial
+ * storage >= 0, the outflow of the halos' exit cells >= 0) and a trip routes the call again on the plan of pairs.          */
 int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[6]);
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,

@@ -356,6 +356,7 @@ static int run_file(const char *path, bool typed, bool rsum) {
         opt.foldable = foldable.data();
     }
     if (rsum) opt.capable = getenv("SINGLE") ? capable.data() : nullptr;
+    if (getenv("HALO")) opt.halo = atoi(getenv("HALO"));
     const auto t0 = std::chrono::steady_clock::now();
     if (rsum ? flow_tables_build_rsum(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)
              : flow_tables_build(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)) {

@@ -1,9 +1,11 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against (1) the golden vectors generated from
 the real reference and (2) the numpy oracle on seeded synthetic inputs.
 
-Tolerances: routing is bit-exact (same operation order as numpy/scipy, -ffp-contract=off) for identical runoff;
-PM and ABCD are fp64 within 1e-9 relative (only exp/log/sqrt/pow implementations differ, a few ulp) -- far
-inside the 1e-6 the north star states.
+Tolerances: the bit-exact routing kernels (asked for by flag: XH_ROUTE_EXACT -- the library's default since round 5 is the
+reassociated form) are bit-exact (same operation order as numpy/scipy, -ffp-contract=off) for identical runoff; tests
+that do not pass the flag run whatever the library ships and hold it to the form's bar (`routed_close`: identical NaN
+masks, |x - ref| <= 1e-9 |ref| + 1e-3 m3 / 1e-9 m3/s).  PM and ABCD are fp64 within 1e-9 relative (only exp/log/sqrt/pow
+implementations differ, a few ulp) -- far inside the 1e-6 the north star states.
 """
 from types import SimpleNamespace
 
@@ -13,6 +15,29 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-9
+EXACT = 256      # XH_ROUTE_EXACT: the bit-exact kernels for this call, whatever the library's default form is
+
+
+def routed_close(x, ref, atol, rtol=1e-9, tag=''):
+    """The bar of the default (reassociated) routing form: identical NaN masks, |x - ref| <= rtol |ref| + atol."""
+    x, ref = np.asarray(x), np.asarray(ref)
+    assert x.shape == ref.shape
+    assert np.array_equal(np.isnan(x), np.isnan(ref)), 'NaN pattern differs ' + str(tag)
+    m = ~np.isnan(ref)
+    excess = np.abs(x[m] - ref[m]) - (atol + rtol * np.abs(ref[m]))
+    assert (excess <= 0).all(), '{}: {} values beyond the bar, largest excess {:.3e}'.format(tag, int((excess > 0).sum()), excess.max())
+
+
+ROUTED_ATOL = {'chs': 1e-3, 'avg': 1e-9}      # m3 / m3 s-1
+
+
+def outputs_close(got, ref, keys, tag=''):
+    """Pipeline outputs: the stages in front of the routing bit for bit, the routed ones within the default form's bar."""
+    for k in keys:
+        if k in ROUTED_ATOL:
+            routed_close(got[k], ref[k], ROUTED_ATOL[k], tag=(tag, k))
+        else:
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (tag, k)
 
 
 def close(x, ref, rtol=RTOL, atol=1e-9):
@@ -283,7 +308,7 @@ def test_streamrouting_golden_bit_exact(hip, golden, tag, flags):
     n = len(S)
     for nday in (28, 29, 30, 31):
         S, favg, F = mrtm.streamrouting(g[tag + '_L'], S, np.zeros(n), g[tag + '_chv'], g['%s_q_%d' % (tag, nday)],
-                                        g[tag + '_area'], nday, 10800, um, flags=flags)
+                                        g[tag + '_area'], nday, 10800, um, flags=flags | EXACT)
         assert np.array_equal(S, g['%s_S_%d' % (tag, nday)])
         assert np.array_equal(favg, g['%s_Favg_%d' % (tag, nday)])
         assert np.array_equal(F, g['%s_F_%d' % (tag, nday)])
@@ -296,7 +321,7 @@ def test_route_series_golden_bit_exact(hip, golden, tag, flags):
     g, t = golden('mrtm'), golden('topo')
     chs, avg, fend = mrtm.route_series(_um(t, tag), g[tag + '_L'], g[tag + '_chv'], g[tag + '_area'],
                                        g[tag + '_series_runoff'], g[tag + '_series_ndays'], int(g['series_spinup']),
-                                       flags=flags)
+                                       flags=flags | EXACT)
     assert np.array_equal(chs, g[tag + '_series_chstorage'])
     assert np.array_equal(avg, g[tag + '_series_avgchflow'])
     assert np.array_equal(fend, g[tag + '_series_Fend'])
@@ -335,7 +360,7 @@ def test_route_synthetic_world_vs_oracle(hip, flags):
     runoff[rng.random(w.ncell) < 0.01] = np.nan          # NaN runoff (NaN precip cells) must propagate identically
     ndays = o_months.set_month_arrays(12, 1972, 1972)[:, 2]
     ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
-    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=flags)
+    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=flags | EXACT)
     for a, b in zip(got, ref):
         assert np.array_equal(a, b, equal_nan=True)
     assert um.plan(hip.get_context()).info()['last_tree_kernel'] == {0: 2, 8: 1, 4: 0}[flags]
@@ -363,7 +388,7 @@ ok = True
 # typed: first build, re-build with what was learnt, steady.  XH_TEST_CALLS: repeated plain calls (the adaptive plain form
 # builds its tables on a host thread from the second call on; the pause lets them be ready for the next call)
 for rep in range(3 if os.environ.get('XH_ROUTE_TYPED') else int(os.environ.get('XH_TEST_CALLS', '1'))):
-    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=int(os.environ.get('XH_TEST_FLAGS', '0')))
+    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=int(os.environ.get('XH_TEST_FLAGS', '0')) | 256)      # (256 = XH_ROUTE_EXACT)
     ok = ok and all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
     if os.environ.get('XH_TEST_CALLS'):
         time.sleep(0.3)

@@ -443,3 +443,81 @@ def test_folded_leaves_in_the_reassociated_form(tmp_path):
     assert out['kernel'] == 4 and out['worst'] < 1e-10 and out['worst_fed'] < 1e-10 and out['worst_guard'] < 1e-10, out
     assert out['info']['folded'] > 50 and out['info_fed']['folded'] == out['info']['folded'] == out['info_end']['folded'], out
     assert out['info_guard']['fold_disabled'] == 1 and out['info_guard']['folded'] == 0, out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Single running sums (round 6): prepared plans pass ONE sum per lane; the cells that may fire and have an upstream neighbour
+# that may -- and a halo below them -- keep the pair form in units of their own (xh_flow_rsum.cpp; tests/corner_world.py).
+
+_SINGLE_CHILD = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+import corner_world as cw
+from oracle import mrtm as o_mrtm
+from xanthos_amd import _hip
+from xanthos_amd.routing import mrtm
+seed, mode = int(sys.argv[2]), sys.argv[3]
+idx, csr, L, v, area = cw.make(seed=seed)
+n = len(L)
+q = cw.runoff(n, seed=seed)
+if mode == 'negative_runoff':
+    q[idx['s0_t1_0'], 3] = -5.0                     # outside the argument (lateral inflow >= 0): the guard must trip
+ndays = np.array([31, 28, 31, 30, 31, 30])
+um = mrtm.UpstreamMatrix(*csr)
+fired, neg_s, neg_f = cw.instrumented(csr, L, v, area, q, ndays)
+ref = o_mrtm.route_series(um.tocsr(), L, v, area, q, ndays, 0)
+got = mrtm.route_series(um, L, v, area, q, ndays, 0)
+plan = um.plan(_hip.get_context())
+worst = 0.0
+for x, r, atol in zip(got, ref, (1e-3, 1e-9, 1e-9)):
+    assert np.array_equal(np.isnan(x), np.isnan(r))
+    err = np.abs(x - r)
+    assert (err <= 1e-9 * np.abs(r) + atol).all(), float((err - 1e-9 * np.abs(r)).max())
+    worst = max(worst, float((err / np.maximum(np.abs(r), 1e6 * atol)).max()))
+info = plan.info()
+print(json.dumps({'kernel': int(info['last_tree_kernel']), 'rsum': plan.rsum_info(), 'worst': worst, 'reroutes': int(info['reroutes']),
+                  'guard_trips': int(plan.typed_info()['guard_trips']),
+                  'neg_storage_cells': int((neg_s > 0).sum()), 'fired_unexpectedly': int(((fired > 0) & (v / L * 10800.0 < 1)).sum()),
+                  'neg_s_sites': [int(neg_s[idx['s%d_A' % k]]) for k in range(3)]}))
+"""
+
+
+def _single_child(tmp_path, seed, mode, env=None):
+    import json
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / 'single_child.py'
+    script.write_text(_SINGLE_CHILD)
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    e = dict(os.environ, XH_FLOW_CHECK='1')
+    e.pop('XH_ROUTE_REASSOC', None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, str(script), root, str(seed), mode], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize('seed', [3, 13, 20])
+def test_single_sum_plan_on_the_corner_world(tmp_path, seed):
+    """The reference's corner S1 >= 0 > S2 (mrtm.py:54, :66-69: negative storage, negative outflow, cells downstream firing
+    that cannot by construction) on the committed world, routed through the plugin API -- ``routing.mrtm.route_series`` prepares
+    the plan from the L, ChV and dt it holds -- on the single-sum plan: within the bar of the oracle, no guard trip."""
+    out = _single_child(tmp_path, seed, 'plain')
+    assert out['neg_storage_cells'] >= 1 and out['fired_unexpectedly'] >= 2, out      # the corner does occur in this world
+    assert out['kernel'] == 4 and out['worst'] < 1e-10, out
+    assert out['rsum']['pair_cells'] > 0 and out['rsum']['fold_disabled'] == 0 and out['guard_trips'] == 0, out
+
+
+def test_single_sum_guards_trip_and_the_call_is_rerouted(tmp_path):
+    """Forced guard trips: (a) no halo (XH_RSUM_HALO=0): the negative outflow of the corner cell leaves the pair units, the exit
+    guard trips; (b) negative runoff in a single unit.  Either way the call is routed again on the plan of pairs -- results
+    within the bar -- and the prepared plan is switched off."""
+    a = _single_child(tmp_path, 3, 'plain', {'XH_RSUM_HALO': '0'})
+    assert a['kernel'] == 4 and a['worst'] < 1e-10, a
+    assert a['rsum']['fold_disabled'] == 1 and a['rsum']['pair_cells'] == -1 and a['guard_trips'] >= 1, a
+    b = _single_child(tmp_path, 3, 'negative_runoff')
+    assert b['kernel'] == 4 and b['worst'] < 1e-10, b
+    assert b['rsum']['fold_disabled'] == 1 and b['rsum']['pair_cells'] == -1 and b['guard_trips'] >= 1, b

@@ -12,7 +12,7 @@ from types import SimpleNamespace as NS
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-os.environ.setdefault('XH_ROUTE_REASSOC', '0')      # this tool holds the BIT-EXACT kernels to the oracle's bits (the default form is tested to 1e-9 elsewhere)
+EXACT = 256      # XH_ROUTE_EXACT: this tool holds the BIT-EXACT kernels to the oracle's bits (the default form is tested to 1e-9 elsewhere)
 from oracle import mrtm as o_mrtm            # noqa: E402
 from xanthos_amd import _hip, synth           # noqa: E402
 from xanthos_amd.routing import mrtm          # noqa: E402
@@ -51,7 +51,7 @@ def one_case(rng, k):
     # calls at the end give the adaptive plain form (tables on a host thread from the second plain call on) time to take over
     adaptive = 0
     for flags in (0, 64, 64, 8, 4, 0, 0, 0, 0):
-        got = mrtm.route_series(um, L, v, w.area, q, ndays, spin, S0=S0, dt=dt, flags=flags)
+        got = mrtm.route_series(um, L, v, w.area, q, ndays, spin, S0=S0, dt=dt, flags=flags | EXACT)
         if flags == 0 and len(used) >= 5:
             time.sleep(0.03)
             adaptive = max(adaptive, um.plan(_hip.get_context(0)).typed_info()['plain_units'])

@@ -19,6 +19,10 @@ constexpr int RING = 8;
 // MODE 3: MODE 0 without the LDS (arithmetic only: what the VALU work alone costs a lone wave).
 // MODE 4: the bit-exact pair form of a (2,3) row (5 ds_read_b128, two sums in stored order) -- round 3's reference point.
 // MODE 5: MODE 0 with the reads issued TWO sub-steps ahead of their use (a lane lag of three iterations per level instead of two).
+// MODE 6 (round 6): the SINGLE-SUM form of a prepared plan (wave_unit<..., SGL = 1>): two ds_read_b64 (the sum of the adjusted
+//         flows of the cell's upstream neighbours, its chain predecessor's), S1 = base + A dt, m = min(S1, 0), F2 = F + m / dt,
+//         S = S1 - m, one ds_write_b64 -- 8 fp64 operations.  MODE 7: the same arithmetic alone (no LDS).
+// MODE 8: a unit none of whose cells may fire (not built: what dropping the clamp would buy): S = S1, F2 = F -- 5 operations.
 template <int MODE>
 __global__ void __launch_bounds__(256) k(double *out, unsigned long long *cyc, double tauinv, double dt, double dtinv, double erl,
                                          const int *perm, int iters) {
@@ -38,7 +42,37 @@ __global__ void __launch_bounds__(256) k(double *out, unsigned long long *cyc, d
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            constexpr int NR = (MODE == 0 || MODE == 5) ? 2 : MODE == 1 ? 1 : MODE == 4 ? 5 : 0;
+            constexpr int NR = (MODE == 0 || MODE == 5 || MODE == 6 || MODE == 8) ? 2 : MODE == 1 ? 1 : MODE == 4 ? 5 : 0;
+            if (MODE >= 6) {      // 8-byte entries
+                lds_d *own1 = (lds_d *)lds + lane;
+                __builtin_amdgcn_sched_barrier(0);
+                if (MODE != 7) {
+                    vn[0].x = ((lds_d *)e[0])[((j + 7) & 7) * SLOT_PAIRS];
+                    vn[1].x = ((lds_d *)e[1])[((j + 7) & 7) * SLOT_PAIRS];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (MODE != 7) __builtin_amdgcn_s_waitcnt(0xC07F | (3 << 8));
+                __builtin_amdgcn_sched_barrier(0);
+                const double F0 = S * tauinv;
+                const double base = __builtin_fma(S, acoef, erldt);
+                const double S1 = __builtin_fma(v[0].x, dt, base);
+                double f2, o;
+                if (MODE == 8) {
+                    f2 = F0;
+                    S = S1;
+                } else {
+                    const double m = __builtin_fmin(S1, 0.0);
+                    f2 = __builtin_fma(m, dtinv, F0);
+                    S = S1 - m;
+                }
+                o = v[1].x + f2;
+                if (MODE != 7) own1[(j & 7) * SLOT_PAIRS] = o;
+                else asm volatile("" ::"v"(o));
+                favg += f2;
+                v[0].x = vn[0].x;
+                v[1].x = vn[1].x;
+                continue;
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int w = 0; w < NR; ++w) (MODE == 5 ? vnn[w & 1] : vn[w]) = e[w][((j + 7) & 7) * SLOT_PAIRS];
@@ -114,5 +148,8 @@ int main() {
     RUN(3, "reassociated: the arithmetic alone (no LDS)")
     RUN(4, "bit-exact pairs (2,3): 5 ds_read_b128, two sums in stored order")
     RUN(5, "reassociated, reads two sub-steps ahead of their use")
+    RUN(6, "single sums: 2 ds_read_b64, 8 fp64 operations, ds_write_b64")
+    RUN(7, "single sums: the arithmetic alone (no LDS)")
+    RUN(8, "single sums without the clamp (a unit that cannot fire; not built)")
     return 0;
 }

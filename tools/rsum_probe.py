@@ -88,6 +88,13 @@ for flag, name in ((0, 'no streams'), (16, 'imports'), (32, 'exports'), (48, 'bo
         print('  %-10s n=%4d cycles/sub-step median %.0f max %.0f; wait data %.1f%% ring %.1f%%' % (
             name, sel.sum(), np.median(loop[sel] / nsub), (loop[sel] / nsub).max(), 100 * np.median(st[sel, 4] / total[sel]),
             100 * np.median(st[sel, 5] / total[sel])))
+pairu = (shape & 64) != 0
+if pairu.any():
+    print('  pair units of the single-sum plan: n=%d cycles/sub-step outside waits %s, of wall %s' % (
+        pairu.sum(), ' '.join('%.0f' % x for x in loop[pairu] / nsub), ' '.join('%.0f' % x for x in total[pairu] / nsub)))
+    hwp = (raw3 >> np.uint64(8)) & np.uint64(0xffffffff)
+    cu_key = ((raw3 >> np.uint64(40)) & np.uint64(15)).astype(np.int64) * 65536 + ((hwp >> np.uint64(8)) & np.uint64(0xff)).astype(np.int64)
+    print('  units on the CUs of pair units (1 each = a CU of its own):', [int((cu_key == k).sum()) for k in cu_key[pairu]])
 for reads in sorted(set(shape & 15)):
     sel = (shape & 15) == reads
     print('  LDS ops per sub-step %d: n=%4d cycles/sub-step median %.0f max %.0f' % (reads, sel.sum(), np.median(loop[sel] / nsub), (loop[sel] / nsub).max()))

@@ -522,8 +522,10 @@ class RoutePlan:
         return dict(zip(keys, list(arr)))
 
     def prepare(self, flow_dist, velocity, dt):
-        """xh_route_plan_prepare: host copies of flow distance and velocity [ncell] and dt; builds the selective plain tables
-        ahead of the first call when this box has learnt the grid's firing cells before.  Cheap no-op otherwise."""
+        """xh_route_plan_prepare: host copies of flow distance and velocity [ncell] and dt.  Makes the PREPARED plan of the
+        default (reassociated) routing form -- folded leaves, single running sums: both rest on which cells can fire -- or, for
+        the bit-exact form, the selective plain tables when this box has learnt the grid's firing cells before.  May be
+        called again: the same data is a cheap no-op, other data replaces the prepared plan."""
         L = np.ascontiguousarray(flow_dist, dtype=np.float64)
         v = np.ascontiguousarray(velocity, dtype=np.float64)
         if L.size != self.ncell or v.size != self.ncell:
@@ -534,7 +536,7 @@ class RoutePlan:
         """The reassociated plan the last call ran on (xh_route_plan_rsum_info)."""
         arr = (c_int64 * 6)()
         self.ctx._check(lib().xh_route_plan_rsum_info(self.handle, arr))
-        return dict(zip(('units', 'folded', 'fold_disabled', 'prepared_folded', 'special', 'prepared_special'), list(arr)))
+        return dict(zip(('units', 'folded', 'fold_disabled', 'prepared_folded', 'pair_cells', 'prepared_pair_cells'), list(arr)))
 
     def typed_info(self):
         """Pair / plain units of the dataflow partition (xh_route_plan_typed_info)."""

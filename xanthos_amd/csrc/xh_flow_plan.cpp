@@ -1198,7 +1198,7 @@ std::string flow_tables_check(int n, const int64_t *indptr, const int32_t *indic
 
 // ---------------------------------------------------------------------------------------------- tables <-> file
 namespace {
-constexpr unsigned long long TABLES_MAGIC = 0x3472546c66485804ull;      // format of flow_tables_save; bump on any change
+constexpr unsigned long long TABLES_MAGIC = 0x3472546c66485805ull;      // format of flow_tables_save; bump on any change
 
 template <class T>
 bool put_vec(FILE *f, const std::vector<T> &v) {
@@ -1220,13 +1220,13 @@ bool get_vec(FILE *f, std::vector<T> &v) {
 }
 template <class F>
 bool tables_io(FILE *f, FlowTables &t, bool write, F &&vec) {
-    int head[14] = {t.n_units, t.n_edges, t.depth, t.n_cells, t.max_imports, t.max_exports, t.n_plain_units, t.skew_ok ? 1 : 0,
-                    t.skew_lmax, t.skew_span, t.typed ? 1 : 0, t.rsum ? 1 : 0, t.n_folded, t.n_special};
+    int head[15] = {t.n_units, t.n_edges, t.depth, t.n_cells, t.max_imports, t.max_exports, t.n_plain_units, t.skew_ok ? 1 : 0,
+                    t.skew_lmax, t.skew_span, t.typed ? 1 : 0, t.rsum ? 1 : 0, t.n_folded, t.n_special, t.n_pair_units};
     if (write ? fwrite(head, sizeof(head), 1, f) != 1 : fread(head, sizeof(head), 1, f) != 1) return false;
     if (!write) {
         t.n_units = head[0], t.n_edges = head[1], t.depth = head[2], t.n_cells = head[3], t.max_imports = head[4];
         t.max_exports = head[5], t.n_plain_units = head[6], t.skew_ok = head[7] != 0, t.skew_lmax = head[8];
-        t.skew_span = head[9], t.typed = head[10] != 0, t.rsum = head[11] != 0, t.n_folded = head[12], t.n_special = head[13];
+        t.skew_span = head[9], t.typed = head[10] != 0, t.rsum = head[11] != 0, t.n_folded = head[12], t.n_special = head[13], t.n_pair_units = head[14];
     }
     return vec(t.cell_of_slot) && vec(t.export_edge) && vec(t.ghost_edge) && vec(t.edge_cons_unit) && vec(t.unit_terms) &&
            vec(t.ent) && vec(t.lag) && vec(t.ghost_lag) && vec(t.unit_p) && vec(t.unit_lmax) && vec(t.unit_glmax) &&

@@ -38,7 +38,10 @@ struct FlowPlanOptions {
     // carry in registers, so it needs no lane, no LDS slot and no level of lag of its own.  nullptr: nothing is folded.
     const unsigned char *foldable = nullptr;
     // Reassociated planner: with `capable` given it makes the SINGLE-SUM partition (xh_flow_rsum.cpp): lanes pass one running
-    // sum instead of a pair, and the cells that can fire AND have an upstream neighbour that can sit alone in `special` units.
+    // sum instead of a pair; the cells that may fire AND have an upstream neighbour that may -- capable cells and `halo` cells
+    // downstream of every capable cell with a capable neighbour -- sit in pair units of their own.
+    int halo = 8;
+    int pair_imports = 16;       // ... and take on at most this many imported streams per unit
 };
 
 struct FlowTables {
@@ -59,7 +62,8 @@ struct FlowTables {
     std::vector<int> ghost_prod;                                 // [units*64] producer cell of imported stream k of the unit
     std::vector<int> fold_of_slot;                               // reassociated form: [units*64] the leaf cell folded into the lane's cell, or -1 (empty: none)
     int n_folded = 0;
-    int n_special = 0;                                           // reassociated form: -1 = pair-sum plan; >= 0 = single-sum plan with that many special cells
+    int n_special = -1;                                          // reassociated form: -1 = plan of pairs; >= 0 = single-sum plan with that many cells in pair units
+    int n_pair_units = 0;                                        // single-sum plan: its pair units (the last ones of unit_order)
 };
 
 // ---- shared by the two planners (xh_flow_plan.cpp: sums in stored order; xh_flow_rsum.cpp: reassociated sums)
@@ -102,6 +106,8 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
                            std::string &err);
 std::string flow_tables_check_rsum(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
                                    const std::vector<char> &handled, const FlowTables &t);
+// bumped with every change of the reassociated planner that alters its partitions (part of the key of the per-box cache)
+int flow_rsum_planner_version();
 
 // Tables to / from a file (the per-box cache of xh_route_plan_prepare: a partition costs tens of milliseconds, reading it
 // back a few).  flow_tables_load returns false on any mismatch of format or size; callers hold what they read to

@@ -17,15 +17,23 @@
 //   * no row-shape rules in the cut or the packing: every unit has the same shape, so pieces are cut for full lanes only;
 //   * the order of a chain is free: children with the tallest (transformed) subtrees go last, which keeps lane lags low.
 //
-// SINGLE-SUM plans (FlowPlanOptions::capable given; kernel side: xh_mrtm_wave_unit.h, SGL).  The pair {sum F, sum F2} is only
-// ever needed by a cell that can fire itself AND has an upstream neighbour that can (a neighbour that cannot fire has
-// F2 = F; a cell that cannot fire has S1 >= S2 >= 0 and uses the adjusted sum only): 8 of the 67,420 cells of the synthetic
-// world.  Everywhere else the lanes pass ONE running sum, that of the adjusted flows, and every lane leaves its own deficit
-// m = min(S1, 0) of the sub-step in the other half of its entry.  A `special` cell reads both halves of its inflow entry:
-// sum F = sum F2 - m_k / dt, where k is its one upstream neighbour that can fire, made the LAST member of the chain.  The
-// partition makes that possible without charging anybody else: a special cell is a piece of its own (every neighbour cut off,
-// the capable one last in the chain of sibling pieces, the cell itself first in its own), and special pieces share units only
-// with each other.  A cell that can fire with TWO upstream neighbours that can is not handled: the plan falls back to pairs.
+// SINGLE-SUM plans (FlowPlanOptions::capable given; kernel side: xh_mrtm_wave_unit.h, SGL).  The pair {sum F, sum F2} of
+// mrtm.py:51 / :66 is only ever needed by a cell that may fire itself AND has an upstream neighbour that may: a neighbour
+// that does not fire has F2 = F, and a cell that cannot fire has S1 >= S2 >= 0 and uses the adjusted sum only.  So
+//   X  = the cells that MAY FIRE: those that can by construction (velocity dt / length >= 1: `capable`) and, below every
+//        cell of D0 = {capable with a capable upstream neighbour}, a HALO of `halo` cells: the reference's own corner
+//        S1 >= 0 > S2 (mrtm.py:54, :66-69) leaves NEGATIVE storage in a D0 cell, its outflow turns negative, and cells
+//        downstream fire that cannot by construction -- as far as the negative flows reach before the tributaries outweigh
+//        them (the halo restarts at every capable cell it meets);
+//   D  = the cells of X with an upstream neighbour in X;   P = D and the upstream neighbours in X of D's cells.
+// The cells of P sit in PAIR units (pieces of their own, units of their own: unit_p bit 4), everything else in SINGLE units
+// (bit 3 alone): their lanes pass ONE running sum, that of the adjusted flows, in 8-byte entries, and export {y, y}.  A
+// pair unit that imports from single units therefore reads F = F2 -- exact, because those producers are not in X (an
+// upstream neighbour in X of a D cell is in P) and a cell outside X does not fire as long as every flow it receives is
+// >= 0, which holds by induction from non-negative runoff and initial storage (guarded in the kernel) once the negative
+// flows of the D cells are confined: the EXIT lanes (lane_flags bit 1: cells of P whose downstream cell is not in P) are
+// guarded, outflow >= 0 in every sub-step, and a trip routes the call again on the plan of pairs.  Chains of sibling
+// pieces run single pieces first, pair pieces last (a single piece behind a pair piece would drop sum F).
 #include <algorithm>
 #include <cstdio>
 #include <numeric>
@@ -51,9 +59,9 @@ struct RPart {
     std::vector<int> e_prod, e_cons, e_kind;      // stream: producer outlet, consumer cell, 0 = opens the chain of e_cons's children
                                                   // (or is its A), 1 = R of the outlet e_cons of a sibling piece
     std::vector<int> unit_of_piece, unit_cells, unit_imp, unit_out, unit_depth;
-    std::vector<char> unit_cheap, unit_special, special;
+    std::vector<char> unit_cheap, unit_special, special, mayfire;      // special: the cell is in P; mayfire: in X (single-sum plans)
     int nunit = 0, nedge = 0, maxdepth = 0, n_cheap = 0;
-    int n_special = -1;               // -1: pair-sum plan (no `capable`, or a cell the single-sum form does not handle)
+    int n_special = -1;               // -1: plan of pairs (no `capable`); >= 0: single-sum plan with that many cells in P
 };
 
 void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P, std::vector<int> &fold_leaf) {
@@ -74,23 +82,40 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         }
         return x;
     };
-    // single-sum plan: the cells that need both sums
-    std::vector<char> &special = P.special;
+    // single-sum plan: X (may fire), D, P (header)
+    std::vector<char> &special = P.special, &mayfire = P.mayfire;
     special.assign(n, 0);
+    mayfire.assign(n, 0);
     if (opt.capable) {
         P.n_special = 0;
-        for (int v = 0; v < n && P.n_special >= 0; ++v) {
+        for (int v = 0; v < n; ++v) mayfire[v] = (t.ok[v] && opt.capable[v]) ? 1 : 0;
+        const int H = std::max(opt.halo, 0);
+        for (int v = 0; v < n; ++v) {
             if (!t.ok[v] || !opt.capable[v]) continue;
-            int nc = 0;
-            for (int k = child_ptr[v]; k < child_ptr[v + 1]; ++k) nc += opt.capable[child[k]] ? 1 : 0;
-            if (nc == 1) {
-                special[v] = 1;
-                P.n_special++;
-            } else if (nc > 1) {
-                P.n_special = -1;      // not handled: pairs for this grid
+            bool d0 = false;
+            for (int k = child_ptr[v]; k < child_ptr[v + 1] && !d0; ++k) d0 = opt.capable[child[k]] != 0;
+            if (!d0) continue;
+            int h = 0;
+            for (int x = ds[v]; x >= 0; x = ds[x]) {
+                if (opt.capable[x]) {
+                    h = 0;                         // may leave negative storage itself: the halo starts again
+                } else {
+                    if (h == H) break;
+                    ++h;
+                }
+                mayfire[x] = 1;
             }
         }
-        if (P.n_special < 0) special.assign(n, 0);
+        for (int v = 0; v < n; ++v) {
+            if (!mayfire[v]) continue;
+            bool d = false;
+            for (int k = child_ptr[v]; k < child_ptr[v + 1]; ++k) d = d || mayfire[child[k]];
+            if (!d) continue;
+            special[v] = 1;
+            for (int k = child_ptr[v]; k < child_ptr[v + 1]; ++k)
+                if (mayfire[child[k]]) special[child[k]] = 1;
+        }
+        for (int v = 0; v < n; ++v) P.n_special += special[v];
     }
     std::vector<int> open_cnt(n, 0), open_imp(n, 0), open_th(n, 0);
     std::vector<int> kids, kept, ths;
@@ -115,7 +140,7 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         // imports of a piece: those of the children kept + one for all the children cut off; two are held back (that one, and
         // the sibling stream this piece takes on if it is cut off itself as a later member of a chain of pieces)
         for (int c : kids)
-            if (!special[v] && !special[c] && total + open_cnt[c] <= cap && imp + open_imp[c] <= G_MAX - 2) {
+            if (special[v] == special[c] && total + open_cnt[c] <= cap && imp + open_imp[c] <= G_MAX - 2) {
                 kept.push_back(c);
                 total += open_cnt[c];
                 imp += open_imp[c];
@@ -163,13 +188,8 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         grp.clear();
         while (p < npiece && ds[roots[p]] == v) grp.push_back(p++);
         // the chain of sibling pieces: shallowest first (each member sits one pipeline level below the one before it)
-        // (single-sum plans: under a special cell the neighbour that can fire goes last -- its entry carries the deficit the
-        // cell needs --; a special cell goes first in its own chain and needs no chain read then)
-        const bool v_special = special[v] != 0;
-        auto rank = [&](int x) {
-            if (v_special && opt.capable[roots[x]]) return 2;
-            return special[roots[x]] ? 0 : 1;
-        };
+        // (single-sum plans: single pieces first, pair pieces last -- a single piece behind a pair piece would drop sum F)
+        auto rank = [&](int x) { return special[roots[x]] ? 1 : 0; };
         std::stable_sort(grp.begin(), grp.end(), [&](int x, int y) {
             if (rank(x) != rank(y)) return rank(x) < rank(y);
             return P.pdepth[x] != P.pdepth[y] ? P.pdepth[x] < P.pdepth[y] : P.psize[x] > P.psize[y];
@@ -198,7 +218,7 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         auto free_piece = [&](int p) { return P.pimp[p] == 0 && ds[roots[p]] < 0; };
         for (int c : queue) {
             const int q = P.piece[c];
-            if (q < 0 || !free_piece(q)) continue;
+            if (q < 0 || !free_piece(q) || special[c]) continue;      // (pair pieces carry no folded leaves)
             for (int k = child_ptr[c]; k < child_ptr[c + 1]; ++k) {
                 const int l = child[k];
                 if (opt.foldable[l] && t.nchild[l] == 0 && P.piece[l] == q) {
@@ -232,6 +252,8 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
     });
     std::vector<int> by_cost(fre);
     std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) { return P.psize[x] < P.psize[y]; });
+    // (pair units pace a single-sum launch; with at most `pair_imports` streams they run the one-round variant of the kernel)
+    const int pair_imp = std::min(std::max(opt.pair_imports, 1), G_MAX);
     int cheap = 0;
     for (int round = 0; round < 4; ++round) {
         P.unit_of_piece.assign(npiece, -1);
@@ -265,10 +287,10 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
                     first_open = P.unit_cells.size();
                 }
                 int u = -1;
-                const char sp = special[roots[p]];      // special pieces (one cell each) only share units with each other
+                const char sp = special[roots[p]];      // pair pieces (single-sum plans) only share units with each other
                 for (size_t b = first_open; b < P.unit_cells.size(); ++b)
-                    if (P.unit_special[b] == sp && P.unit_cells[b] + P.psize[p] <= LANES && P.unit_imp[b] + P.pimp[p] <= (sp ? 8 : G_MAX) &&
-                        P.unit_out[b] + (has_out(p) ? 1 : 0) <= (sp ? 8 : G_MAX)) {
+                    if (P.unit_special[b] == sp && P.unit_cells[b] + P.psize[p] <= LANES && P.unit_imp[b] + P.pimp[p] <= (sp ? pair_imp : G_MAX) &&
+                        P.unit_out[b] + (has_out(p) ? 1 : 0) <= G_MAX) {
                         u = (int)b;
                         break;
                     }
@@ -284,6 +306,7 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         {
             int made = 0, u = -1;
             for (int p : by_cost) {
+                if (special[roots[p]]) continue;
                 if (u < 0 || P.unit_cells[u] + P.psize[p] > LANES) {
                     if (made == cheap) break;
                     u = new_unit(0, true);
@@ -305,6 +328,16 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
             for (int p : by_size) {
                 const int sz = P.psize[p];
                 int u = -1;
+                if (special[roots[p]]) {      // a whole small network in pair form: any pair unit with room, or one of its own
+                    for (int b = 0; b < (int)P.unit_cells.size() && u < 0; ++b)
+                        if (P.unit_special[b] && P.unit_cells[b] + sz <= LANES) u = b;
+                    if (u < 0) {
+                        u = new_unit(0, false);
+                        P.unit_special[u] = 1;
+                    }
+                    put_piece(p, u);
+                    continue;
+                }
                 for (int f = sz; f <= LANES && u < 0; ++f)
                     for (size_t i = bucket[f].size(); i-- > 0;) {
                         const int b = bucket[f][i];
@@ -327,6 +360,8 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
 }
 
 }  // namespace
+
+int flow_rsum_planner_version() { return 6; }
 
 int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign, const int *comp,
                            int ncomp, const FlowPlanOptions &opt, std::vector<char> &handled, FlowTables &out,
@@ -497,8 +532,12 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
         if (fold_leaf[c] >= 0) out.unit_p[u] |= 4;                  // the unit carries folded leaves: the FOLD variant of the kernel
     }
     out.n_special = P.n_special;
-    if (P.n_special >= 0)                                           // single-sum plan: 8 = one running sum, 16 = special unit
-        for (int u = 0; u < nunit; ++u) out.unit_p[u] |= P.unit_special[u] ? 24 : 8;
+    out.n_pair_units = 0;
+    if (P.n_special >= 0)                                           // single-sum plan: bit 3; bit 4: a pair unit (the cells of P)
+        for (int u = 0; u < nunit; ++u) {
+            out.unit_p[u] |= P.unit_special[u] ? 24 : 8;
+            out.n_pair_units += P.unit_special[u] ? 1 : 0;
+        }
     for (int ed = 0; ed < nedge; ++ed) {
         const int u = out.edge_cons_unit[ed];
         const int gl = out.unit_lmax[u] - 2 * (edge_reader_h[ed] + 1);
@@ -506,9 +545,12 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
         out.unit_glmax[u] = std::max(out.unit_glmax[u], gl);
     }
     out.lane_flags.assign(ts, 0);
-    if (P.n_special >= 0)
-        for (int64_t sl = 0; sl < ts; ++sl)
-            if (out.cell_of_slot[sl] >= 0 && opt.capable[out.cell_of_slot[sl]]) out.lane_flags[sl] = 1;
+    if (P.n_special >= 0)      // bit 0: the cell may fire (X); bit 1: an exit lane (a cell of P whose downstream cell is not in P)
+        for (int64_t sl = 0; sl < ts; ++sl) {
+            const int c = out.cell_of_slot[sl];
+            if (c < 0) continue;
+            out.lane_flags[sl] = (unsigned char)((P.mayfire[c] ? 1 : 0) | ((P.special[c] && ds[c] >= 0 && !P.special[ds[c]]) ? 2 : 0));
+        }
     out.unit_plain.assign(nunit, 0);
 
     std::vector<int> unit_exp(nunit, 0);
@@ -521,7 +563,10 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
         auto coupled = [&](int u) { return P.unit_imp[u] > 0 || unit_exp[u] > 0; };
         out.unit_order.resize(nunit);
         std::iota(out.unit_order.begin(), out.unit_order.end(), 0);
+        // (single-sum plans: the pair units close the list -- the kernel gives the first of them a CU of their own)
+        auto pairu = [&](int u) { return P.n_special >= 0 && P.unit_special[u]; };
         std::stable_sort(out.unit_order.begin(), out.unit_order.end(), [&](int x, int y) {
+            if (pairu(x) != pairu(y)) return !pairu(x);
             if (coupled(x) != coupled(y)) return !coupled(x);
             if (cost[x] != cost[y]) return cost[x] < cost[y];
             return P.unit_cells[x] < P.unit_cells[y];
@@ -573,7 +618,20 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
         {
             int nsu = 0;
             for (int u = 0; u < nunit; ++u) nsu += (out.unit_p[u] & 16) ? 1 : 0;
-            fprintf(stderr, "  single-sum plan: %s, %d special cells in %d units\n", P.n_special >= 0 ? "yes" : "no", std::max(P.n_special, 0), nsu);
+            int nx = 0;
+            for (int c = 0; c < n; ++c) nx += (P.n_special >= 0 && P.mayfire[c]) ? 1 : 0;
+            int quiet = 0;      // single units without a cell that may fire
+            for (int u = 0; u < nunit && P.n_special >= 0; ++u) {
+                bool any = (out.unit_p[u] & 16) != 0;
+                for (int k = 0; k < LANES && !any; ++k) any = (out.lane_flags[(int64_t)u * LANES + k] & 1) != 0;
+                quiet += any ? 0 : 1;
+            }
+            for (int u = 0; u < nunit && P.n_special >= 0; ++u)
+                if (out.unit_p[u] & 16)
+                    fprintf(stderr, "  pair unit %d: %d cells, %d imports, %d outlets, depth %d, lmax %d\n", u, P.unit_cells[u], P.unit_imp[u], unit_exp[u],
+                            P.unit_depth[u], out.unit_lmax[u]);
+            fprintf(stderr, "  single-sum plan: %s, %d cells may fire, %d of them in pair form in %d units; %d single units hold no cell that may fire\n",
+                    P.n_special >= 0 ? "yes" : "no", nx, std::max(P.n_special, 0), nsu, quiet);
         }
         fprintf(stderr, "  units by reads (none, A, R, A+R): %d %d %d %d\n  units by lmax/16 (0..13+):", hs[0], hs[1], hs[2], hs[3]);
         for (int k = 0; k < 14; ++k) fprintf(stderr, " %d", hl[k]);
@@ -716,16 +774,29 @@ std::string flow_tables_check_rsum(int n, const int64_t *indptr, const int32_t *
         terms.clear();
         if (!expand(u, a, terms, 0, expand)) return "bad chain at cell " + std::to_string(c);
         if (t.n_special >= 0) {
-            // single-sum plan (lane_flags bit 0: the cell can fire): a cell that can fire with an upstream neighbour that can
-            // reads that neighbour's entry -- the LAST member of the chain, whose first half is its deficit -- in a special unit
+            // single-sum plan (lane_flags bit 0: the cell may fire): a cell that may fire with an upstream neighbour that may
+            // sits in a pair unit, and so do those neighbours; along its chain no value of a single unit follows one of a pair unit
             if ((int64_t)t.lane_flags.size() != ts) return "lane flags";
-            int ncap = 0;
-            for (int x : terms) ncap += (t.lane_flags[slot_of[x]] & 1) ? 1 : 0;
-            if ((t.lane_flags[s] & 1) && ncap > 0) {
-                if (ncap != 1) return "cell " + std::to_string(c) + " can fire and has two upstream neighbours that can";
-                if (!(t.unit_p[u] & 16)) return "special cell " + std::to_string(c) + " in an ordinary unit";
-                if (!(t.lane_flags[slot_of[terms.back()]] & 1)) return "the neighbour of cell " + std::to_string(c) + " that can fire is not the last member of its chain";
+            const bool pair_u = (t.unit_p[u] & 16) != 0;
+            if (pair_u && !(t.lane_flags[s] & 1)) return "cell " + std::to_string(c) + " of a pair unit is not one that may fire";
+            if (pair_u && !t.fold_of_slot.empty() && t.fold_of_slot[s] >= 0) return "folded leaf in a pair unit";
+            int nx = 0;
+            bool seen_pair = false, order_ok = true;
+            for (int x : terms) {
+                const bool xp = (t.unit_p[slot_of[x] / LANES] & 16) != 0;
+                if ((t.lane_flags[slot_of[x]] & 1)) {
+                    ++nx;
+                    if ((t.lane_flags[s] & 1) && !xp) return "neighbour " + std::to_string(x) + " of cell " + std::to_string(c) + " may fire and is not in a pair unit";
+                }
+                if (seen_pair && !xp) order_ok = false;
+                seen_pair = seen_pair || xp;
             }
+            if ((t.lane_flags[s] & 1) && nx > 0) {
+                if (!pair_u) return "cell " + std::to_string(c) + " may fire, has a neighbour that may, and sits in a single unit";
+                if (!order_ok) return "chain of cell " + std::to_string(c) + ": a single unit's value behind a pair unit's";
+            }
+            const bool exit_want = pair_u && t.ds[c] >= 0 && slot_of[t.ds[c]] >= 0 && !(t.unit_p[slot_of[t.ds[c]] / LANES] & 16);
+            if (((t.lane_flags[s] & 2) != 0) != exit_want) return "exit flag of cell " + std::to_string(c);
         }
         if (!t.fold_of_slot.empty() && t.fold_of_slot[s] >= 0) terms.push_back(t.fold_of_slot[s]);      // the leaf the lane carries itself
         want.clear();

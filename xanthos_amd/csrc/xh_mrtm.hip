@@ -357,7 +357,8 @@ struct xh_route_plan {
     FlowPlan *flow_rsum_fold = nullptr;
     double fold_dt = 0.0;
     bool fold_disabled = false;
-    bool fold_tried = false;      // prepare() has asked the planner once (it may have had nothing to fold)
+    bool fold_tried = false;      // prepare() has asked the planner (it may have had nothing to fold)
+    uint64_t prep_key = 0;        // ... for these sets of cells that can fire / leaves that cannot, and this dt
     bool first_checked_fold = false;
     FlowPlan *last_rsum_plan = nullptr;          // the plan the last reassociated call ran on
     bool rsum_failed = false;                    // the planner turned the grid down once: not tried again
@@ -533,6 +534,8 @@ static bool rsum_tables_get(xh_ctx *ctx, xh_route_plan *plan, const unsigned cha
     FlowPlanOptions opt = flow_plan_options(ctx);
     opt.foldable = foldable;
     opt.capable = capable;
+    if (const char *e = getenv("XH_RSUM_HALO")) opt.halo = std::max(atoi(e), 0);      // cells in pair form below a cell that may leave negative storage
+    if (const char *e = getenv("XH_RSUM_PAIR_IMPORTS")) opt.pair_imports = atoi(e);    // experiment: imported streams per pair unit
     std::string cache;
     static const bool cache_on = !(getenv("XH_ROUTE_LEARN_CACHE") && getenv("XH_ROUTE_LEARN_CACHE")[0] == '0');
     if (cache_on && !opt.debug) {
@@ -541,7 +544,8 @@ static bool rsum_tables_get(xh_ctx *ctx, xh_route_plan *plan, const unsigned cha
         else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/xanthos_amd";
         if (!dir.empty()) {
             uint64_t h = plan->topo_hash;
-            const int knobs[2] = {opt.simds, opt.piece_cap};
+            // (the planner's own version: a planner-only rebuild must not find the partitions of the one before it)
+            const int knobs[5] = {opt.simds, opt.piece_cap, opt.halo, opt.pair_imports, flow_rsum_planner_version()};
             for (size_t i = 0; i < sizeof(knobs); ++i) h = (h ^ reinterpret_cast<const unsigned char *>(knobs)[i]) * 1099511628211ull;
             for (const char *b = __DATE__ " " __TIME__; *b; ++b) h = (h ^ (unsigned char)*b) * 1099511628211ull;
             for (const unsigned char *set : {foldable, capable}) {
@@ -1123,21 +1127,43 @@ extern "C" int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const dou
     if (reassoc_wanted(0)) {
         // ... but the PREPARED reassociated plan (xanthos_hip.h, xh_route_plan_rsum_info: folded leaves, single sums) needs
         // exactly what this call brings: which cells can fire.  XH_FLOW_FOLD=0 / XH_RSUM_SINGLE=0: without the one / the other.
+        // A plan may be prepared again: other velocities, lengths or dt that change WHICH cells can fire replace the prepared
+        // plan (and lift a guard trip's ban, which was about the old one); the same sets are a cheap no-op.
         static const bool fold_on = !(getenv("XH_FLOW_FOLD") && getenv("XH_FLOW_FOLD")[0] == '0');
         static const bool single_on = !(getenv("XH_RSUM_SINGLE") && getenv("XH_RSUM_SINGLE")[0] == '0');
-        if ((!fold_on && !single_on) || plan->flow_rsum_fold || plan->fold_disabled || plan->fold_tried || !plan->flow || plan->h_indptr.empty())
-            return XH_OK;
-        plan->fold_tried = true;
+        if ((!fold_on && !single_on) || !plan->flow || plan->h_indptr.empty()) return XH_OK;
         const size_t n = (size_t)plan->ncell;
         std::vector<unsigned char> foldable(n, 0), capable(n, 0);
         size_t nfold = 0;
+        uint64_t key = 1469598103934665603ull;
         for (size_t c = 0; c < n; ++c) {
             const double tauinv = h_velocity[c] / h_flow_dist[c];
             const bool leaf = plan->h_indptr[c + 1] - plan->h_indptr[c] == 1;
             capable[c] = (tauinv * dt <= CAPABLE_THRESHOLD) ? 0 : 1;                                    // (NaN: can fire)
             foldable[c] = (leaf && tauinv >= 0.0 && tauinv * dt <= CAPABLE_THRESHOLD) ? 1 : 0;          // (NaN: not foldable)
             nfold += foldable[c];
+            key = (key ^ (unsigned)(capable[c] | (foldable[c] << 1))) * 1099511628211ull;
         }
+        {
+            unsigned char b[sizeof(double)];
+            memcpy(b, &dt, sizeof(dt));
+            for (unsigned char x : b) key = (key ^ x) * 1099511628211ull;
+            if (key == 0) key = 1;
+        }
+        if (plan->fold_tried && key == plan->prep_key) return XH_OK;
+        if (plan->flow_rsum_fold) {      // prepared for other data: the old plan may still be routing
+            XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (plan->last_rsum_plan == plan->flow_rsum_fold) {
+                plan->last_rsum_plan = nullptr;
+                plan->last_rsum = false;
+            }
+            flow_plan_destroy(plan->flow_rsum_fold);
+            plan->flow_rsum_fold = nullptr;
+            plan->first_checked_fold = false;
+        }
+        plan->fold_tried = true;
+        plan->prep_key = key;
+        plan->fold_disabled = false;
         const bool fold = fold_on && nfold > 0;
         if (!fold && !single_on) return XH_OK;
         std::vector<char> handled;
@@ -1278,7 +1304,7 @@ int xh_route_series_fed(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32
 
 // Marker of a passed first-call check: <dir>/route_ok_<device>_<build>_<topology>; dir = $XH_CACHE_DIR or
 // $HOME/.cache/xanthos_amd.  Failing to read or write it only means the check runs again.
-// (form: 0 the bit-exact kernels, 1 the reassociated form, 2 the reassociated form with folded leaves)
+// (form: 0 the bit-exact kernels, 1 the reassociated form, 2 the prepared reassociated plan: folded leaves "_rf", single sums "_rs")
 static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan, int form) {
     std::string dir;
     if (const char *d = getenv("XH_CACHE_DIR")) dir = d;
@@ -1302,7 +1328,8 @@ static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan
     }
     char name[160];
     snprintf(name, sizeof(name), "/route_ok_%016llx_%016llx_%lld_%lld%s", (unsigned long long)h, (unsigned long long)plan->topo_hash,
-             (long long)plan->ncell, (long long)(plan->flow ? plan->flow->n_units : 0), form == 2 ? "_rf" : form == 1 ? "_r" : "");
+             (long long)plan->ncell, (long long)(plan->flow ? plan->flow->n_units : 0),
+             form == 2 ? ((plan->flow_rsum_fold && plan->flow_rsum_fold->n_special >= 0) ? "_rs" : "_rf") : form == 1 ? "_r" : "");
     return dir + name;
 }
 
@@ -1711,11 +1738,17 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
             if (old_skew && (rc = sched_upload()) != XH_OK) return rc;
             rc = old_skew ? skew_launch(ctx, plan->flow, fs, fio, ctx->stream) : wave_launch(ctx, tree_plan, fs, fio, ctx->stream);
         }
-        if (rc == XH_ERR_LIMIT && tree_plan != plan->flow && !old_skew) rc = wave_launch(ctx, plan->flow, fs, fio, ctx->stream);
-        plan->last_rsum = rc == XH_OK && use_rsum && tree_plan == rsum_plan && !old_skew;
+        // (which plan actually ran: a month shorter than the plan's lane lags, the 32-bit row limit or residency send the call
+        // from the reassociated / typed plan back to the bit-exact one -- everything below speaks of THAT plan then)
+        FlowPlan *ran = tree_plan;
+        if (rc == XH_ERR_LIMIT && tree_plan != plan->flow && !old_skew) {
+            ran = plan->flow;
+            rc = wave_launch(ctx, plan->flow, fs, fio, ctx->stream);
+        }
+        plan->last_rsum = rc == XH_OK && use_rsum && ran == rsum_plan && ran->rsum && !old_skew;
         if (plan->last_rsum) plan->last_rsum_plan = rsum_plan;
         if (plan->last_rsum) plan->last_tree_kernel = 4;
-        plan->last_typed = rc == XH_OK && tree_plan != plan->flow && !old_skew && !plan->last_rsum;
+        plan->last_typed = rc == XH_OK && ran != plan->flow && !old_skew && !plan->last_rsum;
         if (feed && rc == XH_ERR_LIMIT) {      // nothing was launched: the caller completes the runoff and calls again
             xh_span_cancel(sp);
             return XH_ERR_LIMIT;

@@ -33,7 +33,8 @@ struct FlowPlan {
     uint64_t rec_key = 0;                // hash of the schedule / runoff layout the records on the device were made for (0: none)
     FlowBuf d_fold_cell;                 // reassociated form with folded leaves: [units*64] the leaf a lane carries, or -1 (NULL: none)
     int n_folded = 0;
-    int n_special = -1;      // reassociated form: -1 = pairs of sums, >= 0 = single-sum plan with that many special cells
+    int n_special = -1;      // reassociated form: -1 = pairs of sums, >= 0 = single-sum plan with that many cells in pair units
+    int n_pair_units = 0;    // single-sum plan: its pair units (the tail of the claim list; the kernel gives them CUs of their own)
     FlowBuf d_lane_flags, d_ghost_prod;  // typed partition: cells that can fire by construction; producer cell of every imported stream
 };
 

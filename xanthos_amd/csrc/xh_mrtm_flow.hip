@@ -464,6 +464,7 @@ int flow_plan_upload(xh_ctx *ctx, const FlowTables &t, FlowPlan **out) {
     if (!t.fold_of_slot.empty()) rc |= put(ctx, fp->d_fold_cell, t.fold_of_slot);
     fp->n_folded = t.n_folded;
     fp->n_special = t.n_special;
+    fp->n_pair_units = t.n_pair_units;
     if (rc) {
         flow_plan_destroy(fp);
         return XH_ERR_HIP;

@@ -1,17 +1,23 @@
-// MRTM routing, reassociated ("tolerance") form of the time-skewed dataflow kernel (gfx950) -- round 5.
+// MRTM routing, reassociated ("tolerance") form of the time-skewed dataflow kernel (gfx950) -- the DEFAULT routing kernel
+// since round 5 (XH_REASSOC_DEFAULT in xh_mrtm.hip; XH_ROUTE_EXACT / XH_ROUTE_REASSOC=0 / ini `routing_form = exact` select
+// the bit-exact k_mrtm_wave instead, which is also the checker behind XH_ROUTE_VALIDATE).
 //
 // Same machine as k_mrtm_wave (xh_mrtm_wave.hip; the unit's whole run is wave_unit<> of xh_mrtm_wave_unit.h): single-wave units
 // of 64 cells, every unit resident at once, lanes time-skewed by their level, one-way streams in HBM between units, month
 // records, fed runs.  What it gives up is the ORDER of the row sum of mrtm.py:50-51, and with it the bits: every upstream
-// neighbour of a cell passes a running sum {sum F, sum F2} along a chain of lanes (and of pieces: xh_flow_rsum.cpp), so a
-// lane reads two pairs per sub-step whatever its row looks like -- the bit-exact kernel's slowest units read six -- and the
-// explicit Euler update with the "excess flow" rule (mrtm.py:54-69) is fused to eight fp64 operations.  No plain form, no
-// learning, no guard: the first call of a plan is as fast as the twentieth.  Results equal the reference's to rounding
-// (<= 1e-9 relative against the oracle over the full grid and series; the north star's gate is 1e-6) with identical NaN
-// masks; the bit-exact kernel stays the checker (XH_ROUTE_VALIDATE) and the default unless XH_ROUTE_REASSOC is set.
+// neighbour of a cell passes a running sum along a chain of lanes (and of pieces: xh_flow_rsum.cpp), so a lane reads two
+// values per sub-step whatever its row looks like, and the explicit Euler update with the "excess flow" rule
+// (mrtm.py:54-69) is fused.  Results equal the reference's to rounding (<= 1e-9 relative against the oracle over the full
+// grid and series; the north star's gate is 1e-6) with identical NaN masks -- ChStorage and Avg_ChFlow are NOT bit-identical
+// to the reference in this form.
 //
-// Five specialisations instead of 48: units without streams whose cells have no upstream neighbour at all (single-cell
-// networks: nothing to read), without a chain read, with both; units with streams in one or two import rounds.
+// Two kinds of plan (xh_flow_rsum.cpp):
+//   pairs        every lane passes {sum F, sum F2} (16-byte entries, 13 fp64 operations per sub-step); needs nothing but the
+//                topology -- what an unprepared plan routes on, and where a guard trip falls back to;
+//   single sums  (prepared plans: xh_route_plan_prepare knows which cells can fire) every lane passes the ONE sum of the
+//                adjusted flows (8-byte entries, 8 operations), except the few cells that may fire AND have an upstream
+//                neighbour that may: those sit in pair units of their own, which get a CU to themselves (wave_claim).
+// Folded leaves (prepared plans, units without streams) ride in their parents' lanes in either kind.
 #include <algorithm>
 #include "xh_mrtm_wave_unit.h"
 
@@ -31,7 +37,7 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
         if (prio == 3) __builtin_amdgcn_s_setprio(3);
         else if (prio == 1) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(2);
-    } else if (prio == 3 && !(A(balance) & 2)) {
+    } else if (prio == 3) {
         __builtin_amdgcn_s_setprio(3);
     }
     const int p = A(unit_p)[unit];       // 0x400 | 1 (reads the inflow entry) | 2 (reads the chain entry)
@@ -48,16 +54,13 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
         return;
     }
     bool bad = false;
-    if ((p & 8) && (A(balance) & 4) && (unit % 100) == 7 && !(p & 20)) {      // EXPERIMENT (timing only): one unit in a hundred in the pair form
-        if (g2) wave_unit<false, 1, 0, 2, true, true>(ap, l, xtab, qst, fnd, unit);
-        else if (g) wave_unit<false, 1, 0, 1, true, true>(ap, l, xtab, qst, fnd, unit);
-        else wave_unit<false, 1, 0, 0, true, true>(ap, l, xtab, qst, fnd, unit);
-    } else if (p & 8) {      // single-sum plan (xh_flow_rsum.cpp): one running sum per entry; 16: a unit of special cells
-        if (p & 16) {
-            if ((p & 4) || g2 || !g) bad = true;
-            else if (p & 2) wave_unit<false, 1, 0, 1, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
-            else wave_unit<false, 1, 0, 1, false, true, false, 2>(ap, l, xtab, qst, fnd, unit);
-        } else if (p & 4) {      // (a unit that carries folded leaves has no streams)
+    if (p & 16) {             // pair unit of a single-sum plan: the step of the plan of pairs + the exit guard
+        if (!(p & 8) || (p & 4)) bad = true;
+        else if (g2) wave_unit<false, 1, 0, 2, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
+        else if (g) wave_unit<false, 1, 0, 1, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
+        else wave_unit<false, 1, 0, 0, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
+    } else if (p & 8) {      // single unit: one running sum, 8-byte entries
+        if (p & 4) {          // (a unit that carries folded leaves has no streams: xh_flow_rsum.cpp)
             if (g || x || !A(fold_cell)) bad = true;
             else wave_unit<false, 1, 0, 0, true, true, true, 1>(ap, l, xtab, qst, fnd, unit);
         } else if (g2) wave_unit<false, 1, 0, 2, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);

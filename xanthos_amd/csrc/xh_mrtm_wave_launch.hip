@@ -191,9 +191,8 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.months_ready = feed ? feed->months_ready : nullptr;
     a.place_epoch = feed ? feed->place_epoch : nullptr;
     a.epoch = feed ? feed->epoch : 0u;
-    a.balance = (getenv("XH_WAVE_BALANCE") && getenv("XH_WAVE_BALANCE")[0] == '1') ? 1 : 0;      // experiment, see xh_flow_plan.cpp
-    if (fp->rsum && getenv("XH_WAVE_PRIO") && getenv("XH_WAVE_PRIO")[0] == '0') a.balance = 2;
-    if (fp->rsum && getenv("XH_EXP_HEAVY") && getenv("XH_EXP_HEAVY")[0] == '1') a.balance |= 4;      // EXPERIMENT
+    // single-sum plans: their pair units (the tail of the claim list) get a CU to themselves (wave_claim); XH_RSUM_EXCL=0: A/B
+    a.n_excl = (fp->rsum && fp->n_special >= 0 && !(getenv("XH_RSUM_EXCL") && getenv("XH_RSUM_EXCL")[0] == '0')) ? fp->n_pair_units : 0;
     a.fenced = (getenv("XH_ROUTE_FENCED") && getenv("XH_ROUTE_FENCED")[0] == '1') ? 1 : 0;
     if (getenv("XH_ROUTE_FENCED") && getenv("XH_ROUTE_FENCED")[0] == 'l') a.fenced = 4;      // "lag": round 4's publication (vmcnt(8) + PUBLAG), for comparison
     if (!a.fenced && getenv("XH_FEED_POLL") && getenv("XH_FEED_POLL")[0] == 'l') a.fenced = 2;      // experiments (wait_months)

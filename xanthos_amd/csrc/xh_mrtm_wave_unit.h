@@ -39,7 +39,7 @@ constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2, FAULT_PLACE_WAIT = 
 constexpr unsigned FAULT_TEST = 99;
 constexpr int PLACE_KEYS = 16 * 8 * 2 * 16 * 4;      // (xcc, se, sh, cu, simd) of HW_ID / XCC_ID
 
-constexpr int PLACE_WORDS = 16 + PLACE_KEYS;
+constexpr int PLACE_WORDS = 16 + PLACE_KEYS + PLACE_KEYS / 4;      // counters, one word per SIMD, one per CU
 
 struct MonthRec {                             // one iteration of the schedule (spin-up months, then every month)
     int m, nt, g, write;                      // month index, sub-steps, first global sub-step, 1 = simulation pass
@@ -87,8 +87,7 @@ struct WaveArgs {
     const unsigned *months_ready;
     unsigned *place_epoch;
     unsigned epoch;
-    int balance;                      // bit 0: XH_WAVE_BALANCE=1: claim units by LDS-load quarter and SIMD id (placement); default: arrival order
-                                      // bit 1 (k_mrtm_rsum only): XH_WAVE_PRIO=0 (experiment): SIMD partners at equal issue priority
+    int n_excl;                       // k_mrtm_rsum, single-sum plans: the last n_excl units of unit_order (pair units) get a CU to themselves
     int fenced;                       // XH_ROUTE_FENCED=1: agent-scope release / acquire fences around the stream counters (see check())
     char *xbuf;                       // [edges][RS] {F, F2}
     unsigned xbytes;                  // size of the rings
@@ -194,12 +193,26 @@ template <> struct Val<true> {
 // passes that volume on at once (mrtm.py:60, a flow of -1e-15 m3/s), the recurrence over 1 / (tau^-1 dt) sub-steps; both
 // conserve it, and the difference is nine orders below this form's bar (1e-9 m3/s, 1e-3 m3: xh_mrtm.hip k_count_far).
 // FOLD_EPS = 1e-6 m3 keeps the guard from tripping on that while bounding what it lets through to 1e-10 m3/s.
+//
+// SGL (with RSUM; single-sum plans of xh_flow_rsum.cpp, whose header has the argument).  1: a SINGLE unit -- none of its cells
+// may fire AND have an upstream neighbour that may, so the two sums of mrtm.py:51 and :66 are the same number whenever they
+// matter, and the lanes pass ONE running sum, that of the adjusted flows F2, in 8-byte entries (the layout of the plain units:
+// half the LDS traffic); the step is
+//     S1 = base + (sum F2) dt,   m = min(S1, 0),   F2 = F + m / dt,   S = S1 - m
+// (S = 0 exactly where the cell fires, S1 where it does not, NaN where S1 is NaN: min returns the 0).  Outlets export {y, y},
+// imports take the second half of a pair.  2: a PAIR unit of such a plan -- the few cells that do need both sums: the step
+// of SGL = 0, plus the guard of its exit lanes.  Guards (a trip makes the host route the call again on the plan of pairs):
+// the plan was made for the cells that can fire at THIS velocity, length and dt (a cell that can but is not marked trips
+// it), initial storages and -- month by month -- lateral inflows are >= 0 up to a rounding error of the runoff model, and
+// the outflow of every exit lane (lane_flags bit 1: a cell in pair form whose downstream cell is not) stays >= -SGL_XEPS:
+// then every flow a single unit receives is >= 0, and its cells outside the marked set cannot fire.
 template <bool PLAIN, int PRE, int POST, int NG, bool CHAIN, bool RSUM = false, bool FOLD = false, int SGL = 0>
 __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint2 *xtab,
                                           __attribute__((address_space(3))) unsigned *qstage,
                                           __attribute__((address_space(3))) double *fend, const int unit) {
     constexpr bool HAS_G = NG > 0;
-    typedef Val<PLAIN> V;
+    constexpr bool V8 = PLAIN || SGL == 1;             // 8-byte entries: one value per lane instead of a pair
+    typedef Val<V8> V;
     typedef typename V::T val_t;
     typedef typename V::lds_c lds_cv;
     typedef typename V::lds_m lds_mv;
@@ -221,11 +234,10 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     const double area = valid ? A(area)[gc] : 0.0;
     const double S0v = (valid && A(S0)) ? A(S0)[gc] : 0.0;
     // table offsets are entry x 16 (the pair layout); a plain unit's entries are 8 bytes
-    auto ent_off = [](unsigned o) { return PLAIN ? o >> 1 : o; };
+    auto ent_off = [](unsigned o) { return V8 ? o >> 1 : o; };
     static_assert(!RSUM || (!PLAIN && PRE <= 1 && POST == 0), "reassociated form: one inflow entry, pair values");
     static_assert(!FOLD || (RSUM && NG == 0), "folded leaves: reassociated form, units without imports");
-    static_assert(SGL == 0 || RSUM, "single-sum units: reassociated form");
-    static_assert(SGL != 2 || PRE == 1, "special units read their inflow entry");
+    static_assert(SGL == 0 || RSUM, "single-sum plans: reassociated form");
     // the folded leaf of this lane
     const int gcL = FOLD ? A(fold_cell)[slot] : -1;
     const bool validL = FOLD && valid && gcL >= 0;
@@ -239,12 +251,17 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     // or NaN ratio, a negative initial storage -- and, month by month in finalize(), a storage below -FOLD_EPS
     constexpr double FOLD_EPS = 1e-6;
     unsigned gfold = (validL && !(tauL * A(dt) <= 1.0 - 1.0 / 1048576.0 && tauL >= 0.0 && S0L >= 0.0)) ? 1u : 0u;
-    // guard of the single-sum form (SGL; the argument is at the sub-step): its plan was made for the cells that can fire at
-    // THIS velocity, length and dt -- a cell that can but is not marked, a negative initial storage or (month by month,
-    // below) runoff negative beyond a rounding error of the runoff model make the unit give up like the folded leaves' guard
-    constexpr double SGL_EPS = 1e-6;      // m3 per sub-step
+    // guards of a single-sum plan (SGL; the argument is in front of the template)
+    constexpr double SGL_EPS = 1e-6;       // m3 per sub-step: lateral inflow below this trips the guard (the runoff model leaves -1e-17 mm on dry cells)
+    constexpr double SGL_XEPS = 1e-10;     // m3/s: outflow of an exit lane
     unsigned gsgl = 0;
-    if (SGL != 0) gsgl = (valid && ((!(tauinv * A(dt) <= 1.0 - 1.0 / 1048576.0) && !(A(lane_flags)[slot] & 1u)) || S0v < 0.0)) ? 1u : 0u;
+    bool xlane = false;
+    double fmin_seen = 0.0;                // SGL = 2: smallest outflow of this lane so far
+    if (SGL != 0) {
+        const unsigned lf = A(lane_flags)[slot];
+        xlane = valid && (lf & 2u) != 0;
+        gsgl = (valid && (!(tauinv >= 0.0) || (!(tauinv * A(dt) <= 1.0 - 1.0 / 1048576.0) && !(lf & 1u)) || S0v < 0.0)) ? 1u : 0u;
+    }
     constexpr int PRE_N = PRE > 0 ? PRE : 1, POST_N = POST > 0 ? POST : 1;      // (array extents: a side may be empty)
     lds_cchar *epre[PRE_N], *epost[POST_N];
 #pragma unroll
@@ -493,7 +510,8 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alive = false;
         }
-        if ((FOLD && __any(gfold != 0)) || (SGL != 0 && __any(gsgl != 0))) {      // a folded leaf that can fire after all, a single-sum plan made for other data: the host routes again on the plain reassociated plan
+        if (SGL == 2) gsgl |= (xlane && fmin_seen < -SGL_XEPS) ? 4u : 0u;
+        if ((FOLD && __any(gfold != 0)) || (SGL != 0 && __any(gsgl != 0))) {      // a folded leaf that can fire after all, a single-sum plan made for other data: the host routes again on the plan of pairs
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alive = false;
         }
@@ -643,6 +661,9 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             gmis |= (((u.x ^ u.z) | (u.y ^ u.w)) != 0u) ? (1u << r) : 0u;
             typedef unsigned v2u __attribute__((ext_vector_type(2)));
             *reinterpret_cast<__attribute__((address_space(3))) v2u *>(gdst[r]) = v2u{u.x, u.y};
+        } else if (SGL == 1) {      // a single unit takes the sum of the adjusted flows (a single producer exports {y, y})
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<__attribute__((address_space(3))) v2u *>(gdst[r]) = v2u{u.z, u.w};
         } else {
             *reinterpret_cast<__attribute__((address_space(3))) v4u *>(gdst[r]) = u;
         }
@@ -680,6 +701,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     auto store_pair = [&](const val_t v, const double v0, unsigned voff, unsigned soff) {
         v2d p;
         if constexpr (PLAIN) p = v2d{v0, v};      // {trial flow, adjusted flow}: the same bits unless the outlet is one that can fire
+        else if constexpr (SGL == 1) p = v2d{v, v};      // a single unit's running sum: read as F = F2 by a pair unit (exact: see the template's comment)
         else p = v;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, p), xr, voff, soff, AUX_SC1);
     };
@@ -757,18 +779,9 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         val_t(&ac)[PRE_N] = va[j & 1], (&bc)[POST_N] = vb[j & 1], (&an)[PRE_N] = va[(j & 1) ^ 1], (&bn)[POST_N] = vb[(j & 1) ^ 1];
         const val_t rc = vr[j & 1];
         const unsigned so = (unsigned)((j + RING - 1) & (RING - 1)) * SLOTB;
-        if constexpr (SGL != 0) {      // single-sum units read the one running sum (the second half of an entry): 8-byte reads
-            typedef __attribute__((address_space(3))) const double lds_c1;
-            if (CHAIN) vr[(j & 1) ^ 1].y = *(lds_c1 *)(eprv + so + 8u);
-            if (PRE) {
-                if (SGL == 2) an[0] = *(lds_cv *)(epre[0] + so);
-                else an[0].y = *(lds_c1 *)(epre[0] + so + 8u);
-            }
-        } else {
-            if (CHAIN) vr[(j & 1) ^ 1] = *(lds_cv *)(eprv + so);
+        if (CHAIN) vr[(j & 1) ^ 1] = *(lds_cv *)(eprv + so);
 #pragma unroll
-            for (int w = 0; w < PRE; ++w) an[w] = *(lds_cv *)(epre[w] + so);
-        }
+        for (int w = 0; w < PRE; ++w) an[w] = *(lds_cv *)(epre[w] + so);
 #pragma unroll
         for (int w = 0; w < POST; ++w) bn[w] = *(lds_cv *)(epost[w] + so);
         __builtin_amdgcn_sched_barrier(0);
@@ -787,36 +800,14 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
                 favgL += FL;                                                   // mrtm.py:78
                 base = __builtin_fma(FL, dt, base);
             }
-            if constexpr (SGL == 2) {
-                // Special unit of a single-sum plan: its cells can fire and have ONE upstream neighbour k that can, the last
-                // member of the chain they read -- whose entry is {m_k, sum F2}: sum F = sum F2 - m_k / dt, so the trial
-                // storage of mrtm.py:51-54 is S2 - m_k (to rounding) and the step is the pair form's.
-                const double S2 = __builtin_fma(ac[0].y, dt, base);            // mrtm.py:66-69
-                const double S1 = S2 - ac[0].x;                                // mrtm.py:51, 54
-                const bool sx = S1 < 0.0;
+            if constexpr (SGL == 1) {      // single unit (the template's comment): one running sum, 8-byte entries
+                const double S1 = PRE ? __builtin_fma(ac[0], dt, base) : base;
                 const double m = __builtin_fmin(S1, 0.0);
                 const double f2 = __builtin_fma(m, dtinv, F0);                 // mrtm.py:60
-                own[(j & (RING - 1)) * NSLOT] = v2d{m, CHAIN ? rc.y + f2 : f2};
-                double Sn = S2;
-                asm volatile("" : "+v"(Sn));
-                S = sx ? 0.0 : Sn;                                             // mrtm.py:63, 69
+                own[(j & (RING - 1)) * NSLOT] = CHAIN ? rc + f2 : f2;
+                S = S1 - m;                                                    // mrtm.py:63, 69
                 F = f2;
-                favg += f2;
-            } else if constexpr (SGL == 1) {
-                // Single-sum unit: none of its cells is one that can fire AND has an upstream neighbour that can.  For every
-                // other cell the two sums of mrtm.py:51 and :66 are the same number whenever they matter -- a neighbour that
-                // cannot fire has F2 = F; a cell that cannot fire itself has S1 >= S2 >= 0 and uses the adjusted sum only --
-                // so the lanes pass ONE running sum (of the adjusted flows F2) and the step is
-                //     S1 = base + (sum F2) dt,  m = min(S1, 0),  F2 = F + m / dt,  S = S1 - m
-                // (S = 0 exactly where the cell fires, S1 where it does not, NaN where S1 is NaN: min returns the 0).
-                // The entry's first half carries m, the cell's deficit of this sub-step, for the lanes of `special` units.
-                const double S1 = PRE ? __builtin_fma(ac[0].y, dt, base) : base;
-                const double m = __builtin_fmin(S1, 0.0);
-                const double f2 = __builtin_fma(m, dtinv, F0);
-                own[(j & (RING - 1)) * NSLOT] = v2d{m, CHAIN ? rc.y + f2 : f2};
-                S = S1 - m;
-                F = f2;
-                favg += f2;
+                favg += f2;                                                    // mrtm.py:78
             } else {
             const double S1 = PRE ? __builtin_fma(ac[0].x, dt, base) : base;  // trial storage: S + dSdt dt (mrtm.py:51, 54)
             const double S2 = PRE ? __builtin_fma(ac[0].y, dt, base) : base;  // the same with the adjusted inflows (mrtm.py:66-69)
@@ -830,6 +821,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             S = sx ? 0.0 : Sn;                                                 // mrtm.py:63, 69
             F = f2;
             favg += f2;                                                        // mrtm.py:78
+            if (SGL == 2) fmin_seen = __builtin_fmin(fmin_seen, f2);           // exit guard (looked at by check())
             }
         } else if constexpr (PLAIN) {
             double s1 = 0.0;                                                   // UM.dot(F), stored order (mrtm.py:51)
@@ -950,6 +942,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     if (alive) {
         while (itf <= nit) finalize(itf++);
         learn_now();
+        if (SGL == 2) gsgl |= (xlane && fmin_seen < -SGL_XEPS) ? 4u : 0u;
         if ((PLAIN && __any((fired | gmis) != 0)) || (FOLD && __any(gfold != 0)) || (SGL != 0 && __any(gsgl != 0))) {
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alive = false;
@@ -986,7 +979,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
         st[3] = (unsigned long long)((PRE + POST + (CHAIN ? 1 : 0) + 1) & 15) | (any_g ? 16u : 0u) | (any_x ? 32u : 0u) |
-                (PLAIN ? 64u : 0u) | (guard_set ? 128u : 0u) | (gval_any ? 0u : 8u) | ((unsigned long long)hw << 8) | ((unsigned long long)(xcc & 15u) << 40) |
+                ((PLAIN || SGL == 2) ? 64u : 0u) | (guard_set ? 128u : 0u) | (gval_any ? 0u : 8u) | ((unsigned long long)hw << 8) | ((unsigned long long)(xcc & 15u) << 40) |
                 (zone_groups << 44);
         st[4] = cyc_wait_data;
         st[5] = cyc_wait_ring;
@@ -1005,6 +998,11 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
 //      SIMDs hold two units however the dispatcher spread the workgroups.  The second arrivals that stay take the
 //      cheapest units of the list (units without streams: they delay nobody), their SIMD partners the next ones, with
 //      issue priority, everybody else the rest in list order.
+//      Single-sum plans (n_excl > 0): the last n_excl units of the list are the PAIR units, which issue 13 fp64 operations
+//      per sub-step where their neighbours issue 8 -- among three such neighbours on a CU a pair unit is the slowest unit
+//      of the launch.  The first workgroup to register on a CU is its leader; the first leaders (by ticket)
+//      keep their CU for two pair units -- their own and that of the CU's next first arrival --, its other arrivals
+//      leave, and that many more second arrivals elsewhere run a unit.
 // Returns the unit (or -1: a spare workgroup, or a fault) and leaves the issue priority of the workgroup in *prio_sh_p.
 __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *prio_sh_p) {
     int &unit_sh = *unit_sh_p, &prio_sh = *prio_sh_p;
@@ -1015,6 +1013,7 @@ __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *pr
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 15u;
         const unsigned key = ((((xcc * 8u + ((hw >> 13) & 7u)) * 2u + ((hw >> 12) & 1u)) * 16u + ((hw >> 8) & 15u)) * 4u) +
                              ((hw >> 4) & 3u);
+        unsigned *pl_cu = pl + 16 + PLACE_KEYS + (key >> 2);
         const int n_units = A(n_units);
         const unsigned n_wg = gridDim.x;
         unsigned *fault = A(fault);
@@ -1031,10 +1030,19 @@ __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *pr
         };
         auto add = [&](int word) { return __hip_atomic_fetch_add(pl + word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         // words: 0 registered, 1 second arrivals, 2 first arrivals, 3 tickets of the second arrivals, 4 second arrivals
-        // decided, 5 / 6 claims of the partners / of everybody else, 7 tickets of the first arrivals
+        // decided, 5 / 6 claims of the partners / of everybody else, 7 tickets of the first arrivals, 9 CU leaders, 10 their
+        // tickets, 11 first arrivals displaced from exclusive CUs, 12 leaders decided, 13 pair units claimed by exclusive CUs
         const unsigned rank = __hip_atomic_fetch_add(pl + 16 + key, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;
-        if (rank == 0) add(2);
-        else if (rank == 1) add(1);
+        bool leader = false;
+        unsigned cu_rank = 0;                          // order of this first arrival among the first arrivals of its CU
+        if (rank == 0) {
+            add(2);
+            cu_rank = __hip_atomic_fetch_add(pl_cu, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;
+            leader = cu_rank == 0u;
+            if (leader) add(9);
+        } else if (rank == 1) {
+            add(1);
+        }
         const unsigned registered = __hip_atomic_fetch_add(pl + 0, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         // fed run: the last workgroup to register tells the host's side stream that every unit is resident and placed --
         // only then may the kernels that produce the rest of the runoff take the free wave slots (xh_fused.hip)
@@ -1042,43 +1050,69 @@ __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *pr
             __hip_atomic_store(A(place_epoch), A(epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int idx = -1;                                  // -1: fault, -2: spare workgroup, nothing to do
         if (wait_for(pl + 0, n_wg)) {
-            const int firsts = (int)ld_relaxed(pl + 2), seconds = (int)ld_relaxed(pl + 1);
-            const int need2 = max(n_units - firsts, 0);         // second arrivals that must run a unit
-            if (rank >= 2) {
+            const int firsts = (int)ld_relaxed(pl + 2), seconds = (int)ld_relaxed(pl + 1), leaders = (int)ld_relaxed(pl + 9);
+            // exclusive CUs: TWO pair units each (two of them hardly meet in the LDS; a CU per unit would leave three SIMDs
+            // idle and push as many units onto shared SIMDs elsewhere), as many as asked for, as long as the second arrivals
+            // elsewhere can take over the units of the arrivals that leave (up to two first and four second arrivals per CU).
+            // A leader with a ticket claims min(2, first arrivals of its CU) pair units from the END of the list
+            // (pl[13]: units claimed so far) and leaves the count and the first index in its CU's word for its mate.
+            const int n_excl = A(n_excl);
+            int ncu = min((n_excl + 1) / 2, leaders);
+            ncu = max(min(ncu, (seconds - max(n_units - firsts, 0)) / 6), 0);
+            bool excl_cu = false;
+            int displaced = 0, claimed = 0;
+            bool ok = true;
+            if (ncu > 0) {
+                if (leader) {
+                    if ((int)add(10) < ncu) {
+                        const int cnt = (int)(ld_relaxed(pl_cu) & 0xffffu);
+                        int k = min(2, cnt);
+                        const int base = (int)__hip_atomic_fetch_add(pl + 13, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        k = max(min(k, n_excl - base), 0);
+                        if (k > 0) {
+                            __hip_atomic_fetch_or(pl_cu, 0x10000u | ((unsigned)k << 17) | ((unsigned)base << 19), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(pl + 11, (unsigned)(cnt - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            idx = n_units - 1 - base;
+                        }
+                    }
+                    __hip_atomic_fetch_add(pl + 12, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                ok = wait_for(pl + 12, (unsigned)leaders);
+                const unsigned cw = ld_relaxed(pl_cu);
+                excl_cu = (cw & 0x10000u) != 0;
+                displaced = (int)ld_relaxed(pl + 11);
+                claimed = min((int)ld_relaxed(pl + 13), n_excl);
+                if (ok && idx < 0 && excl_cu && rank == 0 && cu_rank == 1u && ((cw >> 17) & 3u) == 2u)
+                    idx = n_units - 1 - ((int)(cw >> 19) + 1);      // the leader's mate: the CU's second pair unit
+            }
+            const int nx = claimed;
+            const int firsts_eff = firsts - displaced;
+            const int need2 = max(n_units - firsts_eff, 0);         // second arrivals that must run a unit
+            if (idx >= 0 || !ok) {
+                // (a pair unit on an exclusive CU, or a fault)
+            } else if (rank >= 2) {
                 idx = -2;
             } else if (rank == 1) {
-                const int t = (int)add(3);
+                const int t = excl_cu ? INT_MAX : (int)add(3);
                 if (t < need2) __hip_atomic_fetch_or(pl + 16 + key, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(pl + 4, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 idx = t < need2 ? t : -2;
                 if (t < need2) prio_sh = 1;
+            } else if (excl_cu) {
+                idx = -2;                                 // the CU belongs to its leader's pair unit
             } else if (wait_for(pl + 4, (unsigned)seconds)) {
                 const bool shared = (ld_relaxed(pl + 16 + key) & 0x10000u) != 0;
-                if (firsts > n_units && (int)add(7) >= n_units) {
+                if (firsts_eff > n_units && (int)add(7) >= n_units - nx) {
                     idx = -2;
                 } else if (shared) {
                     idx = need2 + (int)add(5);
                     prio_sh = 3;
                 } else {
-                    // everybody else: the list's tail is ordered by LDS load (xh_flow_plan.cpp); SIMD s of a CU takes from
-                    // its s-th quarter, so the four units of a CU come from the four quarters (a quarter that has run
-                    // out -- the SIMD ids of the shared SIMDs are not spread evenly -- sends the workgroup to the next one)
-                    const int rest = n_units - 2 * need2, q = (rest + 3) >> 2;
-                    const int s0 = (int)((hw >> 4) & 3u);
-                    const bool balance = (A(balance) & 1) != 0;
-                    if (!balance) {
-                        idx = 2 * need2 + (int)add(6);
-                    } else {
-                        for (int k = 0; k < 4 && idx < 0; ++k) {
-                            const int sq = (s0 + k) & 3, len = min(q, rest - sq * q);
-                            if (len <= 0) continue;
-                            const int t = (int)add(8 + sq);
-                            if (t < len) idx = 2 * need2 + sq * q + t;
-                        }
-                    }
+                    idx = 2 * need2 + (int)add(6);
                 }
+                if (idx >= n_units - nx) idx = -1;      // cannot happen: the ranges add up to the units
             }
-            if (idx >= n_units) idx = -1;      // cannot happen: the three ranges add up to the units
+            if (idx >= n_units) idx = -1;
         }
         if (idx == -1) __hip_atomic_store(fault, FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unit_sh = idx >= 0 ? A(unit_order)[idx] : -1;

@@ -89,7 +89,8 @@ def route_series_device(ctx, um, nmonths, spinup_months, ndays, dt, d_flow_dist,
     return d_chs, d_avg
 
 
-def route_series(UM, flow_dist, velocity, area, runoff, ndays, spinup_months, S0=None, dt=10800, device=0, flags=0):
+def route_series(UM, flow_dist, velocity, area, runoff, ndays, spinup_months, S0=None, dt=10800, device=0, flags=0,
+                 prepare=True):
     """Spin-up then simulation over all months (components.py:273-294). Returns (ChStorage, Avg_ChFlow, F_end)."""
     ctx = _hip.get_context(device)
     um = _as_um(UM)
@@ -97,6 +98,11 @@ def route_series(UM, flow_dist, velocity, area, runoff, ndays, spinup_months, S0
     ncell, nmonths = runoff.shape
     if um.shape[0] != ncell:
         raise ValueError('UM is {} x {} but runoff has {} cells'.format(um.shape[0], um.shape[0], ncell))
+    # which cells can fire follows from the lengths, velocities and dt this call holds: the prepared plan (folded leaves,
+    # single running sums: xh_route_plan_prepare) is the one run_model() routes on -- a cheap no-op when nothing changed
+    # (prepare=False: route on whatever plan there is -- the plan of pairs, unless somebody prepared it)
+    if prepare:
+        um.plan(ctx).prepare(flow_dist, velocity, dt)
     bufs = [ctx.upload(flow_dist), ctx.upload(velocity), ctx.upload(area), ctx.upload(runoff)]
     d_S0 = None if S0 is None else ctx.upload(S0)
     d_F = ctx.empty(ncell)
@@ -115,6 +121,7 @@ def streamrouting(L, S0, F0, ChV, q, area, nday, dt, UM, device=0, flags=0):
     um = _as_um(UM)
     ncell = um.shape[0]
     q = np.asarray(q, dtype=np.float64).reshape(ncell, 1)
+    um.plan(ctx).prepare(L, ChV, dt)          # (see route_series)
     bufs = [ctx.upload(L), ctx.upload(ChV), ctx.upload(area), ctx.upload(q), ctx.upload(S0)]
     d_avg, d_S, d_F = ctx.empty((ncell, 1)), ctx.empty(ncell), ctx.empty(ncell)
     ctx.route_series(um.plan(ctx), 1, 0, [int(nday)], dt, bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], None, d_avg,
