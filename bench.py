@@ -40,8 +40,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/
 SHADER_CLOCK_HZ = 2.4e9        # MI355X peak engine clock (MI355X_MICROARCH.md); s_memtime showed 2.37 GHz under this load
 # lone-wave cost of one routing sub-step, nothing else on the device: a (2,3) row in the bit-exact pair form / a (2,4) row in its
 # plain form (tools/micro/substep_plain.hip, round 3), the reassociated form with both of its reads (tools/micro/substep_rsum.hip,
-# round 5; profiles/round5/substep_rsum.txt)
-SUBSTEP_FLOOR_CYCLES = {'pair': 186.0, 'plain': 137.0, 'reassoc': 104.0}
+# round 5; profiles/round5/substep_rsum.txt), its single-sum form (8-byte entries, 8 fp64 operations: round 6, same tool, mode 6;
+# profiles/round6/substep_rsum.txt)
+SUBSTEP_FLOOR_CYCLES = {'pair': 186.0, 'plain': 137.0, 'reassoc': 104.0, 'single': 77.0}
 LDS_BYTES_PER_CLK = 128.0      # per CU (MI355X_MICROARCH.md, LDS)
 ROUTE_KERNELS = {4: 'k_mrtm_rsum', 2: 'k_mrtm_wave', 3: 'k_mrtm_skew', 1: 'k_mrtm_flow'}
 NCELL, NBASINS = 67420, 235
@@ -308,7 +309,8 @@ def routing_forms(ctx, pipe, log, nsub):
             info = pipe.plan.info()
             kern = int(info['last_tree_kernel'])
             ti = pipe.plan.typed_info()
-            floor = SUBSTEP_FLOOR_CYCLES['reassoc' if kern == 4 else ('plain' if ti['plain_units'] > 0 else 'pair')]
+            single = kern == 4 and pipe.plan.rsum_info()['pair_cells'] >= 0      # the prepared plan: one running sum per lane
+            floor = SUBSTEP_FLOOR_CYCLES[('single' if single else 'reassoc') if kern == 4 else ('plain' if ti['plain_units'] > 0 else 'pair')]
             achieved = ms * 1e-3 / nsub * SHADER_CLOCK_HZ
             rec = {'mrtm_route_ms': ms, 'device_kernel': ROUTE_KERNELS.get(kern, 'k_mrtm_units'), 'units': int(info['flow_units']),
                    'streams': int(info['flow_edges']), 'pipeline_depth': int(info['flow_depth']), 'max_lane_lag': int(info['skew_max_lag']),
@@ -320,6 +322,12 @@ def routing_forms(ctx, pipe, log, nsub):
                 rec['units'] = int(ri['units'])
                 rec['folded_leaves'] = int(ri['folded'])
                 rec['fold_guard_tripped'] = bool(ri['fold_disabled'])
+                rec['plan'] = 'single sums' if single else 'pairs of sums'
+                rec['cells_in_pair_units'] = int(ri['pair_cells'])
+                if single:      # the few pair units pace the launch: their own floor is the pair form's
+                    rec['critical_path']['pacing_units'] = {'form': 'pair units (the cells that may fire next to one that may, '
+                                                                    'a CU each)', 'floor_cycles': SUBSTEP_FLOOR_CYCLES['reassoc'],
+                                                            'frac': SUBSTEP_FLOOR_CYCLES['reassoc'] / achieved}
             # per-unit accounting: one launch with the statistics on (costs the units a few cycles per check; not timed above)
             os.environ['XH_FLOW_STATS'] = '1'
             try:
@@ -332,8 +340,12 @@ def routing_forms(ctx, pipe, log, nsub):
                 raw3 = st[:, 3]
                 loop = st[:, 0].astype(np.float64) / nsub
                 ops = (raw3 & np.uint64(15)).astype(np.int64)                 # LDS operations per sub-step: reads + the own store
-                plain = ((raw3 >> np.uint64(6)) & np.uint64(1)).astype(np.int64)
+                plain = ((raw3 >> np.uint64(6)) & np.uint64(1)).astype(np.int64)       # bit 6: 8-byte entries (plain / single units)
                 lds_bytes = ops * 64 * np.where(plain == 1, 8, 16)             # per unit and sub-step (block transfers: +~3 %)
+                if kern == 4 and single:
+                    pu = plain == 0
+                    rec['pair_units'] = {'n': int(pu.sum()), 'cycles_per_substep_outside_waits': [float(x) for x in np.sort(loop[pu])],
+                                         'cycles_per_substep_of_wall': [float(x) for x in np.sort(st[pu, 1].astype(np.float64) / nsub)]}
                 hw = (raw3 >> np.uint64(8)) & np.uint64(0xffffffff)
                 cu_key = ((raw3 >> np.uint64(40)) & np.uint64(15)).astype(np.int64) * 4096 + ((hw >> np.uint64(8)) & np.uint64(0xff)).astype(np.int64)
                 per_cu = np.bincount(np.unique(cu_key, return_inverse=True)[1], weights=lds_bytes)
@@ -469,10 +481,32 @@ FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X vector fp64 peak (MI355X_MICROARCH.md)
 CALIB_FLOP_PER_MCM = 120.0      # flop-equivalents per member-cell-month ("Calibration")
 
 
+def committed_profile(fname):
+    """The newest profiles/round*/<fname> (counter passes cannot be taken from inside a run: each figure read from such a
+    file carries the file and the date of the pass, and is refused when it is not about the kernel / configuration that ran)."""
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', fname)))):
+        try:
+            return json.load(open(f)), os.path.relpath(f, ROOT)
+        except (OSError, ValueError):
+            continue
+    return {}, None
+
+
 def bench_calib(args, ctx, rank, world_size, dist, torch, backend, log):
+    result = calib_measure(args, ctx, rank, world_size, dist, torch, backend, log)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def calib_measure(args, ctx, rank, world_size, dist, torch, backend, log):
     """BASELINE configs[4]: one step = one differential-evolution generation (trial vectors, objective of every member
     of every basin over spin-up + simulation months, selection, convergence test) of all 235 basins, entirely on the
-    device.  N > 1: the basins are dealt to the ranks by size (strong scaling) and the results gathered at the end."""
+    device.  N > 1: the basins are dealt to the ranks by size (strong scaling) and the results gathered at the end.
+    Returns the result line as a dict."""
     from xanthos_amd import synth
     from xanthos_amd.calibrate.calibrate_abcd import assign_basins, gather_results
     from xanthos_amd.calibrate.config5 import Config5
@@ -534,6 +568,27 @@ def bench_calib(args, ctx, rank, world_size, dist, torch, backend, log):
         'kernels': {k: {'avg_ms': v[0] / args.steps, 'launches': v[1]} for k, v in ms.items()},
         'host_share_of_step': 1.0 - sum(v[0] for v in ms.values()) / (1e3 * elapsed),
     }
+    # MEASURED issue fraction of the two marches: fp64 wave-instructions x 4 cycles over the cycles
+    # the chip's SIMDs have in the marches' time.  SQ_INSTS_VALU of k_calib_march_m<true|false> from the committed counter pass
+    # of `bench.py --workload calib` (tools/profile_round.sh); the time is this run's.  Refused when the pass is not about
+    # this configuration.
+    pmc_i, insts_src = committed_profile('pmc_insts.json')
+    marches = [pmc_i.get('k_calib_march_m<true>'), pmc_i.get('k_calib_march_m<false>')]
+    std_cfg = args.members == 512 and args.months == 480 and args.abcd_spinup == 120 and world_size == 1
+    if all(m and m.get('SQ_INSTS_VALU') for m in marches) and std_cfg:
+        insts = sum(m['SQ_INSTS_VALU'] for m in marches)
+        simds = 4 * int(ctx.cu_count())
+        result['roofline']['valu_issue'] = {
+            'valu_wave_insts_per_generation': insts, 'cycles_per_wave_inst': 4, 'simds': simds, 'clock_hz': SHADER_CLOCK_HZ,
+            'march_ms': kern_ms, 'frac': insts * 4.0 / (simds * kern_ms * 1e-3 * SHADER_CLOCK_HZ),
+            'wave_insts_per_member_cell_month': insts * 64.0 / local_mcm,
+            'source': {'file': insts_src, 'device_kernels': ['k_calib_march_m<true>', 'k_calib_march_m<false>'],
+                       'collected': pmc_i.get('_meta', {}).get('collected')},
+            'note': 'measured: SQ_INSTS_VALU of both marches x 4 cycles / (SIMDs x their time x clock); calib_abcd also holds the '
+                    'basin-mean kernel (microseconds)'}
+    else:
+        result['roofline']['valu_issue'] = {'frac': None, 'refused': 'no counter pass of k_calib_march_m for this configuration in {}'
+                                            .format(insts_src)}
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
         from oracle import calib as o_calib, de as o_de
         pop, en = de.state(0)
@@ -563,12 +618,60 @@ def bench_calib(args, ctx, rank, world_size, dist, torch, backend, log):
         result['parity'] = {'objective_max_rel_err_vs_oracle': worst}
         result['speedup_vs_cpu_baseline'] = value / cpu
         log('cpu baseline: ' + result['cpu_baseline']['sample'])
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     cfg.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return result
+
+
+def secondary_lines(ctx, pipe, args, log, kernel_times, pmc_i, insts_src, parity):
+    """BASELINE configs[1] and configs[4] inside the default run, so that the driver times them too:
+    `pm_abcd` = 10 steps of Penman-Monteith + ABCD on the run's own pipeline and forcing (the parity of their outputs is the
+    run's own gate: the same arrays); `calib` = 3 generations of the 512-member x 235-basin calibration (+ 1 warm-up), with the
+    objective of a few members checked against the oracle.  Never `value`."""
+    import argparse as _ap
+    out = {}
+    steps = 10
+    for _ in range(2):
+        pipe.run(('pm', 'abcd'), fed=False)
+    ctx.sync()
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.run(('pm', 'abcd'), fed=False)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    k = kernel_times(steps)
+    simds = 4 * int(ctx.cu_count())
+    rec = pmc_i.get('k_pm_pet', {})
+    pm = k.get('pm_pet', {})
+    if rec.get('SQ_INSTS_VALU') and pm:
+        pm['valu_frac'] = rec['SQ_INSTS_VALU'] * 4.0 / (simds * pm['avg_ms'] * 1e-3 * SHADER_CLOCK_HZ)
+        pm['valu_source'] = {'file': insts_src, 'device_kernel': 'k_pm_pet', 'collected': pmc_i.get('_meta', {}).get('collected')}
+    out['pm_abcd'] = {
+        'metric': 'cell-months/sec (pm_abcd, 67,420 cells)', 'value': NCELL * args.months * steps / el, 'unit': 'cell-months/s',
+        'steps': steps, 'warmup': 2, 'ms_per_step': 1e3 * el / steps, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'pm_abcd: {} cells x {} months, {} basins, abcd spin-up {} (BASELINE configs[1])'.format(
+            NCELL, args.months, NBASINS, args.abcd_spinup)},
+        'roofline': {'pm_pet': {'bound': 'fp64 valu issue', 'valu_frac': pm.get('valu_frac'), 'hbm_frac': pm.get('frac_of_hbm_peak'),
+                                'avg_ms': pm.get('avg_ms'), 'source': pm.get('valu_source')},
+                     'abcd_sim': {'bound': 'hbm / dependent fp64 chain', 'hbm_frac': k.get('abcd_sim', {}).get('frac_of_hbm_peak'),
+                                  'achieved_GBs': k.get('abcd_sim', {}).get('achieved_GBs'), 'avg_ms': k.get('abcd_sim', {}).get('avg_ms')}},
+        'kernels': k,
+        'parity': {kk: parity[kk] for kk in ('pet', 'aet', 'q', 'sav') if parity and kk in parity} or
+                  'PET / AET / Q / Sav of this pipeline are what the run\'s gate holds to the oracle'}
+    log('secondary pm_abcd: {:.3f} ms per step'.format(out['pm_abcd']['ms_per_step']))
+    # config 5 (frees nothing of the main pipeline: 4.5 GB of 288)
+    cargs = _ap.Namespace(**vars(args))
+    cargs.workload, cargs.months, cargs.steps, cargs.warmup = 'calib', 480, 3, 1
+    cargs.cpu_calib_seconds = 3.0
+    try:
+        line = calib_measure(cargs, ctx, 0, 1, None, None, None, log)
+        out['calib'] = {kk: line[kk] for kk in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'data', 'config',
+                                               'objective_evaluations_per_s', 'roofline', 'kernels', 'parity', 'cpu_baseline')
+                        if kk in line}
+        log('secondary calib: {:.2f} ms per generation'.format(line['ms_per_step']))
+    except Exception as exc:      # never costs the run its line
+        out['calib'] = {'error': str(exc)[:300]}
+    return out
 
 
 def cfg_bounds():
@@ -636,6 +739,9 @@ def main():
                     help='N > 1: rank 0 also runs the WHOLE world unsharded and compares the gathered arrays bit for bit')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-end-to-end', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the secondary lines of the default run (BASELINE configs[1]: 10 steps of pm_abcd; configs[4]: 3 '
+                         'generations of the calibration)')
     ap.add_argument('--cpu-full', action='store_true', help='(the default now; kept for compatibility)')
     ap.add_argument('--cpu-pm-years', type=int, default=5)
     ap.add_argument('--cpu-mrtm-months', type=int, default=0,
@@ -814,6 +920,10 @@ def main():
         if int(info.get('last_tree_kernel', 0)) == 4:
             info['form'] = ('reassociated form (k_mrtm_rsum: row sums as running sums along chains of lanes, two LDS reads per '
                             'sub-step for every unit, fused update; equal to the reference to rounding, see parity.routing_reassociated)')
+            ri = pipe.plan.rsum_info()
+            info['rsum_plan'] = {'kind': 'single sums' if ri['pair_cells'] >= 0 else 'pairs of sums', 'units': int(ri['units']),
+                                 'folded_leaves': int(ri['folded']), 'cells_in_pair_units': int(ri['pair_cells']),
+                                 'guard_tripped': bool(ri['fold_disabled'])}
         info['guard_trips'] = int(ti['guard_trips'])
     log('routing plan: ' + json.dumps(info))
     value = units_per_step * args.steps / elapsed
@@ -871,17 +981,8 @@ def main():
         ran['mrtm_route'] = 'k_mrtm_skew'
     full_config = (args.months == 600 and args.abcd_spinup == 120 and args.routing_spinup == 120 and not sharded)
 
-    def committed(fname):
-        import glob
-        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*', fname)))
-        for f in reversed(files):
-            try:
-                return json.load(open(f)), os.path.relpath(f, ROOT)
-            except (OSError, ValueError):
-                continue
-        return {}, None
-    pmc_t, traffic_src = committed('pmc_traffic.json')
-    pmc_i, insts_src = committed('pmc_insts.json')
+    pmc_t, traffic_src = committed_profile('pmc_traffic.json')
+    pmc_i, insts_src = committed_profile('pmc_insts.json')
     traffic_note = {}
     for k, dev in ran.items():
         if k not in kernels:
@@ -929,10 +1030,17 @@ def main():
         # plain form); achieved = the launch's time per sub-step in shader cycles.
         achieved = us * 1e-6 * SHADER_CLOCK_HZ
         if ran['mrtm_route'] == 'k_mrtm_rsum':
-            fl = SUBSTEP_FLOOR_CYCLES['reassoc']
-            roofline['critical_path'] = {'substeps': nsub, 'form': 'reassociated', 'floor_cycles': fl, 'achieved_cycles': achieved,
+            single = pipe.plan.rsum_info()['pair_cells'] >= 0
+            fl = SUBSTEP_FLOOR_CYCLES['single' if single else 'reassoc']
+            roofline['critical_path'] = {'substeps': nsub, 'form': 'reassociated, single sums' if single else 'reassociated, pairs of sums',
+                                         'floor_cycles': fl, 'achieved_cycles': achieved,
                                          'frac': fl / achieved, 'clock_hz': SHADER_CLOCK_HZ,
-                                         'floor_source': 'tools/micro/substep_rsum.hip (lone wave, both reads, no streams)'}
+                                         'floor_source': 'tools/micro/substep_rsum.hip (lone wave, both reads, no streams; mode 6 for '
+                                                         'single sums)'}
+            if single:
+                roofline['critical_path']['pacing_units'] = {
+                    'form': 'the pair units of the plan (the cells that may fire next to one that may and their halos: a CU each)',
+                    'floor_cycles': SUBSTEP_FLOOR_CYCLES['reassoc'], 'frac': SUBSTEP_FLOOR_CYCLES['reassoc'] / achieved}
         else:
             roofline['critical_path'] = {'substeps': nsub, 'form': 'bit-exact', 'floor_cycles': SUBSTEP_FLOOR_CYCLES['pair'],
                                          'floor_cycles_plain_form': SUBSTEP_FLOOR_CYCLES['plain'],
@@ -1025,6 +1133,8 @@ def main():
                                             if 'routing_reassociated' in parity else 'bit-identical to the oracle',
                                             parity.get('routing_months_checked', 'no routing'))}
             gate_failed = bool(failures) and not args.no_gate
+        if args.workload == 'pm_abcd_mrtm' and not args.no_secondary and full_config:
+            result['secondary'] = secondary_lines(ctx, pipe, args, log, kernel_times, pmc_i, insts_src, result.get('parity'))
     if dist is not None:
         # ranks the collective layer really sees (a sum over the process group, not the launcher's word for it)
         tt = torch.tensor([1.0], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')

@@ -13,11 +13,10 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 # grid did on this machine -- right for a product run, wrong for tests that assert which form a call ran in.  Off unless a test
 # (in a child process) switches it on.
 os.environ.setdefault('XH_ROUTE_LEARN_CACHE', '0')
-# Since round 5 the library routes tree networks in the reassociated form by default (equal to the reference to rounding, not
-# bit for bit).  The suites written against the bit-exact kernels -- which stay the checker -- keep asserting bits, so the
-# default of the test processes is the bit-exact form; tests/test_gpu_reassoc.py, the full-size reassociated test and the
-# default-path tests ask for the other form by flag (a call's flag wins over the environment) or in a child process.
-os.environ.setdefault('XH_ROUTE_REASSOC', '0')
+# (Round 5 pinned every test process to the bit-exact routing kernels with XH_ROUTE_REASSOC=0.  Since round 6 the test processes
+# run what the library ships -- the reassociated form, on prepared plans where the caller holds velocities and lengths -- and
+# hold it to that form's bar; tests that assert BITS ask for the bit-exact kernels by flag: XH_ROUTE_EXACT, which wins over
+# the default and the environment.)
 
 
 def pytest_configure(config):

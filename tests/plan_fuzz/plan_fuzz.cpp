@@ -357,6 +357,7 @@ static int run_file(const char *path, bool typed, bool rsum) {
     }
     if (rsum) opt.capable = getenv("SINGLE") ? capable.data() : nullptr;
     if (getenv("HALO")) opt.halo = atoi(getenv("HALO"));
+    if (getenv("PAIR_IMPORTS")) opt.pair_imports = atoi(getenv("PAIR_IMPORTS"));
     const auto t0 = std::chrono::steady_clock::now();
     if (rsum ? flow_tables_build_rsum(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)
              : flow_tables_build(n, g.indptr.data(), g.indices.data(), g.sign.data(), g.comp.data(), g.ncomp, opt, handled, t, err)) {

@@ -4,6 +4,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 
@@ -184,3 +185,65 @@ def test_calibration_fanout_two_ranks(tmp_path):
     out = tmp_path / 'calib_out'
     outs = _run_two_ranks(tmp_path, CALIB_WORKER, str(out))
     assert 'CALIB_FANOUT_OK' in outs[0]
+
+
+def test_group_takes_no_strangers_and_nothing_pickled(tmp_path):
+    """the rendezvous never unpickles, a peer has to present the job's token in a fixed-size hello, and the
+    raw gather works towards any root.  Three ranks with a token; while rank 0 listens a STRANGER connects first and sends a
+    pickle (it must be dropped, costing the job nothing), then a hello with the wrong token (dropped too)."""
+    script = tmp_path / 'rank.py'
+    script.write_text("""
+import os, pickle, socket, struct, sys, time
+sys.path.insert(0, sys.argv[1])
+from xanthos_amd import launch
+assert 'pickle' not in open(launch.__file__).read().replace('unpickled', '').replace('no pickle', '')
+rank, _, world = launch.env_world()
+port = int(os.environ['MASTER_PORT'])
+if rank == 1:      # plays the stranger before joining properly
+    for payload in (struct.pack('<Q', 40) + pickle.dumps(os.getcwd)[:40], launch._HELLO.pack(b'XHG1', 2, b'wrong'.ljust(64, b'\\0'))):
+        for _ in range(200):
+            try:
+                s = socket.create_connection(('127.0.0.1', port), timeout=1.0)
+                break
+            except OSError:
+                time.sleep(0.05)
+        s.sendall(payload)
+        time.sleep(0.2)
+        s.close()
+g = launch.current_group()
+got = g.gather(bytes([rank]) * (3 + rank), root=1, raw=True)
+assert (got == [b'\\x00' * 3, b'\\x01' * 4, b'\\x02' * 5]) if rank == 1 else got is None, got
+import numpy as np
+tab = g.gather(np.full((2, 3), float(rank)), root=0)
+assert rank != 0 or [float(t[0, 0]) for t in tab] == [0.0, 1.0, 2.0]
+assert g.allreduce(rank, 'sum') == 3
+print('GROUP_OK', rank, flush=True)
+launch.close_group()
+""")
+    code = ("import sys; sys.path.insert(0, %r); from xanthos_amd import launch; "
+            "sys.exit(launch.spawn(3, [%r, %r], one_device=True))" % (ROOT, str(script), ROOT))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0 and out.stdout.count('GROUP_OK') == 3, out.stdout + out.stderr
+
+
+def test_launcher_ends_the_job_when_a_rank_dies(tmp_path):
+    """a rank that dies while the others sit in a collective must not leave run_model(gpus=N) hanging: the
+    launcher supervises all ranks, gives the survivors a grace period and terminates them, and returns the first failure it
+    notices (the dead rank's 9 -- or the 1 of a peer whose collective broke on the closed connection within the same poll)."""
+    script = tmp_path / 'rank.py'
+    script.write_text("""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+from xanthos_amd import launch
+g = launch.current_group()
+if g.rank == 1:
+    os._exit(9)                      # dies after the rendezvous
+g.barrier()                          # the others wait for it here
+time.sleep(600)
+""")
+    code = ("import sys; sys.path.insert(0, %r); from xanthos_amd import launch; "
+            "sys.exit(launch.spawn(3, [%r, %r], one_device=True))" % (ROOT, str(script), ROOT))
+    t0 = time.time()
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, XH_SPAWN_GRACE='2'))
+    assert out.returncode in (9, 1) and time.time() - t0 < 60, (out.returncode, out.stdout + out.stderr)

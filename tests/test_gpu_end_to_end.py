@@ -1,11 +1,24 @@
 """GPU end-to-end (-m gpu): run_model() on a synthetic pm_abcd_mrtm input tree against the oracle chain, the
-calibration driver, and full-size (67,420-cell) checks of each stage."""
+calibration driver, and full-size (67,420-cell) checks of each stage.
+
+Everything here runs what the library ships -- since round 5 the reassociated routing form, since round 6 on prepared plans
+(single running sums, folded leaves) -- and holds the routed values to that form's bar: identical NaN masks,
+|x - ref| <= 1e-9 |ref| + 1e-3 m3 (storage) / 1e-9 m3/s (flow).  The bit-exact kernels are tested by flag elsewhere."""
 from types import SimpleNamespace
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def routed_close(x, ref, atol, rtol=1e-9, tag=''):
+    x, ref = np.asarray(x), np.asarray(ref)
+    assert x.shape == ref.shape
+    assert np.array_equal(np.isnan(x), np.isnan(ref)), 'NaN pattern differs ' + str(tag)
+    m = ~np.isnan(ref)
+    excess = np.abs(x[m] - ref[m]) - (atol + rtol * np.abs(ref[m]))
+    assert (excess <= 0).all(), '{}: {} values beyond the bar, largest excess {:.3e}'.format(tag, int((excess > 0).sum()), excess.max())
 
 
 def rel(x, ref):
@@ -33,13 +46,16 @@ def test_run_model_matches_oracle_chain(example):
     pet = o_pm.run_pmpet(d, w.ncell, w.nlcs, 1971, 1973, 0, 6, w.lc_years)
     _, aet, q, sav = o_abcd.abcd_execute(w.n_basins, w.basin_ids, pet, f['precip'], f['abcd_tmin'], w.abcd_pars, 36, 25, -1)
     assert rel(res.PET, pet) < 1e-10 and rel(res.AET, aet) < 1e-8 and rel(res.Q, q) < 1e-8 and rel(res.Sav, sav) < 1e-8
-    # routing is bit-exact for identical runoff: feed the GPU's own Q to the oracle
+    # routing for identical runoff (the default form: within its bar): feed the GPU's own Q to the oracle
     st = SimpleNamespace(ngridrow=w.nrow, ngridcol=w.ncol)
     um = o_mrtm.upstream_genmatrix(o_mrtm.upstream(w.coords, o_mrtm.downstream(w.coords, w.flow_dir, st), st))
     ndays = o_months.set_month_arrays(36, 1971, 1973)[:, 2]
     # (the loader's ha -> km2 conversion rounds the areas by an ulp, so take the arrays the run actually used)
     chs, avg, _ = o_mrtm.route_series(um, res.data.flow_dist, res.data.str_velocity, res.data.area, res.Q, ndays, 6)
-    assert np.array_equal(res.ChStorage, chs, equal_nan=True) and np.array_equal(res.Avg_ChFlow, avg, equal_nan=True)
+    routed_close(res.ChStorage, chs, 1e-3, tag='ChStorage')
+    routed_close(res.Avg_ChFlow, avg, 1e-9, tag='Avg_ChFlow')
+    info = res.pipe.plan.info()
+    assert info['last_tree_kernel'] == 4 and res.pipe.plan.rsum_info()['pair_cells'] >= 0, (info, res.pipe.plan.rsum_info())
     # per-stage plugin calls give the same arrays as the device-resident simulation
     from xanthos_amd.components import Components
     from xanthos_amd.ini_reader import ConfigReader
@@ -47,7 +63,7 @@ def test_run_model_matches_oracle_chain(example):
     pet2 = c.calculate_pet()
     c.calculate_runoff(pet=pet2)
     assert np.array_equal(pet2, res.PET) and np.array_equal(c.Q, res.Q, equal_nan=True)
-    assert np.array_equal(c.calculate_routing(c.Q), res.Avg_ChFlow, equal_nan=True)
+    routed_close(c.calculate_routing(c.Q), res.Avg_ChFlow, 1e-9, tag='plugin calls')
     import os
     out_csv = os.path.join(root, 'output', 'pm_abcd_mrtm_synth', 'q_mmpermonth_pm_abcd_mrtm_synth.csv')      # reference naming
     assert os.path.isfile(out_csv)
@@ -101,7 +117,8 @@ def test_calibration_recovers_kge(example):
 
 
 def test_full_size_grid_each_stage():
-    """67,420 cells: PM and ABCD on sampled cells / basins vs the oracle, routing 8 months bit-exact vs scipy."""
+    """67,420 cells: PM and ABCD on sampled cells / basins vs the oracle, routing 8 months vs scipy (the default form, through
+    the plugin API: routing.mrtm.route_series prepares its plan from the L, ChV and dt it holds)."""
     from oracle import abcd as o_abcd, mrtm as o_mrtm, pm as o_pm
     from xanthos_amd import _hip, synth
     from xanthos_amd.pipeline import pipeline_from_world
@@ -135,14 +152,19 @@ def test_full_size_grid_each_stage():
                                       pipe.ndays[:8], 0)
     from xanthos_amd.routing import mrtm
     g_chs, g_avg, _ = mrtm.route_series(pipe.um, w.flow_dist, w.velocity, w.area, qh[:, :8].copy(), pipe.ndays[:8], 0)
-    assert np.array_equal(g_chs, chs, equal_nan=True) and np.array_equal(g_avg, avg, equal_nan=True)
+    routed_close(g_chs, chs, 1e-3, tag='chs')
+    routed_close(g_avg, avg, 1e-9, tag='avg')
+    ri = pipe.plan.rsum_info()
+    assert pipe.plan.info()['last_tree_kernel'] == 4 and ri['folded'] > 0 and ri['pair_cells'] >= 0 and ri['fold_disabled'] == 0, ri
     # size-independent property: routing conserves water -- storage change = inflow - outflow at the outlets
     assert np.isnan(g_avg).sum() == np.isnan(avg).sum()
 
 
 def test_basin_sharded_run_equals_whole_world():
     """Shard one world into 3 basin/network-closed shards, run each shard's pipeline on this GPU, reassemble:
-    every output is bit-identical to the unsharded run (what rank 0 holds after the gather on a multi-GPU node)."""
+    PET / AET / Q / Sav are bit-identical to the unsharded run (what rank 0 holds after the gather on a multi-GPU node), the
+    routed outputs within the default form's bar (its sums follow the partition, and a shard's partition is not the world's;
+    with XH_ROUTE_EXACT they are bit-identical too: test_gpu_multirank.py)."""
     from xanthos_amd import _hip, synth
     from xanthos_amd.dist import fill_shard_forcing, make_shards, sub_world
     from xanthos_amd.pipeline import OUTPUTS, pipeline_from_world, topology_from_world
@@ -167,7 +189,10 @@ def test_basin_sharded_run_equals_whole_world():
         for k in OUTPUTS:
             got[k][s.cells] = out[k]
     for k in OUTPUTS:
-        assert np.array_equal(got[k], ref[k], equal_nan=True), k
+        if k in ('chs', 'avg'):
+            routed_close(got[k], ref[k], 1e-3 if k == 'chs' else 1e-9, tag=k)
+        else:
+            assert np.array_equal(got[k], ref[k], equal_nan=True), k
 
 
 def test_calibrate_all_lockstep(example, tmp_path):
@@ -252,7 +277,8 @@ def test_run_model_aggregates_and_future_mode(tmp_path):
     ndays = o_months.set_month_arrays(36, 1971, 1973)[:, 2]
     chs, avg, _ = o_mrtm.route_series(um, res.data.flow_dist, res.data.str_velocity, res.data.area, res.Q, ndays, 6,
                                       S0=chs0[:, -1])
-    assert np.array_equal(res.ChStorage, chs, equal_nan=True) and np.array_equal(res.Avg_ChFlow, avg, equal_nan=True)
+    routed_close(res.ChStorage, chs, 1e-3, tag='ChStorage')
+    routed_close(res.Avg_ChFlow, avg, 1e-9, tag='Avg_ChFlow')
     zero = o_mrtm.route_series(um, res.data.flow_dist, res.data.str_velocity, res.data.area, res.Q, ndays, 6)[0]
     assert not np.array_equal(zero, chs, equal_nan=True)
     out = os.path.join(root, 'output', 'pm_abcd_mrtm_synth')

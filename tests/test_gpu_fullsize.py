@@ -1,11 +1,14 @@
 """GPU tests (-m gpu) at BASELINE.json's full sizes: the 67,420-cell grid through every configuration.
 
-* config 3: 600 + 120 months of routing on the full grid, the dataflow kernel against the ORACLE (scipy CSR, ~3 min of
-  host time, computed once per module), then 20 repetitions, a second context routing concurrently on the same device,
-  background load, and the forced-fault re-route;
+* config 3: 600 + 120 months of routing on the full grid, the dataflow kernels against the ORACLE (scipy CSR, ~3 min of
+  host time, computed once per module) -- the bit-exact kernels (XH_ROUTE_EXACT, by flag) bit for bit, and what the library
+  ships (the reassociated form on the pipeline's prepared plan: single running sums, folded leaves) within its bar -- then, on
+  the shipped form: 20 repetitions, a second context routing concurrently on the same device, background load, the
+  forced-fault re-route;
 * config 1: ``run_model()`` through a generated ``.ini`` on the full grid against the oracle chain;
 * config 4: 480 months, the 235 basins in 8 network-closed shards run one after the other on this GPU and reassembled:
-  bit-identical to the unsharded run (what rank 0 holds after the gather on an 8-GPU node).
+  PET / AET / Q / Sav bit-identical to the unsharded run (what rank 0 holds after the gather on an 8-GPU node), the routed
+  outputs within the default form's bar (its sums follow the partition).
 """
 from types import SimpleNamespace
 
@@ -45,97 +48,122 @@ def full():
     return SimpleNamespace(ctx=ctx, w=w, pipe=pipe, chs=chs, avg=avg)
 
 
-def _check(full, pipe=None, tag=''):
+EXACT = 256      # XH_ROUTE_EXACT
+
+
+def _check_bits(full, pipe=None, tag=''):
+    """The bit-exact kernels: every routed value equal to the oracle's, bit for bit."""
     got = (pipe or full.pipe).download(('chs', 'avg'))
     assert np.array_equal(got['chs'], full.chs, equal_nan=True), tag
     assert np.array_equal(got['avg'], full.avg, equal_nan=True), tag
+
+
+def _check(full, pipe=None, tag=''):
+    """Whatever the library routed with (the default: the reassociated form on the prepared plan; after a forced fault the
+    bit-exact workgroup-per-network kernel): identical NaN masks, every value within 1e-9 |ref| + 1e-3 m3 / 1e-9 m3/s.
+    Returns the largest relative error over the values that are not tiny."""
+    got = (pipe or full.pipe).download(('chs', 'avg'))
+    worst = 0.0
+    for k, ref, atol in (('chs', full.chs, 1e-3), ('avg', full.avg, 1e-9)):
+        x = got[k]
+        assert np.array_equal(np.isnan(x), np.isnan(ref)), (tag, k, 'NaN masks')
+        m = ~np.isnan(ref)
+        err = np.abs(x[m] - ref[m])
+        assert (err <= 1e-9 * np.abs(ref[m]) + atol).all(), (tag, k, float(err.max()))
+        big = np.abs(ref[m]) > 1e6 * atol
+        worst = max(worst, float((err[big] / np.abs(ref[m][big])).max()))
+    return worst
+
+
+def _on_default_plan(pipe, tag=''):
+    """The call was routed by k_mrtm_rsum on the PREPARED plan (folded leaves, single sums), no guard trip."""
+    ri = pipe.plan.rsum_info()
+    assert pipe.plan.info()['last_tree_kernel'] == 4, (tag, pipe.plan.info())
+    assert ri['folded'] > 2500 and ri['pair_cells'] > 0 and ri['fold_disabled'] == 0 and ri['units'] <= 1024, (tag, ri)
 
 
 def test_config3_full_length_routing_equals_oracle(full):
     """67,420 cells x (120 spin-up + 600) months = 175,312 sub-steps: the time-skewed dataflow kernel, the lock-step
     dataflow kernel and the workgroup-per-network kernel are each bit-identical to the oracle (scipy CSR mat-vec)."""
     for flags, kernel in ((0, 2), (8, 1), (4, 0)):
-        full.pipe.route_flags = flags
+        full.pipe.route_flags = flags | EXACT
         full.pipe.out['chs'].zero()
         full.pipe.out['avg'].zero()
         full.pipe.run_mrtm()
-        _check(full, tag=flags)
+        _check_bits(full, tag=flags)
         assert full.pipe.plan.info()['last_tree_kernel'] == kernel
     # validated mode (ADVICE round 2): the dataflow result cross-checked on the device, bit for bit, against the kernel
     # that needs no ordering assumption between units (one workgroup per network, barriers only)
     from xanthos_amd import _hip
     n_val = full.pipe.plan.info()['validated']
-    full.pipe.route_flags = _hip.XH_ROUTE_VALIDATE
+    full.pipe.route_flags = _hip.XH_ROUTE_VALIDATE | EXACT
     full.pipe.out['chs'].zero()
     full.pipe.run_mrtm()
-    _check(full, tag='validated')
+    _check_bits(full, tag='validated')
     assert full.pipe.plan.info()['validated'] == n_val + 1 and full.pipe.plan.info()['last_tree_kernel'] == 2
-    full.pipe.route_flags = 0
+    full.pipe.route_flags = EXACT
     # typed partition (XH_ROUTE_TYPED: pair units only where a neighbour can fire, plain units elsewhere), not the default.
     # The first call finds cells that fire without being expected to (storage driven negative by an adjusted inflow), is
     # routed again in pair form and teaches the plan; the second call runs on mostly plain units.  Same bits both times.
-    full.pipe.route_flags = _hip.XH_ROUTE_TYPED
+    full.pipe.route_flags = _hip.XH_ROUTE_TYPED | EXACT
     for rep in range(3):
         full.pipe.out['chs'].zero()
         full.pipe.out['avg'].zero()
         full.pipe.run_mrtm()
-        _check(full, tag=('typed', rep))
+        _check_bits(full, tag=('typed', rep))
     ti = full.pipe.plan.typed_info()
     assert ti['plain_units'] > 500 and ti['typed_builds'] >= 1 and 0 <= ti['guard_trips'] <= 3, ti
-    full.pipe.route_flags = 0
+    full.pipe.route_flags = EXACT
     full.pipe.run_mrtm()
-    _check(full, tag='pairs again')
+    _check_bits(full, tag='pairs again')
     assert full.pipe.plan.typed_info()['plain_units'] == 0
     # the partition the time-skewed kernel ran on: nearly every lane used (1,054 units would be all of them), far more
     # streams than the 64-cell cut's ~860, all cells in dataflow units
     info = full.pipe.plan.info()
     assert info['flow_cells'] == 67420 and info['fallback_cells'] == 0
     assert 1054 <= info['flow_units'] <= 1075 and info['flow_edges'] > 1200, info
+    full.pipe.route_flags = 0
 
 
 def test_config3_reassociated_routing_within_1e9_of_oracle(full):
-    """the REASSOCIATED form (XH_ROUTE_REASSOC, k_mrtm_rsum: running sums along chains of lanes, fused
-    update -- the library's default) over 67,420 cells x (120 + 600) months against the oracle: identical NaN masks and every
-    one of the 80.9 M routed values within 1e-9 |ref| (+ 1e-3 m3 / 1e-9 m3/s); the north star's gate is 1e-6.  Stage by
-    stage, in the fed order (routing fed while PM and ABCD still run), and cross-checked on the device against the
-    barrier-only bit-exact kernel (XH_ROUTE_VALIDATE compares within 1e-9 for this form)."""
+    """What the library ships (round 5: the REASSOCIATED form, k_mrtm_rsum: running sums along chains of lanes, fused update;
+    round 6: on the pipeline's PREPARED plan -- one running sum per lane, pair units with halos around the cells that may fire
+    next to one that may, folded leaves) over 67,420 cells x (120 + 600) months against the oracle: identical NaN masks and
+    every one of the 80.9 M routed values within 1e-9 |ref| (+ 1e-3 m3 / 1e-9 m3/s); the north star's gate is 1e-6.  Stage by
+    stage, in the fed order (routing fed while PM and ABCD still run), cross-checked on the device against the barrier-only
+    bit-exact kernel (XH_ROUTE_VALIDATE compares within 1e-9 for this form) -- and the same on the plan of PAIRS, which is
+    what an unprepared plan routes on and where a guard trip falls back to (XH_ROUTE_NO_PLAIN asks for it)."""
     from xanthos_amd import _hip
-
-    def within(tag):
-        got = full.pipe.download(('chs', 'avg'))
-        worst = 0.0
-        for k, ref, atol in (('chs', full.chs, 1e-3), ('avg', full.avg, 1e-9)):
-            x = got[k]
-            assert np.array_equal(np.isnan(x), np.isnan(ref)), (tag, k, 'NaN masks')
-            m = ~np.isnan(ref)
-            err = np.abs(x[m] - ref[m])
-            assert (err <= 1e-9 * np.abs(ref[m]) + atol).all(), (tag, k, float(err.max()))
-            big = np.abs(ref[m]) > 1e6 * atol
-            worst = max(worst, float((err[big] / np.abs(ref[m][big])).max()))
-        assert full.pipe.plan.info()['last_tree_kernel'] == 4, tag
-        return worst
-    full.pipe.route_flags = _hip.XH_ROUTE_REASSOC
+    full.pipe.route_flags = 0
     for rep in range(3):
         full.pipe.out['chs'].zero()
         full.pipe.out['avg'].zero()
         full.pipe.run_mrtm()
-        worst = within(('staged', rep))
-    assert worst < 1e-10, worst                       # (measured: 3e-12)
-    info = full.pipe.plan.info()
-    assert info['flow_cells'] == 67420 and 1054 <= info['flow_units'] <= 1075 and info['skew_max_lag'] <= 96, info
+        worst = _check(full, tag=('staged', rep))
+        _on_default_plan(full.pipe, ('staged', rep))
+    assert worst < 1e-10, worst                       # (measured: 5e-12)
     full.pipe.out['chs'].zero()
     full.pipe.out['avg'].zero()
     full.pipe.run(fed=True)
-    within('fed')
+    _check(full, tag='fed')
+    _on_default_plan(full.pipe, 'fed')
     n_val = full.pipe.plan.info()['validated']
-    full.pipe.route_flags = _hip.XH_ROUTE_REASSOC | _hip.XH_ROUTE_VALIDATE
+    full.pipe.route_flags = _hip.XH_ROUTE_VALIDATE
     full.pipe.out['chs'].zero()
     full.pipe.run_mrtm()
-    within('validated')
+    _check(full, tag='validated')
+    _on_default_plan(full.pipe, 'validated')
     assert full.pipe.plan.info()['validated'] == n_val + 1
+    # the plan of pairs
+    full.pipe.route_flags = _hip.XH_ROUTE_NO_PLAIN
+    full.pipe.out['chs'].zero()
+    full.pipe.out['avg'].zero()
+    full.pipe.run_mrtm()
+    assert _check(full, tag='pairs') < 1e-10
+    info, ri = full.pipe.plan.info(), full.pipe.plan.rsum_info()
+    assert info['last_tree_kernel'] == 4 and ri['pair_cells'] == -1 and ri['folded'] == 0 and ri['fold_disabled'] == 0, (info, ri)
+    assert info['flow_cells'] == 67420 and 1054 <= info['flow_units'] <= 1075 and info['skew_max_lag'] <= 96, info
     full.pipe.route_flags = 0
-    full.pipe.run_mrtm()                              # (the module's other tests look at the bit-exact kernel again)
-    _check(full, tag='bit-exact again')
 
 
 _PREPARED_CHILD = r"""
@@ -182,10 +210,10 @@ print(json.dumps(out))
 
 
 def test_config3_prepared_plan_with_folded_leaves_within_1e9_of_oracle(full, tmp_path):
-    """The plan a default process routes on -- reassociated form, PREPARED (leaves that do not fire folded into their downstream
-    cells' lanes: 1,012 units, every one alone on its SIMD) -- at the full grid and length against the oracle: identical NaN
-    masks, every routed value within 1e-9 |ref|, stage by stage and in the fed order, the guard quiet.  In a process of its own:
-    this module runs with XH_ROUTE_REASSOC=0 (conftest), which a library reads once."""
+    """Round 5's prepared plan -- pairs of sums, leaves that do not fire folded into their downstream cells' lanes: 1,012 units,
+    every one alone on its SIMD; XH_RSUM_SINGLE=0 asks for it -- at the full grid and length against the oracle: identical NaN
+    masks, every routed value within 1e-9 |ref|, stage by stage and in the fed order, the guard quiet.  In a process of its own
+    (the switch is read once per process)."""
     import json
     import os
     import subprocess
@@ -196,7 +224,7 @@ def test_config3_prepared_plan_with_folded_leaves_within_1e9_of_oracle(full, tmp
     script = tmp_path / 'prepared_child.py'
     script.write_text(_PREPARED_CHILD)
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
-    env = dict(os.environ, XH_FLOW_CHECK='1')
+    env = dict(os.environ, XH_FLOW_CHECK='1', XH_RSUM_SINGLE='0')
     for k in ('XH_ROUTE_REASSOC', 'XH_FLOW_FOLD'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, str(script), root, str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
@@ -205,7 +233,7 @@ def test_config3_prepared_plan_with_folded_leaves_within_1e9_of_oracle(full, tmp
     assert out['same_runoff'] and out['kernel'] == 4, out
     assert out['staged'] < 1e-10 and out['fed'] < 1e-10, out                    # (measured: 3e-12)
     for info in (out['info'], out['info_fed']):
-        assert info['folded'] > 2500 and info['fold_disabled'] == 0 and info['units'] <= 1024, out
+        assert info['folded'] > 2500 and info['fold_disabled'] == 0 and info['units'] <= 1024 and info['pair_cells'] == -1, out
 
 
 def test_config3_all_cell_pm_abcd_parity(full):
@@ -246,7 +274,7 @@ def test_config3_all_cell_pm_abcd_parity(full):
 
 def test_config3_fused_pipeline_equals_oracle(full):
     """The pipelined call (PM blocks || ABCD march || routing polling for months) on the full grid, five times in a
-    row: PET / AET / Q / Sav identical to the stage-by-stage run, routing identical to the oracle."""
+    row: PET / AET / Q / Sav identical to the stage-by-stage run, routing within the default form's bar of the oracle."""
     keep = {k: full.pipe.out[k].download() for k in ('pet', 'aet', 'q', 'sav')}
     for rep in range(5):
         for k in full.pipe.out:
@@ -255,10 +283,11 @@ def test_config3_fused_pipeline_equals_oracle(full):
         _check(full, tag=rep)
         for k, ref in keep.items():
             assert np.array_equal(full.pipe.out[k].download(), ref, equal_nan=True), (k, rep)
-    assert full.pipe.plan.info()['reroutes'] == 0 and full.pipe.plan.info()['last_tree_kernel'] == 2
+    assert full.pipe.plan.info()['reroutes'] == 0
+    _on_default_plan(full.pipe, 'fused')
     # round 4: the FED order (xh_run_fused mode 1) -- the routing kernel launched after the first 128 months of runoff and
-    # fed the other 472 while it runs -- eight times in a row (the plan moves from the all-pairs to the selective plain form on
-    # the way): all six outputs identical, no re-route
+    # fed the other 472 while it runs -- eight times in a row: PET / AET / Q / Sav identical, the routed outputs within the bar,
+    # no re-route, every call on the prepared plan
     n0 = full.ctx.timing('feed_gate')[1]
     for rep in range(8):
         for k in full.pipe.out:
@@ -268,7 +297,8 @@ def test_config3_fused_pipeline_equals_oracle(full):
         for k, ref in keep.items():
             assert np.array_equal(full.pipe.out[k].download(), ref, equal_nan=True), (k, rep)
     assert full.ctx.timing('feed_gate')[1] == n0 + 8
-    assert full.pipe.plan.info()['reroutes'] == 0 and full.pipe.plan.info()['last_tree_kernel'] == 2
+    assert full.pipe.plan.info()['reroutes'] == 0
+    _on_default_plan(full.pipe, 'fed')
 
 
 def test_config3_twenty_repetitions_and_background_load(full):
@@ -287,6 +317,7 @@ def test_config3_twenty_repetitions_and_background_load(full):
                 bg.run(('pm', 'abcd'))
         full.pipe.run_mrtm()
         _check(full, tag=rep)
+        _on_default_plan(full.pipe, rep)
         other.sync()
     assert full.pipe.plan.info()['reroutes'] == 0
     other.close()
@@ -336,7 +367,7 @@ def test_config3_forced_fault_is_rerouted(full):
             pipe.out['chs'].zero()
             pipe.run_mrtm()
             _check(full, pipe=pipe, tag=(tag, skipped))
-            if pipe.plan.info()['last_tree_kernel'] == 2:
+            if pipe.plan.info()['last_tree_kernel'] == 4:      # the dataflow kernel of the default form is back
                 return skipped
             skipped += 1
             assert skipped <= 8, 'the dataflow kernels never came back'
@@ -411,13 +442,16 @@ def test_config1_run_model_full_grid(tmp_path):
     um = o_mrtm.upstream_genmatrix(o_mrtm.upstream(w.coords, o_mrtm.downstream(w.coords, w.flow_dir, st), st))
     ndays = o_months.set_month_arrays(nm, 1971, 1973)[:, 2]
     chs, avg, _ = o_mrtm.route_series(um, res.data.flow_dist, res.data.str_velocity, res.data.area, res.Q, ndays, 12)
-    assert np.array_equal(res.ChStorage, chs, equal_nan=True) and np.array_equal(res.Avg_ChFlow, avg, equal_nan=True)
+    ref = SimpleNamespace(chs=chs, avg=avg)
+    got = SimpleNamespace(download=lambda keys: {'chs': res.ChStorage, 'avg': res.Avg_ChFlow})
+    assert _check(ref, pipe=got, tag='run_model') < 1e-10
+    _on_default_plan(res.pipe, 'run_model')
 
 
 def test_config4_eight_shards_480_months():
     """BASELINE config 4's workload emulated on one GPU: 1971-2010, the 235 basins packed into 8 network-closed shards,
     each shard's pipeline run on this GPU with shard-local forcing generation, outputs reassembled in grid order:
-    bit-identical to the unsharded run for all six outputs."""
+    PET / AET / Q / Sav bit-identical to the unsharded run, ChStorage / Avg_ChFlow within the default form's bar."""
     from xanthos_amd import _hip, synth
     from xanthos_amd.dist import fill_shard_forcing, make_shards, sub_world
     from xanthos_amd.pipeline import OUTPUTS, pipeline_from_world, topology_from_world
@@ -443,7 +477,14 @@ def test_config4_eight_shards_480_months():
         pipe.run()
         out = pipe.download()
         for k in OUTPUTS:
-            assert np.array_equal(out[k], ref[k][s.cells], equal_nan=True), (k, s.rank)
+            if k in ('chs', 'avg'):      # (the default form's sums follow the partition: a shard's is not the world's)
+                x, r, atol = out[k], ref[k][s.cells], 1e-3 if k == 'chs' else 1e-9
+                assert np.array_equal(np.isnan(x), np.isnan(r)), (k, s.rank)
+                m = ~np.isnan(r)
+                assert (np.abs(x[m] - r[m]) <= 1e-9 * np.abs(r[m]) + atol).all(), (k, s.rank)
+            else:
+                assert np.array_equal(out[k], ref[k][s.cells], equal_nan=True), (k, s.rank)
+        assert pipe.plan.info()['last_tree_kernel'] == 4 and pipe.plan.rsum_info()['fold_disabled'] == 0, s.rank
         seen[s.cells] = True
         for a in list(pipe.out.values()) + list(pipe.forcing.values()) + [pipe.d_tairprev]:
             a.free()
@@ -467,7 +508,7 @@ def test_adaptive_plain_form_survives_changes_of_forcing_and_velocity():
     ctx.synth_forcing(5, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.001)
     pipe.run(('pm', 'abcd'), fused=False)
     ctx.sync()
-    pipe.route_flags = _hip.XH_ROUTE_VALIDATE
+    pipe.route_flags = _hip.XH_ROUTE_VALIDATE | EXACT       # (the bit-exact kernel's machinery is the subject)
     forms, builds = [], []
     for phase in range(3):
         if phase == 1:

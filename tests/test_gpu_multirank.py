@@ -234,8 +234,8 @@ def test_run_model_on_n_ranks_writes_the_same_files(tmp_path, nranks, form):
         script.write_text(RUN_MODEL_PARENT)
         env = dict(os.environ)
         env.update({'XH_ONE_DEVICE': '1', 'XH_RCCL_LIBRARY': _fake_rccl(), 'XH_FAKE_RCCL_DIR': str(tmp_path)})
-        for k in ('RANK', 'WORLD_SIZE', 'XH_ROUTE_REASSOC'):      # (conftest.py pins the TEST processes to the bit-exact form;
-            env.pop(k, None)                                      #  these run the library's default unless the ini says otherwise)
+        for k in ('RANK', 'WORLD_SIZE', 'XH_ROUTE_REASSOC'):      # (the library's default unless the ini says otherwise)
+            env.pop(k, None)
         r = subprocess.run([sys.executable, str(script), ROOT, ini, str(n)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and 'PARENT_OK' in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
         if n > 1:

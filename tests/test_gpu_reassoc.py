@@ -4,7 +4,8 @@ The form keeps the VALUE of every row sum of mrtm.py:50-51 but not its order (ru
 the update of mrtm.py:54-69, so its results equal the reference's to rounding, not bit for bit.  The bar written here:
 identical NaN masks and |x - ref| <= 1e-9 |ref| + atol on every routed value (atol 1e-3 m3 for storages, 1e-9 m3/s for
 flows: far below anything a cell holds or passes) against the golden vectors of the real reference and against the oracle.
-The north star's gate is 1e-6.  The bit-exact kernels stay the default and the checker (XH_ROUTE_VALIDATE).
+The north star's gate is 1e-6.  This form is the library's default since round 5; the bit-exact kernels (XH_ROUTE_EXACT) stay
+the checker (XH_ROUTE_VALIDATE).  Round 6: prepared plans pass ONE running sum per lane (the tests at the end of this file).
 """
 from types import SimpleNamespace as NS
 
@@ -159,11 +160,13 @@ def test_route_reassoc_deep_chain_fires_and_initial_storage(hip):
 
 
 @pytest.mark.parametrize('dt', [7200, 17280, 86400])
-def test_route_reassoc_other_time_steps(hip, dt):
+def test_route_reassoc_other_time_steps(hip, dt, tmp_path, monkeypatch):
     """dt = 2 h, 4.8 h (odd sub-step counts per month) and one day (months shorter than the lane lags: the flag then leaves the
-    call to the lock-step kernel, bit-exact -- still within the bar)."""
+    call to the lock-step kernel, bit-exact -- still within the bar; and the call is NOT on record as one routed by the
+    reassociated kernel: ADVICE round 5 -- no first-check marker of that form is written for a kernel that never ran)."""
     from oracle import mrtm as o_mrtm
     from xanthos_amd.routing import mrtm
+    monkeypatch.setenv('XH_CACHE_DIR', str(tmp_path / 'cache'))
     w, um = _world(seed=5)
     rng = np.random.default_rng(dt)
     q = rng.gamma(2.0, 30.0, (w.ncell, 5))
@@ -172,6 +175,11 @@ def test_route_reassoc_other_time_steps(hip, dt):
     got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, q, ndays, 1, dt=dt, flags=REASSOC)
     series_close(got, ref, dt)
     assert um.plan(hip.get_context()).info()['last_tree_kernel'] == (4 if dt < 86400 else 1)
+    marks = [f.name for f in (tmp_path / 'cache').iterdir() if f.name.startswith('route_ok_')] if (tmp_path / 'cache').exists() else []
+    reassoc_marks = [m for m in marks if m.endswith(('_r', '_rf', '_rs'))]
+    assert (len(reassoc_marks) == 1) == (dt < 86400), marks
+    if dt == 86400:
+        assert um.plan(hip.get_context()).rsum_info()['units'] == 0
 
 
 def test_route_reassoc_fuzz(hip):
@@ -224,8 +232,8 @@ def test_fed_pipeline_with_reassoc_routing(hip):
 
 
 def test_run_model_default_routing_form_against_the_oracle_chain(tmp_path):
-    """run_model() as a user meets it since round 5 -- no flag, no environment switch, so the reassociated routing form (a child
-    process: conftest.py pins the test processes themselves to the bit-exact form) -- against the oracle chain PM -> ABCD ->
+    """run_model() as a user meets it since round 5 -- no flag, no environment switch, so the reassociated routing form (in a
+    child process, so that nothing this test process has set is in the way) -- against the oracle chain PM -> ABCD ->
     MRTM: PET / AET / Q / Sav as before, ChStorage / Avg_ChFlow within the form's bar; and ``routing_form = exact`` in the ini
     gives the bit-exact kernels back."""
     import json
@@ -338,11 +346,13 @@ print(json.dumps({'kernel': int(info['last_tree_kernel']), 'units': int(info['fl
 
 
 @pytest.mark.parametrize('env', [{}, {'XH_FLOW_PIECE_CAP': '64'}, {'XH_FLOW_PIECE_CAP': '20'}, {'XH_FLOW_PIECE_CAP': '5'},
-                                 {'XH_FLOW_RS': '2048', 'XH_FLOW_SPARE': '3'}, {'XH_ROUTE_FENCED': 'lag'}, {'XH_ROUTE_FENCED': '1'},
+                                 {'XH_FLOW_RS': '16384', 'XH_FLOW_SPARE': '3'}, {'XH_ROUTE_FENCED': 'lag'}, {'XH_ROUTE_FENCED': '1'},
                                  {'XH_FLOW_CHECK': '1', 'XH_FLOW_PIECE_CAP': '12'}])
 def test_route_reassoc_partition_variants(env, tmp_path):
     """The reassociated planner under other piece capacities (64: few streams, long chains; 5: a stream per handful of cells,
-    chains of pieces everywhere), ring sizes and spare workgroups, the lagged and the fully fenced publication, and the
+    chains of pieces everywhere), ring sizes (larger than the launch would pick: a ring below its formula -- 2,048 sub-steps
+    here -- starves this plan's longest stream until a bounded wait gives up and the call is re-routed, round 6) and spare
+    workgroups, the lagged and the fully fenced publication, and the
     planner's invariant checker inside the library: every variant within the bar of the oracle (a child process each: the
     switches are read when the library builds its plan)."""
     import json

@@ -88,7 +88,8 @@ for flag, name in ((0, 'no streams'), (16, 'imports'), (32, 'exports'), (48, 'bo
         print('  %-10s n=%4d cycles/sub-step median %.0f max %.0f; wait data %.1f%% ring %.1f%%' % (
             name, sel.sum(), np.median(loop[sel] / nsub), (loop[sel] / nsub).max(), 100 * np.median(st[sel, 4] / total[sel]),
             100 * np.median(st[sel, 5] / total[sel])))
-pairu = (shape & 64) != 0
+single_plan = pipe.plan.rsum_info()['pair_cells'] >= 0      # bit 64: 8-byte entries = a single unit; the others are its pair units
+pairu = ((shape & 64) == 0) if single_plan else np.zeros(len(shape), dtype=bool)
 if pairu.any():
     print('  pair units of the single-sum plan: n=%d cycles/sub-step outside waits %s, of wall %s' % (
         pairu.sum(), ' '.join('%.0f' % x for x in loop[pairu] / nsub), ' '.join('%.0f' % x for x in total[pairu] / nsub)))

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get('XH_LIBRARY') or os.path.join(_HERE, 'libxanthos_hip.s
 XH_ROUTE_DEFAULT, XH_ROUTE_FORCE_FALLBACK, XH_ROUTE_ATOMIC, XH_ROUTE_NO_DATAFLOW, XH_ROUTE_NO_SKEW = 0, 1, 2, 4, 8
 XH_ROUTE_TEST_FAULT, XH_ROUTE_VALIDATE, XH_ROUTE_TYPED = 16, 32, 64
 XH_ROUTE_REASSOC, XH_ROUTE_EXACT = 128, 256      # reassociated (tolerance) form of the routing kernel / the bit-exact kernels
+XH_ROUTE_NO_PLAIN = 0x4000                       # (xh_common.h, what a guard trip re-routes with) pairs of sums in every unit: not the prepared plan
 
 
 class HipUnavailable(RuntimeError):

@@ -41,7 +41,8 @@ struct FlowPlanOptions {
     // sum instead of a pair; the cells that may fire AND have an upstream neighbour that may -- capable cells and `halo` cells
     // downstream of every capable cell with a capable neighbour -- sit in pair units of their own.
     int halo = 8;
-    int pair_imports = 16;       // ... and take on at most this many imported streams per unit
+    int pair_imports = 8;        // ... and take on at most this many imported streams per unit (one import round of the kernel: 12.4-12.6
+                                 // against 12.7 ms with 16 -- round 6, same box)
 };
 
 struct FlowTables {

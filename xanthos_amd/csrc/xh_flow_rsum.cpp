@@ -214,47 +214,58 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
     //      ONE of its foldable leaf children into its lane.  The pieces shrink; what this buys is units: 67,420 cells are 2.9 %
     //      more than the chip's lanes, and the ~40 SIMDs that had to hold two units each ended the kernel.
     fold_leaf.assign(n, -1);
-    if (opt.foldable) {
-        auto free_piece = [&](int p) { return P.pimp[p] == 0 && ds[roots[p]] < 0; };
+    // fold_pieces(ok): every cell of a piece `ok` accepts takes ONE of its foldable leaf children (same piece) into its lane;
+    // returns the lanes saved
+    auto fold_pieces = [&](auto &&accept) {
+        int saved = 0;
         for (int c : queue) {
             const int q = P.piece[c];
-            if (q < 0 || !free_piece(q) || special[c]) continue;      // (pair pieces carry no folded leaves)
+            if (q < 0 || fold_leaf[c] >= 0 || special[c] || !accept(q)) continue;      // (pair pieces carry no folded leaves)
             for (int k = child_ptr[c]; k < child_ptr[c + 1]; ++k) {
                 const int l = child[k];
                 if (opt.foldable[l] && t.nchild[l] == 0 && P.piece[l] == q) {
                     fold_leaf[c] = l;
+                    P.psize[q]--;
+                    P.piece[l] = -1;
+                    ++saved;
                     break;
                 }
             }
         }
-        for (int c = 0; c < n; ++c)
-            if (fold_leaf[c] >= 0) {
-                P.psize[P.piece[fold_leaf[c]]]--;
-                P.piece[fold_leaf[c]] = -1;
-            }
         queue.erase(std::remove_if(queue.begin(), queue.end(), [&](int c) { return P.piece[c] < 0; }), queue.end());
-    }
-    // pieces that carry folded leaves may only sit in units WITHOUT streams (they must not fill the free lanes of a unit that
-    // others wait for: the whole unit pays for the folded lanes)
+        return saved;
+    };
+    if (opt.foldable) fold_pieces([&](int p) { return P.pimp[p] == 0 && ds[roots[p]] < 0; });
+    // pieces that carry folded leaves may only sit in units WITHOUT IMPORTS (the kernel's FOLD variant), and must not fill the
+    // free lanes of a unit that others wait for: the whole unit pays for the folded lanes
     std::vector<char> has_fold(npiece, 0);
-    for (int c = 0; c < n; ++c)
-        if (fold_leaf[c] >= 0) has_fold[P.piece[c]] = 1;
+    auto mark_folds = [&]() {
+        std::fill(has_fold.begin(), has_fold.end(), 0);
+        for (int c = 0; c < n; ++c)
+            if (fold_leaf[c] >= 0) has_fold[P.piece[c]] = 1;
+    };
+    mark_folds();
 
     // ---- packing.  Pieces with a stream in or out: equal pipeline depth per unit (a unit then only ever waits for units
     //      strictly upstream or downstream of it), first-fit decreasing.  Whole small networks wait for nobody and fill free
     //      lanes anywhere; the `cheap` cheapest of them (single cells first: they read nothing; then the smallest) are kept
     //      together as units for the SIMDs that must hold two waves.
     auto has_out = [&](int p) { return ds[roots[p]] >= 0; };
-    std::vector<int> dep, fre;
-    for (int p = 0; p < npiece; ++p) (P.pimp[p] > 0 || has_out(p) ? dep : fre).push_back(p);
-    std::stable_sort(dep.begin(), dep.end(), [&](int x, int y) {
-        return P.pdepth[x] != P.pdepth[y] ? P.pdepth[x] < P.pdepth[y] : P.psize[x] > P.psize[y];
-    });
-    std::vector<int> by_cost(fre);
-    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) { return P.psize[x] < P.psize[y]; });
     // (pair units pace a single-sum launch; with at most `pair_imports` streams they run the one-round variant of the kernel)
     const int pair_imp = std::min(std::max(opt.pair_imports, 1), G_MAX);
     int cheap = 0;
+    // pack(): the partition for the pieces as they are now; returns the units beyond the SIMDs left for them
+    auto pack = [&](bool cheap_units) {
+    std::vector<int> dep, fre;
+    for (int p = 0; p < npiece; ++p) (P.pimp[p] > 0 || has_out(p) ? dep : fre).push_back(p);
+    std::stable_sort(dep.begin(), dep.end(), [&](int x, int y) {      // (pieces with folded leaves first: they share units)
+        if (P.pdepth[x] != P.pdepth[y]) return P.pdepth[x] < P.pdepth[y];
+        if (has_fold[x] != has_fold[y]) return has_fold[x] > has_fold[y];
+        return P.psize[x] > P.psize[y];
+    });
+    std::vector<int> by_cost(fre);
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) { return P.psize[x] < P.psize[y]; });
+    int need = 0;
     for (int round = 0; round < 4; ++round) {
         P.unit_of_piece.assign(npiece, -1);
         P.unit_cells.clear();
@@ -306,7 +317,7 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         {
             int made = 0, u = -1;
             for (int p : by_cost) {
-                if (special[roots[p]]) continue;
+                if (special[roots[p]] || has_fold[p]) continue;      // (cheap units: neither pair form nor folded leaves)
                 if (u < 0 || P.unit_cells[u] + P.psize[p] > LANES) {
                     if (made == cheap) break;
                     u = new_unit(0, true);
@@ -353,15 +364,56 @@ void rsum_partition(const Tree &t, const FlowPlanOptions &opt, int cap, RPart &P
         }
         P.nunit = (int)P.unit_cells.size();
         P.n_cheap = cheap;
-        const int need = opt.simds > 0 ? std::max(P.nunit - opt.simds, 0) : 0;
-        if (need <= cheap) break;
+        // (single-sum plans: every pair unit gets a CU of its own -- wave_claim --, whose other three SIMDs stay empty)
+        int npair = 0;
+        for (char c : P.unit_special) npair += c ? 1 : 0;
+        const int simds_left = opt.simds - (opt.simds >= 64 ? std::min(3 * npair, opt.simds / 4) : 0);
+        need = opt.simds > 0 ? std::max(P.nunit - simds_left, 0) : 0;
+        if (need <= cheap || !cheap_units) break;
         cheap = need + (round > 0 ? 2 : 0);
     }
+    return need;
+    };
+    // More units than SIMDs: lanes can be saved where folding costs least -- in pieces WITHOUT IMPORTS (the upstream ends of the
+    // rivers: many leaves, and their units, the cheapest of the launch, stay cheaper than the pair units that pace it even
+    // with the folded leaves' four operations), the pieces with the most leaves to fold first, until the units fit.  What is
+    // still missing then is covered the old way: cheap units of single cells for the SIMDs that must hold two.
+    int need = pack(false);
+    for (int pass = 0; pass < 4 && need > 0 && opt.foldable; ++pass) {      // (units only merge within a pipeline level: a pass may fall short)
+        std::vector<int> gain(npiece, 0);
+        for (int c : queue) {
+            const int q = P.piece[c];
+            if (q < 0 || special[c] || fold_leaf[c] >= 0 || P.pimp[q] != 0) continue;
+            for (int k = child_ptr[c]; k < child_ptr[c + 1]; ++k)
+                if (opt.foldable[child[k]] && t.nchild[child[k]] == 0 && P.piece[child[k]] == q) {
+                    gain[q]++;
+                    break;
+                }
+        }
+        std::vector<int> order;
+        for (int p = 0; p < npiece; ++p)
+            if (gain[p] > 0) order.push_back(p);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return gain[x] > gain[y]; });
+        // (a unit's worth of lanes more than the count says: the packing is not perfect)
+        const int want = (need + 1) * LANES + LANES / 2;
+        std::vector<char> chosen(npiece, 0);
+        int got = 0;
+        for (int p : order) {
+            if (got >= want) break;
+            chosen[p] = 1;
+            got += gain[p];
+        }
+        if (got == 0) break;
+        fold_pieces([&](int p) { return chosen[p] != 0; });
+        mark_folds();
+        need = pack(false);
+    }
+    if (need > 0) pack(true);
 }
 
 }  // namespace
 
-int flow_rsum_planner_version() { return 6; }
+int flow_rsum_planner_version() { return 8; }
 
 int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign, const int *comp,
                            int ncomp, const FlowPlanOptions &opt, std::vector<char> &handled, FlowTables &out,
@@ -395,9 +447,17 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
             RPart &Q = cand[k];
             int indep = 0;
             for (int u = 0; u < Q.nunit; ++u) indep += (Q.unit_imp[u] == 0 && Q.unit_out[u] == 0) ? 1 : 0;
-            const int extra = opt.simds > 0 ? std::max(Q.nunit - opt.simds, 0) : 0;
-            // units beyond the SIMD count share a SIMD, and only units without streams may (the claim order below)
-            const long score = 1000000L * std::max(2 * extra - indep, 0) + 1000L * Q.nunit + Q.nedge / 8;
+            int npair = 0;
+            for (char c : Q.unit_special) npair += c ? 1 : 0;
+            const int extra = opt.simds > 0 ? std::max(Q.nunit - (opt.simds - (opt.simds >= 64 ? std::min(3 * npair, opt.simds / 4) : 0)), 0) : 0;
+            // units beyond the SIMD count share a SIMD, and only units without streams may (the claim order below); then as
+            // few units as possible that pay for folded leaves although others wait for them; then few units, few streams
+            std::vector<char> ufold(Q.nunit, 0);
+            for (int c = 0; c < n; ++c)
+                if (cand_fold[k][c] >= 0) ufold[Q.unit_of_piece[Q.piece[c]]] = 1;
+            int fold_streams = 0;
+            for (int u = 0; u < Q.nunit; ++u) fold_streams += (ufold[u] && (Q.unit_imp[u] > 0 || Q.unit_out[u] > 0)) ? 1 : 0;
+            const long score = 1000000L * std::max(2 * extra - indep, 0) + 20000L * fold_streams + 1000L * Q.nunit + Q.nedge / 8;
             if (opt.debug)
                 fprintf(stderr, "flow plan (reassociated): piece capacity %d -> %d units, %d streams, %d units without streams, depth %d\n",
                         opt.piece_cap > 0 ? opt.piece_cap : caps[k], Q.nunit, Q.nedge, indep, Q.maxdepth + 1);

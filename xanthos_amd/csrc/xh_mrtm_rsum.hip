@@ -60,8 +60,8 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
         else if (g) wave_unit<false, 1, 0, 1, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
         else wave_unit<false, 1, 0, 0, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
     } else if (p & 8) {      // single unit: one running sum, 8-byte entries
-        if (p & 4) {          // (a unit that carries folded leaves has no streams: xh_flow_rsum.cpp)
-            if (g || x || !A(fold_cell)) bad = true;
+        if (p & 4) {          // (a unit that carries folded leaves has no imports: xh_flow_rsum.cpp)
+            if (g || !A(fold_cell)) bad = true;
             else wave_unit<false, 1, 0, 0, true, true, true, 1>(ap, l, xtab, qst, fnd, unit);
         } else if (g2) wave_unit<false, 1, 0, 2, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);
         else if (g) wave_unit<false, 1, 0, 1, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
         else if (p & 1) wave_unit<false, 1, 0, 0, false, true, false, 1>(ap, l, xtab, qst, fnd, unit);
         else wave_unit<false, 0, 0, 0, false, true, false, 1>(ap, l, xtab, qst, fnd, unit);
     } else if (p & 4) {
-        if (g || x || !A(fold_cell)) bad = true;
+        if (g || !A(fold_cell)) bad = true;
         else wave_unit<false, 1, 0, 0, true, true, true>(ap, l, xtab, qst, fnd, unit);
     } else if (g2) wave_unit<false, 1, 0, 2, true, true>(ap, l, xtab, qst, fnd, unit);
     else if (g) wave_unit<false, 1, 0, 1, true, true>(ap, l, xtab, qst, fnd, unit);

@@ -192,7 +192,12 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.place_epoch = feed ? feed->place_epoch : nullptr;
     a.epoch = feed ? feed->epoch : 0u;
     // single-sum plans: their pair units (the tail of the claim list) get a CU to themselves (wave_claim); XH_RSUM_EXCL=0: A/B
-    a.n_excl = (fp->rsum && fp->n_special >= 0 && !(getenv("XH_RSUM_EXCL") && getenv("XH_RSUM_EXCL")[0] == '0')) ? fp->n_pair_units : 0;
+    a.n_excl = 0;
+    if (fp->rsum && fp->n_special >= 0) {
+        const char *e = getenv("XH_RSUM_EXCL");      // 0: no exclusive CUs; 2: two pair units per CU (both measured slower: wave_claim)
+        const int per_cu = (e && e[0] == '2') ? 2 : 1;
+        if (!(e && e[0] == '0')) a.n_excl = std::min(fp->n_pair_units, 0xffff) | (per_cu << 16);
+    }
     a.fenced = (getenv("XH_ROUTE_FENCED") && getenv("XH_ROUTE_FENCED")[0] == '1') ? 1 : 0;
     if (getenv("XH_ROUTE_FENCED") && getenv("XH_ROUTE_FENCED")[0] == 'l') a.fenced = 4;      // "lag": round 4's publication (vmcnt(8) + PUBLAG), for comparison
     if (!a.fenced && getenv("XH_FEED_POLL") && getenv("XH_FEED_POLL")[0] == 'l') a.fenced = 2;      // experiments (wait_months)

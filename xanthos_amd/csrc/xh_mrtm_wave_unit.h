@@ -87,7 +87,8 @@ struct WaveArgs {
     const unsigned *months_ready;
     unsigned *place_epoch;
     unsigned epoch;
-    int n_excl;                       // k_mrtm_rsum, single-sum plans: the last n_excl units of unit_order (pair units) get a CU to themselves
+    int n_excl;                       // k_mrtm_rsum, single-sum plans: the last (n_excl & 0xffff) units of unit_order (pair units) get CUs to
+                                      // themselves, n_excl >> 16 (1 or 2) to a CU
     int fenced;                       // XH_ROUTE_FENCED=1: agent-scope release / acquire fences around the stream counters (see check())
     char *xbuf;                       // [edges][RS] {F, F2}
     unsigned xbytes;                  // size of the rings
@@ -979,7 +980,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
         st[3] = (unsigned long long)((PRE + POST + (CHAIN ? 1 : 0) + 1) & 15) | (any_g ? 16u : 0u) | (any_x ? 32u : 0u) |
-                ((PLAIN || SGL == 2) ? 64u : 0u) | (guard_set ? 128u : 0u) | (gval_any ? 0u : 8u) | ((unsigned long long)hw << 8) | ((unsigned long long)(xcc & 15u) << 40) |
+                (V8 ? 64u : 0u) | (guard_set ? 128u : 0u) | (gval_any ? 0u : 8u) | ((unsigned long long)hw << 8) | ((unsigned long long)(xcc & 15u) << 40) |
                 (zone_groups << 44);
         st[4] = cyc_wait_data;
         st[5] = cyc_wait_ring;
@@ -1001,8 +1002,8 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
 //      Single-sum plans (n_excl > 0): the last n_excl units of the list are the PAIR units, which issue 13 fp64 operations
 //      per sub-step where their neighbours issue 8 -- among three such neighbours on a CU a pair unit is the slowest unit
 //      of the launch.  The first workgroup to register on a CU is its leader; the first leaders (by ticket)
-//      keep their CU for two pair units -- their own and that of the CU's next first arrival --, its other arrivals
-//      leave, and that many more second arrivals elsewhere run a unit.
+//      keep their CU for their pair unit (optionally a second one, run by the CU's next first arrival), its other
+//      arrivals leave, and that many more second arrivals elsewhere run a unit.
 // Returns the unit (or -1: a spare workgroup, or a fault) and leaves the issue priority of the workgroup in *prio_sh_p.
 __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *prio_sh_p) {
     int &unit_sh = *unit_sh_p, &prio_sh = *prio_sh_p;
@@ -1051,14 +1052,14 @@ __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *pr
         int idx = -1;                                  // -1: fault, -2: spare workgroup, nothing to do
         if (wait_for(pl + 0, n_wg)) {
             const int firsts = (int)ld_relaxed(pl + 2), seconds = (int)ld_relaxed(pl + 1), leaders = (int)ld_relaxed(pl + 9);
-            // exclusive CUs: TWO pair units each (two of them hardly meet in the LDS; a CU per unit would leave three SIMDs
-            // idle and push as many units onto shared SIMDs elsewhere), as many as asked for, as long as the second arrivals
-            // elsewhere can take over the units of the arrivals that leave (up to two first and four second arrivals per CU).
-            // A leader with a ticket claims min(2, first arrivals of its CU) pair units from the END of the list
+            // exclusive CUs: one pair unit each (n_excl >> 16 = 2: two -- measured, round 6: two pair units on a CU slow each
+            // other down by 15-20 cycles per sub-step, 13.8-14.4 ms against 13.1), as many as asked for, as long as the second
+            // arrivals elsewhere can take over the units of the arrivals that leave (up to three first and four second arrivals
+            // per CU).  A leader with a ticket claims min(per_cu, first arrivals of its CU) pair units from the END of the list
             // (pl[13]: units claimed so far) and leaves the count and the first index in its CU's word for its mate.
-            const int n_excl = A(n_excl);
-            int ncu = min((n_excl + 1) / 2, leaders);
-            ncu = max(min(ncu, (seconds - max(n_units - firsts, 0)) / 6), 0);
+            const int n_excl = A(n_excl) & 0xffff, per_cu = max(min(A(n_excl) >> 16, 2), 1);      // pair units per exclusive CU
+            int ncu = min((n_excl + per_cu - 1) / per_cu, leaders);
+            ncu = max(min(ncu, (seconds - max(n_units - firsts, 0)) / 7), 0);
             bool excl_cu = false;
             int displaced = 0, claimed = 0;
             bool ok = true;
@@ -1066,7 +1067,7 @@ __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *pr
                 if (leader) {
                     if ((int)add(10) < ncu) {
                         const int cnt = (int)(ld_relaxed(pl_cu) & 0xffffu);
-                        int k = min(2, cnt);
+                        int k = min(per_cu, cnt);
                         const int base = (int)__hip_atomic_fetch_add(pl + 13, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         k = max(min(k, n_excl - base), 0);
                         if (k > 0) {

@@ -101,7 +101,7 @@ def route_series(UM, flow_dist, velocity, area, runoff, ndays, spinup_months, S0
     # which cells can fire follows from the lengths, velocities and dt this call holds: the prepared plan (folded leaves,
     # single running sums: xh_route_plan_prepare) is the one run_model() routes on -- a cheap no-op when nothing changed
     # (prepare=False: route on whatever plan there is -- the plan of pairs, unless somebody prepared it)
-    if prepare:
+    if prepare and not flags & _hip.XH_ROUTE_EXACT:
         um.plan(ctx).prepare(flow_dist, velocity, dt)
     bufs = [ctx.upload(flow_dist), ctx.upload(velocity), ctx.upload(area), ctx.upload(runoff)]
     d_S0 = None if S0 is None else ctx.upload(S0)
@@ -121,7 +121,8 @@ def streamrouting(L, S0, F0, ChV, q, area, nday, dt, UM, device=0, flags=0):
     um = _as_um(UM)
     ncell = um.shape[0]
     q = np.asarray(q, dtype=np.float64).reshape(ncell, 1)
-    um.plan(ctx).prepare(L, ChV, dt)          # (see route_series)
+    if not flags & _hip.XH_ROUTE_EXACT:
+        um.plan(ctx).prepare(L, ChV, dt)      # (see route_series)
     bufs = [ctx.upload(L), ctx.upload(ChV), ctx.upload(area), ctx.upload(q), ctx.upload(S0)]
     d_avg, d_S, d_F = ctx.empty((ncell, 1)), ctx.empty(ncell), ctx.empty(ncell)
     ctx.route_series(um.plan(ctx), 1, 0, [int(nday)], dt, bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], None, d_avg,
