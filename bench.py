@@ -1069,6 +1069,29 @@ def main():
     gate_failed = False
     if sharded:
         result['gather'] = gather.report()
+        result['gather_kind'] = result['gather']['kind']
+        result['gather_exposed_ms'] = result['gather']['exposed_ms']
+        # What one world sharded over N GPUs CAN deliver (terms 1 + 2 + 4): read `value` against this, not
+        # against N x the one-GPU line.  The routing of a shard is as many sequential sub-steps as the routing of the world, so
+        # term 2 hardly shrinks with N; the hardware's scaling is in `replicas` (independent scenarios) and the calibration
+        # fan-out.  Terms from THIS run, rank 0's shard: kernels timed with HIP events, the tail of the gather from the run.
+        k_ = kernels
+        front = sum(k_[n_]['avg_ms'] for n_ in ('pm_pet', 'abcd_spinup', 'abcd_basin_mean', 'abcd_sim') if n_ in k_)
+        lead_months = max(args.abcd_spinup, args.routing_spinup, 1)
+        term1 = front * min(1.0, (lead_months + 8) / float(args.months)) if n_fed else front
+        term2 = k_['mrtm_route']['avg_ms'] if 'mrtm_route' in k_ else 0.0
+        term4 = result['gather']['exposed_ms']
+        result['scaling_model'] = {
+            'n_gpus': world_size, 'what': 'ONE world, basins sharded: step = PM + ABCD in front of the routing + routing of the '
+                                          'slowest rank\'s networks + the gather of ChStorage / Avg_ChFlow behind it',
+            'term1_front_ms': term1, 'term2_route_ms': term2, 'term4_gather_tail_ms': term4,
+            'modelled_step_ms': (term1 + term2 + (term4 or 0.0) + 0.1) if term4 is not None else None,
+            'measured_step_ms': ms_per_step, 'terms_from': 'rank 0 of this run (HIP events)',
+            'sequential_substeps': int(sum(int(d * 86400 / 10800) for d in pipe.ndays) +
+                                       sum(int(d * 86400 / 10800) for d in pipe.ndays[:args.routing_spinup])) if 'mrtm' in args.stages else 0,
+            'note': 'strong scaling of one world is flat by construction (the sub-steps of the routing are sequential whatever the '
+                    'cells per GPU: BASELINE.md sections 4 and 7); the north star\'s >= 6 x at 8 GPUs is met by the modes without a '
+                    'sequential dependence across ranks: `replicas` below and the calibration fan-out (--workload calib)'}
         if args.check_gather:
             # what rank 0 holds after the gather against the same world run unsharded on its own GPU (same seed: the random
             # streams are keyed on the global cell index), every output, bit for bit

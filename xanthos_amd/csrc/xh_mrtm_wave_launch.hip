@@ -132,29 +132,36 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
 
     // every unit resident at once (see flow_launch for the LDS-share sizing): one workgroup more per CU than the even split
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    // spare workgroups (k_mrtm_wave, "which unit this workgroup runs"): one per CU, as long as two waves per SIMD hold all
-    int n_wg = fp->n_units + cus;
-    if (n_wg > 8 * cus) n_wg = std::max(fp->n_units, 8 * cus);
-    {
-        const char *env = getenv("XH_FLOW_SPARE");            // experiments only
-        if (env) n_wg = fp->n_units + std::max(atoi(env), 0);
-    }
-    int per_cu = (n_wg + cus - 1) / cus + 1;
-    {
-        const char *env = getenv("XH_FLOW_PER_CU_EXTRA");     // experiments only
-        if (env) per_cu += atoi(env);
-    }
+    // the reassociated plan (xh_flow_rsum.cpp) has a kernel of its own: same argument block, same protocol (xh_mrtm_rsum.hip)
+    const void *kernel = fp->rsum ? wave_rsum_kernel() : wave_exact_kernel();
     const size_t lds_static = (size_t)RING * NSLOT * sizeof(v2d) + LANES * sizeof(uint2) + 2 * LANES * sizeof(unsigned) +
                               LANES * sizeof(double) + 64 +     // + fend_sh, unit_sh / prio_sh, padded
                               (fp->rsum ? 2 * LANES * sizeof(unsigned) + LANES * sizeof(double) : 0);      // (k_mrtm_rsum: the folded leaves' halves)
-    const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
-    size_t lds = share > lds_static + 1024 ? share - lds_static : 0;
-    // the reassociated plan (xh_flow_rsum.cpp) has a kernel of its own: same argument block, same protocol (xh_mrtm_rsum.hip)
-    const void *kernel = fp->rsum ? wave_rsum_kernel() : wave_exact_kernel();
-    XH_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int resident = 0;
-    XH_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kernel, LANES, lds));
-    if ((int64_t)(resident - 1) * cus < n_wg || n_wg > 8 * cus) return XH_ERR_LIMIT;
+    // single-sum plans: their pair units (the tail of the claim list) get a CU to themselves (wave_claim); XH_RSUM_EXCL=0: A/B
+    int n_excl = 0;
+    if (fp->rsum && fp->n_special >= 0 && fp->n_pair_units > 0 && !(getenv("XH_RSUM_EXCL") && getenv("XH_RSUM_EXCL")[0] == '0'))
+        n_excl = std::min(fp->n_pair_units, 0xffff);
+    int n_wg = 0, resident = 0;
+    size_t lds = 0;
+    {
+        // spare workgroups (k_mrtm_wave, "which unit this workgroup runs"): one per CU, as long as two waves per SIMD hold all
+        n_wg = fp->n_units + cus;
+        if (n_wg > 8 * cus) n_wg = std::max(fp->n_units, 8 * cus);
+        {
+            const char *env = getenv("XH_FLOW_SPARE");            // experiments only
+            if (env) n_wg = fp->n_units + std::max(atoi(env), 0);
+        }
+        int per_cu = (n_wg + cus - 1) / cus + 1;
+        {
+            const char *env = getenv("XH_FLOW_PER_CU_EXTRA");     // experiments only
+            if (env) per_cu += atoi(env);
+        }
+        const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
+        lds = share > lds_static + 1024 ? share - lds_static : 0;
+        XH_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        XH_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kernel, LANES, lds));
+        if ((int64_t)(resident - 1) * cus < n_wg || n_wg > 8 * cus) return XH_ERR_LIMIT;
+    }
 
     WaveArgs a;
     a.cell_of_slot = static_cast<const int *>(fp->d_cell_of_slot.p);
@@ -191,13 +198,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.months_ready = feed ? feed->months_ready : nullptr;
     a.place_epoch = feed ? feed->place_epoch : nullptr;
     a.epoch = feed ? feed->epoch : 0u;
-    // single-sum plans: their pair units (the tail of the claim list) get a CU to themselves (wave_claim); XH_RSUM_EXCL=0: A/B
-    a.n_excl = 0;
-    if (fp->rsum && fp->n_special >= 0) {
-        const char *e = getenv("XH_RSUM_EXCL");      // 0: no exclusive CUs; 2: two pair units per CU (both measured slower: wave_claim)
-        const int per_cu = (e && e[0] == '2') ? 2 : 1;
-        if (!(e && e[0] == '0')) a.n_excl = std::min(fp->n_pair_units, 0xffff) | (per_cu << 16);
-    }
+    a.n_excl = n_excl;
     a.fenced = (getenv("XH_ROUTE_FENCED") && getenv("XH_ROUTE_FENCED")[0] == '1') ? 1 : 0;
     if (getenv("XH_ROUTE_FENCED") && getenv("XH_ROUTE_FENCED")[0] == 'l') a.fenced = 4;      // "lag": round 4's publication (vmcnt(8) + PUBLAG), for comparison
     if (!a.fenced && getenv("XH_FEED_POLL") && getenv("XH_FEED_POLL")[0] == 'l') a.fenced = 2;      // experiments (wait_months)

@@ -87,8 +87,7 @@ struct WaveArgs {
     const unsigned *months_ready;
     unsigned *place_epoch;
     unsigned epoch;
-    int n_excl;                       // k_mrtm_rsum, single-sum plans: the last (n_excl & 0xffff) units of unit_order (pair units) get CUs to
-                                      // themselves, n_excl >> 16 (1 or 2) to a CU
+    int n_excl;                       // k_mrtm_rsum, single-sum plans: the last n_excl units of unit_order (pair units) get a CU each to themselves
     int fenced;                       // XH_ROUTE_FENCED=1: agent-scope release / acquire fences around the stream counters (see check())
     char *xbuf;                       // [edges][RS] {F, F2}
     unsigned xbytes;                  // size of the rings
@@ -1002,8 +1001,8 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
 //      Single-sum plans (n_excl > 0): the last n_excl units of the list are the PAIR units, which issue 13 fp64 operations
 //      per sub-step where their neighbours issue 8 -- among three such neighbours on a CU a pair unit is the slowest unit
 //      of the launch.  The first workgroup to register on a CU is its leader; the first leaders (by ticket)
-//      keep their CU for their pair unit (optionally a second one, run by the CU's next first arrival), its other
-//      arrivals leave, and that many more second arrivals elsewhere run a unit.
+//      keep their CU for their pair unit, its other arrivals leave, and that many more second arrivals elsewhere run
+//      a unit.
 // Returns the unit (or -1: a spare workgroup, or a fault) and leaves the issue priority of the workgroup in *prio_sh_p.
 __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *prio_sh_p) {
     int &unit_sh = *unit_sh_p, &prio_sh = *prio_sh_p;
@@ -1052,13 +1051,15 @@ __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *pr
         int idx = -1;                                  // -1: fault, -2: spare workgroup, nothing to do
         if (wait_for(pl + 0, n_wg)) {
             const int firsts = (int)ld_relaxed(pl + 2), seconds = (int)ld_relaxed(pl + 1), leaders = (int)ld_relaxed(pl + 9);
-            // exclusive CUs: one pair unit each (n_excl >> 16 = 2: two -- measured, round 6: two pair units on a CU slow each
-            // other down by 15-20 cycles per sub-step, 13.8-14.4 ms against 13.1), as many as asked for, as long as the second
-            // arrivals elsewhere can take over the units of the arrivals that leave (up to three first and four second arrivals
-            // per CU).  A leader with a ticket claims min(per_cu, first arrivals of its CU) pair units from the END of the list
-            // (pl[13]: units claimed so far) and leaves the count and the first index in its CU's word for its mate.
-            const int n_excl = A(n_excl) & 0xffff, per_cu = max(min(A(n_excl) >> 16, 2), 1);      // pair units per exclusive CU
-            int ncu = min((n_excl + per_cu - 1) / per_cu, leaders);
+            // exclusive CUs: ONE pair unit each (two on a CU slow each other down by 15-20 cycles per sub-step: 13.8-14.4 ms
+            // against 13.1, round 6), as many as asked for, as long as the second arrivals elsewhere can take over the units of
+            // the arrivals that do not run one (up to three first and four second arrivals per CU).  A leader with a ticket
+            // claims a pair unit from the END of the list (pl[13]: units claimed so far) and marks its CU.
+            // (Sealing the exclusive CUs against other kernels -- their other arrivals resident, asleep -- was built and measured
+            // in round 6 and removed: the fillers of a fed step do not cost the pair units anything there;
+            // profiles/round6/fed_penalty.txt.)
+            const int n_excl = A(n_excl);
+            int ncu = min(n_excl, leaders);
             ncu = max(min(ncu, (seconds - max(n_units - firsts, 0)) / 7), 0);
             bool excl_cu = false;
             int displaced = 0, claimed = 0;
@@ -1067,24 +1068,19 @@ __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *pr
                 if (leader) {
                     if ((int)add(10) < ncu) {
                         const int cnt = (int)(ld_relaxed(pl_cu) & 0xffffu);
-                        int k = min(per_cu, cnt);
-                        const int base = (int)__hip_atomic_fetch_add(pl + 13, (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        k = max(min(k, n_excl - base), 0);
-                        if (k > 0) {
-                            __hip_atomic_fetch_or(pl_cu, 0x10000u | ((unsigned)k << 17) | ((unsigned)base << 19), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_fetch_add(pl + 11, (unsigned)(cnt - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int base = (int)add(13);
+                        if (base < n_excl) {
+                            __hip_atomic_fetch_or(pl_cu, 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(pl + 11, (unsigned)(cnt - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             idx = n_units - 1 - base;
                         }
                     }
                     __hip_atomic_fetch_add(pl + 12, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 ok = wait_for(pl + 12, (unsigned)leaders);
-                const unsigned cw = ld_relaxed(pl_cu);
-                excl_cu = (cw & 0x10000u) != 0;
+                excl_cu = (ld_relaxed(pl_cu) & 0x10000u) != 0;
                 displaced = (int)ld_relaxed(pl + 11);
                 claimed = min((int)ld_relaxed(pl + 13), n_excl);
-                if (ok && idx < 0 && excl_cu && rank == 0 && cu_rank == 1u && ((cw >> 17) & 3u) == 2u)
-                    idx = n_units - 1 - ((int)(cw >> 19) + 1);      // the leader's mate: the CU's second pair unit
             }
             const int nx = claimed;
             const int firsts_eff = firsts - displaced;
@@ -1100,7 +1096,7 @@ __device__ __forceinline__ int wave_claim(WaveArgsK *ap, int *unit_sh_p, int *pr
                 idx = t < need2 ? t : -2;
                 if (t < need2) prio_sh = 1;
             } else if (excl_cu) {
-                idx = -2;                                 // the CU belongs to its leader's pair unit
+                idx = -2;                              // the CU belongs to its leader's pair unit
             } else if (wait_for(pl + 4, (unsigned)seconds)) {
                 const bool shared = (ld_relaxed(pl + 16 + key) & 0x10000u) != 0;
                 if (firsts_eff > n_units && (int)add(7) >= n_units - nx) {
