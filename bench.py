@@ -38,11 +38,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 SHADER_CLOCK_HZ = 2.4e9        # MI355X peak engine clock (MI355X_MICROARCH.md); s_memtime showed 2.37 GHz under this load
-# lone-wave cost of one routing sub-step, nothing else on the device: a (2,3) row in the bit-exact pair form / a (2,4) row in its
-# plain form (tools/micro/substep_plain.hip, round 3), the reassociated form with both of its reads (tools/micro/substep_rsum.hip,
+# lone-wave cost of one routing sub-step, nothing else on the device: a (2,3) row in the bit-exact pair form
+# (tools/micro/substep_plain.hip, round 3), the reassociated form with both of its reads (tools/micro/substep_rsum.hip,
 # round 5; profiles/round5/substep_rsum.txt), its single-sum form (8-byte entries, 8 fp64 operations: round 6, same tool, mode 6;
 # profiles/round6/substep_rsum.txt)
-SUBSTEP_FLOOR_CYCLES = {'pair': 186.0, 'plain': 137.0, 'reassoc': 104.0, 'single': 77.0}
+SUBSTEP_FLOOR_CYCLES = {'pair': 186.0, 'reassoc': 104.0, 'single': 77.0}
 LDS_BYTES_PER_CLK = 128.0      # per CU (MI355X_MICROARCH.md, LDS)
 ROUTE_KERNELS = {4: 'k_mrtm_rsum', 2: 'k_mrtm_wave', 3: 'k_mrtm_skew', 1: 'k_mrtm_flow'}
 NCELL, NBASINS = 67420, 235
@@ -285,8 +285,8 @@ def cpu_baseline(pipe, world, args, log):
 
 def routing_forms(ctx, pipe, log, nsub):
     """Secondary measurement, never `value`: the routing kernel ALONE in both of its forms on the run's own runoff -- the
-    reassociated form (XH_ROUTE_REASSOC, the default: k_mrtm_rsum) and the bit-exact one (XH_ROUTE_EXACT: k_mrtm_wave in its
-    steady state, i.e. after the adaptive plain form has taken over) -- each with the figures of merit of DESIGN.md section 5:
+    reassociated form (XH_ROUTE_REASSOC, the default: k_mrtm_rsum) and the bit-exact one (XH_ROUTE_EXACT: k_mrtm_wave, every unit
+    in pair form: the checker) -- each with the figures of merit of DESIGN.md section 5:
     `critical_path` (shader cycles per sub-step of the launch against the lone-wave floor of the form) and, from one more
     launch with the per-unit accounting switched on (XH_FLOW_STATS=1: st[3] holds each unit's LDS operations per sub-step and
     the SIMD it ran on), `lds` = LDS bytes a CU moves per sub-step / (128 B/clk x achieved cycles) and the slowest unit."""
@@ -294,12 +294,11 @@ def routing_forms(ctx, pipe, log, nsub):
     flags0 = pipe.route_flags
     out = {}
     try:
-        for name, flag, warm in (('reassociated', _hip.XH_ROUTE_REASSOC, 2), ('bit_exact', _hip.XH_ROUTE_EXACT, 6)):
+        for name, flag, warm in (('reassociated', _hip.XH_ROUTE_REASSOC, 2), ('bit_exact', _hip.XH_ROUTE_EXACT, 2)):
             pipe.route_flags = flag
-            for _ in range(warm):                          # bit-exact: the selective plain form arrives after a few calls
+            for _ in range(warm):
                 pipe.run_mrtm()
                 ctx.sync()
-                time.sleep(0.05)
             ctx.timing_reset()
             for _ in range(3):
                 pipe.run_mrtm()
@@ -308,13 +307,11 @@ def routing_forms(ctx, pipe, log, nsub):
             ms /= max(n, 1)
             info = pipe.plan.info()
             kern = int(info['last_tree_kernel'])
-            ti = pipe.plan.typed_info()
             single = kern == 4 and pipe.plan.rsum_info()['pair_cells'] >= 0      # the prepared plan: one running sum per lane
-            floor = SUBSTEP_FLOOR_CYCLES[('single' if single else 'reassoc') if kern == 4 else ('plain' if ti['plain_units'] > 0 else 'pair')]
+            floor = SUBSTEP_FLOOR_CYCLES[('single' if single else 'reassoc') if kern == 4 else 'pair']
             achieved = ms * 1e-3 / nsub * SHADER_CLOCK_HZ
             rec = {'mrtm_route_ms': ms, 'device_kernel': ROUTE_KERNELS.get(kern, 'k_mrtm_units'), 'units': int(info['flow_units']),
                    'streams': int(info['flow_edges']), 'pipeline_depth': int(info['flow_depth']), 'max_lane_lag': int(info['skew_max_lag']),
-                   'plain_units': int(ti['plain_units']) if kern != 4 else 0,
                    'critical_path': {'substeps': nsub, 'floor_cycles': floor, 'achieved_cycles': achieved, 'frac': floor / achieved,
                                      'clock_hz': SHADER_CLOCK_HZ}}
             if kern == 4:      # which reassociated plan: leaves folded into their downstream cells' lanes (the prepared plan)
@@ -358,7 +355,7 @@ def routing_forms(ctx, pipe, log, nsub):
                               'bytes_per_clk_peak': LDS_BYTES_PER_CLK, 'cycles_per_substep': float(ach),
                               'measured_clock_hz': float(clock)}
                 rec['slowest_unit'] = {'cycles_per_substep_outside_waits': float(loop[slow]), 'lds_ops_per_substep': int(ops[slow]),
-                                       'reads_per_substep': int(ops[slow]) - 1, 'plain_form': bool(plain[slow])}
+                                       'reads_per_substep': int(ops[slow]) - 1, 'eight_byte_entries': bool(plain[slow])}
                 rec['unit_cycles_per_substep'] = {'median': float(np.median(loop)), 'p90': float(np.percentile(loop, 90)),
                                                   'max': float(loop.max())}
             out[name] = rec
@@ -912,11 +909,7 @@ def main():
                        'one world on one GPU')
     info = pipe.plan.info() if pipe.plan is not None else {}
     if pipe.plan is not None:
-        # which form the routing units ran in at the end of the timed steps: a plan that is routed on again and again
-        # switches from the all-pairs partition to the selective plain form after a few calls (adaptive)
-        ti = pipe.plan.typed_info()
-        info['form'] = ('selective plain form ({} of {} units plain; adaptive, tables built on a host thread during the first '
-                        'calls)'.format(ti['plain_units'], ti['typed_units']) if ti['plain_units'] > 0 else 'all units in pair form')
+        info['form'] = 'bit-exact kernels, every unit in pair form'
         if int(info.get('last_tree_kernel', 0)) == 4:
             info['form'] = ('reassociated form (k_mrtm_rsum: row sums as running sums along chains of lanes, two LDS reads per '
                             'sub-step for every unit, fused update; equal to the reference to rounding, see parity.routing_reassociated)')
@@ -924,7 +917,7 @@ def main():
             info['rsum_plan'] = {'kind': 'single sums' if ri['pair_cells'] >= 0 else 'pairs of sums', 'units': int(ri['units']),
                                  'folded_leaves': int(ri['folded']), 'cells_in_pair_units': int(ri['pair_cells']),
                                  'guard_tripped': bool(ri['fold_disabled'])}
-        info['guard_trips'] = int(ti['guard_trips'])
+        info['guard_trips'] = int(pipe.plan.rsum_info()['guard_trips'])
     log('routing plan: ' + json.dumps(info))
     value = units_per_step * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -975,10 +968,6 @@ def main():
     # date of the pass, and is REFUSED (null, with the reason) when that is not the kernel that ran here.
     ran = {'pm_pet': 'k_pm_pet', 'abcd_spinup': 'k_abcd<true>', 'abcd_sim': 'k_abcd_tile<false',
            'mrtm_route': ROUTE_KERNELS.get(int(info.get('last_tree_kernel', 0)), 'k_mrtm_units')}
-    if os.environ.get('XH_ABCD_KERNEL') in ('0', '64'):
-        ran['abcd_sim'] = 'k_abcd<false>' if os.environ['XH_ABCD_KERNEL'] == '0' else 'k_abcd_tile<false'
-    if os.environ.get('XH_MRTM_SKEW') == '2':
-        ran['mrtm_route'] = 'k_mrtm_skew'
     full_config = (args.months == 600 and args.abcd_spinup == 120 and args.routing_spinup == 120 and not sharded)
 
     pmc_t, traffic_src = committed_profile('pmc_traffic.json')
@@ -1043,9 +1032,7 @@ def main():
                     'floor_cycles': SUBSTEP_FLOOR_CYCLES['reassoc'], 'frac': SUBSTEP_FLOOR_CYCLES['reassoc'] / achieved}
         else:
             roofline['critical_path'] = {'substeps': nsub, 'form': 'bit-exact', 'floor_cycles': SUBSTEP_FLOOR_CYCLES['pair'],
-                                         'floor_cycles_plain_form': SUBSTEP_FLOOR_CYCLES['plain'],
                                          'achieved_cycles': achieved, 'frac': SUBSTEP_FLOOR_CYCLES['pair'] / achieved,
-                                         'frac_plain_form': SUBSTEP_FLOOR_CYCLES['plain'] / achieved,
                                          'clock_hz': SHADER_CLOCK_HZ,
                                          'floor_source': 'tools/micro/substep_plain.hip (lone wave, no neighbours, no streams)'}
 

@@ -144,30 +144,23 @@ void xh_route_plan_destroy(xh_route_plan *plan);
  * [7]=dataflow units, [8]=stream edges between them, [9]=pipeline depth, [10]=cells routed by the dataflow kernel,
  * [11]=most imported streams of one unit, [12]=deepest lane lag of the time-skewed layout in sub-steps (-1: layout
  * not available), [13]=kernel that routed the tree networks in the last xh_route_series call on this plan (0 none,
- * 1 lock-step units with monthly streams, 2 time-skewed units, 3 time-skewed units on round 2's kernel because the
- * grid's rows lie beyond the 32-bit offsets of the current one), [14]=calls of this plan re-run with one workgroup per
+ * 1 lock-step units with monthly streams -- months shorter than the lane lags, or rows beyond the time-skewed kernels'
+ * 32-bit offsets --, 2 time-skewed units of the bit-exact kernel k_mrtm_wave, 4 the reassociated kernel k_mrtm_rsum: the
+ * default), [14]=calls of this plan re-run with one workgroup per
  * network after a device fault, [15]=calls cross-checked by XH_ROUTE_VALIDATE */
 int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]);
 
-/* The dataflow kernels run units in two forms.  A PAIR unit gathers {trial flow, adjusted flow} of every upstream
- * neighbour and forms both row sums of mrtm.py:50-69.  A PLAIN unit gathers one value per neighbour and forms one sum:
- * valid when no neighbour of its cells can fire (mrtm.py:54), which is decided from velocity * dt / flow distance of the
- * call (cells with a ratio above 1 - 2^-20 and their downstream cells go to pair units) and GUARDED in the kernel: a plain
- * lane that fires after all makes the next synchronising call route the series again in pair form.  The typed partition
- * is built on the first xh_route_series of a plan and rebuilt when later data give another set of such cells.
- * Cells seen firing without being expected to (storage driven negative by an adjusted inflow, mrtm.py:66-69, can make
- * cells further downstream fire) are recorded on the device and count as cells that can fire from the next call on, so
- * a plan settles after a call or two on given data.
- * info[0] = plain units of the partition that routed the last call (0: every unit in pair form), [1] = typed
- * partitions built so far, [2] = guard faults so far (-1: more than 8, the plan keeps every unit in pair form),
- * [3] = units of the typed partition.  Selected by the flag XH_ROUTE_TYPED or XH_ROUTE_TYPED=1 in the environment.            */
-int xh_route_plan_typed_info(const xh_route_plan *plan, int64_t info[4]);
-/* Optional, before the first xh_route_series of a plan, with the HOST copies of the arrays the calls will pass on the device:
- * if this box has routed this grid (same topology, velocity, flow distance and dt) before, the cells it learnt then are read
- * from $XH_CACHE_DIR or ~/.cache/xanthos_amd and the selective plain tables are built here -- e.g. on the thread that made
- * the plan, beside the forcing upload -- so that the FIRST call already routes on them instead of in pair form (24.4 ->
- * 23.3 ms at the full grid).  Either way the plan keeps the file up to date from its confirmed calls.  Results never depend
- * on it (the guard of the plain units covers what the file does not know).  XH_ROUTE_LEARN_CACHE=0 switches it off.       */
+/* (Rounds 3-5 had a second, PLAIN form of the bit-exact kernel's units here -- selected by XH_ROUTE_TYPED or learnt call by
+ * call, with xh_route_plan_typed_info.  Retired in round 6: the bit-exact kernels are the checker and the XH_ROUTE_EXACT
+ * option now, every unit of theirs in pair form; what knows which cells can fire is the PREPARED plan of the default form,
+ * below.) */
+/* Optional, with the HOST copies of the arrays the calls will pass on the device: makes the PREPARED plan of the default
+ * (reassociated) routing form -- xh_route_plan_rsum_info below says what is in it -- from WHICH cells can fire at these
+ * velocities, lengths and dt.  The package's own callers do it for the user (the pipeline on its planning thread beside the
+ * forcing upload; routing.mrtm.route_series / streamrouting from the L, ChV and dt they hold).  May be called again: the same
+ * data is a no-op, other data replaces the prepared plan.  Results never depend on it (the kernel guards what the plan
+ * assumes; a trip routes the call again on the plan of pairs).  Partitions are kept per box under $XH_CACHE_DIR or
+ * ~/.cache/xanthos_amd (XH_ROUTE_LEARN_CACHE=0: not).  A no-op in a process whose default form is the bit-exact one. */
 int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const double *h_flow_dist, const double *h_velocity, double dt);
 
 /* Diagnostics: with XH_FLOW_STATS=1 in the environment the dataflow kernel records, per unit, {shader cycles inside the
@@ -219,13 +212,7 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
                                        output bit; synchronous; XH_ERR_DEVICE on a difference.  Also switched on for every
                                        call by XH_ROUTE_VALIDATE=1 in the environment.  xh_route_plan_info[15] counts the
                                        validated calls.                                                            */
-#define XH_ROUTE_TYPED 64           /* dataflow units in pair AND plain form from this call on (xh_route_plan_typed_info); also
-                                       XH_ROUTE_TYPED=1 in the environment; XH_FLOW_PLAIN_MIN_READS=n picks the selective
-                                       form (only the units that read >= n values per sub-step).  Without the flag a plan
-                                       that is routed on repeatedly takes up the selective form (n = 5) by itself: the
-                                       tables are built on a host thread from the second plain call on and used once
-                                       they are ready, no call waits for them (XH_ROUTE_AUTO=0 switches that off).  Same
-                                       bits in every form; DESIGN.md 4.3                                            */
+/* (64 was XH_ROUTE_TYPED until round 5: ignored now) */
 #define XH_ROUTE_REASSOC 128        /* tree networks by the REASSOCIATED form of the time-skewed kernel (k_mrtm_rsum): the row sum
                                        of mrtm.py:50-51 travels as running sums along chains of lanes (two LDS reads per
                                        sub-step for every unit instead of up to six) and the update of mrtm.py:54-69 is fused.
@@ -237,9 +224,10 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
                                        bit-exact kernels).  XH_ROUTE_VALIDATE then compares within 1e-9.               */
 #define XH_ROUTE_EXACT 256          /* the bit-exact kernels for this call (every row sum in scipy's stored order) whatever
                                        the default says                                                                  */
-/* The reassociated plan the last call ran on: info[6] = {its units; the leaves it folded into their downstream cells' lanes;
+/* The reassociated plan the last call ran on: info[8] = {its units; the leaves it folded into their downstream cells' lanes;
  * 1 if a guard trip has switched the prepared plan off; folded leaves of the prepared plan; cells in pair form of the plan
- * the last call ran on, -1 if ALL its lanes pass pairs of sums; the same for the prepared plan (-1: pairs, or none prepared)}.
+ * the last call ran on, -1 if ALL its lanes pass pairs of sums; the same for the prepared plan (-1: pairs, or none prepared);
+ * calls routed again on the plan of pairs after a guard trip, so far; pair units of the plan the last call ran on}.
  * The PREPARED plan is the one xh_route_plan_prepare makes from the call's velocities, lengths and dt (reassociated form
  * only; XH_FLOW_FOLD=0 / XH_RSUM_SINGLE=0 switch its two parts off):
  *  - leaves that cannot fire (velocity * dt / length < 1) of river networks small enough to have no streams are carried by
@@ -250,7 +238,7 @@ int xh_mrtm_um_csr(int64_t ncell, const int64_t *h_upid, int64_t *h_indptr, int3
  *    sends negative flows -- and those few sit in pair units of their own.
  * Both rest on which cells can fire; the kernel guards the assumptions (folded leaves' storage, lateral inflow and initial
  * storage >= 0, the outflow of the halos' exit cells >= 0) and a trip routes the call again on the plan of pairs.          */
-int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[6]);
+int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[8]);
 int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                     const int32_t *h_ndays, double dt,
                     const double *d_flow_dist, const double *d_velocity, const double *d_area,

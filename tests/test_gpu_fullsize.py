@@ -101,22 +101,6 @@ def test_config3_full_length_routing_equals_oracle(full):
     full.pipe.run_mrtm()
     _check_bits(full, tag='validated')
     assert full.pipe.plan.info()['validated'] == n_val + 1 and full.pipe.plan.info()['last_tree_kernel'] == 2
-    full.pipe.route_flags = EXACT
-    # typed partition (XH_ROUTE_TYPED: pair units only where a neighbour can fire, plain units elsewhere), not the default.
-    # The first call finds cells that fire without being expected to (storage driven negative by an adjusted inflow), is
-    # routed again in pair form and teaches the plan; the second call runs on mostly plain units.  Same bits both times.
-    full.pipe.route_flags = _hip.XH_ROUTE_TYPED | EXACT
-    for rep in range(3):
-        full.pipe.out['chs'].zero()
-        full.pipe.out['avg'].zero()
-        full.pipe.run_mrtm()
-        _check_bits(full, tag=('typed', rep))
-    ti = full.pipe.plan.typed_info()
-    assert ti['plain_units'] > 500 and ti['typed_builds'] >= 1 and 0 <= ti['guard_trips'] <= 3, ti
-    full.pipe.route_flags = EXACT
-    full.pipe.run_mrtm()
-    _check_bits(full, tag='pairs again')
-    assert full.pipe.plan.typed_info()['plain_units'] == 0
     # the partition the time-skewed kernel ran on: nearly every lane used (1,054 units would be all of them), far more
     # streams than the 64-cell cut's ~860, all cells in dataflow units
     info = full.pipe.plan.info()
@@ -490,50 +474,3 @@ def test_config4_eight_shards_480_months():
             a.free()
         pipe.plan.close()
     assert seen.all()
-
-
-def test_adaptive_plain_form_survives_changes_of_forcing_and_velocity():
-    """Repeated plain calls on one plan switch to the selective plain form (tables made on a host thread).  Another forcing
-    on the same plan keeps it (which cells fire is a matter of velocity x dt / length and of the network, and the pair-form
-    call had learnt them); other stream velocities change the set of cells that can fire: that call routes in pair form,
-    the tables are rebuilt in the background and taken up again.  Every call is cross-checked on the device against the
-    workgroup-per-network kernel (XH_ROUTE_VALIDATE: any differing output bit is XH_ERR_DEVICE), whatever form it ran in."""
-    import time
-    from xanthos_amd import _hip, synth
-    from xanthos_amd.pipeline import pipeline_from_world
-    ctx = _hip.get_context(0)
-    w = synth.make_world()
-    nm = 120
-    pipe = pipeline_from_world(ctx, w, nm, 1961, 60, 24)
-    ctx.synth_forcing(5, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.001)
-    pipe.run(('pm', 'abcd'), fused=False)
-    ctx.sync()
-    pipe.route_flags = _hip.XH_ROUTE_VALIDATE | EXACT       # (the bit-exact kernel's machinery is the subject)
-    forms, builds = [], []
-    for phase in range(3):
-        if phase == 1:
-            # another scenario on the same plan: 40 x the runoff in a band of cells, none elsewhere
-            q = pipe.out['q'].download()
-            q2 = np.where(np.isnan(q), np.nan, 0.0)
-            band = (np.arange(w.ncell) % 7) == 3
-            q2[band] = q[band] * 40.0
-            pipe.out['q'].upload(q2)
-        if phase == 2:
-            v = np.array(w.velocity, dtype=np.float64)
-            v[::11] *= 3.0                               # more reaches shorter than velocity x dt: more cells can fire
-            pipe.d_velocity.upload(v)
-        for rep in range(5):
-            pipe.run_mrtm()
-            ctx.sync()                                   # a difference found by the validation would raise here
-            ti = pipe.plan.typed_info()
-            forms.append(ti['plain_units'])
-            builds.append(ti['typed_builds'])
-            time.sleep(0.3)                              # lets the planner thread finish between calls
-    info = pipe.plan.info()
-    assert info['validated'] >= 15 and info['reroutes'] == 0, info
-    assert forms[0] == 0 and min(forms[3:10]) > 0 and builds[9] == builds[4], (forms, builds)      # forcing: the plan stays
-    assert forms[10] == 0 and forms[14] > 0 and builds[14] > builds[9], (forms, builds)           # velocity: pair form, new tables
-    assert 0 <= pipe.plan.typed_info()['guard_trips'] <= 4
-    for a in list(pipe.out.values()) + list(pipe.forcing.values()):
-        a.free()
-    pipe.plan.close()

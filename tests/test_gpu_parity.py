@@ -386,37 +386,25 @@ rng = np.random.default_rng(11)
 runoff = rng.gamma(2.0, 30.0, (w.ncell, 12))
 ndays = o_months.set_month_arrays(12, 1973, 1973)[:, 2]
 ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
-import os, time
+import os
 ok = True
-# typed: first build, re-build with what was learnt, steady.  XH_TEST_CALLS: repeated plain calls (the adaptive plain form
-# builds its tables on a host thread from the second call on; the pause lets them be ready for the next call)
-for rep in range(3 if os.environ.get('XH_ROUTE_TYPED') else int(os.environ.get('XH_TEST_CALLS', '1'))):
+for rep in range(int(os.environ.get('XH_TEST_CALLS', '1'))):
     got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=int(os.environ.get('XH_TEST_FLAGS', '0')) | 256)      # (256 = XH_ROUTE_EXACT)
     ok = ok and all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
-    if os.environ.get('XH_TEST_CALLS'):
-        time.sleep(0.3)
 plan = um.plan(_hip.get_context())
 info = plan.info()
 print(json.dumps({'ok': bool(ok), 'kernel': int(info['last_tree_kernel']), 'units': int(info['flow_units']),
-                  'edges': int(info['flow_edges']), 'reroutes': int(info['reroutes']), 'typed': plan.typed_info()}))
+                  'edges': int(info['flow_edges']), 'reroutes': int(info['reroutes'])}))
 """
 
 
-@pytest.mark.parametrize('env', [{}, {'XH_FLOW_PIECE_CAP': '64', 'XH_FLOW_CHAIN': '0'}, {'XH_FLOW_PIECE_CAP': '20'},
-                                 {'XH_FLOW_CUTRULE': '0', 'XH_FLOW_TLIMIT': '9'}, {'XH_FLOW_SPARE': '0'},
-                                 {'XH_FLOW_SPARE': '700'}, {'XH_FLOW_RS': '16384'}, {'XH_ROUTE_TYPED': '1'},
-                                 {'XH_ROUTE_TYPED': '1', 'XH_FLOW_PLAIN_MIN_READS': '5'},
-                                 {'XH_ROUTE_TYPED': '1', 'XH_FLOW_PLAIN_MIN_READS': '3'}, {'XH_TEST_CALLS': '6'},
-                                 {'XH_TEST_CALLS': '6', 'XH_ROUTE_AUTO': '0'},
-                                 {'XH_TEST_CALLS': '6', 'XH_FLOW_PLAIN_MIN_READS': '3'},
-                                 {'XH_FLOW_LANE_TRIALS': '300'}, {'XH_FLOW_LANE_TRIALS': '300', 'XH_TEST_CALLS': '6'},
-                                 {'XH_FLOW_LANE_TRIALS': '300', 'XH_TEST_FLAGS': '8'}])
+@pytest.mark.parametrize('env', [{}, {'XH_FLOW_PIECE_CAP': '64'}, {'XH_FLOW_PIECE_CAP': '20'}, {'XH_FLOW_SPARE': '0'},
+                                 {'XH_FLOW_SPARE': '700'}, {'XH_FLOW_RS': '16384'}, {'XH_TEST_CALLS': '4'},
+                                 {'XH_TEST_FLAGS': '8'}])
 def test_route_partition_variants_bit_exact(env, tmp_path):
-    """The knobs of the dataflow partition (piece capacity, chains, which children become streams, class-aware packing,
-    spare workgroups, ring size; typed partition, and its selective form: only the units with the longest rows run in
-    plain form; cells moved to other lanes of their unit against LDS bank conflicts, for the time-skewed and -- flags 8 -- the
-    lock-step kernel) change which cells share a wave and who waits for whom -- never a bit of the result.  Each
-    variant routes the 3000-cell world in a process of its own (the knobs are read once per process) against the oracle."""
+    """The knobs of the bit-exact kernel's dataflow partition (piece capacity, spare workgroups, ring size; repeated calls on one
+    plan; the lock-step kernel, flags 8) change which cells share a wave and who waits for whom -- never a bit of the result.
+    Each variant routes the 3000-cell world in a process of its own (the knobs are read once per process) against the oracle."""
     import json
     import os
     import subprocess
@@ -433,21 +421,14 @@ def test_route_partition_variants_bit_exact(env, tmp_path):
     assert res['ok'] and res['kernel'] == (1 if env.get('XH_TEST_FLAGS') == '8' else 2) and res['reroutes'] == 0, res
     if env.get('XH_FLOW_PIECE_CAP') == '20':
         assert res['edges'] > 150, res          # many more streams than the default cut
-    if env.get('XH_ROUTE_TYPED'):
-        assert res['typed']['typed_builds'] >= 1 and res['typed']['plain_units'] >= 1, res
-    if env.get('XH_TEST_CALLS'):        # repeated plain calls: the adaptive plain form takes over, unless switched off
-        if env.get('XH_ROUTE_AUTO') == '0':
-            assert res['typed']['typed_builds'] == 0 and res['typed']['plain_units'] == 0, res
-        else:
-            assert res['typed']['typed_builds'] >= 1 and res['typed']['plain_units'] >= 1, res
 
 
-@pytest.mark.parametrize('limit,kernel', [(3000 * 12 * 8, 2), (3000 * 12 * 8 - 1, 3)])
+@pytest.mark.parametrize('limit,kernel', [(3000 * 12 * 8, 2), (3000 * 12 * 8 - 1, 1)])
 def test_route_row_offset_limit(limit, kernel, tmp_path):
     """k_mrtm_wave addresses a cell's runoff row with a 32-bit byte offset: a grid whose rows reach 4 GiB must be routed
     by a kernel with 64-bit offsets instead of wrapping silently.  XH_WAVE_ROW_LIMIT moves the limit down to the 3000-cell x
-    12-month world: exactly at the limit the current kernel routes it, one byte below round 2's kernel does -- bit-exact
-    either way."""
+    12-month world: exactly at the limit the time-skewed kernel routes it, one byte below the lock-step kernel does --
+    bit-exact either way."""
     import json
     import os
     import subprocess
@@ -770,49 +751,6 @@ def test_fault_inside_a_fed_call_is_settled_silently(hip):
     outputs_close(got, ref, OUTPUTS, 'backed off')
 
 
-def test_fed_routing_notices_new_velocities_in_place(hip):
-    """In the fed order the routing call's question to the device -- do the same cells fire as when the plain-form tables
-    were made? -- is asked in front of the first block of PM + ABCD (xh_route_precheck) and read without a wait when the
-    routing is launched.  Velocities overwritten IN PLACE (same device pointer) between two calls, so that other cells can
-    fire, must be noticed by that early question: the call falls back to the pair form, the tables are made again, and
-    every call equals the stage-by-stage order on the new velocities."""
-    import time
-    from xanthos_amd import synth
-    from xanthos_amd.pipeline import OUTPUTS, pipeline_from_world
-    ctx = hip.get_context()
-    w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=7, seed=29, outlet_frac=0.02)
-    nm = 240
-    pipe = pipeline_from_world(ctx, w, nm, 1971, 25, 24, route_flags=EXACT)      # (the bit-exact kernel's adaptive plain form)
-    ctx.synth_forcing(31, w.ncell, nm, ctx.upload(w.latitude), pipe.alloc_forcing(), nan_frac=0.002)
-
-    def check(tag):
-        pipe.run(fed=False, fused=False)
-        ref = pipe.download()
-        for rep in range(6):            # the adaptive plain form takes over after a few calls (tables made on a host thread)
-            for k in OUTPUTS:
-                pipe.out[k].zero()
-            pipe.run(fed=True, fused=False)
-            got = pipe.download()
-            for k in OUTPUTS:
-                assert np.array_equal(got[k], ref[k], equal_nan=True), (tag, k, rep)
-            time.sleep(0.2)
-        return pipe.plan.typed_info()
-    t0 = check('first velocities')
-    assert t0['plain_units'] >= 1 and t0['typed_builds'] >= 1, t0
-    # other cells can fire now: a fifth of the slow cells get fast, the fast ones slow (velocity * dt / length across 1)
-    rng = np.random.default_rng(3)
-    ratio = w.velocity * 10800.0 / w.flow_dist
-    v2 = w.velocity.copy()
-    flip = rng.random(w.ncell) < 0.2
-    v2[flip & (ratio <= 1.0)] *= 3.0 / np.maximum(ratio[flip & (ratio <= 1.0)], 0.05)
-    v2[ratio > 1.0] *= 0.5 / ratio[ratio > 1.0]
-    assert ((v2 * 10800.0 / w.flow_dist > 1.0) != (ratio > 1.0)).sum() > 50
-    pipe.d_velocity.upload(v2)
-    t1 = check('new velocities, same pointer')
-    assert t1['typed_builds'] > t0['typed_builds'], (t0, t1)
-    assert pipe.plan.info()['reroutes'] == 0
-
-
 def test_prepared_plan_notices_new_velocities_in_place(hip):
     """The default form's counterpart: the pipeline's prepared plan (single running sums, folded leaves) was made for the
     cells that can fire at the velocities it was given.  Velocities overwritten IN PLACE so that other cells can fire are
@@ -905,66 +843,3 @@ def test_first_dataflow_call_of_a_plan_is_cross_checked(hip, tmp_path, monkeypat
         held(got)
         seen.append(um5.plan(hip.get_context()).info()['validated'])
     assert seen == [0, 0, 1, 1, 1, 2, 2], seen
-
-
-LEARN_CHILD = r'''
-import json, os, sys, time
-sys.path.insert(0, sys.argv[1])
-import numpy as np
-from types import SimpleNamespace as NS
-from oracle import months as o_months, mrtm as o_mrtm
-from xanthos_amd import _hip, synth
-from xanthos_amd.routing import mrtm
-ctx = _hip.get_context(0)
-w = synth.make_world(nrow=60, ncol=120, ncell=3000, n_basins=5, seed=3, outlet_frac=0.02)
-st = NS(ngridrow=w.nrow, ngridcol=w.ncol)
-um = mrtm.upstream_genmatrix(mrtm.upstream(w.coords, mrtm.downstream(w.coords, w.flow_dir, st), st))
-rng = np.random.default_rng(11)
-runoff = rng.gamma(2.0, 30.0, (w.ncell, 12))
-ndays = o_months.set_month_arrays(12, 1973, 1973)[:, 2]
-ref = o_mrtm.route_series(um.tocsr(), w.flow_dist, w.velocity, w.area, runoff, ndays, 2)
-plan = um.plan(ctx)
-plan.prepare(w.flow_dist, w.velocity, 10800.0)
-first = plan.typed_info()
-ok, after = True, []
-for call in range(int(sys.argv[2])):
-    got = mrtm.route_series(um, w.flow_dist, w.velocity, w.area, runoff, ndays, 2, flags=256)      # XH_ROUTE_EXACT: its learning is the subject
-    ok = ok and all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
-    after.append(plan.typed_info())
-    time.sleep(0.3)
-print(json.dumps({'ok': bool(ok), 'prepared_builds': int(first['typed_builds']), 'after': after, 'reroutes': int(plan.info()['reroutes']),
-                  'files': sorted(f for f in os.listdir(os.environ['XH_CACHE_DIR']) if f.startswith('learnt_'))}))
-'''
-
-
-def test_learnt_cells_are_kept_per_box_and_the_next_process_starts_plain(tmp_path):
-    """xh_route_plan_prepare (round 4; the review's "call one runs plain"): the set of cells whose neighbours need {F, F2}
-    pairs cannot be fixed from velocity * dt / length alone (profiles/round4/fired_cells.txt), so what a run learns is kept
-    per box.  Process 1 finds nothing, routes in pair form, switches to the selective plain form after a few calls and leaves
-    the file; process 2 builds the selective tables before its FIRST call and routes that call on plain units, without a guard
-    trip -- bit-identical to the oracle either way."""
-    import json
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / 'learn_child.py'
-    script.write_text(LEARN_CHILD)
-    # (a process whose default form is the bit-exact one: what xh_route_plan_prepare prepares follows the process's default)
-    env = dict(os.environ, XH_CACHE_DIR=str(tmp_path / 'cache'), XH_ROUTE_LEARN_CACHE='1', XH_ROUTE_REASSOC='0')
-    os.makedirs(env['XH_CACHE_DIR'])
-
-    def run(calls):
-        out = subprocess.run([sys.executable, str(script), root, str(calls)], env=env, stdout=subprocess.PIPE,
-                             stderr=subprocess.PIPE, text=True, timeout=300)
-        assert out.returncode == 0, out.stderr[-2000:]
-        return json.loads(out.stdout.strip().splitlines()[-1])
-    one = run(6)
-    assert one['ok'] and one['reroutes'] == 0 and one['prepared_builds'] == 0, one
-    assert one['after'][0]['plain_units'] == 0                       # the first call of a box that knows nothing: pair form
-    assert one['after'][-1]['plain_units'] >= 1 and len(one['files']) == 1, one
-    two = run(2)
-    assert two['ok'] and two['reroutes'] == 0 and two['prepared_builds'] == 1, two
-    assert two['after'][0]['plain_units'] >= 1 and two['after'][0]['guard_trips'] == 0, two      # call one runs plain
-    assert two['after'][0]['typed_builds'] == 1 and set(one['files']) <= set(two['files']), two
-    assert any('.tables_' in f for f in two['files'])                # the selective tables are kept beside the learnt cells

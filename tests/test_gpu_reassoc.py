@@ -346,13 +346,13 @@ print(json.dumps({'kernel': int(info['last_tree_kernel']), 'units': int(info['fl
 
 
 @pytest.mark.parametrize('env', [{}, {'XH_FLOW_PIECE_CAP': '64'}, {'XH_FLOW_PIECE_CAP': '20'}, {'XH_FLOW_PIECE_CAP': '5'},
-                                 {'XH_FLOW_RS': '16384', 'XH_FLOW_SPARE': '3'}, {'XH_ROUTE_FENCED': 'lag'}, {'XH_ROUTE_FENCED': '1'},
+                                 {'XH_FLOW_RS': '16384', 'XH_FLOW_SPARE': '3'}, {'XH_ROUTE_FENCED': '1'},
                                  {'XH_FLOW_CHECK': '1', 'XH_FLOW_PIECE_CAP': '12'}])
 def test_route_reassoc_partition_variants(env, tmp_path):
     """The reassociated planner under other piece capacities (64: few streams, long chains; 5: a stream per handful of cells,
     chains of pieces everywhere), ring sizes (larger than the launch would pick: a ring below its formula -- 2,048 sub-steps
     here -- starves this plan's longest stream until a bounded wait gives up and the call is re-routed, round 6) and spare
-    workgroups, the lagged and the fully fenced publication, and the
+    workgroups, the fully fenced publication, and the
     planner's invariant checker inside the library: every variant within the bar of the oracle (a child process each: the
     switches are read when the library builds its plan)."""
     import json
@@ -488,7 +488,7 @@ for x, r, atol in zip(got, ref, (1e-3, 1e-9, 1e-9)):
     worst = max(worst, float((err / np.maximum(np.abs(r), 1e6 * atol)).max()))
 info = plan.info()
 print(json.dumps({'kernel': int(info['last_tree_kernel']), 'rsum': plan.rsum_info(), 'worst': worst, 'reroutes': int(info['reroutes']),
-                  'guard_trips': int(plan.typed_info()['guard_trips']),
+                  'guard_trips': int(plan.rsum_info()['guard_trips']),
                   'neg_storage_cells': int((neg_s > 0).sum()), 'fired_unexpectedly': int(((fired > 0) & (v / L * 10800.0 < 1)).sum()),
                   'neg_s_sites': [int(neg_s[idx['s%d_A' % k]]) for k in range(3)]}))
 """

@@ -1,7 +1,7 @@
 """Stress of the fed order's hand-over (xh_run_fused mode 1): many full-grid calls with a first block so small that the
-routing units always reach months the side stream has not delivered yet (XH_FEED_FIRST=128) -- every unit parks in the
+routing units always reach months the side stream has not delivered yet (the library's 128 months) -- every unit parks in the
 months-ready wait and has to be woken by the word.  Counts calls, re-routes (bounded-wait timeouts) and mismatches.
-python tools/feed_stress.py [calls]      (XH_FEED_POLL=load: the plain-load poll, for comparison)"""
+python tools/feed_stress.py [calls]"""
 import os
 import sys
 import time
@@ -9,7 +9,6 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault('XH_FEED_FIRST', '128')
 from xanthos_amd import _hip, synth                      # noqa: E402
 from xanthos_amd.pipeline import pipeline_from_world    # noqa: E402
 
@@ -46,6 +45,5 @@ for i in range(calls):
         bad += 0 if same else 1
         print('call {:4d}  {:.1f} ms  identical {}'.format(i, 1e3 * times[-1], same), flush=True)
 t = np.array(times) * 1e3
-print('calls {}  faults {}  mismatches {}  reroutes {}  ms per call: median {:.2f} p90 {:.2f} max {:.2f}  poll {}'.format(
-    calls, faults, bad, pipe.plan.info()['reroutes'], np.median(t), np.percentile(t, 90), t.max(),
-    os.environ.get('XH_FEED_POLL', 'rmw')))
+print('calls {}  faults {}  mismatches {}  reroutes {}  ms per call: median {:.2f} p90 {:.2f} max {:.2f}'.format(
+    calls, faults, bad, pipe.plan.info()['reroutes'], np.median(t), np.percentile(t, 90), t.max()))

@@ -39,7 +39,7 @@ if os.environ.get('XH_STATS_LOOP'):
     print('back-to-back steps: mrtm_route avg ms', ms / n)
 st = pipe.plan.stats().astype(np.float64)
 nsub = sum(int(d) * 8 for d in pipe.ndays)
-print('plan', pipe.plan.info(), 'typed', pipe.plan.typed_info())
+print('plan', pipe.plan.info(), 'reassociated', pipe.plan.rsum_info())
 print('route ms', ms / n, 'substeps', nsub, 'us/substep', ms / n * 1e3 / nsub)
 raw3 = pipe.plan.stats()[:, 3]
 if os.environ.get('XH_STATS_SAVE'):

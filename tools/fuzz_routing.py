@@ -47,23 +47,17 @@ def one_case(rng, k):
     w, um, nm, spin, dt, ndays, q, L, v, S0, ncell = c.w, c.um, c.nm, c.spin, c.dt, c.ndays, c.q, c.L, c.v, c.S0, c.ncell
     ref = o_mrtm.route_series(um.tocsr(), L, v, w.area, q, ndays, spin, S0=S0, dt=dt)
     used = []
-    # 64 = XH_ROUTE_TYPED, twice: the second call runs on the partition the first one taught (cells seen firing); the plain
-    # calls at the end give the adaptive plain form (tables on a host thread from the second plain call on) time to take over
-    adaptive = 0
-    for flags in (0, 64, 64, 8, 4, 0, 0, 0, 0):
+    for flags in (0, 8, 4, 0):
         got = mrtm.route_series(um, L, v, w.area, q, ndays, spin, S0=S0, dt=dt, flags=flags | EXACT)
-        if flags == 0 and len(used) >= 5:
-            time.sleep(0.03)
-            adaptive = max(adaptive, um.plan(_hip.get_context(0)).typed_info()['plain_units'])
         for a, b in zip(got, ref):
             if not np.array_equal(a, b, equal_nan=True):
                 plan = um.plan(_hip.get_context(0))
                 bad = ~((a == b) | (np.isnan(a) & np.isnan(b)))
                 raise AssertionError('case {} flags {}: ncell {} months {} spin {} dt {} mismatch in {} values of {} cells; '
-                                     'plan {} typed {}'.format(k, flags, ncell, nm, spin, dt, int(bad.sum()),
-                                                               int(bad.reshape(len(bad), -1).any(axis=1).sum()), plan.info(),
-                                                               plan.typed_info()))
+                                     'plan {}'.format(k, flags, ncell, nm, spin, dt, int(bad.sum()),
+                                                      int(bad.reshape(len(bad), -1).any(axis=1).sum()), plan.info()))
         used.append(um.plan(_hip.get_context(0)).info()['last_tree_kernel'])
+    adaptive = 0
     return ncell, nm, spin, dt, used, adaptive
 
 
@@ -77,10 +71,8 @@ def main():
         ncell, nm, spin, dt, used, adaptive = one_case(rng, k)
         kernels[used[0]] = kernels.get(used[0], 0) + 1
         n_adaptive += adaptive > 0
-        print('case {:3d}: {:5d} cells {:2d} months spin {:2d} dt {:6.0f} kernels {} adaptive plain units {} ok'.format(
-            k, ncell, nm, spin, dt, used, adaptive), flush=True)
-    print('{} cases bit-exact in {:.0f} s; default path used kernels {}; the adaptive plain form took over in {} cases'.format(
-        n, time.time() - t0, kernels, n_adaptive))
+        print('case {:3d}: {:5d} cells {:2d} months spin {:2d} dt {:6.0f} kernels {} ok'.format(k, ncell, nm, spin, dt, used), flush=True)
+    print('{} cases bit-exact in {:.0f} s; the time-skewed path (flags 0) used kernels {}'.format(n, time.time() - t0, kernels))
 
 
 if __name__ == '__main__':

@@ -25,7 +25,7 @@ zg = (raw3 >> np.uint64(44)).astype(np.float64)
 st = st.astype(np.float64)
 nsub = sum(int(d) * 8 for d in pipe.ndays)
 groups = nsub / 16.0
-print('route ms', ms / n, 'typed', pipe.plan.typed_info())
+print('route ms', ms / n, 'reassociated', pipe.plan.rsum_info())
 plain, total, zone, fin = st[:, 0], st[:, 1], st[:, 4], st[:, 5]
 print('units', len(st), 'boundary groups per unit: median %.0f of %.0f' % (np.median(zg), groups))
 for flag, name in ((0, 'isolated'), (16, 'imports'), (32, 'exports'), (48, 'both')):

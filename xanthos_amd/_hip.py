@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('XH_LIBRARY') or os.path.join(_HERE, 'libxanthos_hip.so')
 
 XH_ROUTE_DEFAULT, XH_ROUTE_FORCE_FALLBACK, XH_ROUTE_ATOMIC, XH_ROUTE_NO_DATAFLOW, XH_ROUTE_NO_SKEW = 0, 1, 2, 4, 8
-XH_ROUTE_TEST_FAULT, XH_ROUTE_VALIDATE, XH_ROUTE_TYPED = 16, 32, 64
+XH_ROUTE_TEST_FAULT, XH_ROUTE_VALIDATE = 16, 32
 XH_ROUTE_REASSOC, XH_ROUTE_EXACT = 128, 256      # reassociated (tolerance) form of the routing kernel / the bit-exact kernels
 XH_ROUTE_NO_PLAIN = 0x4000                       # (xh_common.h, what a guard trip re-routes with) pairs of sums in every unit: not the prepared plan
 
@@ -85,7 +85,6 @@ SIGNATURES = {
     'xh_route_plan_destroy': (None, [_P]),
     'xh_route_plan_info': (c_int, [_P, POINTER(c_int64)]),
     'xh_route_plan_stats': (c_int, [_P, c_int64, _P, POINTER(c_int64)]),
-    'xh_route_plan_typed_info': (c_int, [_P, _P]),
     'xh_route_plan_rsum_info': (c_int, [_P, POINTER(c_int64)]),
     'xh_route_plan_prepare': (c_int, [_P, _P, _P, _P, c_double]),
     'xh_mrtm_downstream': (c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
@@ -535,15 +534,10 @@ class RoutePlan:
 
     def rsum_info(self):
         """The reassociated plan the last call ran on (xh_route_plan_rsum_info)."""
-        arr = (c_int64 * 6)()
+        arr = (c_int64 * 8)()
         self.ctx._check(lib().xh_route_plan_rsum_info(self.handle, arr))
-        return dict(zip(('units', 'folded', 'fold_disabled', 'prepared_folded', 'pair_cells', 'prepared_pair_cells'), list(arr)))
-
-    def typed_info(self):
-        """Pair / plain units of the dataflow partition (xh_route_plan_typed_info)."""
-        arr = (c_int64 * 4)()
-        self.ctx._check(lib().xh_route_plan_typed_info(self.handle, arr))
-        return dict(zip(('plain_units', 'typed_builds', 'guard_trips', 'typed_units'), list(arr)))
+        return dict(zip(('units', 'folded', 'fold_disabled', 'prepared_folded', 'pair_cells', 'prepared_pair_cells', 'guard_trips',
+                         'pair_units'), list(arr)))
 
     def stats(self):
         """[units, 6] uint64 per-unit accounting of the last launch (needs XH_FLOW_STATS=1), or None."""

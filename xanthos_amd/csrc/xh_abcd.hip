@@ -440,18 +440,11 @@ int xh_abcd_prepare(xh_ctx *ctx, int64_t ncell, int32_t nmonths, int32_t spinup,
     return XH_OK;
 }
 
-// XH_ABCD_KERNEL = 0 / 32 / 64 forces the thread-per-cell kernel or the tiled kernel with that many cells per wave for
-// both passes (profiling; results are identical).  Default: spin-up on the thread-per-cell kernel -- it writes nothing,
-// so staging its reads through LDS only adds work (0.09 ms against 0.18 ms for 120 months) -- and the simulation on the
-// tiled kernel (whole-line traffic: 0.61 ms against 0.81 ms for 67,420 x 600).
-static int abcd_env() {
-    static const int v = [] {
-        const char *e = getenv("XH_ABCD_KERNEL");
-        const int x = e ? atoi(e) : -1;
-        return (x == 0 || x == 32 || x == 64) ? x : -1;
-    }();
-    return v;
-}
+// Which kernel marches: the spin-up on the thread-per-cell kernel -- it writes nothing, so staging its reads through LDS only
+// adds work (0.09 ms against 0.18 ms for 120 months) -- and the simulation on the tiled kernel (whole-line traffic: 0.61 ms
+// against 0.81 ms for 67,420 x 600).  (XH_ABCD_KERNEL / XH_ABCD_CPW forced other choices until round 5: measured, recorded
+// in profiles/round2-3, removed.)
+static int abcd_env() { return -1; }
 
 int xh_abcd_enqueue_spinup(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, const double *d_pars,
                            const double *d_pet, const double *d_precip, const double *d_tmin) {
@@ -511,10 +504,6 @@ int xh_abcd_enqueue_sim(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, int
                 cpw = c;
                 break;
             }
-        if (const char *env = getenv("XH_ABCD_CPW")) {      // experiments: 32 / 40 / 48
-            const int v = atoi(env);
-            if (v == 32 || v == 40 || v == 48) cpw = v;
-        }
     }
     const unsigned blocks_cpw = (unsigned)((ncell + cpw - 1) / cpw);
     double *state = whole ? nullptr : s.d_state;

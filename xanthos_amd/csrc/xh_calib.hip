@@ -473,11 +473,9 @@ int xh_calib_problem_plan(xh_ctx *ctx, int32_t nbasins, const int64_t *h_ncell, 
     XH_REQUIRE(ctx, npar == 4 || npar == 5, "xh_calib_objective: npar must be 4 (no snow) or 5");
     XH_REQUIRE(ctx, (npar == 5) == (h_tmin_t != nullptr), "xh_calib_objective: npar = 5 requires tmin and vice versa");
     XH_REQUIRE(ctx, spinup >= 25 && spinup <= nmonths, "xh_calib_objective: spin-up must be in [25, nmonths]");
-    // member-lane kernel when the population fills its waves of 64 members to at least 3/4 (XH_CALIB_LAYOUT = 0 / 1
-    // forces one: profiling and tests)
+    // member-lane kernel when the population fills its waves of 64 members to at least 3/4
     const int mblocks = (nmembers + 63) / 64;
-    int ml = (4 * nmembers >= 3 * 64 * mblocks) ? 1 : 0;
-    if (const char *e = getenv("XH_CALIB_LAYOUT")) ml = (e[0] == '1') ? 1 : (e[0] == '0' ? 0 : ml);
+    const int ml = (4 * nmembers >= 3 * 64 * mblocks) ? 1 : 0;
     *member_lanes = ml;
     const int cs = ml ? CM : 64;                                 // cells per chunk
     basins.assign(nbasins, xh_calib_basin());

@@ -5,12 +5,27 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
 #include <vector>
 
 #include "xanthos_hip.h"
+
+// The library's switches (README lists them).  One place reads each of them.
+static inline bool xh_env_on(const char *name, bool dflt) {      // "0" = off, anything else = on, unset = dflt
+    const char *e = getenv(name);
+    return e ? e[0] != '0' : dflt;
+}
+static inline std::string xh_cache_dir() {      // per-box cache of partitions and first-check markers; "" = none
+    if (const char *d = getenv("XH_CACHE_DIR")) return d;
+    if (const char *h = getenv("HOME")) return std::string(h) + "/.cache/xanthos_amd";
+    return std::string();
+}
+static inline bool xh_plan_cache_on() { return xh_env_on("XH_ROUTE_LEARN_CACHE", true); }      // partitions kept per box
+static inline bool xh_flow_debug() { return getenv("XH_FLOW_DEBUG") != nullptr; }               // partition statistics on stderr
+static inline bool xh_flow_check() { return getenv("XH_FLOW_CHECK") != nullptr; }               // planner invariants on every plan
 
 struct xh_timer_slot {
     double done_ms = 0.0;

@@ -81,18 +81,20 @@ int xh_fault_check(xh_ctx *ctx) {
         return XH_OK;
     }
     // Either a bounded wait between routing units timed out (the device is shared and the units were not all resident)
-    // or a plain unit met an input its shortcut does not cover (XH_FAULT_GUARD): the dataflow kernels of these calls left
-    // invalid outputs.  Clear the word and route them again -- after a guard fault with every unit in pair form (still
-    // the dataflow kernel; the plan stops using plain units), otherwise, or if that faults too, with one workgroup per
-    // network (no waits between workgroups).
+    // or a guard of a PREPARED routing plan tripped (XH_FAULT_GUARD: a folded leaf that can fire after all, negative runoff or
+    // initial storage, a negative outflow leaving a halo of pair units): the dataflow kernels of these calls left invalid
+    // outputs.  Clear the word and route them again -- after a guard fault on the plan of pairs (still the dataflow kernel;
+    // the prepared plan is given up), otherwise, or if that faults too, with one workgroup per network (no waits between
+    // workgroups).
     XH_HIP(ctx, hipMemsetAsync(ctx->d_fault, 0, 64, ctx->stream));
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t seq_now = ctx->work_seq;
     const bool later_work = !pending.empty() && seq_now != pending.back().seq_after;
     bool pairs_first = code == XH_FAULT_GUARD;
     if (pairs_first) {
-        fprintf(stderr, "[libxanthos_hip] a cell that cannot overdraw its channel by velocity * dt / length did (denormal "
-                "storage, negative runoff or initial storage): routing %zu call(s) again with every unit in pair form\n",
+        fprintf(stderr, "[libxanthos_hip] a guard of the prepared routing plan tripped (a cell that cannot overdraw its channel by "
+                "velocity * dt / length did: negative runoff or initial storage, other velocities than the plan was prepared "
+                "for, a negative outflow beyond a halo): routing %zu call(s) again on the plan of pairs\n",
                 pending.size());
         for (const xh_route_record &r : pending) {
             int rc = xh_route_rerun(ctx, r, true);
@@ -143,7 +145,7 @@ int xh_fault_check(xh_ctx *ctx) {
     if (later_work)
         return xh_fail(ctx, XH_ERR_DEVICE, "routing kernel fault %u: the routing outputs were recomputed %s and are valid "
                        "now, but results of calls enqueued after xh_route_series read the invalid ones and must be recomputed",
-                       code, pairs_first ? "by the dataflow kernel with every unit in pair form (a plain unit's guard had tripped)"
+                       code, pairs_first ? "by the dataflow kernel on the plan of pairs (a guard of the prepared plan had tripped)"
                                          : "with the workgroup-per-network kernel");
     return XH_OK;
 }

@@ -52,15 +52,13 @@ int fused_resources(xh_ctx *ctx, size_t n_events) {
         // bounded wait, a fault, a re-route: observed).  Streams of different priority never share a queue.
         int least = 0, greatest = 0;
         XH_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        // (the context's stream has the default priority 0; a device whose range has nothing below it gets the other end;
-        // XH_FEED_PRIO=high / low: experiments)
-        int prio = least != 0 ? least : greatest;
+        // (the context's stream has the default priority 0; a device whose range has nothing below it gets the other end)
+        const int prio = least != 0 ? least : greatest;
         // one priority level only: the side stream would share the context stream's hardware queues and its kernels could sit
         // behind the routing kernel that waits for them -- no fed order on such a device (run_fed turns the call down)
         ctx->feed_queue_ok = least != greatest;
-        if (const char *env = getenv("XH_FEED_PRIO")) prio = env[0] == 'h' ? greatest : least;
         XH_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream[0], hipStreamNonBlocking, prio));
-        if (getenv("XH_FLOW_DEBUG")) fprintf(stderr, "[libxanthos_hip] side stream priority %d (range %d .. %d)\n", prio, least, greatest);
+        if (xh_flow_debug()) fprintf(stderr, "[libxanthos_hip] side stream priority %d (range %d .. %d)\n", prio, least, greatest);
     }
     while (ctx->side_events.size() < n_events) {
         hipEvent_t e = nullptr;
@@ -108,8 +106,8 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
         b0 = std::max(b0, (int)((std::max(need, 0ll) + 15) & ~15ll));
     }
     b0 = std::max(b0, 32);
-    if (const char *env = getenv("XH_FEED_FIRST"))      // experiments
-        b0 = std::max((std::max(a->abcd_spinup, a->routing_spinup) + 15) & ~15, atoi(env) & ~15);
+    // (more months in front do not pay: 128 / 160 / 192 / 224 / 256 at the full grid give 13.9 / 14.0 / 14.1 / 14.1 / 14.3 ms per
+    // step, round 6: profiles/round6/fed_penalty.txt)
     hipStream_t A = ctx->stream, B = ctx->side_stream[0];
     auto pm_block = [&](hipStream_t st, int m0, int m1) {
         return xh_pm_enqueue(ctx, st, pm, m0, m1 - m0, a->d_tas, a->d_tmin, a->d_rhs, a->d_wind, a->d_rsds, a->d_rlds, a->d_tairprev,
@@ -141,15 +139,7 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
     double *staged = reinterpret_cast<double *>(static_cast<char *>(ctx->d_feed) + 256);
     hipEvent_t ev_blk0 = ctx->side_events[0], ev_done = ctx->side_events[1];
 
-    // what the routing call will want to know from the device goes first: by the time the call is made the answer is on the
-    // host, and the launch is put together while the first block still runs (xh_route_precheck)
-    static const bool precheck = !(getenv("XH_ROUTE_PRECHECK") && getenv("XH_ROUTE_PRECHECK")[0] == '0');      // 0: A/B runs
-    int rc = precheck ? xh_route_precheck(ctx, a->plan, a->d_flow_dist, a->d_velocity, a->dt) : XH_OK;
-    if (rc) return rc;
-    struct PreGuard {
-        xh_route_plan *plan;
-        ~PreGuard() { xh_route_precheck_cancel(plan); }
-    } pre_guard{a->plan};
+    int rc;
     rc = pm_block(A, 0, b0);
     if (rc) return rc;
     rc = xh_abcd_enqueue_spinup(ctx, A, ab, a->d_pars, a->d_pet, a->d_precip, a->d_abcd_tmin);
@@ -180,10 +170,7 @@ int run_fed(xh_ctx *ctx, const xh_fused_args *a, xh_pm_setup &pm, xh_abcd_setup 
     std::string first_error;
     auto rest = [&]() -> int {
         XH_HIP(ctx, hipStreamWaitEvent(B, ev_blk0, 0));
-        static const unsigned long long gate_ticks = [] {
-            const char *env = getenv("XH_FEED_GATE_US");
-            return (unsigned long long)(env ? atoll(env) : 20000) * 100ull;
-        }();
+        constexpr unsigned long long gate_ticks = 20000ull * 100ull;      // 20 ms of the 100 MHz counter
         {   // (its timer also tells callers how many calls were routed this way: xh_timing_get "feed_gate")
             xh_span sp = xh_span_begin_on(ctx, "feed_gate", B);
             hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, B, w_epoch, feed.epoch, gate_ticks);

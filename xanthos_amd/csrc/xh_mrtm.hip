@@ -343,11 +343,7 @@ struct xh_route_plan {
     DevBuf d_class_units[N_CLASS];
     std::vector<int> rest_units[N_CLASS];        // only the units of networks the dataflow kernel does not route
     DevBuf d_rest_units[N_CLASS];
-    FlowPlan *flow = nullptr;                    // tree-shaped networks as single-wave dataflow units, every unit in pair form
-    // Typed partition (pair + plain units, xh_flow_plan.h): depends on WHICH cells can fire, i.e. on velocity, flow
-    // distance and dt, which only arrive with xh_route_series.  Built on the first call from a copy of the topology and
-    // rebuilt when a later call's data give another set of such cells (one small kernel per call checks).
-    FlowPlan *flow_typed = nullptr;
+    FlowPlan *flow = nullptr;                    // tree-shaped networks as single-wave dataflow units of the BIT-EXACT kernels
     // Reassociated form (XH_ROUTE_REASSOC; xh_flow_rsum.cpp, k_mrtm_rsum): a partition of its own over the same cells, made
     // with the plan when the environment asks for the form, else on the first call that does.  Needs nothing of a call's data.
     FlowPlan *flow_rsum = nullptr;
@@ -369,28 +365,7 @@ struct xh_route_plan {
     std::vector<int8_t> h_sign;
     std::vector<int> h_comp;
     int h_ncomp = 0;
-    DevBuf d_capable;                            // [ncell] flags the typed plan was built for
-    DevBuf d_learn;                              // [ncell] cells a kernel saw firing although they were not expected to: they
-                                                 // count as cells that can fire from the next call on (k_capable)
-    int guard_trips = 0;
-    unsigned *d_cap_diff = nullptr, *h_cap_diff = nullptr;      // cells whose flag differs this call (device word, pinned mirror)
-    bool typed_disabled = false;                 // a guard fault showed that the plain form does not hold for this data
-    int64_t typed_builds = 0;
-    bool last_typed = false;                     // the last call ran on the typed plan
-    int typed_sel = -1;                          // plain_min_reads the typed plan at hand was built with (0 = full typed form)
-    // Adaptive plain form (default; XH_ROUTE_AUTO=0 switches it off).  A plan that is routed on again and again -- a
-    // scenario sweep, the bench loop -- is worth a second partition: from the second plain call on, a host thread builds the
-    // SELECTIVE tables (xh_flow_plan.h: all-pairs partition, only the units with the longest rows in plain form) for the
-    // cells seen firing so far; the call that finds them ready uploads them and routes on them from then on (-4 to -5 % per
-    // call).  A caller who routes once or twice never pays for it.  What can go wrong is covered by the
-    // machinery of the typed form: a guard trip re-routes the call in pair form and the tables are rebuilt, in the
-    // background again, with what was learnt.
-    int64_t auto_calls = 0;
-    std::thread auto_thread;
-    std::atomic<int> auto_state{0};              // 0 idle, 1 thread building, 2 tables ready, 3 failed (stays off)
-    FlowTables auto_tables;
-    std::vector<unsigned char> auto_cap;         // the flags the tables in the making are for
-    std::string auto_err;
+    int guard_trips = 0;                         // calls routed again on the plan of pairs after a guard of the prepared plan tripped
     int last_tree_kernel = 0;                    // last xh_route_series: 0 none, 1 monthly streams, 2 time-skewed
     int64_t reroutes = 0;                        // calls re-run with one workgroup per network after a device fault
     // After a fault the dataflow kernels are skipped for the next `skip_calls` calls of this plan (the device is shared:
@@ -408,14 +383,6 @@ struct xh_route_plan {
     int64_t dataflow_calls = 0;
     bool validate_due = false;
     uint64_t topo_hash = 0;
-    // xh_route_plan_prepare: what a run LEARNS about a grid -- the cells that fire although velocity * dt / length says they
-    // cannot -- is kept per box (a file beside the first-check marker, keyed by topology, velocity, flow distance and dt), so
-    // that the next process can build the selective plain tables BEFORE its first call (on the thread that makes the plan)
-    // and route its first call on them.  The guard still covers whatever the file does not know.
-    bool prepared = false;
-    std::string learn_path;
-    std::vector<unsigned char> learn_saved;
-    int learn_looks = 0, learn_trips_seen = 0;
     int64_t n_rest_units = 0, n_fb_rest = 0;
     bool fb_rest_single_ds = true;
     DevBuf d_fbr_cells, d_fbr_ptr, d_fbr_col, d_fbr_sgn, d_fbr_ds;
@@ -432,11 +399,6 @@ struct xh_route_plan {
     hipEvent_t ev_fork = nullptr, ev_join[N_CLASS + 1] = {};
     hipStream_t fb_stream = nullptr;
     void *d_pool = nullptr;     // the allocation behind the tables uploaded at create (UploadPool)
-    // xh_route_precheck: the typed plan's "same cells can fire?" question asked ahead of the call that needs the answer
-    hipEvent_t ev_pre = nullptr;
-    bool pre_armed = false;
-    const double *pre_flow_dist = nullptr, *pre_velocity = nullptr;
-    double pre_dt = 0.0;
 };
 
 namespace {
@@ -535,13 +497,9 @@ static bool rsum_tables_get(xh_ctx *ctx, xh_route_plan *plan, const unsigned cha
     opt.foldable = foldable;
     opt.capable = capable;
     if (const char *e = getenv("XH_RSUM_HALO")) opt.halo = std::max(atoi(e), 0);      // cells in pair form below a cell that may leave negative storage
-    if (const char *e = getenv("XH_RSUM_PAIR_IMPORTS")) opt.pair_imports = atoi(e);    // experiment: imported streams per pair unit
     std::string cache;
-    static const bool cache_on = !(getenv("XH_ROUTE_LEARN_CACHE") && getenv("XH_ROUTE_LEARN_CACHE")[0] == '0');
-    if (cache_on && !opt.debug) {
-        std::string dir;
-        if (const char *d = getenv("XH_CACHE_DIR")) dir = d;
-        else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/xanthos_amd";
+    if (xh_plan_cache_on() && !opt.debug) {
+        const std::string dir = xh_cache_dir();
         if (!dir.empty()) {
             uint64_t h = plan->topo_hash;
             // (the planner's own version: a planner-only rebuild must not find the partitions of the one before it)
@@ -596,7 +554,7 @@ static int rsum_plan_build(xh_ctx *ctx, xh_route_plan *plan) {
     FlowTables t;
     if (!rsum_tables_get(ctx, plan, nullptr, nullptr, t, handled)) return XH_OK;
     if (t.n_cells != plan->flow->n_cells) return XH_OK;      // must route exactly the cells the bit-exact plan routes
-    if (getenv("XH_FLOW_CHECK")) {
+    if (xh_flow_check()) {
         const std::string bad = flow_tables_check_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
                                                        plan->h_sign.data(), handled, t);
         if (!bad.empty()) return xh_fail(ctx, XH_ERR_ARG, "reassociated flow plan check: %s", bad.c_str());
@@ -669,23 +627,16 @@ extern "C" int xh_route_plan_create(xh_ctx *ctx, int64_t ncell, const int64_t *h
     plan->largest_network = ncomp ? *std::max_element(comp_size.begin(), comp_size.end()) : 0;
 
     lap("validation + components");
-    // ---- tree-shaped networks also get a dataflow layout (xh_mrtm_flow.hip); XH_MRTM_FLOW=0 disables it
+    // ---- tree-shaped networks also get a dataflow layout (xh_mrtm_flow.hip)
     std::vector<char> flow_cell;
     {
-        const char *env = getenv("XH_MRTM_FLOW");
-        if (!(env && env[0] == '0')) {
-            const int frc = flow_plan_build(ctx, n, h_indptr, h_indices, h_sign, comp, ncomp, nullptr, flow_cell, &plan->flow);
-            if (frc) {
-                route_plan_free(plan, false);
-                return frc;
-            }
+        const int frc = flow_plan_build(ctx, n, h_indptr, h_indices, h_sign, comp, ncomp, flow_cell, &plan->flow);
+        if (frc) {
+            route_plan_free(plan, false);
+            return frc;
         }
         if (flow_cell.empty()) flow_cell.assign(n, 0);
         if (plan->flow) {
-            if (hipMalloc(&plan->d_learn.p, (size_t)n + 256) != hipSuccess || hipMemset(plan->d_learn.p, 0, (size_t)n + 256) != hipSuccess) {
-                route_plan_free(plan, false);
-                return xh_fail(ctx, XH_ERR_HIP, "xh_route_plan_create: device allocation failed");
-            }
             {
                 uint64_t h = 1469598103934665603ull;      // FNV-1a over the CSR structure
                 auto mix = [&](const void *p, size_t nbytes) {
@@ -915,7 +866,6 @@ static void route_plan_free(xh_route_plan *plan, bool settle) {
     }
     if (plan->fb_stream) (void)hipStreamDestroy(plan->fb_stream);
     if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
-    if (plan->ev_pre) (void)hipEventDestroy(plan->ev_pre);
     for (int k = 0; k <= N_CLASS; ++k)
         if (plan->ev_join[k]) (void)hipEventDestroy(plan->ev_join[k]);
     DevBuf *bufs[] = {&plan->d_cell_of_slot, &plan->d_ent, &plan->d_cnt, &plan->d_fb_cells, &plan->d_fb_ptr,
@@ -924,15 +874,9 @@ static void route_plan_free(xh_route_plan *plan, bool settle) {
                       &plan->d_fbr_col, &plan->d_fbr_sgn, &plan->d_fbr_ds};
     for (DevBuf *b : bufs) free_buf(*b);
     if (plan->d_pool) (void)hipFree(plan->d_pool);
-    if (plan->auto_thread.joinable()) plan->auto_thread.join();
     flow_plan_destroy(plan->flow);
-    flow_plan_destroy(plan->flow_typed);
     flow_plan_destroy(plan->flow_rsum);
     flow_plan_destroy(plan->flow_rsum_fold);
-    free_buf(plan->d_capable);
-    free_buf(plan->d_learn);
-    if (plan->d_cap_diff) (void)hipFree(plan->d_cap_diff);
-    if (plan->h_cap_diff) (void)hipHostFree(plan->h_cap_diff);
     delete plan;
 }
 
@@ -948,7 +892,7 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
     info[5] = plan->total_slots;
     info[6] = plan->all_single_ds ? 1 : 0;
     int64_t fi[5];
-    flow_plan_info(plan->last_rsum ? plan->last_rsum_plan : (plan->last_typed ? plan->flow_typed : plan->flow), fi);
+    flow_plan_info(plan->last_rsum ? plan->last_rsum_plan : plan->flow, fi);
     info[7] = fi[0];                  // dataflow units
     info[8] = fi[1];                  // stream edges
     info[9] = fi[2];                  // pipeline depth
@@ -965,7 +909,7 @@ extern "C" int xh_route_plan_info(const xh_route_plan *plan, int64_t info[16]) {
 extern "C" int xh_route_plan_stats(xh_route_plan *plan, int64_t max_words, uint64_t *h_words, int64_t *n_words) {
     if (!plan || !n_words) return XH_ERR_ARG;
     std::vector<unsigned long long> st;
-    int rc = flow_stats_fetch(plan->ctx, plan->last_rsum ? plan->last_rsum_plan : (plan->last_typed ? plan->flow_typed : plan->flow), st);
+    int rc = flow_stats_fetch(plan->ctx, plan->last_rsum ? plan->last_rsum_plan : plan->flow, st);
     if (rc) return rc;
     *n_words = (int64_t)st.size();
     if (h_words)
@@ -1009,19 +953,8 @@ __global__ void __launch_bounds__(256) k_count_far(const double *a, const double
 
 // Which cells can fire (mrtm.py:54: dSdt * dt < -S).  With non-negative inflows dSdt >= -F = -S * tauinv, so a cell whose
 // tauinv * dt stays below 1 cannot (rounding: three operations of relative error 2^-53 each against a margin of 2^-20;
-// denormal storage and negative inputs are outside the argument and are what the kernel's guard is for).  A NaN ratio
-// counts as "can".  flags_new[c] is written, and compared with the flags the typed plan was built for.
+// negative inputs are outside the argument and are what the guards of the prepared plans are for).  A NaN ratio counts as "can".
 constexpr double CAPABLE_THRESHOLD = 1.0 - 1.0 / 1048576.0;
-__global__ void __launch_bounds__(256) k_capable(const double *velocity, const double *flow_dist, double dt, int n,
-                                                 const unsigned char *learn, unsigned char *flags_new,
-                                                 const unsigned char *flags_plan, unsigned *diff) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const double tauinv = velocity[c] / flow_dist[c];                          // mrtm.py:40
-    const unsigned char cap = ((tauinv * dt <= CAPABLE_THRESHOLD) ? 0 : 1) | (learn[c] ? 1 : 0);
-    flags_new[c] = cap;
-    if (!flags_plan || flags_plan[c] != cap) atomicAdd(diff, 1u);
-}
 
 // XH_ROUTE_VALIDATE: the call has just been routed by a dataflow kernel into the caller's arrays; route it again with one
 // workgroup per network (barriers, no streams, no reliance on the ordering of write-through stores) into scratch arrays
@@ -1085,35 +1018,7 @@ static int route_validate(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int
     return XH_OK;
 }
 
-// After a dataflow call has been confirmed (stream synchronised, no fault): look at what the kernels have learnt so far and
-// keep it for later processes.  The first few confirmed calls of a plan and every call after a guard trip; 1 byte per cell.
-static void learn_save(xh_route_plan *plan) {
-    if (plan->learn_path.empty() || !plan->d_learn.p) return;
-    if (plan->learn_looks >= 4 && plan->learn_trips_seen == plan->guard_trips) return;
-    plan->learn_looks += 1;
-    plan->learn_trips_seen = plan->guard_trips;
-    std::vector<unsigned char> now((size_t)plan->ncell);
-    if (hipMemcpy(now.data(), plan->d_learn.p, now.size(), hipMemcpyDeviceToHost) != hipSuccess) {
-        (void)hipGetLastError();
-        return;
-    }
-    if (now == plan->learn_saved) return;
-    const std::string tmp = plan->learn_path + ".tmp." + std::to_string((long long)getpid());      // ranks may write the same file
-    const std::string dir = plan->learn_path.substr(0, plan->learn_path.rfind('/'));
-    for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
-        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
-    if (FILE *f = fopen(tmp.c_str(), "wb")) {
-        const bool ok = fwrite(now.data(), 1, now.size(), f) == now.size();
-        fclose(f);
-        if (ok && rename(tmp.c_str(), plan->learn_path.c_str()) == 0) plan->learn_saved.swap(now);
-        else (void)remove(tmp.c_str());
-    }
-}
-
-void xh_route_confirm(const xh_route_record &r) {
-    r.plan->fault_streak = 0;
-    learn_save(r.plan);
-}
+void xh_route_confirm(const xh_route_record &r) { r.plan->fault_streak = 0; }
 
 extern "C" int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const double *h_flow_dist, const double *h_velocity,
                                      double dt) {
@@ -1121,16 +1026,13 @@ extern "C" int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const dou
     XH_REQUIRE(ctx, plan->ctx == ctx, "xh_route_plan_prepare: plan belongs to another context");
     XH_REQUIRE(ctx, h_flow_dist && h_velocity && dt > 0.0, "xh_route_plan_prepare: bad argument");
     XH_HIP(ctx, hipSetDevice(ctx->device));                      // may be called from a host thread of its own (run_model())
-    static const bool enabled = !(getenv("XH_ROUTE_LEARN_CACHE") && getenv("XH_ROUTE_LEARN_CACHE")[0] == '0');
-    // (what is prepared below -- the selective plain tables of the BIT-EXACT kernel -- is of no use to a process whose calls
-    // route in the reassociated form by default; a call that asks for XH_ROUTE_EXACT later learns the way it always did)
+    // (nothing to prepare for a process whose calls route in the bit-exact form by default: XH_ROUTE_REASSOC=0)
     if (reassoc_wanted(0)) {
-        // ... but the PREPARED reassociated plan (xanthos_hip.h, xh_route_plan_rsum_info: folded leaves, single sums) needs
+        // the PREPARED reassociated plan (xanthos_hip.h, xh_route_plan_rsum_info: folded leaves, single sums) needs
         // exactly what this call brings: which cells can fire.  XH_FLOW_FOLD=0 / XH_RSUM_SINGLE=0: without the one / the other.
         // A plan may be prepared again: other velocities, lengths or dt that change WHICH cells can fire replace the prepared
         // plan (and lift a guard trip's ban, which was about the old one); the same sets are a cheap no-op.
-        static const bool fold_on = !(getenv("XH_FLOW_FOLD") && getenv("XH_FLOW_FOLD")[0] == '0');
-        static const bool single_on = !(getenv("XH_RSUM_SINGLE") && getenv("XH_RSUM_SINGLE")[0] == '0');
+        static const bool fold_on = xh_env_on("XH_FLOW_FOLD", true), single_on = xh_env_on("XH_RSUM_SINGLE", true);
         if ((!fold_on && !single_on) || !plan->flow || plan->h_indptr.empty()) return XH_OK;
         const size_t n = (size_t)plan->ncell;
         std::vector<unsigned char> foldable(n, 0), capable(n, 0);
@@ -1172,7 +1074,7 @@ extern "C" int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const dou
             (t.n_folded == 0 && t.n_special < 0))
             return XH_OK;
         if (t.n_cells != plan->flow->n_cells) return XH_OK;
-        if (getenv("XH_FLOW_CHECK")) {
+        if (xh_flow_check()) {
             const std::string bad = flow_tables_check_rsum((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
                                                            plan->h_sign.data(), handled, t);
             if (!bad.empty()) return xh_fail(ctx, XH_ERR_ARG, "reassociated flow plan check (prepared plan): %s", bad.c_str());
@@ -1182,93 +1084,6 @@ extern "C" int xh_route_plan_prepare(xh_ctx *ctx, xh_route_plan *plan, const dou
         plan->fold_dt = dt;
         return XH_OK;
     }
-    if (!enabled || plan->prepared || plan->flow_typed || !plan->flow || !plan->flow->skew_ok || plan->h_indptr.empty() ||
-        !plan->d_learn.p)
-        return XH_OK;
-    std::string dir;
-    if (const char *d = getenv("XH_CACHE_DIR")) dir = d;
-    else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/xanthos_amd";
-    if (dir.empty()) return XH_OK;
-    const size_t n = (size_t)plan->ncell;
-    uint64_t h = 1469598103934665603ull;
-    auto mix = [&](const void *p, size_t nbytes) {
-        const unsigned char *b = static_cast<const unsigned char *>(p);
-        for (size_t i = 0; i < nbytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
-    };
-    mix(h_flow_dist, n * sizeof(double));
-    mix(h_velocity, n * sizeof(double));
-    mix(&dt, sizeof(dt));
-    char name[160];
-    snprintf(name, sizeof(name), "/learnt_%016llx_%016llx_%lld", (unsigned long long)plan->topo_hash, (unsigned long long)h,
-             (long long)plan->ncell);
-    plan->learn_path = dir + name;      // from here on confirmed calls keep the file up to date
-    std::vector<unsigned char> learnt(n, 0);
-    bool have = false;
-    if (FILE *f = fopen(plan->learn_path.c_str(), "rb")) {
-        have = fread(learnt.data(), 1, n, f) == n;
-        fclose(f);
-    }
-    if (!have) return XH_OK;            // nothing known on this box yet: the first calls route in pair form and learn
-    plan->learn_saved = learnt;
-    // the cells that can fire: by construction (the same expression as k_capable), or seen firing in an earlier run
-    std::vector<unsigned char> cap(n);
-    for (size_t c = 0; c < n; ++c) {
-        const double tauinv = h_velocity[c] / h_flow_dist[c];
-        cap[c] = (unsigned char)(((tauinv * dt <= CAPABLE_THRESHOLD) ? 0 : 1) | (learnt[c] ? 1 : 0));
-    }
-    // The selective tables for exactly these cells: read back if this library build has made them on this box before (a
-    // partition is 15-50 ms of host time, the file a few; held to the planner's own invariant checker before use), else made
-    // now and kept.
-    FlowTables t;
-    {
-        uint64_t hc = 1469598103934665603ull;
-        for (size_t c = 0; c < n; ++c) hc = (hc ^ cap[c]) * 1099511628211ull;
-        for (const char *b = __DATE__ " " __TIME__; *b; ++b) hc = (hc ^ (unsigned char)*b) * 1099511628211ull;
-        const FlowPlanOptions opt = flow_plan_options(ctx);
-        hc = (hc ^ (uint64_t)opt.lane_trials) * 1099511628211ull;
-        char tn[64];
-        snprintf(tn, sizeof(tn), ".tables_%016llx", (unsigned long long)hc);
-        const std::string tpath = plan->learn_path + tn;
-        bool loaded = flow_tables_load(tpath.c_str(), t) && t.n_units > 0 &&
-                      (int64_t)t.cell_of_slot.size() == (int64_t)t.n_units * 64;
-        if (loaded) {
-            std::vector<char> handled(n, 0);
-            for (int c : t.cell_of_slot)
-                if (c >= 0 && (size_t)c < n) handled[c] = 1;
-            loaded = flow_tables_check((int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(), plan->h_sign.data(),
-                                       handled, t, cap.data()).empty();
-        }
-        if (!loaded) {
-            std::vector<char> handled;
-            std::string err;
-            if (flow_tables_host(opt, (int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(), plan->h_sign.data(),
-                                 plan->h_comp, plan->h_ncomp, cap.data(), 5, handled, t, err) != 0)
-                return XH_OK;
-            if (t.n_plain_units > 0) (void)flow_tables_save(t, tpath.c_str());
-        }
-    }
-    if (t.n_plain_units == 0) return XH_OK;      // no plain form for this grid: nothing lost
-    const size_t nb = (n + 255) & ~size_t(255);
-    bool ok = hipMalloc(&plan->d_capable.p, 2 * nb) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void **>(&plan->d_cap_diff), 64) == hipSuccess &&
-              hipHostMalloc(reinterpret_cast<void **>(&plan->h_cap_diff), 64, hipHostMallocDefault) == hipSuccess &&
-              hipMemcpy(plan->d_capable.p, cap.data(), n, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(plan->d_learn.p, learnt.data(), n, hipMemcpyHostToDevice) == hipSuccess;
-    if (ok) ok = flow_plan_upload(ctx, t, &plan->flow_typed) == XH_OK && plan->flow_typed != nullptr;
-    if (!ok) {                          // back to the state of an unprepared plan
-        (void)hipGetLastError();
-        free_buf(plan->d_capable);
-        if (plan->d_cap_diff) (void)hipFree(plan->d_cap_diff);
-        if (plan->h_cap_diff) (void)hipHostFree(plan->h_cap_diff);
-        plan->d_cap_diff = plan->h_cap_diff = nullptr;
-        flow_plan_destroy(plan->flow_typed);
-        plan->flow_typed = nullptr;
-        (void)hipMemset(plan->d_learn.p, 0, n);
-        return XH_OK;
-    }
-    plan->typed_builds += 1;
-    plan->typed_sel = 5;
-    plan->prepared = true;
     return XH_OK;
 }
 
@@ -1306,9 +1121,7 @@ int xh_route_series_fed(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32
 // $HOME/.cache/xanthos_amd.  Failing to read or write it only means the check runs again.
 // (form: 0 the bit-exact kernels, 1 the reassociated form, 2 the prepared reassociated plan: folded leaves "_rf", single sums "_rs")
 static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan, int form) {
-    std::string dir;
-    if (const char *d = getenv("XH_CACHE_DIR")) dir = d;
-    else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/xanthos_amd";
+    const std::string dir = xh_cache_dir();
     if (dir.empty()) return std::string();
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](const char *t) {
@@ -1323,7 +1136,8 @@ static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan
         (void)hipRuntimeGetVersion(&rt);
         (void)hipDriverGetVersion(&drv);
         char ver[96];
-        snprintf(ver, sizeof(ver), "rt%d drv%d %s", rt, drv, getenv("XH_TEST_RUNTIME_TAG") ? getenv("XH_TEST_RUNTIME_TAG") : "");
+        const char *tag = getenv("XH_TEST_RUNTIME_TAG");
+        snprintf(ver, sizeof(ver), "rt%d drv%d %s", rt, drv, tag ? tag : "");
         mix(ver);
     }
     char name[160];
@@ -1342,7 +1156,7 @@ static int last_form(const xh_route_plan *plan) {
 }
 
 static bool first_check_needed(xh_ctx *ctx, xh_route_plan *plan, int form) {
-    static const bool enabled = !(getenv("XH_ROUTE_VALIDATE_FIRST") && getenv("XH_ROUTE_VALIDATE_FIRST")[0] == '0');
+    static const bool enabled = xh_env_on("XH_ROUTE_VALIDATE_FIRST", true);
     bool &checked = first_checked_of(plan, form);
     if (!enabled || checked || !plan->flow) return false;
     const std::string path = first_check_path(ctx, plan, form);
@@ -1379,7 +1193,7 @@ static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         if (!feed) plan->skip_calls -= 1;      // (a fed call is turned down below and comes back as an ordinary one: counted there)
         flags |= XH_ROUTE_NO_DATAFLOW;
     }
-    static const bool validate_env = getenv("XH_ROUTE_VALIDATE") && getenv("XH_ROUTE_VALIDATE")[0] == '1';
+    static const bool validate_env = xh_env_on("XH_ROUTE_VALIDATE", false);
     bool validate = validate_env || (flags & XH_ROUTE_VALIDATE) != 0;
     flags &= ~XH_ROUTE_VALIDATE;
     // first dataflow call of this plan on a box / build that has not passed the cross-check yet: checked like XH_ROUTE_VALIDATE
@@ -1444,15 +1258,13 @@ static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
 
 int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r, bool dataflow_pairs) {
     bool used_flow = false;
-    if (!dataflow_pairs) r.plan->reroutes += 1;      // (guard re-runs are counted apart: xh_route_plan_typed_info[2])
+    if (!dataflow_pairs) r.plan->reroutes += 1;      // (guard re-runs are counted apart: xh_route_plan_rsum_info[6])
     int flags = r.flags & ~XH_ROUTE_TEST_FAULT;
     if (dataflow_pairs) {
-        // The cells that fired unexpectedly are on record (d_learn) and this pair-form run records every other one of the
-        // series, so the next call's partition knows them.  If the guard keeps tripping all the same, the plain form is
-        // given up for this plan.
-        if (++r.plan->guard_trips > 8) r.plan->typed_disabled = true;
-        // (a reassociated call: the guard was that of the folded leaves -- one of them can fire with this call's data; the
-        // plan with folded leaves is given up, XH_ROUTE_NO_PLAIN below routes on the one without)
+        // A guard of the PREPARED reassociated plan tripped (a folded leaf that can fire with this call's data after all,
+        // negative runoff or initial storage, a negative outflow leaving a halo): the prepared plan is given up until the
+        // plan is prepared for other data, XH_ROUTE_NO_PLAIN below routes on the plan of pairs, which assumes nothing
+        r.plan->guard_trips += 1;
         if (r.plan->last_rsum && r.plan->last_rsum_plan == r.plan->flow_rsum_fold) r.plan->fold_disabled = true;
         flags |= XH_ROUTE_NO_PLAIN;
     } else {
@@ -1462,7 +1274,7 @@ int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r, bool dataflow_pairs) {
                              r.area, r.runoff, r.S0, r.chs, r.avg, r.S_end, r.F_end, flags, &used_flow);
 }
 
-extern "C" int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[6]) {
+extern "C" int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[8]) {
     if (!plan || !info) return XH_ERR_ARG;
     const FlowPlan *fp = plan->last_rsum ? plan->last_rsum_plan : nullptr;
     info[0] = fp ? fp->n_units : 0;
@@ -1471,46 +1283,9 @@ extern "C" int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[6
     info[3] = plan->flow_rsum_fold ? plan->flow_rsum_fold->n_folded : 0;
     info[4] = fp ? fp->n_special : -1;
     info[5] = plan->flow_rsum_fold ? plan->flow_rsum_fold->n_special : -1;
+    info[6] = plan->guard_trips;
+    info[7] = fp ? fp->n_pair_units : 0;
     return XH_OK;
-}
-
-extern "C" int xh_route_plan_typed_info(const xh_route_plan *plan, int64_t info[4]) {
-    if (!plan || !info) return XH_ERR_ARG;
-    info[0] = (plan->last_typed && plan->flow_typed) ? plan->flow_typed->n_plain_units : 0;
-    info[1] = plan->typed_builds;
-    info[2] = plan->typed_disabled ? -1 : plan->guard_trips;
-    info[3] = plan->flow_typed ? plan->flow_typed->n_units : 0;
-    return XH_OK;
-}
-
-// Fed order (xh_fused.hip, run_fed): a routing call on a plan that has typed tables asks the device whether the cells that
-// can fire are still the ones the tables were made for (k_capable) and needs the answer on the host before it can launch.
-// Asked inside the call, the host waits for everything in front of it on the stream -- the first block of PM + ABCD -- and the
-// device then idles while the launch is put together (~0.1 ms of a 25 ms step, `tools/step_gaps.py`).  Asked here, in front
-// of that block, the answer is back long before the call: velocity, flow distance, dt and the learnt cells are what they
-// will be then (nothing in between writes them; the pointers and dt are compared, and run_fed cancels what it does not use).
-int xh_route_precheck(xh_ctx *ctx, xh_route_plan *plan, const double *d_flow_dist, const double *d_velocity, double dt) {
-    if (!ctx || !plan || plan->ctx != ctx) return XH_OK;
-    plan->pre_armed = false;
-    if (!plan->flow_typed || !plan->d_capable.p || !plan->d_cap_diff || !plan->h_cap_diff || plan->ncell == 0) return XH_OK;
-    if (!plan->ev_pre) XH_HIP(ctx, hipEventCreateWithFlags(&plan->ev_pre, hipEventDisableTiming));
-    const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
-    unsigned char *d_cap_new = static_cast<unsigned char *>(plan->d_capable.p) + nb;
-    XH_HIP(ctx, hipMemsetAsync(plan->d_cap_diff, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_capable, dim3((unsigned)((plan->ncell + 255) / 256)), dim3(256), 0, ctx->stream, d_velocity, d_flow_dist,
-                       dt, (int)plan->ncell, static_cast<const unsigned char *>(plan->d_learn.p), d_cap_new,
-                       static_cast<const unsigned char *>(plan->d_capable.p), plan->d_cap_diff);
-    XH_HIP(ctx, hipMemcpyAsync(plan->h_cap_diff, plan->d_cap_diff, 4, hipMemcpyDeviceToHost, ctx->stream));
-    XH_HIP(ctx, hipEventRecord(plan->ev_pre, ctx->stream));
-    plan->pre_flow_dist = d_flow_dist;
-    plan->pre_velocity = d_velocity;
-    plan->pre_dt = dt;
-    plan->pre_armed = true;
-    return XH_OK;
-}
-
-void xh_route_precheck_cancel(xh_route_plan *plan) {
-    if (plan) plan->pre_armed = false;
 }
 
 static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
@@ -1569,135 +1344,16 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         XH_HIP(ctx, hipMemcpyAsync(d_wr, swr.data(), (size_t)nit, hipMemcpyHostToDevice, ctx->stream));
         return XH_OK;
     };
-    // typed partition: does the plan at hand fit this call's velocity / flow distance / dt?  (answered by the sync below)
-    // Off by default: measured on MI355X (profiles/round3), the typed partition does not beat the all-pair one yet -- its
-    // pair units (the cells downstream of cells that can fire, with their imports) pace the run.  XH_ROUTE_TYPED (flag) or
-    // XH_ROUTE_TYPED=1 (environment) selects it; results are bit-identical either way.
-    static const bool typed_env = getenv("XH_ROUTE_TYPED") && getenv("XH_ROUTE_TYPED")[0] == '1';
-    static const bool auto_env = !(getenv("XH_ROUTE_AUTO") && getenv("XH_ROUTE_AUTO")[0] == '0');
-    static const bool old_skew_env = getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] != '1';
     // Reassociated form (XH_ROUTE_REASSOC, flag or environment): a partition of its own, nothing to learn -- the typed / adaptive
     // machinery below is for the bit-exact kernel only.
-    bool use_rsum = reassoc_wanted(flags) && plan->flow && !old_skew_env &&
+    bool use_rsum = reassoc_wanted(flags) && plan->flow &&
                     (flags & (XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_ATOMIC)) == 0;
     if (use_rsum) {
         if ((rc = rsum_plan_build(ctx, plan)) != XH_OK) return rc;
         use_rsum = plan->flow_rsum != nullptr;
     }
     flags &= ~(XH_ROUTE_REASSOC | XH_ROUTE_EXACT);
-    const bool typed_ok = plan->flow && !plan->typed_disabled && !plan->h_indptr.empty() && !use_rsum &&
-                          (flags & (XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_NO_PLAIN)) == 0;
-    const bool explicit_typed = (typed_env || (flags & XH_ROUTE_TYPED) != 0) && typed_ok;
-    // adaptive: plain calls only (no test / validation / variant flag), time-skewed kernel in use, months long enough for it
-    const bool auto_typed = !explicit_typed && auto_env && typed_ok && !old_skew_env && plan->flow->skew_ok &&
-                            (flags & (XH_ROUTE_ATOMIC | XH_ROUTE_TEST_FAULT)) == 0 && plan->auto_state.load() != 3;
-    if (auto_typed) plan->auto_calls += 1;
-    // (a plan prepared from the box's cache of learnt cells has its selective tables already: they are tried from call one)
-    bool want_typed = explicit_typed || (auto_typed && (plan->auto_calls >= 2 || plan->prepared));
-    const int sel_env = getenv("XH_FLOW_PLAIN_MIN_READS") ? atoi(getenv("XH_FLOW_PLAIN_MIN_READS")) : -1;
-    const int sel_want = sel_env >= 0 ? sel_env : (explicit_typed ? 0 : 5);
-    unsigned char *d_cap_new = nullptr;
-    if (want_typed) {
-        const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
-        if (!plan->d_capable.p || !plan->d_cap_diff || !plan->h_cap_diff) {
-            // all three or none: a partial failure must not leave a plan that later calls take for ready
-            const bool ok = (plan->d_capable.p || hipMalloc(&plan->d_capable.p, 2 * nb) == hipSuccess) &&
-                            (plan->d_cap_diff || hipMalloc(reinterpret_cast<void **>(&plan->d_cap_diff), 64) == hipSuccess) &&
-                            (plan->h_cap_diff || hipHostMalloc(reinterpret_cast<void **>(&plan->h_cap_diff), 64,
-                                                               hipHostMallocDefault) == hipSuccess);
-            if (!ok) {
-                (void)hipGetLastError();
-                free_buf(plan->d_capable);
-                if (plan->d_cap_diff) (void)hipFree(plan->d_cap_diff);
-                if (plan->h_cap_diff) (void)hipHostFree(plan->h_cap_diff);
-                plan->d_cap_diff = plan->h_cap_diff = nullptr;
-                if (explicit_typed) return xh_fail(ctx, XH_ERR_HIP, "xh_route_series: no memory for the typed plan's cell flags");
-                plan->auto_state.store(3);      // adaptive plain form stays off for this plan: pair form from here on
-                want_typed = false;
-            }
-        }
-    }
-    // (fed order: the question was put to the device in front of the first block of PM + ABCD -- xh_route_precheck -- and the
-    // answer has long arrived: no wait for the stream in the middle of the step)
-    const bool prechecked = plan->pre_armed && want_typed && plan->flow_typed && plan->pre_flow_dist == d_flow_dist &&
-                            plan->pre_velocity == d_velocity && plan->pre_dt == dt;
-    plan->pre_armed = false;
-    if (want_typed) {
-        const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
-        d_cap_new = static_cast<unsigned char *>(plan->d_capable.p) + nb;
-        if (!prechecked) {
-            XH_HIP(ctx, hipMemsetAsync(plan->d_cap_diff, 0, 4, ctx->stream));
-            hipLaunchKernelGGL(k_capable, dim3((unsigned)((plan->ncell + 255) / 256)), dim3(256), 0, ctx->stream, d_velocity,
-                               d_flow_dist, dt, (int)plan->ncell, static_cast<const unsigned char *>(plan->d_learn.p), d_cap_new,
-                               plan->flow_typed ? static_cast<const unsigned char *>(plan->d_capable.p) : nullptr, plan->d_cap_diff);
-            XH_HIP(ctx, hipMemcpyAsync(plan->h_cap_diff, plan->d_cap_diff, 4, hipMemcpyDeviceToHost, ctx->stream));
-        }
-    }
-    if (prechecked) XH_HIP(ctx, hipEventSynchronize(plan->ev_pre));
-    else if (want_typed) XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // does the typed plan at hand fit this call (same cells that can fire, same form)?
-    const bool typed_fits = want_typed && plan->flow_typed && *plan->h_cap_diff == 0 && plan->typed_sel == sel_want;
-    bool use_typed = typed_fits;
-    if (explicit_typed && !typed_fits) {
-        // (re)build at once: the set of cells that can fire changed, the other form was asked for, or this is the first call
-        if (plan->auto_thread.joinable()) plan->auto_thread.join();      // its tables are for another request
-        if (plan->auto_state.load() != 3) plan->auto_state.store(0);
-        const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
-        std::vector<unsigned char> cap((size_t)plan->ncell);
-        XH_HIP(ctx, hipMemcpy(cap.data(), d_cap_new, cap.size(), hipMemcpyDeviceToHost));
-        XH_HIP(ctx, hipMemcpy(plan->d_capable.p, d_cap_new, nb, hipMemcpyDeviceToDevice));
-        flow_plan_destroy(plan->flow_typed);
-        plan->flow_typed = nullptr;
-        std::vector<char> handled;
-        FlowTables t;
-        std::string err;
-        if (flow_tables_host(flow_plan_options(ctx), (int)plan->ncell, plan->h_indptr.data(), plan->h_indices.data(),
-                             plan->h_sign.data(), plan->h_comp, plan->h_ncomp, cap.data(), sel_want, handled, t, err) != 0)
-            return xh_fail(ctx, XH_ERR_ARG, "%s", err.c_str());
-        const int frc = flow_plan_upload(ctx, t, &plan->flow_typed);
-        if (frc) return frc;
-        plan->typed_builds += 1;
-        plan->typed_sel = sel_want;
-        use_typed = plan->flow_typed != nullptr;
-    } else if (auto_typed && want_typed && !typed_fits) {
-        // adaptive: never wait for a partition.  Tables ready -> take them if they are for today's cells; nothing in the
-        // making -> start a host thread on them; this call routes in pair form either way unless the tables fit.
-        const size_t nb = ((size_t)plan->ncell + 255) & ~size_t(255);
-        int st = plan->auto_state.load();
-        if (st == 2) {
-            plan->auto_thread.join();
-            std::vector<unsigned char> cap((size_t)plan->ncell);
-            XH_HIP(ctx, hipMemcpy(cap.data(), d_cap_new, cap.size(), hipMemcpyDeviceToHost));
-            if (cap == plan->auto_cap) {
-                flow_plan_destroy(plan->flow_typed);
-                plan->flow_typed = nullptr;
-                const int frc = flow_plan_upload(ctx, plan->auto_tables, &plan->flow_typed);
-                plan->auto_tables = FlowTables();
-                if (frc) return frc;
-                XH_HIP(ctx, hipMemcpy(plan->d_capable.p, d_cap_new, nb, hipMemcpyDeviceToDevice));
-                plan->typed_builds += 1;
-                plan->typed_sel = sel_want;
-                use_typed = plan->flow_typed != nullptr;
-            }
-            plan->auto_state.store(0);
-            st = 0;
-        }
-        if (st == 0 && !use_typed) {
-            plan->auto_cap.resize((size_t)plan->ncell);
-            XH_HIP(ctx, hipMemcpy(plan->auto_cap.data(), d_cap_new, plan->auto_cap.size(), hipMemcpyDeviceToHost));
-            plan->auto_state.store(1);
-            xh_route_plan *pl = plan;
-            const FlowPlanOptions opt = flow_plan_options(ctx);      // read here: the thread must not need the context
-            plan->auto_thread = std::thread([pl, opt, sel_want] {
-                std::vector<char> handled;
-                const int rc2 = flow_tables_host(opt, (int)pl->ncell, pl->h_indptr.data(), pl->h_indices.data(), pl->h_sign.data(),
-                                                 pl->h_comp, pl->h_ncomp, pl->auto_cap.data(), sel_want, handled, pl->auto_tables,
-                                                 pl->auto_err);
-                pl->auto_state.store(rc2 == 0 && pl->auto_tables.n_plain_units > 0 ? 2 : 3);
-            });
-        }
-    }
-    FlowPlan *tree_plan = (use_typed && plan->flow_typed && plan->flow_typed->n_plain_units > 0) ? plan->flow_typed : plan->flow;
+    FlowPlan *tree_plan = plan->flow;
     FlowPlan *rsum_plan = plan->flow_rsum;
     if (use_rsum && plan->flow_rsum_fold && !plan->fold_disabled && dt == plan->fold_dt && (flags & XH_ROUTE_NO_PLAIN) == 0)
         rsum_plan = plan->flow_rsum_fold;      // leaves that cannot fire carried by their parents' lanes (guarded in the kernel)
@@ -1707,7 +1363,7 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
     const bool atomic = (flags & XH_ROUTE_ATOMIC) != 0;
     bool use_flow = !force_fb && plan->flow != nullptr && (flags & XH_ROUTE_NO_DATAFLOW) == 0;
     // fed call: every cell must be routed by k_mrtm_wave (the other kernels read the runoff array itself, at once)
-    if (feed && (!use_flow || plan->n_rest_units > 0 || plan->n_fb_rest > 0 || old_skew_env)) return XH_ERR_LIMIT;
+    if (feed && (!use_flow || plan->n_rest_units > 0 || plan->n_fb_rest > 0)) return XH_ERR_LIMIT;
 
     xh_span sp = xh_span_begin(ctx, "mrtm_route");
     // (kernels on the class streams wait for ev_fork: whatever they read must be in the stream before it is recorded)
@@ -1727,37 +1383,25 @@ static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, 
         const FlowSched fs{nmonths, nit, ntmax, ntmin, sg[nit], d_m, d_nt, d_g, d_secs, d_wr, dt,
                            (flags & XH_ROUTE_TEST_FAULT) != 0, nt_even, sm.data(), snt.data(), sg.data(), ssecs.data(),
                            swr.data()};
-        const FlowIO fio{d_flow_dist, d_velocity, d_area, d_runoff, d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end,
-                         static_cast<unsigned char *>(plan->d_learn.p), feed};
-        // time-skewed units first; months shorter than the deepest lane lag (long dt) use the monthly-stream kernel
-        static const bool skew_env = !(getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] == '0');
+        const FlowIO fio{d_flow_dist, d_velocity, d_area, d_runoff, d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end, feed};
+        // time-skewed units first; months shorter than the deepest lane lag (long dt) and grids beyond the kernel's 32-bit row
+        // offsets use the lock-step kernel (k_mrtm_flow)
         rc = XH_ERR_LIMIT;
         plan->last_tree_kernel = 2;
-        static const bool old_skew = getenv("XH_MRTM_SKEW") && getenv("XH_MRTM_SKEW")[0] == '2';      // round 2's kernel, for comparison
-        if (skew_env && (flags & XH_ROUTE_NO_SKEW) == 0) {
-            if (old_skew && (rc = sched_upload()) != XH_OK) return rc;
-            rc = old_skew ? skew_launch(ctx, plan->flow, fs, fio, ctx->stream) : wave_launch(ctx, tree_plan, fs, fio, ctx->stream);
-        }
+        if ((flags & XH_ROUTE_NO_SKEW) == 0) rc = wave_launch(ctx, tree_plan, fs, fio, ctx->stream);
         // (which plan actually ran: a month shorter than the plan's lane lags, the 32-bit row limit or residency send the call
-        // from the reassociated / typed plan back to the bit-exact one -- everything below speaks of THAT plan then)
+        // from the reassociated plan back to the bit-exact one -- everything below speaks of THAT plan then)
         FlowPlan *ran = tree_plan;
-        if (rc == XH_ERR_LIMIT && tree_plan != plan->flow && !old_skew) {
+        if (rc == XH_ERR_LIMIT && tree_plan != plan->flow && (flags & XH_ROUTE_NO_SKEW) == 0) {
             ran = plan->flow;
             rc = wave_launch(ctx, plan->flow, fs, fio, ctx->stream);
         }
-        plan->last_rsum = rc == XH_OK && use_rsum && ran == rsum_plan && ran->rsum && !old_skew;
+        plan->last_rsum = rc == XH_OK && use_rsum && ran == rsum_plan && ran->rsum;
         if (plan->last_rsum) plan->last_rsum_plan = rsum_plan;
         if (plan->last_rsum) plan->last_tree_kernel = 4;
-        plan->last_typed = rc == XH_OK && ran != plan->flow && !old_skew && !plan->last_rsum;
         if (feed && rc == XH_ERR_LIMIT) {      // nothing was launched: the caller completes the runoff and calls again
             xh_span_cancel(sp);
             return XH_ERR_LIMIT;
-        }
-        // what the round-3 kernel cannot take (rows beyond its 32-bit offsets) the round-2 time-skewed kernel may still
-        if (rc == XH_ERR_LIMIT && skew_env && !old_skew && (flags & XH_ROUTE_NO_SKEW) == 0) {
-            if ((rc = sched_upload()) != XH_OK) return rc;
-            rc = skew_launch(ctx, plan->flow, fs, fio, ctx->stream);
-            if (rc == XH_OK) plan->last_tree_kernel = 3;
         }
         if (rc == XH_ERR_LIMIT) {
             plan->last_tree_kernel = 1;

@@ -1,5 +1,5 @@
-// Internal interface between xh_mrtm.hip (plan + API), xh_mrtm_flow.hip (tree partition + monthly-stream dataflow
-// kernel) and xh_mrtm_skew.hip (time-skewed dataflow kernel on the same partition).
+// Internal interface between xh_mrtm.hip (plan + API), xh_mrtm_flow.hip (tree partition + lock-step dataflow kernel) and the
+// time-skewed dataflow kernels on the same partition (xh_mrtm_wave.hip, xh_mrtm_rsum.hip; launch: xh_mrtm_wave_launch.hip).
 #pragma once
 #include <string>
 #include <vector>
@@ -13,11 +13,11 @@ struct FlowBuf {
 
 // Partition of the tree-shaped river networks into single-wave units (64 lanes = 64 cells) linked by one-way streams.
 struct FlowPlan {
-    int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0, max_exports = 0, n_plain_units = 0;
+    int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0, max_exports = 0;
     bool rsum = false;                   // reassociated form (xh_flow_rsum.cpp tables, k_mrtm_rsum): wave_launch only
     int max_cell = -1;                   // largest grid index of a routed cell (the time-skewed kernel's 32-bit row offsets)
     FlowBuf d_cell_of_slot, d_ent, d_export_edge, d_ghost_edge, d_edge_cons_unit, d_unit_terms;
-    // time-skewed layout (xh_mrtm_skew.hip); skew_ok = every row has <= 4 terms either side of its diagonal
+    // time-skewed layout; skew_ok = every row has <= 4 terms either side of its diagonal
     bool skew_ok = false;
     int skew_lmax = 0;                   // largest lane lag of any unit (sub-steps)
     int skew_span = 1;                   // most pipeline levels a stream jumps over (consumer depth - producer depth)
@@ -26,8 +26,6 @@ struct FlowPlan {
     void *d_x = nullptr;
     size_t x_bytes = 0;
     unsigned long long *d_stats = nullptr;
-    unsigned *d_trace = nullptr;         // XH_FLOW_TRACE=<file>: month-end times of every unit, dumped by flow_stats_fetch
-    size_t trace_words = 0;
     void *d_skew_args = nullptr;         // argument block of the time-skewed kernel (rewritten, stream-ordered, by every launch)
     std::vector<char> h_rec, h_fin;      // host copies of the month records of the last launch (sources of asynchronous copies)
     uint64_t rec_key = 0;                // hash of the schedule / runoff layout the records on the device were made for (0: none)
@@ -35,7 +33,7 @@ struct FlowPlan {
     int n_folded = 0;
     int n_special = -1;      // reassociated form: -1 = pairs of sums, >= 0 = single-sum plan with that many cells in pair units
     int n_pair_units = 0;    // single-sum plan: its pair units (the tail of the claim list; the kernel gives them CUs of their own)
-    FlowBuf d_lane_flags, d_ghost_prod;  // typed partition: cells that can fire by construction; producer cell of every imported stream
+    FlowBuf d_lane_flags;    // single-sum plans: [units*64] bit 0 the cell may fire, bit 1 an exit lane (xh_flow_rsum.cpp)
 };
 
 struct FlowSched {
@@ -68,34 +66,27 @@ struct FlowFeed {
 struct FlowIO {
     const double *flow_dist, *velocity, *area, *runoff, *S0;
     double *chs, *avg, *S_end, *F_end;
-    unsigned char *learn;             // [ncell] cells seen firing unexpectedly (xh_mrtm_wave.hip); never NULL for wave_launch
     const FlowFeed *feed = nullptr;   // wave_launch only: runoff arrives while the kernel runs (see FlowFeed)
 };
 
 // Partition every tree-shaped river network (each cell drains to at most one cell, no cycle, standard UP - I rows)
-// into single-wave units linked by one-way streams.  handled[c] = 1 for the cells these units route.
-// capable: nullptr = every unit in pair form; else [n] flags of the cells that can fire (typed partition: pair and plain
-// units, xh_flow_plan.h).
+// into single-wave units linked by one-way streams (every unit in pair form).  handled[c] = 1 for the cells these units route.
 int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
-                    const std::vector<int> &comp, int ncomp, const unsigned char *capable, std::vector<char> &handled,
-                    FlowPlan **out);
-// The two halves of flow_plan_build.  flow_tables_host is plain host work (no HIP call, no context: it may run on a
-// thread of its own while the context is busy, or gone); plain_min_reads >= 0 overrides the environment's
-// XH_FLOW_PLAIN_MIN_READS.  flow_plan_upload allocates and fills the device tables.
+                    const std::vector<int> &comp, int ncomp, std::vector<char> &handled, FlowPlan **out);
+// The two halves of flow_plan_build.  flow_tables_host is plain host work (no HIP call, no context).  flow_plan_upload
+// allocates and fills the device tables.
 FlowPlanOptions flow_plan_options(const xh_ctx *ctx);      // device size + the XH_FLOW_* switches of the environment
 int flow_tables_host(FlowPlanOptions opt, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
-                     const std::vector<int> &comp, int ncomp, const unsigned char *capable, int plain_min_reads,
-                     std::vector<char> &handled, FlowTables &t, std::string &err);
+                     const std::vector<int> &comp, int ncomp, std::vector<char> &handled, FlowTables &t, std::string &err);
 int flow_plan_upload(xh_ctx *ctx, const FlowTables &t, FlowPlan **out);
 void flow_plan_destroy(FlowPlan *fp);
 // info: [0] units, [1] stream edges, [2] pipeline depth (levels), [3] cells, [4] max imports of a unit
 void flow_plan_info(const FlowPlan *fp, int64_t info[5]);
 // Enqueue the persistent dataflow kernel on `st`. Returns XH_ERR_LIMIT if the units cannot all be resident.
 int flow_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st);
-// Same contract for the time-skewed kernel; XH_ERR_LIMIT also when the schedule does not suit it (months shorter
-// than the deepest lane lag, rows wider than 4 + 1 + 4) -- the caller then uses flow_launch.
-int skew_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st);
-// Round 3's time-skewed kernel (xh_mrtm_wave.hip): same contract, same plan tables, pair and plain units.
+// Same contract for the time-skewed kernels (k_mrtm_wave / k_mrtm_rsum, by the plan's kind); XH_ERR_LIMIT also when the
+// schedule does not suit them (months shorter than the deepest lane lag, rows wider than 4 + 1 + 4, rows beyond 32-bit
+// offsets) -- the caller then uses flow_launch.
 int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st);
 const void *wave_rsum_kernel();      // k_mrtm_rsum (xh_mrtm_rsum.hip): the kernel wave_launch starts for a reassociated plan
 const void *wave_exact_kernel();     // k_mrtm_wave (xh_mrtm_wave.hip)

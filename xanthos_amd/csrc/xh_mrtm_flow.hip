@@ -44,7 +44,6 @@ namespace {
 
 constexpr int W_MAX = 9;          // terms per row: 8 D8 neighbours + the diagonal
 constexpr int LANES = 64;         // cells per unit (one per lane)
-constexpr int G_MAX = 16;         // imported streams, and outlets, per unit (16 = two block-transfer rounds of the skewed kernel)
 constexpr int NPAIR = 2 * LANES + 1;       // LDS pairs per flow buffer: cells, ghost slots (one per lane), constant zero
 constexpr int RING = 4;           // months of stream kept in HBM per edge
 constexpr int PF = 8;             // sub-steps of ghost prefetch held in registers
@@ -301,13 +300,12 @@ void flow_plan_destroy(FlowPlan *fp) {
     FlowBuf *bufs[] = {&fp->d_cell_of_slot, &fp->d_ent,      &fp->d_export_edge, &fp->d_ghost_edge,
                        &fp->d_edge_cons_unit, &fp->d_unit_terms, &fp->d_lag,        &fp->d_ghost_lag,
                        &fp->d_ent2,         &fp->d_eprev,       &fp->d_unit_order,  &fp->d_unit_p,     &fp->d_unit_lmax,   &fp->d_unit_glmax,
-                       &fp->d_lane_flags,   &fp->d_ghost_prod,   &fp->d_fold_cell};
+                       &fp->d_lane_flags,   &fp->d_fold_cell};
     for (FlowBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (fp->d_x) (void)hipFree(fp->d_x);
     if (fp->d_skew_args) (void)hipFree(fp->d_skew_args);
     if (fp->d_stats) (void)hipFree(fp->d_stats);
-    if (fp->d_trace) (void)hipFree(fp->d_trace);
     delete fp;
 }
 
@@ -325,69 +323,40 @@ FlowPlanOptions flow_plan_options(const xh_ctx *ctx) {
     FlowPlanOptions o;
     o.simds = 4 * (ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 0);
     if (const char *e = getenv("XH_FLOW_PIECE_CAP")) o.piece_cap = std::min(std::max(atoi(e), 1), LANES);
-    o.chain = !(getenv("XH_FLOW_CHAIN") && getenv("XH_FLOW_CHAIN")[0] == '0');
-    o.cut_rule = !(getenv("XH_FLOW_CUTRULE") && getenv("XH_FLOW_CUTRULE")[0] == '0');
-    if (const char *e = getenv("XH_FLOW_TLIMIT")) o.tlimit = o.tlimit_typed = atoi(e);
-    if (const char *e = getenv("XH_FLOW_TLIMIT_PLAIN")) o.tlimit_plain = atoi(e);
-    if (const char *e = getenv("XH_FLOW_FULL_JOIN")) o.full_join = atoi(e);
-    if (const char *e = getenv("XH_FLOW_PAIR_STREAMS")) o.pair_streams = std::min(std::max(atoi(e), 1), G_MAX);
-    if (const char *e = getenv("XH_FLOW_PLAIN_MIN_READS")) o.plain_min_reads = atoi(e);
-    o.debug = getenv("XH_FLOW_DEBUG") != nullptr;
-    o.balance_lds = getenv("XH_WAVE_BALANCE") && getenv("XH_WAVE_BALANCE")[0] == '1';
-    if (const char *e = getenv("XH_FLOW_LANE_TRIALS")) o.lane_trials = std::max(atoi(e), 0);
+    o.debug = xh_flow_debug();
     return o;
 }
 
 int flow_tables_host(FlowPlanOptions opt, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
-                     const std::vector<int> &comp, int ncomp, const unsigned char *capable, int plain_min_reads,
-                     std::vector<char> &handled, FlowTables &t, std::string &err) {
+                     const std::vector<int> &comp, int ncomp, std::vector<char> &handled, FlowTables &t, std::string &err) {
     handled.assign(n, 0);
     t = FlowTables();
     if (n == 0) return 0;
-    opt.capable = capable;
-    if (plain_min_reads >= 0) opt.plain_min_reads = plain_min_reads;
+    opt.capable = nullptr;      // every unit in pair form
     if (flow_tables_build(n, indptr, indices, sign, comp.data(), ncomp, opt, handled, t, err) != 0) return -1;
     if (t.n_units == 0) return 0;
-    if (getenv("XH_FLOW_CHECK")) {      // the invariants the host fuzzer holds the planner to, on this very plan
-        const std::string bad = flow_tables_check(n, indptr, indices, sign, handled, t, capable);
+    if (xh_flow_check()) {      // the invariants the host fuzzer holds the planner to, on this very plan
+        const std::string bad = flow_tables_check(n, indptr, indices, sign, handled, t, nullptr);
         if (!bad.empty()) {
             err = "flow plan check: " + bad;
             return -1;
-        }
-    }
-    if (const char *dump = getenv("XH_FLOW_DUMP")) {      // partition as int32 rows [n]: downstream cell, piece, unit, height
-        if (FILE *f = fopen(dump, "wb")) {
-            fwrite(&n, sizeof(int), 1, f);
-            fwrite(t.ds.data(), sizeof(int), n, f);
-            fwrite(t.piece_of_cell.data(), sizeof(int), n, f);
-            fwrite(t.unit_of_cell.data(), sizeof(int), n, f);
-            fwrite(t.height_of_cell.data(), sizeof(int), n, f);
-            std::vector<int> up(n, -1);      // shape word of the cell's unit (terms | chained << 8 | plain << 9)
-            for (int c = 0; c < n; ++c)
-                if (t.unit_of_cell[c] >= 0) up[c] = t.unit_p[t.unit_of_cell[c]];
-            fwrite(up.data(), sizeof(int), n, f);
-            fclose(f);
         }
     }
     return 0;
 }
 
 int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
-                    const std::vector<int> &comp, int ncomp, const unsigned char *capable, std::vector<char> &handled,
-                    FlowPlan **out) {
+                    const std::vector<int> &comp, int ncomp, std::vector<char> &handled, FlowPlan **out) {
     *out = nullptr;
     FlowTables t;
     std::string err;
     const FlowPlanOptions opt = flow_plan_options(ctx);
     // The all-pairs partition of a grid is the same every time (topology, planner options, library build): 50-70 ms of host
-    // time at the full grid, a few to read back.  Kept in the per-box cache beside the learnt cells (xh_route_plan_prepare;
-    // XH_ROUTE_LEARN_CACHE=0 switches both off) and held to the planner's own invariant checker before it is used.
+    // time at the full grid, a few to read back.  Kept in the per-box cache (XH_CACHE_DIR; XH_ROUTE_LEARN_CACHE=0 switches the
+    // caches of partitions off) and held to the planner's own invariant checker before it is used.
     std::string cache;
-    static const bool cache_on = !(getenv("XH_ROUTE_LEARN_CACHE") && getenv("XH_ROUTE_LEARN_CACHE")[0] == '0');
-    if (cache_on && !capable && n > 0 && !opt.debug && !getenv("XH_FLOW_DUMP")) {
-        std::string dir;
-        if (const char *d = getenv("XH_CACHE_DIR")) dir = d;
-        else if (const char *h = getenv("HOME")) dir = std::string(h) + "/.cache/xanthos_amd";
+    if (xh_plan_cache_on() && n > 0 && !opt.debug) {
+        const std::string dir = xh_cache_dir();
         if (!dir.empty()) {
             uint64_t h = 1469598103934665603ull;
             auto mix = [&](const void *p, size_t nbytes) {
@@ -398,8 +367,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
             mix(indptr, sizeof(int64_t) * (size_t)(n + 1));
             if (nnz) mix(indices, sizeof(int32_t) * (size_t)nnz);
             if (nnz) mix(sign, (size_t)nnz);
-            const int knobs[11] = {opt.simds, opt.piece_cap, opt.chain, opt.cut_rule, opt.tlimit, opt.tlimit_typed, opt.tlimit_plain,
-                                   opt.full_join, opt.pair_streams, (opt.plain_min_reads << 1) | (opt.balance_lds ? 1 : 0), opt.lane_trials};
+            const int knobs[5] = {opt.simds, opt.piece_cap, opt.chain, opt.cut_rule, opt.tlimit};
             mix(knobs, sizeof(knobs));
             const char *stamp = __DATE__ " " __TIME__;
             mix(stamp, strlen(stamp));
@@ -417,7 +385,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
             }
         }
     }
-    if (flow_tables_host(opt, n, indptr, indices, sign, comp, ncomp, capable, -1, handled, t, err) != 0)
+    if (flow_tables_host(opt, n, indptr, indices, sign, comp, ncomp, handled, t, err) != 0)
         return xh_fail(ctx, XH_ERR_ARG, "%s", err.c_str());
     if (!cache.empty() && t.n_units > 0) {
         const std::string dir = cache.substr(0, cache.rfind('/'));
@@ -441,7 +409,6 @@ int flow_plan_upload(xh_ctx *ctx, const FlowTables &t, FlowPlan **out) {
     fp->n_cells = t.n_cells;
     fp->max_imports = t.max_imports;
     fp->max_exports = t.max_exports;
-    fp->n_plain_units = t.n_plain_units;
     fp->rsum = t.rsum;
     for (int c : t.cell_of_slot) fp->max_cell = std::max(fp->max_cell, c);
     for (int c : t.fold_of_slot) fp->max_cell = std::max(fp->max_cell, c);
@@ -460,7 +427,6 @@ int flow_plan_upload(xh_ctx *ctx, const FlowTables &t, FlowPlan **out) {
     rc |= put(ctx, fp->d_unit_lmax, t.unit_lmax);
     rc |= put(ctx, fp->d_unit_glmax, t.unit_glmax);
     rc |= put(ctx, fp->d_lane_flags, t.lane_flags);
-    rc |= put(ctx, fp->d_ghost_prod, t.ghost_prod);
     if (!t.fold_of_slot.empty()) rc |= put(ctx, fp->d_fold_cell, t.fold_of_slot);
     fp->n_folded = t.n_folded;
     fp->n_special = t.n_special;
@@ -479,18 +445,6 @@ int flow_stats_fetch(xh_ctx *ctx, FlowPlan *fp, std::vector<unsigned long long> 
     out.resize((size_t)fp->n_units * 6);
     XH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     XH_HIP(ctx, hipMemcpy(out.data(), fp->d_stats, out.size() * 8, hipMemcpyDeviceToHost));
-    if (const char *path = getenv("XH_FLOW_TRACE")) {
-        if (fp->d_trace && fp->trace_words) {
-            std::vector<unsigned> tr(fp->trace_words);
-            XH_HIP(ctx, hipMemcpy(tr.data(), fp->d_trace, tr.size() * 4, hipMemcpyDeviceToHost));
-            if (FILE *f = fopen(path, "wb")) {
-                const int nu = fp->n_units;
-                fwrite(&nu, 4, 1, f);
-                fwrite(tr.data(), 4, tr.size(), f);
-                fclose(f);
-            }
-        }
-    }
     return XH_OK;
 }
 
@@ -518,11 +472,7 @@ int flow_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     // split needs, because the even split itself (5 x 32 KiB on a 160 KiB CU) was measured to admit one fewer than
     // hipOccupancyMaxActiveBlocksPerMultiprocessor reports (routing 18.0 ms -> 10.7 ms for 120 months).
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-    int per_cu = (fp->n_units + cus - 1) / cus + 1;
-    {
-        const char *env = getenv("XH_FLOW_PER_CU_EXTRA");     // experiments only
-        if (env) per_cu += atoi(env);
-    }
+    const int per_cu = (fp->n_units + cus - 1) / cus + 1;
     const size_t lds_static = 2 * (size_t)NPAIR * sizeof(double2);
     const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
     size_t lds = share > lds_static + 1024 ? share - lds_static : 0;      // dynamic part on top of the static buffers

@@ -56,26 +56,26 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2
     bool bad = false;
     if (p & 16) {             // pair unit of a single-sum plan: the step of the plan of pairs + the exit guard
         if (!(p & 8) || (p & 4)) bad = true;
-        else if (g2) wave_unit<false, 1, 0, 2, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
-        else if (g) wave_unit<false, 1, 0, 1, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
-        else wave_unit<false, 1, 0, 0, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
+        else if (g2) wave_unit<1, 0, 2, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
+        else if (g) wave_unit<1, 0, 1, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
+        else wave_unit<1, 0, 0, true, true, false, 2>(ap, l, xtab, qst, fnd, unit);
     } else if (p & 8) {      // single unit: one running sum, 8-byte entries
         if (p & 4) {          // (a unit that carries folded leaves has no imports: xh_flow_rsum.cpp)
             if (g || !A(fold_cell)) bad = true;
-            else wave_unit<false, 1, 0, 0, true, true, true, 1>(ap, l, xtab, qst, fnd, unit);
-        } else if (g2) wave_unit<false, 1, 0, 2, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);
-        else if (g) wave_unit<false, 1, 0, 1, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);
-        else if ((p & 2) || x) wave_unit<false, 1, 0, 0, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);
-        else if (p & 1) wave_unit<false, 1, 0, 0, false, true, false, 1>(ap, l, xtab, qst, fnd, unit);
-        else wave_unit<false, 0, 0, 0, false, true, false, 1>(ap, l, xtab, qst, fnd, unit);
+            else wave_unit<1, 0, 0, true, true, true, 1>(ap, l, xtab, qst, fnd, unit);
+        } else if (g2) wave_unit<1, 0, 2, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);
+        else if (g) wave_unit<1, 0, 1, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);
+        else if ((p & 2) || x) wave_unit<1, 0, 0, true, true, false, 1>(ap, l, xtab, qst, fnd, unit);
+        else if (p & 1) wave_unit<1, 0, 0, false, true, false, 1>(ap, l, xtab, qst, fnd, unit);
+        else wave_unit<0, 0, 0, false, true, false, 1>(ap, l, xtab, qst, fnd, unit);
     } else if (p & 4) {
         if (g || !A(fold_cell)) bad = true;
-        else wave_unit<false, 1, 0, 0, true, true, true>(ap, l, xtab, qst, fnd, unit);
-    } else if (g2) wave_unit<false, 1, 0, 2, true, true>(ap, l, xtab, qst, fnd, unit);
-    else if (g) wave_unit<false, 1, 0, 1, true, true>(ap, l, xtab, qst, fnd, unit);
-    else if ((p & 2) || x) wave_unit<false, 1, 0, 0, true, true>(ap, l, xtab, qst, fnd, unit);
-    else if (p & 1) wave_unit<false, 1, 0, 0, false, true>(ap, l, xtab, qst, fnd, unit);
-    else wave_unit<false, 0, 0, 0, false, true>(ap, l, xtab, qst, fnd, unit);
+        else wave_unit<1, 0, 0, true, true, true>(ap, l, xtab, qst, fnd, unit);
+    } else if (g2) wave_unit<1, 0, 2, true, true>(ap, l, xtab, qst, fnd, unit);
+    else if (g) wave_unit<1, 0, 1, true, true>(ap, l, xtab, qst, fnd, unit);
+    else if ((p & 2) || x) wave_unit<1, 0, 0, true, true>(ap, l, xtab, qst, fnd, unit);
+    else if (p & 1) wave_unit<1, 0, 0, false, true>(ap, l, xtab, qst, fnd, unit);
+    else wave_unit<0, 0, 0, false, true>(ap, l, xtab, qst, fnd, unit);
     if (bad && threadIdx.x == 0)      // a shape the planner does not produce: a fault rather than wrong results
         __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

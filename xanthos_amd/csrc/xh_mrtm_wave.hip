@@ -16,14 +16,10 @@
 //     out of range, which the buffer resource drops) and one transfer round unless a unit really has more than 8 imports
 //     / outlets, (c) reads one 32-byte record per month.
 //
-//   * PLAIN units.  The second row sum of mrtm.py (:66-69, with the flows adjusted by the "excess flow" rule) differs
-//     from the first only where an UPSTREAM NEIGHBOUR fired, and a cell can only fire if velocity * dt / length > 1
-//     (1.1 % of the synthetic world's cells; see flow_typed_partition for the argument and its guard).  A unit none of
-//     whose cells has such a neighbour gathers ONE 8-byte value per term instead of a {F, F2} pair and forms ONE sum:
-//     13 + (pre + post) fp64 operations instead of 13 + 2 (pre + post), ds_read_b64 (~8 cycles) instead of ds_read_b128
-//     (~15): 137 instead of 198 cycles for a (2,4) row.  A lane of a plain unit that fires after all (denormal storage,
-//     negative runoff or initial storage: outside the argument) raises FAULT_GUARD and the call is routed again with
-//     every unit in pair form; so do imported pairs whose halves differ.  Results never depend on the shortcut.
+//   (Rounds 3-5 also had PLAIN units here -- one 8-byte value per term where no upstream neighbour can fire, with a guard, a
+//   learning pass and per-box caches of the cells seen firing: the bit-exact kernel's way to 22.5 ms.  Since round 5 the
+//   reassociated kernel k_mrtm_rsum routes by default and this one is the CHECKER and the XH_ROUTE_EXACT option: the
+//   adaptive machinery was retired in round 6 -- every unit in pair form, 25 ms at the full grid, nothing to learn.)
 //
 // Which workgroup runs which unit is settled at the top of the kernel, not by the workgroup id (see k_mrtm_wave).
 #include <algorithm>
@@ -31,12 +27,8 @@
 
 namespace {
 
-// Two waves per SIMD must fit (more units than SIMDs): at most 256 registers.  (XH_WAVE_WPE=3: experiment -- 168 registers,
-// what several worlds per GPU in one launch would need; DESIGN 4.3 "B worlds".)
-#ifndef XH_WAVE_WPE
-#define XH_WAVE_WPE 2
-#endif
-__global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(XH_WAVE_WPE, XH_WAVE_WPE))) k_mrtm_wave(const WaveArgs *ap_) {
+// Two waves per SIMD must fit (more units than SIMDs): at most 256 registers.
+__global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mrtm_wave(const WaveArgs *ap_) {
     WaveArgsK *ap = (WaveArgsK *)ap_;
     __shared__ __attribute__((aligned(16))) v2d lds[RING * NSLOT];
     __shared__ uint2 xtab[LANES];
@@ -58,31 +50,26 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(XH_W
     } else if (prio == 3) {
         __builtin_amdgcn_s_setprio(3);
     }
-    const int p = A(unit_p)[unit];       // uniform per workgroup: terms before | after the diagonal << 4 | chained << 8 | plain << 9
+    const int p = A(unit_p)[unit];       // uniform per workgroup: terms before | after the diagonal << 4 | chained << 8
     const bool has_ghost = A(ghost_edge)[(int64_t)unit * LANES + threadIdx.x] >= 0;      // lane k: the unit's k-th import
     const bool g = __any(has_ghost), g2 = __any(has_ghost && threadIdx.x >= 8);
     char *l = reinterpret_cast<char *>(lds);
     __attribute__((address_space(3))) unsigned *qst = (__attribute__((address_space(3))) unsigned *)qstage_sh;
     __attribute__((address_space(3))) double *fnd = (__attribute__((address_space(3))) double *)fend_sh;
     fend_sh[threadIdx.x] = 0.0;
-    // one specialisation per (terms before, terms after, imports?, chained?, plain?): an LDS read costs a lone wave 8-15
-    // cycles of issue, so no unit should read padding it does not need
+    // one specialisation per (terms before, terms after, imports?, chained?): an LDS read costs a lone wave 8-15 cycles of
+    // issue, so no unit should read padding it does not need
     // NG1 = true compiles the one-round form too (the shapes most units have; each form is ~45 KB of code and ~10 s of
     // compile time, so the rare shapes send every unit with imports through the two-round form)
-#define WAVE_FORM(PLAINF, PRE, POST, CHAINED, NG1)                                                        \
-    case (PRE) | ((POST) << 4) | ((CHAINED) ? 0x100 : 0) | ((PLAINF) ? 0x200 : 0):                        \
-        if (g2 || (g && !(NG1))) wave_unit<PLAINF, PRE, POST, 2, CHAINED>(ap, l, xtab, qst, fnd, unit);        \
-        else if (g) wave_unit<PLAINF, PRE, POST, (NG1) ? 1 : 2, CHAINED>(ap, l, xtab, qst, fnd, unit);         \
-        else wave_unit<PLAINF, PRE, POST, 0, CHAINED>(ap, l, xtab, qst, fnd, unit);                            \
+#define WAVE_FORM(PRE, POST, CHAINED, NG1)                                                        \
+    case (PRE) | ((POST) << 4) | ((CHAINED) ? 0x100 : 0):                                         \
+        if (g2 || (g && !(NG1))) wave_unit<PRE, POST, 2, CHAINED>(ap, l, xtab, qst, fnd, unit);        \
+        else if (g) wave_unit<PRE, POST, (NG1) ? 1 : 2, CHAINED>(ap, l, xtab, qst, fnd, unit);         \
+        else wave_unit<PRE, POST, 0, CHAINED>(ap, l, xtab, qst, fnd, unit);                            \
         break;
-#define WAVE_PAIR(PRE, POST, CHAINED) WAVE_FORM(false, PRE, POST, CHAINED, false)
-#define WAVE_PAIR1(PRE, POST, CHAINED) WAVE_FORM(false, PRE, POST, CHAINED, true)
-#define WAVE_PLAIN(PRE, POST, CHAINED) WAVE_FORM(true, PRE, POST, CHAINED, false)
-#define WAVE_PLAIN1(PRE, POST, CHAINED) WAVE_FORM(true, PRE, POST, CHAINED, true)
+#define WAVE_PAIR(PRE, POST, CHAINED) WAVE_FORM(PRE, POST, CHAINED, false)
+#define WAVE_PAIR1(PRE, POST, CHAINED) WAVE_FORM(PRE, POST, CHAINED, true)
     switch (p) {
-#ifdef XH_WAVE_STUDY      // ISA study build (hipcc -S -DXH_WAVE_STUDY): one pair and one plain shape, nothing else
-        WAVE_PAIR(2, 3, false) WAVE_PLAIN(2, 3, false)
-#else
         WAVE_PAIR1(1, 1, false) WAVE_PAIR1(1, 2, false) WAVE_PAIR1(1, 3, false) WAVE_PAIR1(1, 4, false)
         WAVE_PAIR(2, 1, false) WAVE_PAIR1(2, 2, false) WAVE_PAIR1(2, 3, false) WAVE_PAIR1(2, 4, false)
         WAVE_PAIR(3, 1, false) WAVE_PAIR1(3, 2, false) WAVE_PAIR(3, 3, false) WAVE_PAIR(3, 4, false)
@@ -90,18 +77,9 @@ __global__ void __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(XH_W
         // chained units: front side 3 or 4 summed on the way, 1 or 2 terms left to read (flow_plan_build)
         WAVE_PAIR(1, 1, true) WAVE_PAIR1(1, 2, true) WAVE_PAIR1(1, 3, true) WAVE_PAIR(1, 4, true)
         WAVE_PAIR(2, 1, true) WAVE_PAIR1(2, 2, true) WAVE_PAIR1(2, 3, true) WAVE_PAIR(2, 4, true)
-        // plain units come in fewer shapes (a padded 8-byte term costs ~13 cycles): flow_plain_class rounds up to these
-        WAVE_PLAIN(1, 1, false) WAVE_PLAIN(1, 2, false) WAVE_PLAIN(1, 3, false) WAVE_PLAIN(2, 2, false)
-        WAVE_PLAIN1(2, 3, false) WAVE_PLAIN1(2, 4, false) WAVE_PLAIN1(3, 3, false) WAVE_PLAIN(4, 4, false)
-        // (the few units with the longest rows: in the selective plan they are the ones that pace the run)
-        WAVE_PLAIN(4, 2, false) WAVE_PLAIN(3, 4, false) WAVE_PLAIN(4, 3, false)
-        WAVE_PLAIN(1, 2, true) WAVE_PLAIN1(1, 3, true) WAVE_PLAIN1(1, 4, true) WAVE_PLAIN1(2, 3, true) WAVE_PLAIN(2, 4, true)
-#endif
         default:      // not produced by the plan; a fault rather than wrong results
             if (threadIdx.x == 0) __hip_atomic_store(A(fault), FAULT_PLACE_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#undef WAVE_PLAIN1
-#undef WAVE_PLAIN
 #undef WAVE_PAIR1
 #undef WAVE_PAIR
 #undef WAVE_FORM

@@ -23,7 +23,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     if (!fp || fp->n_units == 0) return XH_OK;
     // a lane must have left month it - 1 before the unit's clock reaches month it + 1 (one pending snapshot per lane)
     if (!fp->skew_ok || fp->max_imports > 8 * SK_R || fp->max_exports > 8 * SK_R || s.ntmin < fp->skew_lmax + 2 * GROUP) {
-        if (getenv("XH_FLOW_DEBUG"))
+        if (xh_flow_debug())
             fprintf(stderr, "time-skewed kernel not used: skew_ok %d, imports %d, outlets %d, shortest month %d sub-steps, largest lag %d\n",
                     (int)fp->skew_ok, fp->max_imports, fp->max_exports, s.ntmin, fp->skew_lmax);
         return XH_ERR_LIMIT;
@@ -36,7 +36,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         if (const char *env = getenv("XH_WAVE_ROW_LIMIT")) limit = std::min<uint64_t>(limit, strtoull(env, nullptr, 10));
         const uint64_t stride = io.feed ? 128u : (uint64_t)s.nmonths * 8u;
         if ((uint64_t)(fp->max_cell + 1) * stride > limit || (io.feed && (int64_t)fp->max_cell >= io.feed->ncell)) {
-            if (getenv("XH_FLOW_DEBUG"))
+            if (xh_flow_debug())
                 fprintf(stderr, "round-3 time-skewed kernel not used: %d rows x %d months x 8 B exceed its 32-bit row offsets\n",
                         fp->max_cell + 1, s.nmonths);
             return XH_ERR_LIMIT;
@@ -45,7 +45,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     // Ring size.  A consumer asks for ~2 CH + lag sub-steps ahead of its clock, a producer may run RS - CH - lag ahead.  A
     // stream that jumps over k pipeline levels (a tributary that joins the main stem far downstream: its consumer also
     // waits for units k levels below the producer) needs the lead of all of them in its ring: every level trails the one
-    // above by PUBLAG + RING + lag + CH + GROUP + up to CH of check granularity ~ 400-450 sub-steps.  With a shorter ring
+    // above by RING + lag + CH + GROUP + up to CH of check granularity ~ 400-450 sub-steps.  With a shorter ring
     // nobody deadlocks, but the producer is held at the ring limit, its other consumers starve, and every linked unit ends
     // up waiting a quarter of the time (round 2: 32.7 instead of 26.7 ms with 2,048 sub-steps and a 6-level jump).
     int rs = 2048;
@@ -139,7 +139,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
                               (fp->rsum ? 2 * LANES * sizeof(unsigned) + LANES * sizeof(double) : 0);      // (k_mrtm_rsum: the folded leaves' halves)
     // single-sum plans: their pair units (the tail of the claim list) get a CU to themselves (wave_claim); XH_RSUM_EXCL=0: A/B
     int n_excl = 0;
-    if (fp->rsum && fp->n_special >= 0 && fp->n_pair_units > 0 && !(getenv("XH_RSUM_EXCL") && getenv("XH_RSUM_EXCL")[0] == '0'))
+    if (fp->rsum && fp->n_special >= 0 && fp->n_pair_units > 0 && xh_env_on("XH_RSUM_EXCL", true))
         n_excl = std::min(fp->n_pair_units, 0xffff);
     int n_wg = 0, resident = 0;
     size_t lds = 0;
@@ -151,11 +151,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
             const char *env = getenv("XH_FLOW_SPARE");            // experiments only
             if (env) n_wg = fp->n_units + std::max(atoi(env), 0);
         }
-        int per_cu = (n_wg + cus - 1) / cus + 1;
-        {
-            const char *env = getenv("XH_FLOW_PER_CU_EXTRA");     // experiments only
-            if (env) per_cu += atoi(env);
-        }
+        const int per_cu = (n_wg + cus - 1) / cus + 1;
         const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
         lds = share > lds_static + 1024 ? share - lds_static : 0;
         XH_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -185,8 +181,6 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.rec = d_rec;
     a.fin = d_fin;
     a.lane_flags = static_cast<const unsigned char *>(fp->d_lane_flags.p);
-    a.ghost_prod = static_cast<const int *>(fp->d_ghost_prod.p);
-    a.learn = io.learn;
     a.dt = s.dt;
     a.dtinv = 1.0 / s.dt;
     a.flow_dist = io.flow_dist;
@@ -199,9 +193,9 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.place_epoch = feed ? feed->place_epoch : nullptr;
     a.epoch = feed ? feed->epoch : 0u;
     a.n_excl = n_excl;
-    a.fenced = (getenv("XH_ROUTE_FENCED") && getenv("XH_ROUTE_FENCED")[0] == '1') ? 1 : 0;
-    if (getenv("XH_ROUTE_FENCED") && getenv("XH_ROUTE_FENCED")[0] == 'l') a.fenced = 4;      // "lag": round 4's publication (vmcnt(8) + PUBLAG), for comparison
-    if (!a.fenced && getenv("XH_FEED_POLL") && getenv("XH_FEED_POLL")[0] == 'l') a.fenced = 2;      // experiments (wait_months)
+    // XH_ROUTE_FENCED=1: agent-scope release / acquire fences around the stream counters -- the publication the HIP memory model
+    // asks for (+76 % on this kernel: profiles/round5/fence_mid_ab.txt); the default is the measured `sc1` hand-off (check())
+    a.fenced = xh_env_on("XH_ROUTE_FENCED", false) ? 1 : 0;
     a.S0 = io.S0;
     a.chs = io.chs;
     a.avg = io.avg;
@@ -227,15 +221,8 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         if (env && env[0] == '1') {
             if (!fp->d_stats) XH_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&fp->d_stats), (size_t)fp->n_units * 48));
             a.stats = fp->d_stats;
-            if (getenv("XH_FLOW_TRACE")) {
-                if (fp->d_trace) (void)hipFree(fp->d_trace);
-                fp->trace_words = (size_t)fp->n_units * (size_t)(s.nit + 1);
-                XH_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&fp->d_trace), fp->trace_words * 4));
-                XH_HIP(ctx, hipMemsetAsync(fp->d_trace, 0, fp->trace_words * 4, st));
-            }
         }
     }
-    a.trace = fp->d_trace;
     a.fold_cell = static_cast<const int *>(fp->d_fold_cell.p);
     if (!fp->d_skew_args) XH_HIP(ctx, hipMalloc(&fp->d_skew_args, sizeof(WaveArgs) + 256));
     // stream-ordered: the previous launch has finished reading the block before this one rewrites it

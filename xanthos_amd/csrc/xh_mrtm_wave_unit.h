@@ -1,6 +1,6 @@
 // Device code shared by the two time-skewed dataflow routing kernels:
 //   k_mrtm_wave (xh_mrtm_wave.hip)   every row sum in scipy's stored order: bit-identical to the reference, one
-//                                    specialisation per row shape, pair and plain units
+//                                    specialisation per row shape (pair units: every lane passes {F, F2})
 //   k_mrtm_rsum (xh_mrtm_rsum.hip)   the reassociated ("tolerance") form: running sums along chains of lanes, two reads per
 //                                    sub-step for every unit, the update fused (xh_flow_rsum.cpp plans it)
 // wave_unit() is one unit's whole run; wave_claim() settles which unit a workgroup runs.  Included by exactly those two
@@ -34,7 +34,6 @@ constexpr int SK_R = 2;                       // block-transfer rounds: up to 8 
 #define XH_WAVE_CH 256                        // (128 until round 4: 23.55 -> 23.35 ms at the full grid, same box, two runs each)
 #endif
 constexpr int CH = XH_WAVE_CH;                // iterations between flow-control checks (multiple of GROUP)
-constexpr int PUBLAG = 64;                    // a check publishes the stores older than this many iterations
 constexpr unsigned FAULT_DATA_WAIT = 1, FAULT_RING_WAIT = 2, FAULT_PLACE_WAIT = 3, FAULT_GUARD = XH_FAULT_GUARD;
 constexpr unsigned FAULT_TEST = 99;
 constexpr int PLACE_KEYS = 16 * 8 * 2 * 16 * 4;      // (xcc, se, sh, cu, simd) of HW_ID / XCC_ID
@@ -65,9 +64,7 @@ struct WaveArgs {
     const unsigned *ent2;             // [2][SK_P][units*64] LDS entry offsets x 16 (before / after the diagonal)
     const unsigned *eprev;            // [units*64] chained units: entry x 16 of the pair this lane's own flows are added to
     const int *unit_p, *unit_lmax, *unit_glmax;
-    const unsigned char *lane_flags;  // [units*64] bit 0: the cell can fire by construction (exempt from the guard of plain units)
-    const int *ghost_prod;            // [units*64] cell that produces imported stream k of the unit
-    unsigned char *learn;             // [ncell] set for cells seen firing although they were not expected to (see check())
+    const unsigned char *lane_flags;  // [units*64] single-sum plans (k_mrtm_rsum): bit 0 the cell may fire, bit 1 an exit lane (xh_flow_rsum.cpp)
     int64_t total_slots;
     int nmonths, nit, total;
     const int *unit_order;            // [units] claim list: units without streams by rising cost, then the others
@@ -97,7 +94,6 @@ struct WaveArgs {
     unsigned *done;                   // [units] sub-steps consumed
     unsigned *fault;
     unsigned long long *stats;
-    unsigned *trace;                  // [units][nit + 1] 100 MHz ticks at which each unit finished each month (XH_FLOW_TRACE, with stats)
     const int *fold_cell;             // (at the end: k_mrtm_rsum only) [units*64] the leaf cell a lane carries besides its own, or -1; NULL: none
 };
 
@@ -150,8 +146,8 @@ __device__ __forceinline__ T xh_ldarg(__attribute__((address_space(4))) const T 
 }
 #define A(f) xh_ldarg(&ap->f)
 
-// value exchanged between lanes: {F, F2} in a pair unit, the one flow in a plain unit
-template <bool PLAIN> struct Val;
+// value exchanged between lanes: the pair {F, F2} (or {sum F, sum F2}), or the one running sum of a single unit (SGL = 1)
+template <bool ONE> struct Val;
 template <> struct Val<false> {
     typedef v2d T;
     typedef __attribute__((address_space(3))) const v2d lds_c;
@@ -206,12 +202,12 @@ template <> struct Val<true> {
 // it), initial storages and -- month by month -- lateral inflows are >= 0 up to a rounding error of the runoff model, and
 // the outflow of every exit lane (lane_flags bit 1: a cell in pair form whose downstream cell is not) stays >= -SGL_XEPS:
 // then every flow a single unit receives is >= 0, and its cells outside the marked set cannot fire.
-template <bool PLAIN, int PRE, int POST, int NG, bool CHAIN, bool RSUM = false, bool FOLD = false, int SGL = 0>
+template <int PRE, int POST, int NG, bool CHAIN, bool RSUM = false, bool FOLD = false, int SGL = 0>
 __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint2 *xtab,
                                           __attribute__((address_space(3))) unsigned *qstage,
                                           __attribute__((address_space(3))) double *fend, const int unit) {
     constexpr bool HAS_G = NG > 0;
-    constexpr bool V8 = PLAIN || SGL == 1;             // 8-byte entries: one value per lane instead of a pair
+    constexpr bool V8 = SGL == 1;                      // 8-byte entries: one value per lane instead of a pair
     typedef Val<V8> V;
     typedef typename V::T val_t;
     typedef typename V::lds_c lds_cv;
@@ -233,9 +229,9 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     const double acoef = 1.0 - tauinv * A(dt);                                    // RSUM: share of the storage a sub-step keeps
     const double area = valid ? A(area)[gc] : 0.0;
     const double S0v = (valid && A(S0)) ? A(S0)[gc] : 0.0;
-    // table offsets are entry x 16 (the pair layout); a plain unit's entries are 8 bytes
+    // table offsets are entry x 16 (the pair layout); a single unit's entries are 8 bytes
     auto ent_off = [](unsigned o) { return V8 ? o >> 1 : o; };
-    static_assert(!RSUM || (!PLAIN && PRE <= 1 && POST == 0), "reassociated form: one inflow entry, pair values");
+    static_assert(!RSUM || (PRE <= 1 && POST == 0), "reassociated form: one inflow entry");
     static_assert(!FOLD || (RSUM && NG == 0), "folded leaves: reassociated form, units without imports");
     static_assert(SGL == 0 || RSUM, "single-sum plans: reassociated form");
     // the folded leaf of this lane
@@ -273,12 +269,6 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     // feed reads the last one's value as ONE term.  The additions and their order are the row sum's own.
     lds_cchar *eprv = lds0 + (CHAIN ? ent_off(A(eprev)[slot]) : 0u);
     lds_mv *own = (lds_mv *)lds0 + lane;
-    // plain units keep the trial flows of their cells in a second ring (8 slots x 64 doubles behind the first): an outlet
-    // that CAN fire (gval == 0) exports the true {F, F2} pair to the pair unit downstream of it
-    typedef __attribute__((address_space(3))) double lds_d;
-    typedef __attribute__((address_space(3))) const double lds_cd;
-    constexpr unsigned SIDE0 = RING * NSLOT * 8u;
-    lds_d *own0 = (lds_d *)(lds0 + SIDE0) + lane;
     const int xedge = A(export_edge)[slot];
     const int gedge = A(ghost_edge)[slot];
     const bool has_x = xedge >= 0, has_g = gedge >= 0;
@@ -307,7 +297,6 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     unsigned gfull[SK_R], xbyte[SK_R];      // ring base | position of the next import block; ring base + 16 i for stores
     lds_mv *gdst[SK_R];
     lds_cv *xsrc[SK_R];
-    lds_cd *xsrc0[SK_R];
 #pragma unroll
     for (int r = 0; r < SK_R; ++r) {
         const int k = r * 8 + grp;
@@ -320,26 +309,18 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         const uint2 t = xon ? xtab[k] : make_uint2((unsigned)lane, 0u);
         xbyte[r] = xon ? t.y * (maskb + 1u) + (unsigned)sub * 16u : oob;
         xsrc[r] = (lds_cv *)(lds0 + sub * SLOTB) + t.x;
-        xsrc0[r] = (lds_cd *)(lds0 + SIDE0 + sub * LANES * 8u) + t.x;
     }
 #pragma unroll
     for (int k = 0; k < RING; ++k) {
         own[k * NSLOT] = V::zero();
         own[k * NSLOT + LANES] = V::zero();
         if (lane == 0) own[k * NSLOT + 2 * LANES] = V::zero();
-        if (PLAIN) own0[k * LANES] = 0.0;
     }
 
     const double dt = A(dt), dtinv = A(dtinv);
     double S = 0.0, F = 0.0, favg = 0.0, erl = 0.0;
     double snapS = 0.0, snapA = 0.0;
     int nx = A(lag)[slot];                                  // iteration at which this lane enters its next month
-    // Guard / learning.  `fired` becomes 1 when this lane's cell fires although it is not among the cells that can by
-    // construction (gval = 0 for those).  In a plain unit that invalidates the run (check()); in a pair unit it is only
-    // noted.  Either way the cell is recorded in `learn`, the host adds it to the cells that can fire and the next
-    // partition treats it accordingly.  `gmis`: a block lane of a plain unit imported a pair whose halves differ.
-    unsigned fired = 0, gmis = 0;
-    const unsigned gval = (valid && (A(lane_flags)[slot] & 1u) == 0) ? 1u : 0u;
     // pointers the month bookkeeping needs, read once (nine scalar registers; the sub-step loop holds no scalar loads)
     const double *p_runoff = A(runoff);
     double *p_chs = A(chs), *p_avg = A(avg);
@@ -368,7 +349,6 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         r.q_off = p_rec[i].q_off;
         return r;
     };
-    unsigned *p_trace = A(trace);
     const int nmo = A(nmonths);
     // The runoff of the month after next travels global memory -> LDS without a register (global_load_lds_dword, lane L's
     // dword lands at M0 + instruction offset + 4 L: tools/micro/lds_dma.hip) and is read out of LDS a month later.  As an
@@ -441,8 +421,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             // from a copy of the line that an earlier poll left in this XCD's L2 (a unit that polls while every other unit is
             // parked in the same wait has no traffic that would ever evict such a copy).  Rare path: once per call and unit.
             unsigned v = 0;
-            if (A(fenced) == 2) v = ld_relaxed(p);      // XH_FEED_POLL=load: the plain agent-scope load, for comparison
-            else if (lane == 0) v = __hip_atomic_fetch_add(const_cast<unsigned *>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) v = __hip_atomic_fetch_add(const_cast<unsigned *>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
             if (v >= need) {
                 mready = v;
@@ -461,15 +440,15 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
 
     // ---- flow control, every CH iterations, at a group start.  Every block of 8 iterations issues at least one
-    //      stream access, so "all but the 8 youngest memory operations have completed" covers every store older than
-    //      PUBLAG iterations without draining the loads that are two blocks ahead.
+    //      stream access (the round-4 form of the publication counted on that: "all but the 8 youngest memory operations
+    //      have completed" + a lag of 64 iterations).
     //      MEMORY-ORDERING ASSUMPTION (outside the HIP memory model, stated here because everything rests on it): the
     //      stream stores are write-through `sc1` buffer stores, and a write-through store retires (leaves vmcnt) only
     //      when the memory side has acknowledged it; since round 5 the publication waits for `s_waitcnt vmcnt(0)` -- ALL
     //      of the wave's memory operations, the form the guide measured for `sc1` hand-offs -- so every stream store
     //      issued so far is visible at agent scope; only then is the
     //      counter advanced (relaxed agent-scope store, itself ordered behind the waitcnt by the "memory" clobber).  (Until
-    //      round 4: vmcnt(8) + the in-order retirement of vmcnt + a publication lag of PUBLAG iterations; XH_ROUTE_FENCED=lag.)  A
+    //      round 4: vmcnt(8) + the in-order retirement of vmcnt + a publication lag of 64 iterations.)  A
     //      consumer reads the counter with an agent-scope load and the data with `sc1` loads, which re-fetch past its
     //      XCD's L2.  No release / acquire fences.  Evidence: every full-size launch of the test suite bit-identical to
     //      the oracle, XH_ROUTE_VALIDATE (the same call routed by the barrier-only kernel and compared on the device),
@@ -483,33 +462,19 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(q) : "memory");
         return v;
     };
-    auto learn_now = [&]() {
-        if (fired && valid) A(learn)[gc] = 1;
-        if (PLAIN && HAS_G && gmis) {       // block lane (k, i): the producer of import k fired
-#pragma unroll
-            for (int r = 0; r < SK_R; ++r)
-                if ((gmis >> r) & 1u) A(learn)[A(ghost_prod)[(int64_t)unit * LANES + r * 8 + grp]] = 1;
-        }
-    };
     auto check = [&](int n) {
         const unsigned long long w0 = __builtin_amdgcn_s_memtime();
         // Round 5, the default since: EVERY memory operation of the wave has been acknowledged before the counter
         // store -- `s_waitcnt vmcnt(0)` in front of the flag, the guide's measured `sc1` hand-off form, without the L2 write-back
         // of a release fence; the import loads two blocks ahead are simply waited for.  Priced on both kernels, same box,
         // alternating (profiles/round5/fence_mid_ab.txt): 15.08 - 15.38 against 15.16 - 15.36 ms (reassociated), 22.0 - 22.9
-        // against 22.3 - 23.0 (bit-exact) -- nothing; the full release / acquire pair costs +76 % / +40 %.  XH_ROUTE_FENCED=lag
-        // (fenced == 4) is round 4's form for comparison: all but the 8 youngest operations + a publication lag of PUBLAG.
+        // against 22.3 - 23.0 (bit-exact) -- nothing; the full release / acquire pair costs +76 % / +40 % (XH_ROUTE_FENCED=1).
+        // (Until round 4: all but the 8 youngest operations + a publication lag of 64 sub-steps.)
         // (The second wait is a statement of its own BEHIND the counted one, without register operands: pend_* are registers
         // of loads in flight until that wait, and anything that makes the compiler copy them first -- a branch around the wait
         // did, and every stream-linked unit then read counters that had not arrived -- reads garbage.)
         asm volatile("s_waitcnt vmcnt(8)" : "+v"(pend_ready), "+v"(pend_done) : : "memory");   // older stores acknowledged, pend_* in
-        const bool lagged = A(fenced) == 4;
-        if (!lagged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (PLAIN && __any((fired | gmis) != 0)) {       // the plain form does not hold for this input: give up, the host re-routes
-            learn_now();
-            __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            alive = false;
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (SGL == 2) gsgl |= (xlane && fmin_seen < -SGL_XEPS) ? 4u : 0u;
         if ((FOLD && __any(gfold != 0)) || (SGL != 0 && __any(gsgl != 0))) {      // a folded leaf that can fire after all, a single-sum plan made for other data: the host routes again on the plan of pairs
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -517,8 +482,8 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         }
         const bool fenced = A(fenced) == 1;
         if (any_x) {      // publish what has certainly been stored, then make sure the next CH iterations have ring space
-            // (everything stored so far is acknowledged: publish it all; the lagged form holds back PUBLAG sub-steps)
-            const int pub = min(max(n - (lagged ? PUBLAG : 0) - RING - lmax, 0), total);
+            // (everything stored so far is acknowledged: publish it all)
+            const int pub = min(max(n - RING - lmax, 0), total);
             // XH_ROUTE_FENCED=1: the publication the HIP memory model asks for -- an agent-scope release (buffer_wbl2 sc1 +
             // s_waitcnt vmcnt(0): every memory operation of the wave drained, the XCD's L2 written back) in front of the
             // counter store, an agent-scope acquire behind the consumer's counter load.  Measured on MI355X at the full grid
@@ -551,7 +516,6 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     // ---- month bookkeeping for all lanes at once: outputs of iteration it - 1, lateral inflow of iteration it + 1.
     //      One 32-byte record per month involved (rec has three zero records past the end: no bounds tests).
     auto finalize = [&](int it) {
-        if (p_trace && lane == 0) p_trace[(int64_t)unit * (nit + 1) + it] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt_begin);
         const FinRec f = fc;
         fc = ld_fin(it + 1 <= nit ? it + 1 : nit + 1);      // used a month from now: nobody waits for it
         // The runoff loaded a month ago is consumed BEFORE this month's output stores are issued: after them, the wait for
@@ -657,11 +621,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         return v;
     };
     auto import_drop = [&](int r, const v4u u) {
-        if (PLAIN) {       // a plain unit takes F; the adjusted flow must be the same bits, or the unit is not plain after all
-            gmis |= (((u.x ^ u.z) | (u.y ^ u.w)) != 0u) ? (1u << r) : 0u;
-            typedef unsigned v2u __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<__attribute__((address_space(3))) v2u *>(gdst[r]) = v2u{u.x, u.y};
-        } else if (SGL == 1) {      // a single unit takes the sum of the adjusted flows (a single producer exports {y, y})
+        if (SGL == 1) {      // a single unit takes the sum of the adjusted flows (a single producer exports {y, y})
             typedef unsigned v2u __attribute__((ext_vector_type(2)));
             *reinterpret_cast<__attribute__((address_space(3))) v2u *>(gdst[r]) = v2u{u.z, u.w};
         } else {
@@ -673,11 +633,9 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     // the LDS ring (before the end of this sub-step overwrites slot 0).  The block is stored one sub-step later
     // (block_store), behind that sub-step's counted wait: stored at once, the wave would sit out the LDS latency.
     val_t xb[SK_R];
-    double xb0[SK_R];
 #pragma unroll
     for (int r = 0; r < SK_R; ++r) {
         xb[r] = V::zero();
-        xb0[r] = 0.0;
     }
     auto block_io = [&](const int b) {
         if (HAS_G) {      // the unit's rounds, unconditionally (NG is a template argument): with a run-time branch around the
@@ -691,25 +649,20 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         }
         if (any_x) {
             xb[0] = *xsrc[0];
-            if (PLAIN) xb0[0] = *xsrc0[0];
-            if (x2) {
-                xb[1] = *xsrc[1];
-                if (PLAIN) xb0[1] = *xsrc0[1];
-            }
+            if (x2) xb[1] = *xsrc[1];
         }
     };
-    auto store_pair = [&](const val_t v, const double v0, unsigned voff, unsigned soff) {
+    auto store_pair = [&](const val_t v, unsigned voff, unsigned soff) {
         v2d p;
-        if constexpr (PLAIN) p = v2d{v0, v};      // {trial flow, adjusted flow}: the same bits unless the outlet is one that can fire
-        else if constexpr (SGL == 1) p = v2d{v, v};      // a single unit's running sum: read as F = F2 by a pair unit (exact: see the template's comment)
+        if constexpr (SGL == 1) p = v2d{v, v};      // a single unit's running sum: read as F = F2 by a pair unit (exact: see the template's comment)
         else p = v;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, p), xr, voff, soff, AUX_SC1);
     };
     auto block_store = [&](int m0) {
         if (any_x) {
             const unsigned xpos = ((unsigned)(m0 - RING - lmax) * 16u) & maskb;   // 8 sub-steps, never wrapping
-            store_pair(xb[0], xb0[0], xbyte[0], xpos);
-            if (x2) store_pair(xb[1], xb0[1], xbyte[1], xpos);
+            store_pair(xb[0], xbyte[0], xpos);
+            if (x2) store_pair(xb[1], xbyte[1], xpos);
         }
     };
 
@@ -823,27 +776,6 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             favg += f2;                                                        // mrtm.py:78
             if (SGL == 2) fmin_seen = __builtin_fmin(fmin_seen, f2);           // exit guard (looked at by check())
             }
-        } else if constexpr (PLAIN) {
-            double s1 = 0.0;                                                   // UM.dot(F), stored order (mrtm.py:51)
-#pragma unroll
-            for (int w = 0; w < PRE; ++w) s1 += ac[w];
-            s1 -= F0;
-#pragma unroll
-            for (int w = 0; w < POST; ++w) s1 += bc[w];
-            const double dsdt = s1 + erl;
-            const double d = dsdt * dt;
-            const bool sx = d < (-S);                                          // mrtm.py:54
-            const double f2 = sx ? (dsdt + F0) + S * dtinv : F0;               // mrtm.py:60
-            own[(j & (RING - 1)) * NSLOT] = CHAIN ? rc + f2 : f2;
-            own0[(j & (RING - 1)) * LANES] = F0;
-            // no neighbour of this row can have been adjusted (or the guard below trips somewhere and the call is routed
-            // again in pair form), so the second sum of mrtm.py:66-69 is the first, bit for bit
-            double Sn = S + d;
-            asm volatile("" : "+v"(Sn));
-            S = sx ? 0.0 : Sn;                                                 // mrtm.py:63, 69
-            fired = sx ? gval : fired;                                         // guard: only the cells expected to may fire in a plain unit
-            F = f2;
-            favg += f2;                                                        // mrtm.py:78
         } else {
             double s1 = 0.0, s2 = 0.0;                                         // UM.dot(F), stored order (mrtm.py:51)
 #pragma unroll
@@ -867,7 +799,6 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             double Sn = S + dsdt2 * dt;
             asm volatile("" : "+v"(Sn));            // keeps the second sum out of an exec-masked region
             S = sx ? 0.0 : Sn;                                                 // mrtm.py:63, 69
-            fired = sx ? gval : fired;                                         // noted for the next partition (learn)
             F = f2;
             favg += f2;                                                        // mrtm.py:78
         }
@@ -941,9 +872,8 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     }
     if (alive) {
         while (itf <= nit) finalize(itf++);
-        learn_now();
         if (SGL == 2) gsgl |= (xlane && fmin_seen < -SGL_XEPS) ? 4u : 0u;
-        if ((PLAIN && __any((fired | gmis) != 0)) || (FOLD && __any(gfold != 0)) || (SGL != 0 && __any(gsgl != 0))) {
+        if ((FOLD && __any(gfold != 0)) || (SGL != 0 && __any(gsgl != 0))) {
             __hip_atomic_store(A(fault), FAULT_GUARD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alive = false;
         }
@@ -951,8 +881,8 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
     if (alive) {
         if (any_x) {      // last block, then everything is published
             const unsigned xpos = ((unsigned)(N - RING - lmax) * 16u) & maskb;
-            store_pair(*xsrc[0], PLAIN ? *xsrc0[0] : 0.0, xbyte[0], xpos);
-            if (x2) store_pair(*xsrc[1], PLAIN ? *xsrc0[1] : 0.0, xbyte[1], xpos);
+            store_pair(*xsrc[0], xbyte[0], xpos);
+            if (x2) store_pair(*xsrc[1], xbyte[1], xpos);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // write-through stores acknowledged
             if (A(fenced) == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             if (has_x) __hip_atomic_store(A(ready) + xedge, (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -968,8 +898,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
             if (A(F_end)) A(F_end)[gcL] = fend[LANES + lane];
         }
     }
-    const bool guard_set = __any((fired | gmis) != 0);
-    const bool gval_any = __any(gval != 0);
+    const bool guard_set = __any((gfold | gsgl) != 0);
     if (A(stats) && lane == 0) {
         unsigned long long *st = A(stats) + (int64_t)unit * 6;
         const unsigned long long cyc = __builtin_amdgcn_s_memtime() - cyc_begin;
@@ -979,7 +908,7 @@ __device__ __forceinline__ void wave_unit(WaveArgsK *ap, char *lds_generic, uint
         const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));
         st[3] = (unsigned long long)((PRE + POST + (CHAIN ? 1 : 0) + 1) & 15) | (any_g ? 16u : 0u) | (any_x ? 32u : 0u) |
-                (V8 ? 64u : 0u) | (guard_set ? 128u : 0u) | (gval_any ? 0u : 8u) | ((unsigned long long)hw << 8) | ((unsigned long long)(xcc & 15u) << 40) |
+                (V8 ? 64u : 0u) | (guard_set ? 128u : 0u) | ((unsigned long long)hw << 8) | ((unsigned long long)(xcc & 15u) << 40) |
                 (zone_groups << 44);
         st[4] = cyc_wait_data;
         st[5] = cyc_wait_ring;

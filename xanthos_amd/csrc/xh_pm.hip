@@ -597,13 +597,9 @@ int xh_pm_enqueue(xh_ctx *ctx, hipStream_t st, xh_pm_setup &s, int m_begin, int 
     const int64_t items = s.ncell * (int64_t)(m_count / 2);
     // grid-stride loop with a whole number of passes per thread: a block of months (xh_run_fused) is only ~1.5 passes of
     // the capped grid, and a ragged last pass would leave a quarter of the chip idle for it
-    // XH_PM_BLOCK=64 / 128 / 256: threads per workgroup (experiments: one-wave workgroups fit a SIMD's free registers
-    // whatever the other SIMDs of the CU hold)
-    static const int bsz_env = [] {
-        const int v = getenv("XH_PM_BLOCK") ? atoi(getenv("XH_PM_BLOCK")) : 0;
-        return (v == 64 || v == 128 || v == 256) ? v : 0;
-    }();
-    const int bsz = bsz_env ? bsz_env : ((s.block == 64 || s.block == 128) ? s.block : 256);
+    // (threads per workgroup: the caller's choice -- one-wave workgroups fit a SIMD's free registers whatever the other SIMDs
+    // of the CU hold: the fillers of a fed run --, default 256)
+    const int bsz = (s.block == 64 || s.block == 128) ? s.block : 256;
     const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * 32 * (256 / bsz);
     const int64_t need = (items + bsz - 1) / bsz;
     const int64_t passes = (need + cap - 1) / cap;
@@ -614,23 +610,13 @@ int xh_pm_enqueue(xh_ctx *ctx, hipStream_t st, xh_pm_setup &s, int m_begin, int 
                            s.d_pressure);
         s.pressure_done = true;
     }
-    // XH_PM_PAIRED=0 / 1 forces a variant (experiments); otherwise the caller's choice (xh_pm_setup::paired: the fillers
-    // of a fed run), default k_pm_pet
-    static const int paired_env = getenv("XH_PM_PAIRED") ? atoi(getenv("XH_PM_PAIRED")) : -1;
-    const bool paired = paired_env >= 0 ? paired_env != 0 : s.paired;
-    // XH_PM_LDS_PAD=<bytes of dynamic LDS>: experiments on the kernel's speed at reduced occupancy (100000 -> one workgroup
-    // per CU = one wave per SIMD, what a PM wave has beside a routing wave)
-    static const size_t pad = getenv("XH_PM_LDS_PAD") ? (size_t)atoll(getenv("XH_PM_LDS_PAD")) : 0;
-    if (pad) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pm_pet), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pm_pet2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-    }
-    if (paired)
-        hipLaunchKernelGGL(k_pm_pet2, dim3((unsigned)blocks), dim3(bsz), pad, st, static_cast<const PmTablesDev *>(s.d_tab),
+    // the caller's choice of variant (xh_pm_setup::paired: the fillers of a fed run), default k_pm_pet
+    if (s.paired)
+        hipLaunchKernelGGL(k_pm_pet2, dim3((unsigned)blocks), dim3(bsz), 0, st, static_cast<const PmTablesDev *>(s.d_tab),
                            s.d_lcy, s.ncell, s.nmonths, m_begin, m_count, d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds,
                            d_tairprev, d_lct, s.d_pressure, d_pet);
     else
-        hipLaunchKernelGGL(k_pm_pet, dim3((unsigned)blocks), dim3(bsz), pad, st, static_cast<const PmTablesDev *>(s.d_tab),
+        hipLaunchKernelGGL(k_pm_pet, dim3((unsigned)blocks), dim3(bsz), 0, st, static_cast<const PmTablesDev *>(s.d_tab),
                            s.d_lcy, s.ncell, s.nmonths, m_begin, m_count, d_tas, d_tmin, d_rhs, d_wind, d_rsds, d_rlds,
                            d_tairprev, d_lct, s.d_pressure, d_pet);
     xh_span_end(sp);

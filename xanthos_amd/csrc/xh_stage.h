@@ -48,8 +48,6 @@ int xh_abcd_enqueue_sim(xh_ctx *ctx, hipStream_t st, const xh_abcd_setup &s, int
 struct FlowFeed;
 // The typed plan's "do the same cells fire?" check enqueued ahead of the call that needs its answer (xh_mrtm.hip); _cancel
 // drops an answer that was not used.
-int xh_route_precheck(xh_ctx *ctx, xh_route_plan *plan, const double *d_flow_dist, const double *d_velocity, double dt);
-void xh_route_precheck_cancel(xh_route_plan *plan);
 int xh_route_series_fed(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months, const int32_t *h_ndays,
                         double dt, const double *d_flow_dist, const double *d_velocity, const double *d_area,
                         const double *d_runoff, const double *d_S0, double *d_chstorage, double *d_avgchflow,
