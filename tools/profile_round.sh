@@ -28,7 +28,7 @@ timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d gpurun_out/prof_insts_calib -- python3 bench.py --workload calib --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/prof_cyc_calib -- python3 bench.py --workload calib --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 tools/pmc_insts_json.py gpurun_out/pmc_insts.json gpurun_out/prof_insts gpurun_out/prof_cyc gpurun_out/prof_insts_calib gpurun_out/prof_cyc_calib > /dev/null
-(python3 tools/pmc_summary.py gpurun_out/prof_insts; python3 tools/pmc_summary.py gpurun_out/prof_cyc) | grep -E "k_pm_pet|k_abcd|k_mrtm_wave|k_mrtm_rsum" > gpurun_out/pmc_insts.txt
+(python3 tools/pmc_summary.py gpurun_out/prof_insts; python3 tools/pmc_summary.py gpurun_out/prof_cyc) | grep -E "k_pm_pet|k_abcd|k_mrtm_wave|k_mrtm_rsum|k_mrtm_units" > gpurun_out/pmc_insts.txt
 (python3 tools/pmc_summary.py gpurun_out/prof_insts_calib; python3 tools/pmc_summary.py gpurun_out/prof_cyc_calib) | grep -E "k_calib" >> gpurun_out/pmc_insts.txt
 timeout 900 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.log
 timeout 300 python3 bench.py --workload pm_abcd --steps 10 --warmup 2 > gpurun_out/bench_pm_abcd.json 2> gpurun_out/bench_pm_abcd.log
@@ -38,7 +38,7 @@ cp gpurun_out/prof_trace_calib/*/*kernel_stats.csv gpurun_out/kernel_stats_calib
 timeout 300 python3 bench.py --steps 20 --warmup 5 --order staged --no-end-to-end --no-cpu-baseline > gpurun_out/bench_staged.json 2> /dev/null
 timeout 300 python3 tools/feed_interference.py 2>&1 | grep -E "stage by stage|fed" > gpurun_out/feed_interference.txt
 timeout 600 python3 tools/feed_stress.py 150 2>&1 | tail -3 > gpurun_out/feed_stress.txt
-XH_FLOW_DEBUG=1 XH_FLOW_STATS=1 timeout 300 python3 tools/flow_stats.py 720 > gpurun_out/flow_unit_cycles.txt 2>&1
+XH_FLOW_STATS=1 timeout 300 python3 tools/flow_stats.py 720 > gpurun_out/flow_unit_cycles.txt 2>&1
 XH_STATS_ROUTE_SPIN=120 XH_STATS_ABCD_SPIN=120 XH_STATS_LOOP=5 timeout 300 python3 tools/flow_stats.py 600 2>&1 | grep -E "back-to-back|histogram|wave\(s\)" > gpurun_out/flow_pipelined.txt
 head -c 600 gpurun_out/bench.json; echo; head -8 gpurun_out/kernel_stats.csv | cut -c1-160; cat gpurun_out/pmc_traffic.json | head -50
 # the N = 2 dry run on this box's one GPU (both ranks on device 0, gloo process group, RCCL stand-in named by path)

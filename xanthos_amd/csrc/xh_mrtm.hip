@@ -31,6 +31,7 @@
 #include <unistd.h>
 
 #include "xh_mrtm_flow.h"
+#include "xh_mrtm_plan.h"
 
 namespace {
 
@@ -38,7 +39,7 @@ constexpr int W_MAX = 9;             // 8 D8 neighbours + the diagonal
 constexpr int W_BASE = 3;            // terms per row gathered branch-free (diagonal + two tributaries)
 constexpr int UNIT_MAX_CELLS = 3072;  // 44 B of LDS per cell: pair buffers + tail-term table
 constexpr int BIN_CELLS = 256;       // small networks share a single-wave workgroup of up to this many cells
-constexpr int N_CLASS = 8;
+constexpr int N_CLASS = XH_ROUTE_N_CLASS;
 
 struct UnitClass {
     int nt, kc;
@@ -319,12 +320,6 @@ __global__ void __launch_bounds__(256) k_fb_finish(FbArgs a) {
     if (a.F_end) a.F_end[c] = a.F2[c];
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    bool pooled = false;        // p points into an UploadPool's allocation (freed with the pool, not on its own)
-};
-
 template <typename T>
 int upload(xh_ctx *ctx, DevBuf &b, const std::vector<T> &v) {
     b.bytes = v.size() * sizeof(T);
@@ -334,72 +329,6 @@ int upload(xh_ctx *ctx, DevBuf &b, const std::vector<T> &v) {
 }
 
 }  // namespace
-
-struct xh_route_plan {
-    xh_ctx *ctx = nullptr;
-    int64_t ncell = 0, n_networks = 0, largest_network = 0, n_units = 0, largest_unit = 0, total_slots = 0;
-    // LDS units, grouped by class
-    std::vector<int> class_units[N_CLASS];       // slot0 of the units of each class (every network)
-    DevBuf d_class_units[N_CLASS];
-    std::vector<int> rest_units[N_CLASS];        // only the units of networks the dataflow kernel does not route
-    DevBuf d_rest_units[N_CLASS];
-    FlowPlan *flow = nullptr;                    // tree-shaped networks as single-wave dataflow units of the BIT-EXACT kernels
-    // Reassociated form (XH_ROUTE_REASSOC; xh_flow_rsum.cpp, k_mrtm_rsum): a partition of its own over the same cells, made
-    // with the plan when the environment asks for the form, else on the first call that does.  Needs nothing of a call's data.
-    FlowPlan *flow_rsum = nullptr;
-    // ... and the same with FOLDED LEAVES (xh_flow_rsum.cpp, FlowPlanOptions::foldable): which leaves cannot fire depends on
-    // velocity, flow distance and dt, so this one is made by xh_route_plan_prepare from the host copies (XH_FLOW_FOLD=1); the
-    // kernel guards the assumption and a trip routes the call again on flow_rsum and switches the folded plan off
-    FlowPlan *flow_rsum_fold = nullptr;
-    double fold_dt = 0.0;
-    bool fold_disabled = false;
-    bool fold_tried = false;      // prepare() has asked the planner (it may have had nothing to fold)
-    uint64_t prep_key = 0;        // ... for these sets of cells that can fire / leaves that cannot, and this dt
-    bool first_checked_fold = false;
-    FlowPlan *last_rsum_plan = nullptr;          // the plan the last reassociated call ran on
-    bool rsum_failed = false;                    // the planner turned the grid down once: not tried again
-    bool last_rsum = false;                      // the last call was routed by k_mrtm_rsum
-    bool first_checked_rsum = false;
-    std::vector<int64_t> h_indptr;
-    std::vector<int32_t> h_indices;
-    std::vector<int8_t> h_sign;
-    std::vector<int> h_comp;
-    int h_ncomp = 0;
-    int guard_trips = 0;                         // calls routed again on the plan of pairs after a guard of the prepared plan tripped
-    int last_tree_kernel = 0;                    // last xh_route_series: 0 none, 1 monthly streams, 2 time-skewed
-    int64_t reroutes = 0;                        // calls re-run with one workgroup per network after a device fault
-    // After a fault the dataflow kernels are skipped for the next `skip_calls` calls of this plan (the device is shared:
-    // every further attempt would first sit out a bounded wait), doubling with every fault in a row up to 256 calls; a
-    // dataflow call confirmed fault-free resets the streak (xh_route_confirm).
-    int fault_streak = 0, skip_calls = 0;
-    int64_t validated = 0;                       // calls cross-checked against the workgroup-per-network kernel (XH_ROUTE_VALIDATE)
-    // The dataflow kernels' streams rest on an ordering assumption outside the HIP memory model (xh_mrtm_wave.hip, check()).
-    // So that no product run is unverified on a new box, the FIRST dataflow call of a plan is cross-checked like
-    // XH_ROUTE_VALIDATE unless a marker file says this library build already passed on this device with this topology
-    // (route_first_check_*; XH_ROUTE_VALIDATE_FIRST=0 switches it off).
-    bool first_checked = false;
-    // ... and every XH_ROUTE_VALIDATE_EVERY-th dataflow call of a long-lived plan is cross-checked again (default 1,000; 0 =
-    // never): one clean pass says little about call 10^4 of a server that routes scenarios all day (~0.25 s each time)
-    int64_t dataflow_calls = 0;
-    bool validate_due = false;
-    uint64_t topo_hash = 0;
-    int64_t n_rest_units = 0, n_fb_rest = 0;
-    bool fb_rest_single_ds = true;
-    DevBuf d_fbr_cells, d_fbr_ptr, d_fbr_col, d_fbr_sgn, d_fbr_ds;
-    DevBuf d_cell_of_slot, d_ent, d_cnt;
-    // fallback
-    int64_t n_fb = 0;
-    bool fb_single_ds = true;
-    DevBuf d_fb_cells, d_fb_ptr, d_fb_col, d_fb_sgn, d_fb_ds;
-    // whole-graph copies so XH_ROUTE_FORCE_FALLBACK can route everything
-    DevBuf d_all_cells, d_all_ptr, d_all_col, d_all_sgn, d_all_ds;
-    bool all_single_ds = true;
-    int64_t all_nnz = 0;
-    hipStream_t streams[N_CLASS] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[N_CLASS + 1] = {};
-    hipStream_t fb_stream = nullptr;
-    void *d_pool = nullptr;     // the allocation behind the tables uploaded at create (UploadPool)
-};
 
 namespace {
 
@@ -479,7 +408,7 @@ static int reassoc_env() {
     }();
     return v;
 }
-static bool reassoc_wanted(int flags) {
+bool reassoc_wanted(int flags) {
     if (flags & XH_ROUTE_EXACT) return false;
     if (flags & XH_ROUTE_REASSOC) return true;
     return reassoc_env() >= 0 ? reassoc_env() == 1 : XH_REASSOC_DEFAULT != 0;
@@ -917,106 +846,10 @@ extern "C" int xh_route_plan_stats(xh_route_plan *plan, int64_t max_words, uint6
     return XH_OK;
 }
 
-static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
-                             const int32_t *h_ndays, double dt, const double *d_flow_dist, const double *d_velocity,
-                             const double *d_area, const double *d_runoff, const double *d_S0, double *d_chstorage,
-                             double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow,
-                             const FlowFeed *feed = nullptr);
-
-// Comparison of two arrays the way the tests compare with the oracle (numpy.array_equal(..., equal_nan=True)): equal values,
-// or NaN in both -- the payload and sign of a NaN depend on the order in which a kernel's instructions met it, and the two
-// kernels differ there (first seen when the first call of every plan became a checked call: 3 values of a fuzz case with NaN
-// runoff): XH_ROUTE_VALIDATE
-__global__ void __launch_bounds__(256) k_count_diff(const unsigned long long *a, const unsigned long long *b, int64_t n,
-                                                    unsigned long long *count) {
-    unsigned long long local = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double x = __longlong_as_double((long long)a[i]), y = __longlong_as_double((long long)b[i]);
-        local += (x == y || (x != x && y != y)) ? 0ull : 1ull;
-    }
-    if (local) atomicAdd(count, local);
-}
-
-// The same for a call routed by the reassociated form (XH_ROUTE_REASSOC): equal to rounding, not bit for bit.  A value counts
-// when it is farther from the checker's than 1e-9 of it (+ 1e-9 of the array's scale `tiny`, for storages that the excess-flow
-// rule has just emptied), or NaN on one side only.
-__global__ void __launch_bounds__(256) k_count_far(const double *a, const double *b, int64_t n, double rel, double tiny,
-                                                   unsigned long long *count) {
-    unsigned long long local = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double x = a[i], y = b[i];
-        const bool xn = x != x, yn = y != y;
-        local += (xn || yn) ? (xn != yn ? 1ull : 0ull) : ((fabs(x - y) <= rel * fabs(y) + tiny) ? 0ull : 1ull);
-    }
-    if (local) atomicAdd(count, local);
-}
-
 // Which cells can fire (mrtm.py:54: dSdt * dt < -S).  With non-negative inflows dSdt >= -F = -S * tauinv, so a cell whose
 // tauinv * dt stays below 1 cannot (rounding: three operations of relative error 2^-53 each against a margin of 2^-20;
 // negative inputs are outside the argument and are what the guards of the prepared plans are for).  A NaN ratio counts as "can".
 constexpr double CAPABLE_THRESHOLD = 1.0 - 1.0 / 1048576.0;
-
-// XH_ROUTE_VALIDATE: the call has just been routed by a dataflow kernel into the caller's arrays; route it again with one
-// workgroup per network (barriers, no streams, no reliance on the ordering of write-through stores) into scratch arrays
-// and compare every output bit.  Synchronous; a debugging / CI mode.
-static int route_validate(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months, const int32_t *h_ndays,
-                          double dt, const double *d_flow_dist, const double *d_velocity, const double *d_area,
-                          const double *d_runoff, const double *d_S0, const double *d_chs, const double *d_avg,
-                          const double *d_S_end, const double *d_F_end, int32_t flags) {
-    int rc = xh_settle(ctx);          // a fault of the dataflow run is settled (re-routed) first: then there is nothing to validate
-    if (rc) return rc;
-    const size_t nc = (size_t)plan->ncell, big = nc * (size_t)nmonths * sizeof(double);
-    double *t_chs = nullptr, *t_avg = nullptr, *t_S = nullptr, *t_F = nullptr;
-    unsigned long long *d_cnt = nullptr, h_cnt = 0;
-    auto release = [&]() {
-        for (void *p : {(void *)t_chs, (void *)t_avg, (void *)t_S, (void *)t_F, (void *)d_cnt})
-            if (p) (void)hipFree(p);
-    };
-    hipError_t e = hipSuccess;
-    if (d_chs) e = hipMalloc(reinterpret_cast<void **>(&t_chs), big);
-    if (e == hipSuccess && d_avg) e = hipMalloc(reinterpret_cast<void **>(&t_avg), big);
-    if (e == hipSuccess && d_S_end) e = hipMalloc(reinterpret_cast<void **>(&t_S), nc * sizeof(double));
-    if (e == hipSuccess && d_F_end) e = hipMalloc(reinterpret_cast<void **>(&t_F), nc * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_cnt), sizeof(unsigned long long));
-    if (e != hipSuccess) {
-        release();
-        return xh_fail(ctx, XH_ERR_HIP, "XH_ROUTE_VALIDATE: no memory for the second set of outputs");
-    }
-    bool used = false;
-    const int routed_by = plan->last_tree_kernel;
-    const bool by_rsum = plan->last_rsum;       // routed by the reassociated form: equal to rounding, compared within 1e-9
-    rc = route_series_impl(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
-                           t_chs, t_avg, t_S, t_F, (flags | XH_ROUTE_NO_DATAFLOW) & ~XH_ROUTE_TEST_FAULT, &used);
-    plan->last_tree_kernel = routed_by;
-    plan->last_rsum = by_rsum;
-    if (!rc) {
-        (void)hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), ctx->stream);
-        // (storages in m3, flows in m3/s: the absolute terms are far below anything a grid cell holds or passes)
-        auto cmp = [&](const double *a, const double *b, size_t n, double tiny) {
-            if (!(a && b && n)) return;
-            if (by_rsum)
-                hipLaunchKernelGGL(k_count_far, dim3(1024), dim3(256), 0, ctx->stream, a, b, (int64_t)n, 1e-9, tiny, d_cnt);
-            else
-                hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, ctx->stream,
-                                   reinterpret_cast<const unsigned long long *>(a),
-                                   reinterpret_cast<const unsigned long long *>(b), (int64_t)n, d_cnt);
-        };
-        cmp(d_chs, t_chs, nc * (size_t)nmonths, 1e-3);
-        cmp(d_avg, t_avg, nc * (size_t)nmonths, 1e-9);
-        cmp(d_S_end, t_S, nc, 1e-3);
-        cmp(d_F_end, t_F, nc, 1e-9);
-        if (hipMemcpyAsync(&h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess)
-            rc = xh_fail(ctx, XH_ERR_HIP, "XH_ROUTE_VALIDATE: comparison failed to run");
-    }
-    release();
-    if (rc) return rc;
-    plan->validated += 1;
-    if (h_cnt)
-        return xh_fail(ctx, XH_ERR_DEVICE, "XH_ROUTE_VALIDATE: %llu output values of the dataflow routing kernel differ from "
-                       "the workgroup-per-network kernel%s", h_cnt, by_rsum ? " by more than 1e-9 (reassociated form)" : "");
-    return XH_OK;
-}
 
 void xh_route_confirm(const xh_route_record &r) { r.plan->fault_streak = 0; }
 
@@ -1092,188 +925,6 @@ void xh_route_backoff(xh_route_plan *plan) {      // once per fault event and pl
     plan->skip_calls = 4 << plan->fault_streak;      // 8, 16, ... 256 calls without the dataflow kernels
 }
 
-static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
-                             const int32_t *h_ndays, double dt, const double *d_flow_dist,
-                             const double *d_velocity, const double *d_area, const double *d_runoff,
-                             const double *d_S0, double *d_chstorage, double *d_avgchflow, double *d_S_end,
-                             double *d_F_end, int32_t flags, const FlowFeed *feed);
-
-extern "C" int xh_route_series(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
-                               const int32_t *h_ndays, double dt, const double *d_flow_dist,
-                               const double *d_velocity, const double *d_area, const double *d_runoff,
-                               const double *d_S0, double *d_chstorage, double *d_avgchflow, double *d_S_end,
-                               double *d_F_end, int32_t flags) {
-    return route_series_call(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
-                             d_chstorage, d_avgchflow, d_S_end, d_F_end, flags, nullptr);
-}
-
-// The runoff source of the routing kernel is the staged copy named by `feed`, filled while the kernel runs; d_runoff is the
-// [ncell, nmonths] array the same months end up in, and what a re-run after a fault reads (complete by then).
-int xh_route_series_fed(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months, const int32_t *h_ndays,
-                        double dt, const double *d_flow_dist, const double *d_velocity, const double *d_area,
-                        const double *d_runoff, const double *d_S0, double *d_chstorage, double *d_avgchflow,
-                        int32_t flags, const FlowFeed *feed) {
-    return route_series_call(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
-                             d_chstorage, d_avgchflow, nullptr, nullptr, flags, feed);
-}
-
-// Marker of a passed first-call check: <dir>/route_ok_<device>_<build>_<topology>; dir = $XH_CACHE_DIR or
-// $HOME/.cache/xanthos_amd.  Failing to read or write it only means the check runs again.
-// (form: 0 the bit-exact kernels, 1 the reassociated form, 2 the prepared reassociated plan: folded leaves "_rf", single sums "_rs")
-static std::string first_check_path(const xh_ctx *ctx, const xh_route_plan *plan, int form) {
-    const std::string dir = xh_cache_dir();
-    if (dir.empty()) return std::string();
-    uint64_t h = 1469598103934665603ull;
-    auto mix = [&](const char *t) {
-        for (; *t; ++t) h = (h ^ (unsigned char)*t) * 1099511628211ull;
-    };
-    mix(ctx->prop.name);
-    mix(ctx->prop.gcnArchName);
-    mix(__DATE__ " " __TIME__);      // this translation unit's build: a new library build checks again
-    {   // the HIP runtime and the driver the pass was recorded under: the ordering the streams rely on is theirs as much as
-        // the silicon's (XH_TEST_RUNTIME_TAG: appended, so that a test can stand in for "another runtime")
-        int rt = 0, drv = 0;
-        (void)hipRuntimeGetVersion(&rt);
-        (void)hipDriverGetVersion(&drv);
-        char ver[96];
-        const char *tag = getenv("XH_TEST_RUNTIME_TAG");
-        snprintf(ver, sizeof(ver), "rt%d drv%d %s", rt, drv, tag ? tag : "");
-        mix(ver);
-    }
-    char name[160];
-    snprintf(name, sizeof(name), "/route_ok_%016llx_%016llx_%lld_%lld%s", (unsigned long long)h, (unsigned long long)plan->topo_hash,
-             (long long)plan->ncell, (long long)(plan->flow ? plan->flow->n_units : 0),
-             form == 2 ? ((plan->flow_rsum_fold && plan->flow_rsum_fold->n_special >= 0) ? "_rs" : "_rf") : form == 1 ? "_r" : "");
-    return dir + name;
-}
-
-static bool &first_checked_of(xh_route_plan *plan, int form) {
-    return form == 2 ? plan->first_checked_fold : form == 1 ? plan->first_checked_rsum : plan->first_checked;
-}
-
-static int last_form(const xh_route_plan *plan) {
-    return !plan->last_rsum ? 0 : (plan->flow_rsum_fold && plan->last_rsum_plan == plan->flow_rsum_fold) ? 2 : 1;
-}
-
-static bool first_check_needed(xh_ctx *ctx, xh_route_plan *plan, int form) {
-    static const bool enabled = xh_env_on("XH_ROUTE_VALIDATE_FIRST", true);
-    bool &checked = first_checked_of(plan, form);
-    if (!enabled || checked || !plan->flow) return false;
-    const std::string path = first_check_path(ctx, plan, form);
-    if (!path.empty()) {
-        if (FILE *f = fopen(path.c_str(), "r")) {
-            fclose(f);
-            checked = true;
-            return false;
-        }
-    }
-    return true;
-}
-
-static void first_check_passed(xh_ctx *ctx, xh_route_plan *plan, int form) {
-    first_checked_of(plan, form) = true;
-    const std::string path = first_check_path(ctx, plan, form);
-    if (path.empty()) return;
-    const std::string dir = path.substr(0, path.rfind('/'));
-    for (size_t i = 1; i <= dir.size(); ++i)      // mkdir -p
-        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0755);
-    if (FILE *f = fopen(path.c_str(), "w")) {
-        fprintf(f, "dataflow routing equal to the workgroup-per-network kernel, %s, on %s\n", form ? "within 1e-9" : "bit for bit", ctx->prop.name);
-        fclose(f);
-    }
-}
-
-static int route_series_call(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
-                             const int32_t *h_ndays, double dt, const double *d_flow_dist,
-                             const double *d_velocity, const double *d_area, const double *d_runoff,
-                             const double *d_S0, double *d_chstorage, double *d_avgchflow, double *d_S_end,
-                             double *d_F_end, int32_t flags, const FlowFeed *feed) {
-    bool used_flow = false;
-    if (plan && plan->skip_calls > 0 && (flags & XH_ROUTE_TEST_FAULT) == 0) {      // recently faulted: see xh_route_plan
-        if (!feed) plan->skip_calls -= 1;      // (a fed call is turned down below and comes back as an ordinary one: counted there)
-        flags |= XH_ROUTE_NO_DATAFLOW;
-    }
-    static const bool validate_env = xh_env_on("XH_ROUTE_VALIDATE", false);
-    bool validate = validate_env || (flags & XH_ROUTE_VALIDATE) != 0;
-    flags &= ~XH_ROUTE_VALIDATE;
-    // first dataflow call of this plan on a box / build that has not passed the cross-check yet: checked like XH_ROUTE_VALIDATE
-    const bool plain_call = plan && (flags & (XH_ROUTE_NO_DATAFLOW | XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_ATOMIC | XH_ROUTE_TEST_FAULT)) == 0;
-    const bool want_rsum = plan && reassoc_wanted(flags) && (flags & XH_ROUTE_NO_SKEW) == 0;
-    const int want_form = !want_rsum ? 0 : (plan->flow_rsum_fold && !plan->fold_disabled && dt == plan->fold_dt) ? 2 : 1;
-    bool first_check = !validate && plain_call && first_check_needed(ctx, plan, want_form);
-    if (plain_call && plan->flow) {
-        const char *ev = getenv("XH_ROUTE_VALIDATE_EVERY");      // (read per call: a long-lived caller may change its mind)
-        const int64_t every = ev ? (int64_t)atoll(ev) : (int64_t)1000;
-        if (plan->validate_due && !feed) {      // the fed call that was due came back as an ordinary one: checked now
-            first_check = first_check || !validate;
-            plan->validate_due = false;
-        } else {
-            plan->dataflow_calls += 1;
-            if (!validate && !first_check && every > 0 && plan->dataflow_calls % every == 0) {      // handled like the first one
-                first_check = true;
-                plan->validate_due = feed != nullptr;      // (a fed call cannot be checked at once: turned down below)
-            }
-        }
-    }
-    validate = validate || first_check;
-    // a fed call cannot be cross-checked at once (the second routing would read runoff that does not exist yet), nor
-    // routed by anything but the dataflow kernel that knows how to wait for it
-    // (XH_ROUTE_TEST_FAULT is taken: the fault word is raised in front of the launch, the units that have to wait give up, and
-    // the call is settled like any faulted one -- routed again from the runoff array, complete by then)
-    if (feed && (validate || (flags & (XH_ROUTE_NO_DATAFLOW | XH_ROUTE_NO_SKEW | XH_ROUTE_FORCE_FALLBACK | XH_ROUTE_ATOMIC)) != 0))
-        return XH_ERR_LIMIT;
-    int rc = route_series_impl(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff,
-                               d_S0, d_chstorage, d_avgchflow, d_S_end, d_F_end, flags, &used_flow, feed);
-    if (rc || !used_flow) return rc;
-    // remember the call until a synchronisation has confirmed that no bounded wait timed out (xh_fault_check)
-    xh_route_record r;
-    r.plan = plan;
-    r.nmonths = nmonths;
-    r.spinup_months = spinup_months;
-    r.flags = flags;
-    r.ndays.assign(h_ndays, h_ndays + nmonths);
-    r.dt = dt;
-    r.flow_dist = d_flow_dist;
-    r.velocity = d_velocity;
-    r.area = d_area;
-    r.runoff = d_runoff;
-    r.S0 = d_S0;
-    r.chs = d_chstorage;
-    r.avg = d_avgchflow;
-    r.S_end = d_S_end;
-    r.F_end = d_F_end;
-    r.seq_after = ctx->work_seq;
-    r.fed = feed != nullptr;
-    ctx->pending_routes.push_back(std::move(r));
-    rc = xh_fault_collect(ctx);
-    if (rc || !validate) return rc;
-    const int64_t reroutes_before = ctx->reroutes;
-    rc = route_validate(ctx, plan, nmonths, spinup_months, h_ndays, dt, d_flow_dist, d_velocity, d_area, d_runoff, d_S0,
-                        d_chstorage, d_avgchflow, d_S_end, d_F_end, flags);
-    // (a call that had to be re-routed was not routed by the dataflow kernel in the end: nothing was checked)
-    if (rc == XH_OK && ctx->reroutes == reroutes_before && (first_check || !first_checked_of(plan, last_form(plan))))
-        first_check_passed(ctx, plan, last_form(plan));
-    return rc;
-}
-
-int xh_route_rerun(xh_ctx *ctx, const xh_route_record &r, bool dataflow_pairs) {
-    bool used_flow = false;
-    if (!dataflow_pairs) r.plan->reroutes += 1;      // (guard re-runs are counted apart: xh_route_plan_rsum_info[6])
-    int flags = r.flags & ~XH_ROUTE_TEST_FAULT;
-    if (dataflow_pairs) {
-        // A guard of the PREPARED reassociated plan tripped (a folded leaf that can fire with this call's data after all,
-        // negative runoff or initial storage, a negative outflow leaving a halo): the prepared plan is given up until the
-        // plan is prepared for other data, XH_ROUTE_NO_PLAIN below routes on the plan of pairs, which assumes nothing
-        r.plan->guard_trips += 1;
-        if (r.plan->last_rsum && r.plan->last_rsum_plan == r.plan->flow_rsum_fold) r.plan->fold_disabled = true;
-        flags |= XH_ROUTE_NO_PLAIN;
-    } else {
-        flags |= XH_ROUTE_NO_DATAFLOW;
-    }
-    return route_series_impl(ctx, r.plan, r.nmonths, r.spinup_months, r.ndays.data(), r.dt, r.flow_dist, r.velocity,
-                             r.area, r.runoff, r.S0, r.chs, r.avg, r.S_end, r.F_end, flags, &used_flow);
-}
-
 extern "C" int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[8]) {
     if (!plan || !info) return XH_ERR_ARG;
     const FlowPlan *fp = plan->last_rsum ? plan->last_rsum_plan : nullptr;
@@ -1288,7 +939,7 @@ extern "C" int xh_route_plan_rsum_info(const xh_route_plan *plan, int64_t info[8
     return XH_OK;
 }
 
-static int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
+int route_series_impl(xh_ctx *ctx, xh_route_plan *plan, int32_t nmonths, int32_t spinup_months,
                              const int32_t *h_ndays, double dt, const double *d_flow_dist, const double *d_velocity,
                              const double *d_area, const double *d_runoff, const double *d_S0, double *d_chstorage,
                              double *d_avgchflow, double *d_S_end, double *d_F_end, int32_t flags, bool *used_flow,

@@ -47,6 +47,9 @@ struct PmTablesDev {
 // the class loop counter alone, i.e. wave-uniform: they are read straight from the (read-only, restrict) table in global
 // memory, which the compiler turns into scalar loads -- as LDS reads they were 85 % of the kernel's 46 M LDS
 // wave-instructions, each ~16 cycles of a lone wave's issue.
+// (Round 6 tried the other way round once more, VERDICT round 5 item 6: the class block staged in LDS and read with broadcast
+// reads loses 5 % -- pm_pet 1.72 -> 1.81 ms --, and with class l + 1 read ahead into registers while class l computes 59 %
+// -- 2.73 ms: the 40 extra registers cost the third wave per SIMD.  profiles/round6/pm_class_lds_ab.txt.  Not built in.)
 struct PmLds {
     double one_m_alpha[XH_MAX_LCS][12], lai[XH_MAX_LCS][12], fc[XH_MAX_LCS][12], inv_lai[XH_MAX_LCS][12];
 };
