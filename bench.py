@@ -578,11 +578,16 @@ def calib_measure(args, ctx, rank, world_size, dist, torch, backend, log):
         result['roofline']['valu_issue'] = {
             'valu_wave_insts_per_generation': insts, 'cycles_per_wave_inst': 4, 'simds': simds, 'clock_hz': SHADER_CLOCK_HZ,
             'march_ms': kern_ms, 'frac': insts * 4.0 / (simds * kern_ms * 1e-3 * SHADER_CLOCK_HZ),
+            # the same against the cycles the marches really had in the counter pass (SQ_BUSY_CYCLES is summed over the chip's 32
+            # shader engines: the clock under this fp64 load is ~2.2-2.3 GHz, not the 2.4 GHz of `frac`)
+            'frac_at_measured_clock': (insts * 4.0 / (simds * sum(m['SQ_BUSY_CYCLES'] for m in marches) / 32.0)
+                                       if all(m.get('SQ_BUSY_CYCLES') for m in marches) else None),
             'wave_insts_per_member_cell_month': insts * 64.0 / local_mcm,
             'source': {'file': insts_src, 'device_kernels': ['k_calib_march_m<true>', 'k_calib_march_m<false>'],
                        'collected': pmc_i.get('_meta', {}).get('collected')},
             'note': 'measured: SQ_INSTS_VALU of both marches x 4 cycles / (SIMDs x their time x clock); calib_abcd also holds the '
-                    'basin-mean kernel (microseconds)'}
+                    'basin-mean kernel (microseconds); quarter-rate instructions (one v_rsq_f64 and the conversions of exp() per '
+                    'member-cell-month) are counted as 4 cycles like the rest, so the marches are closer to the issue limit than frac says'}
     else:
         result['roofline']['valu_issue'] = {'frac': None, 'refused': 'no counter pass of k_calib_march_m for this configuration in {}'
                                             .format(insts_src)}

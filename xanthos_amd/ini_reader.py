@@ -237,8 +237,9 @@ class ConfigReader:
             alt = m.get('alt_runoff')
             self.alt_runoff = None if alt in (None, 'none') else os.path.join(self.rt_model_dir, alt)
             # (not a key of the reference) which form of the routing kernel: `reassociated` -- row sums as running sums along
-            # chains of lanes, equal to the reference to rounding (<= 1e-9), ~1.5 x faster --, `exact` -- every sum in scipy's
-            # stored order, bit-identical to the reference --, or the library default (XH_ROUTE_REASSOC in the environment)
+            # chains of lanes, equal to the reference to rounding (<= 1e-9 relative; NOT bit for bit), twice as fast --, `exact`
+            # -- every sum in scipy's stored order, ChStorage / Avg_ChFlow bit-identical to the reference --, or `default`: the
+            # library's, which is `reassociated` since round 5 (XH_ROUTE_REASSOC=0 in the environment makes it `exact`)
             self.routing_form = str(m.get('routing_form', 'default')).strip().lower()
             if self.routing_form not in ('default', 'reassociated', 'exact'):
                 raise ValidationException("routing_form must be 'reassociated', 'exact' or 'default', not '{}'".format(
