@@ -2,10 +2,10 @@
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all
 // Random river networks -- D8-like forests on grids, chains, stars, single cells, 10^5 cells -- and inputs that are NOT
 // trees (cycles, cells with two downstream rows, rows without a diagonal), with and without a set of cells that can
-// fire (typed partition), under several planner options.  Every plan must pass flow_tables_check: every cell in exactly
-// one slot, streams strictly down the pipeline, <= 16 imports / outlets per unit, even lane lags consistent with the
-// "two iterations earlier" rule, every row -- expanded through its chains -- equal to the CSR row in stored order
-// (mrtm.py:50-51), plain units free of cells that need pairs.
+// fire (the reassociated planner's single-sum plans), under several planner options.  Every plan must pass
+// flow_tables_check: every cell in exactly one slot, streams strictly down the pipeline, <= 16 imports / outlets per unit,
+// even lane lags consistent with the "two iterations earlier" rule, every row -- expanded through its chains -- equal to the
+// CSR row in stored order (mrtm.py:50-51); the reassociated plans flow_tables_check_rsum.
 //   usage: plan_fuzz [cases] [seed]
 #include <algorithm>
 #include <unistd.h>
@@ -158,6 +158,22 @@ static Graph make_grid(std::mt19937_64 &rng, int w, int h, double p_outlet, int 
     return g;
 }
 
+// the tables of a plan as one number (PLAN_HASH=1: to compare two builds of the planner)
+static unsigned long long tables_hash(const FlowTables &t) {
+    unsigned long long hsh = 1469598103934665603ull;
+    auto mix = [&](const void *q, size_t bytes) {
+        const unsigned char *b = static_cast<const unsigned char *>(q);
+        for (size_t i = 0; i < bytes; ++i) hsh = (hsh ^ b[i]) * 1099511628211ull;
+    };
+    auto mv = [&](const auto &v) { if (!v.empty()) mix(v.data(), v.size() * sizeof(v[0])); };
+    int head[8] = {t.n_units, t.n_edges, t.depth, t.n_cells, t.max_imports, t.max_exports, t.skew_lmax, t.skew_span};
+    mix(head, sizeof(head));
+    mv(t.cell_of_slot), mv(t.export_edge), mv(t.ghost_edge), mv(t.edge_cons_unit), mv(t.unit_terms), mv(t.ent), mv(t.lag), mv(t.ghost_lag);
+    mv(t.unit_p), mv(t.unit_lmax), mv(t.unit_glmax), mv(t.unit_order), mv(t.ent2), mv(t.eprev), mv(t.edge_prod_cell), mv(t.edge_cons_cell);
+    mv(t.unit_depth), mv(t.piece_of_cell), mv(t.unit_of_cell), mv(t.height_of_cell), mv(t.ds), mv(t.ghost_prod), mv(t.lane_flags);
+    return hsh;
+}
+
 static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
     const int kind = idx % 11;
     int w, h, bad = 0;
@@ -179,11 +195,8 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
     opt.chain = rng() % 4 != 0;
     opt.cut_rule = rng() % 4 != 0;
     opt.tlimit = 3 + (int)(rng() % 7);
-    opt.tlimit_plain = 3 + (int)(rng() % 7);
-    opt.tlimit_typed = 3 + (int)(rng() % 5);
-    opt.full_join = (int)(rng() % 12);
-    opt.pair_streams = 4 + (int)(rng() % 13);
-    opt.plain_min_reads = rng() % 2 ? 0 : 2 + (int)(rng() % 6);      // selective plain form in half of the cases
+    for (int k = 0; k < 4; ++k) (void)rng();      // (options of the typed partitions, gone in round 6: the cases stay what they were)
+    if (rng() % 2 == 0) (void)rng();
     opt.lane_trials = idx % 3 == 1 ? 60 : 0;                         // lanes re-assigned against bank conflicts in a third
     std::vector<unsigned char> capable;
     if (rng() % 3 != 0) {
@@ -199,16 +212,17 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
         fprintf(stderr, "case %d (kind %d, %d cells): build failed: %s\n", idx, kind, g.n, err.c_str());
         return 1;
     }
+    if (getenv("PLAN_HASH")) printf("hash %d %016llx\n", idx, tables_hash(t));      // (to compare two builds of the planner)
     for (int c = 0; c < g.n; ++c)
         if ((handled[c] != 0) != (g.tree_cell[c] != 0)) {
             fprintf(stderr, "case %d (kind %d, %d cells): cell %d handled %d, tree %d\n", idx, kind, g.n, c, (int)handled[c],
                     (int)g.tree_cell[c]);
             return 1;
         }
-    const std::string bad_msg = flow_tables_check(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, t, opt.capable);
+    const std::string bad_msg = flow_tables_check(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, t);
     if (!bad_msg.empty()) {
-        fprintf(stderr, "case %d (kind %d, %d cells, cap %d, chain %d, cut %d, typed %d): %s\n", idx, kind, g.n, opt.piece_cap,
-                (int)opt.chain, (int)opt.cut_rule, (int)(opt.capable != nullptr), bad_msg.c_str());
+        fprintf(stderr, "case %d (kind %d, %d cells, cap %d, chain %d, cut %d): %s\n", idx, kind, g.n, opt.piece_cap,
+                (int)opt.chain, (int)opt.cut_rule, bad_msg.c_str());
         return 1;
     }
     // The per-box cache (xh_route_plan_prepare, flow_plan_build) keeps tables in a file: what comes back must be what went
@@ -218,13 +232,13 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
         snprintf(path, sizeof(path), "/tmp/plan_fuzz_%d_%d.tables", (int)getpid(), idx);
         FlowTables u;
         bool ok = flow_tables_save(t, path) && flow_tables_load(path, u);
-        ok = ok && u.n_units == t.n_units && u.n_edges == t.n_edges && u.depth == t.depth && u.n_plain_units == t.n_plain_units &&
+        ok = ok && u.n_units == t.n_units && u.n_edges == t.n_edges && u.depth == t.depth &&
              u.skew_ok == t.skew_ok && u.skew_lmax == t.skew_lmax && u.skew_span == t.skew_span && u.cell_of_slot == t.cell_of_slot &&
              u.ent2 == t.ent2 && u.eprev == t.eprev && u.lag == t.lag && u.ghost_lag == t.ghost_lag && u.unit_p == t.unit_p &&
              u.unit_order == t.unit_order && u.export_edge == t.export_edge && u.ghost_edge == t.ghost_edge &&
              u.edge_cons_unit == t.edge_cons_unit && u.lane_flags == t.lane_flags && u.ghost_prod == t.ghost_prod &&
-             u.unit_plain == t.unit_plain && u.ent == t.ent;
-        ok = ok && flow_tables_check(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, u, opt.capable).empty();
+             u.ent == t.ent;
+        ok = ok && flow_tables_check(g.n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, u).empty();
         if (ok) {      // cut the file short: the loader has to notice
             FILE *f = fopen(path, "rb+");
             if (f) {
@@ -241,8 +255,8 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
         }
     }
     if (verbose)
-        printf("case %d kind %d: %d cells, %d units (%d plain), %d streams, depth %d, max lag %d\n", idx, kind, g.n, t.n_units,
-               t.n_plain_units, t.n_edges, t.depth, t.skew_lmax);
+        printf("case %d kind %d: %d cells, %d units, %d streams, depth %d, max lag %d\n", idx, kind, g.n, t.n_units, t.n_edges, t.depth,
+               t.skew_lmax);
     // The reassociated form of the same graph (xh_flow_rsum.cpp): the same cells routed, its own invariants, the file round trip
     {
         std::vector<char> handled_r;
@@ -257,7 +271,7 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
                 foldable[c] = (g.indptr[c + 1] - g.indptr[c] == 1) && (capable.empty() || !capable[c]) && (rng() % 8 != 0);
             opt_r.foldable = foldable.data();
         }
-        // single-sum plans: the cells that can fire given (as the typed cases have them), or drawn here at 2 / 10 / 40 %
+        // single-sum plans: the cells that can fire as drawn above (two thirds of the cases), or drawn here at 2 / 10 / 40 %
         std::vector<unsigned char> capable_r;
         if (opt_r.capable == nullptr && idx % 3 != 2) {
             const unsigned dens = (idx % 3 == 0) ? 2u : ((idx / 3) % 2 ? 10u : 40u);
@@ -295,9 +309,9 @@ static int run_case(std::mt19937_64 &rng, int idx, bool verbose) {
     return 0;
 }
 
-// plan_fuzz --file topo.bin [typed 0|1] [reassociated 0|1] : the planner on a topology written by tools/dump_topology.py
+// plan_fuzz --file topo.bin [ignored] [reassociated 0|1] : the planner on a topology written by tools/dump_topology.py
 // (int32 n, int64 nnz, indptr[n+1] int64, indices[nnz] int32, sign[nnz] int8, capable[n] uint8), with statistics
-static int run_file(const char *path, bool typed, bool rsum) {
+static int run_file(const char *path, bool rsum) {
     FILE *f = fopen(path, "rb");
     if (!f) return 2;
     int32_t n = 0;
@@ -334,17 +348,12 @@ static int run_file(const char *path, bool typed, bool rsum) {
     FlowPlanOptions opt;
     opt.simds = 1024;
     opt.debug = true;
-    if (getenv("FULL_JOIN")) opt.full_join = atoi(getenv("FULL_JOIN"));
-    if (getenv("PLAIN_MIN_READS")) opt.plain_min_reads = atoi(getenv("PLAIN_MIN_READS"));
-    if (getenv("TLIMIT")) opt.tlimit = opt.tlimit_typed = atoi(getenv("TLIMIT"));
-    if (getenv("TLIMIT_PLAIN")) opt.tlimit_plain = atoi(getenv("TLIMIT_PLAIN"));
+    if (getenv("TLIMIT")) opt.tlimit = atoi(getenv("TLIMIT"));
     if (getenv("PIECE_CAP")) opt.piece_cap = atoi(getenv("PIECE_CAP"));
-    if (getenv("PAIR_STREAMS")) opt.pair_streams = atoi(getenv("PAIR_STREAMS"));
     if (getenv("LANE_TRIALS")) opt.lane_trials = atoi(getenv("LANE_TRIALS"));
     int ncap = 0;
     for (unsigned char c : capable) ncap += c;
     printf("%d cells, %lld entries, %d cells can fire\n", n, (long long)nnz, ncap);
-    opt.capable = typed ? capable.data() : nullptr;
     std::vector<char> handled;
     FlowTables t;
     std::string err;
@@ -366,8 +375,9 @@ static int run_file(const char *path, bool typed, bool rsum) {
     }
     printf("flow_tables_build%s: %.1f ms\n", rsum ? "_rsum" : "", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     const std::string bad = rsum ? flow_tables_check_rsum(n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, t)
-                                 : flow_tables_check(n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, t, opt.capable);
+                                 : flow_tables_check(n, g.indptr.data(), g.indices.data(), g.sign.data(), handled, t);
     printf("check: %s\n", bad.empty() ? "ok" : bad.c_str());
+    if (getenv("PLAN_HASH")) printf("hash file %016llx\n", tables_hash(t));
     if (const char *dc = getenv("DUMP_CELLS")) {      // DUMP_CELLS=a,b,c: where the planner put these cells
         std::vector<int> slot_of(n, -1);
         for (size_t sl = 0; sl < t.cell_of_slot.size(); ++sl)
@@ -403,7 +413,7 @@ static int run_file(const char *path, bool typed, bool rsum) {
 }
 
 int main(int argc, char **argv) {
-    if (argc > 2 && std::string(argv[1]) == "--file") return run_file(argv[2], argc > 3 ? atoi(argv[3]) != 0 : true, argc > 4 && atoi(argv[4]) != 0);
+    if (argc > 2 && std::string(argv[1]) == "--file") return run_file(argv[2], argc > 4 && atoi(argv[4]) != 0);
     const int cases = argc > 1 ? atoi(argv[1]) : 200;
     const unsigned long long seed = argc > 2 ? strtoull(argv[2], nullptr, 10) : 20240807ull;
     std::mt19937_64 rng(seed);

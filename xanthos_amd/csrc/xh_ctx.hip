@@ -114,6 +114,13 @@ int xh_fault_check(xh_ctx *ctx) {
         fprintf(stderr, "[libxanthos_hip] routing fault %u (a bounded wait between routing units timed out: the device is "
                 "shared and the units were not all resident); re-routing %zu call(s) with one workgroup per network\n",
                 code, pending.size());
+        {
+            extern unsigned *xh_wave_last_place();
+            unsigned w[16] = {0};
+            if (xh_wave_last_place() && hipMemcpy(w, xh_wave_last_place(), sizeof(w), hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "[libxanthos_hip]   placement words: registered %u seconds %u firsts %u t3 %u decided4 %u c5 %u c6 %u t7 %u | leaders %u t10 %u displaced %u decided12 %u claimed13 %u\n",
+                        w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[9], w[10], w[11], w[12], w[13]);
+        }
         if (ctx->d_feed) {      // a fed call (xh_run_fused mode 1): how far the side stream had come
             unsigned w[48] = {0};
             if (hipMemcpy(w, ctx->d_feed, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess) {

@@ -33,7 +33,7 @@ constexpr unsigned SK_ZERO = 2u * LANES * 16u;
 }  // namespace
 
 void xh_flow::tree_analyse(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign, const int *comp, int ncomp,
-                  const unsigned char *capable, Tree &t) {
+                  Tree &t) {
     t.n = n;
     t.indptr = indptr;
     t.indices = indices;
@@ -99,12 +99,6 @@ void xh_flow::tree_analyse(int n, const int64_t *indptr, const int32_t *indices,
             else ++(past ? t.cell_post[c] : t.cell_pre[c]);
         }
     }
-    t.typed = capable != nullptr;
-    t.capable = capable;
-    t.must_full.assign(n, 0);
-    if (capable)
-        for (int c = 0; c < n; ++c)
-            if (t.ok[c] && capable[c] && t.ds[c] >= 0) t.must_full[t.ds[c]] = 1;
 }
 
 namespace {
@@ -112,10 +106,8 @@ namespace {
 // Partition for one piece capacity: pieces, their stream edges and pipeline depth, units.
 struct Partition {
     std::vector<int> queue, piece, closed_roots, piece_of_root, piece_size, piece_imp, piece_depth;
-    std::vector<char> piece_full, piece_must;
     std::vector<int> edge_prod_cell, edge_cons_cell, edge_of_prod;
     std::vector<int> unit_of_piece, unit_cells_n, unit_imp_n, unit_depth;
-    std::vector<char> unit_full;
     int nunit = 0, nedge = 0, maxdepth = 0;
 };
 
@@ -143,13 +135,7 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
         }
         return x;
     };
-    std::vector<int> open_cnt(n, 0), open_imp(n, 0), open_pre(n, 0), open_post(n, 0);
-    std::vector<char> open_full(n, 0), open_must(n, 0);
-    // Selective plain form: the units that read sel_reads values or more are to run in plain form, which a single cell
-    // that needs pairs forbids.  Such cells have short rows themselves (they sit below a fast, short reach), so a piece
-    // that holds one is kept from growing into long rows: the child piece that would bring them becomes a stream.
-    const int sel = t.sel_reads;
-    auto sel_bad = [&](bool must, int pre, int post) { return sel > 0 && must && std::max(pre, 1) + std::max(post, 1) >= sel; };
+    std::vector<int> open_cnt(n, 0), open_imp(n, 0);
     std::vector<int> &closed_roots = P.closed_roots;            // piece roots in closing order (upstream pieces first)
     std::vector<int> kids;
     for (size_t qi = 0; qi < queue.size(); ++qi) {
@@ -158,43 +144,14 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
         std::sort(kids.begin(), kids.end(), [&](int x, int y) {
             return open_cnt[x] != open_cnt[y] ? open_cnt[x] < open_cnt[y] : x < y;
         });
-        // Typed partition: which children's open pieces may join v's at all.  Pair form must not spread downstream (a
-        // piece that needs pairs ends at the cell that needs them), and a cell that needs pairs does not drag a large plain
-        // sub-piece into pair form: it imports that sub-piece's outlet instead.  A cell that can fire is thereby either
-        // inside the pair piece of its consumer or the OUTLET of a plain piece (its consumer always needs pairs, so the
-        // cut falls right above it): plain units export the true {F, F2} pair of such an outlet.
-        const bool v_full = t.typed && t.must_full[v];
-        unsigned allowed = 0;
-        for (size_t i = 0; i < kids.size(); ++i) {
-            const int c = kids[i];
-            bool ok = true;
-            if (t.typed) {
-                if (!v_full && open_full[c]) ok = false;
-                // ... nor one whose rows are longer than its own: every row of a pair unit is read as pairs (~25 cycles
-                // per term), and the pair units are the ones that pace a typed run
-                if (v_full && !open_full[c] &&
-                    (open_cnt[c] > opt.full_join || open_pre[c] > std::max(cell_pre[v], 1) || open_post[c] > std::max(cell_post[v], 1)))
-                    ok = false;
-            }
-            if (ok) allowed |= 1u << i;
-        }
         int total = 1, imp = (int)kids.size();
         unsigned keep = 0;                          // bit i: kids[i]'s open piece joins v's
-        {
-            bool must = sel > 0 && t.must_full[v];
-            int pre = cell_pre[v], post = cell_post[v];
-            for (size_t i = 0; i < kids.size(); ++i) {
-                const int c = kids[i];
-                if (((allowed >> i) & 1u) && total + open_cnt[c] <= cap && imp - 1 + open_imp[c] <= G_MAX &&
-                    (!sel_bad(must || open_must[c], std::max(pre, open_pre[c]), std::max(post, open_post[c])) ||
-                     sel_bad(must, pre, post))) {
-                    keep |= 1u << i;
-                    total += open_cnt[c];
-                    imp += open_imp[c] - 1;
-                    must = must || open_must[c];
-                    pre = std::max(pre, open_pre[c]);
-                    post = std::max(post, open_post[c]);
-                }
+        for (size_t i = 0; i < kids.size(); ++i) {
+            const int c = kids[i];
+            if (total + open_cnt[c] <= cap && imp - 1 + open_imp[c] <= G_MAX) {
+                keep |= 1u << i;
+                total += open_cnt[c];
+                imp += open_imp[c] - 1;
             }
         }
         if (opt.cut_rule && keep + 1 != (1u << kids.size()) && cell_pre[v] >= 3 && kids.size() <= 8) {
@@ -221,20 +178,13 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
             // what it takes to keep its chain)
             int best_reads = v_reads(keep), best_total = total;
             for (unsigned kp = 0; kp < (1u << kids.size()); ++kp) {
-                if (kp & ~allowed) continue;
                 int tt = 1, im = (int)kids.size();
-                bool must = sel > 0 && t.must_full[v];
-                int pre = cell_pre[v], post = cell_post[v];
                 for (size_t i = 0; i < kids.size(); ++i)
                     if ((kp >> i) & 1u) {
                         tt += open_cnt[kids[i]];
                         im += open_imp[kids[i]] - 1;
-                        must = must || open_must[kids[i]];
-                        pre = std::max(pre, open_pre[kids[i]]);
-                        post = std::max(post, open_post[kids[i]]);
                     }
                 if (tt > LANES || im > G_MAX) continue;
-                if (sel_bad(must, pre, post) && !sel_bad(sel > 0 && t.must_full[v], cell_pre[v], cell_post[v])) continue;
                 const int r = v_reads(kp);
                 const bool over = tt > cap, best_over = best_total > cap;
                 if (r < best_reads || (r == best_reads && (over != best_over ? !over : tt > best_total))) {
@@ -251,25 +201,13 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
                     imp += open_imp[kids[i]] - 1;
                 }
         }
-        bool full = v_full, must = sel > 0 && t.must_full[v];
-        open_pre[v] = cell_pre[v];
-        open_post[v] = cell_post[v];
         for (size_t i = 0; i < kids.size(); ++i) {
             const int c = kids[i];
-            if ((keep >> i) & 1u) {
-                dsu[find(c)] = v;      // c's open piece joins v's
-                full = full || open_full[c];
-                must = must || open_must[c];
-                open_pre[v] = std::max(open_pre[v], open_pre[c]);
-                open_post[v] = std::max(open_post[v], open_post[c]);
-            } else {
-                closed_roots.push_back(c);             // c's piece is final; its outlet streams into v
-            }
+            if ((keep >> i) & 1u) dsu[find(c)] = v;      // c's open piece joins v's
+            else closed_roots.push_back(c);              // c's piece is final; its outlet streams into v
         }
         open_cnt[v] = total;
         open_imp[v] = imp;
-        open_full[v] = full ? 1 : 0;
-        open_must[v] = must ? 1 : 0;
         if (ds[v] < 0) {
             closed_roots.push_back(v);
         } else if (--left[ds[v]] == 0) {
@@ -285,8 +223,6 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
     P.piece_size.assign(npiece, 0);
     P.piece_imp.assign(npiece, 0);
     P.piece_depth.assign(npiece, 0);
-    P.piece_full.assign(npiece, 0);
-    P.piece_must.assign(npiece, 0);
     std::vector<int> ppre(npiece, 0), ppost(npiece, 0), pdir(npiece, 0);
     for (int v : queue) {
         const int q = P.piece_of_root[find(v)];
@@ -294,8 +230,6 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
         P.piece_size[q]++;
         ppre[q] = std::max(ppre[q], cell_pre[v]);
         ppost[q] = std::max(ppost[q], cell_post[v]);
-        if (t.typed && t.must_full[v]) P.piece_full[q] = 1;
-        if (sel > 0 && t.must_full[v]) P.piece_must[q] = 1;
     }
     // front-side terms a cell still reads one by one when its unit is chained (see emit_tables): the prefix of cells of
     // its own piece (the first may be an imported stream) counts as one
@@ -328,7 +262,7 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
     P.maxdepth = npiece ? *std::max_element(P.piece_depth.begin(), P.piece_depth.end()) : 0;
 
     // ---- packing.  Pieces with a stream in or out: equal depth per unit (a unit then only ever waits for units
-    //      strictly upstream or downstream of it), pieces that need pairs first, then first-fit decreasing.  Pieces
+    //      strictly upstream or downstream of it), first-fit decreasing.  Pieces
     //      without streams -- whole small networks -- wait for nobody and go wherever lanes are free; the `cheap_units`
     //      cheapest of them (fewest row terms) are kept together instead: units for the SIMDs that must hold two waves.
     auto has_out = [&](int p) { return ds[closed_roots[p]] >= 0; };
@@ -337,7 +271,6 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
     for (int p = 0; p < npiece; ++p) (P.piece_imp[p] > 0 || has_out(p) ? dep : fre).push_back(p);
     std::stable_sort(dep.begin(), dep.end(), [&](int x, int y) {
         if (P.piece_depth[x] != P.piece_depth[y]) return P.piece_depth[x] < P.piece_depth[y];
-        if (P.piece_full[x] != P.piece_full[y]) return P.piece_full[x] > P.piece_full[y];
         return P.piece_size[x] > P.piece_size[y];
     });
     int cheap_units = 0;
@@ -346,12 +279,9 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
         P.unit_cells_n.clear();
         P.unit_imp_n.clear();
         P.unit_depth.clear();
-        P.unit_full.clear();
         std::vector<int> unit_out_n;                                   // outlets: <= G_MAX too
         std::vector<int> upre, udir, upost;                            // longest sides of the unit's rows
-        std::vector<char> umust;                                       // selective: the unit holds a cell that needs pairs
-        auto new_unit = [&](int depth, bool full) {
-            umust.push_back(0);
+        auto new_unit = [&](int depth) {
             P.unit_cells_n.push_back(0);
             P.unit_imp_n.push_back(0);
             unit_out_n.push_back(0);
@@ -359,7 +289,6 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
             udir.push_back(0);
             upost.push_back(0);
             P.unit_depth.push_back(depth);
-            P.unit_full.push_back(full ? 1 : 0);
             return (int)P.unit_cells_n.size() - 1;
         };
         auto put_piece = [&](int p, int u) {
@@ -370,27 +299,12 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
             upre[u] = std::max(upre[u], ppre[p]);
             udir[u] = std::max(udir[u], pdir[p]);
             upost[u] = std::max(upost[u], ppost[p]);
-            umust[u] = umust[u] || P.piece_must[p];
         };
-        // selective plain form: a unit is heavy (reads sel or more values, to run in plain form) or holds cells that need
-        // pairs, never both -- unless the piece alone is both, which no packing can help
-        auto sel_ok = [&](int p, int u) {
-            if (sel <= 0 || P.unit_cells_n[u] == 0 || !(umust[u] || P.piece_must[p])) return true;
-            const int tt = reads_of(std::max(upre[u], ppre[p]), std::max(udir[u], pdir[p]), std::max(upost[u], ppost[p]));
-            return tt < sel;
-        };
-        // a piece joins a unit only if the unit then reads no more values per sub-step than the limit of its kind, or than
-        // the piece or the unit need on their own: the slowest unit paces the run, and it is the one with the longest
-        // rows.  A piece that needs pairs never joins a plain unit (it would turn every row of it into pairs); a plain
-        // piece may fill the free lanes of a pair unit.
+        // a piece joins a unit only if the unit then reads no more values per sub-step than the limit, or than the piece or
+        // the unit need on their own: the slowest unit paces the run, and it is the one with the longest rows
         auto class_ok = [&](int p, int u) {
-            if (!sel_ok(p, u)) return false;
-            if (t.typed && P.piece_full[p] && !P.unit_full[u]) return P.unit_cells_n[u] == 0;
-            const int tl = !t.typed ? opt.tlimit : (P.unit_full[u] ? opt.tlimit_typed : opt.tlimit_plain);
             const int tt = reads_of(std::max(upre[u], ppre[p]), std::max(udir[u], pdir[p]), std::max(upost[u], ppost[p]));
-            // a plain piece that fills free lanes of a pair unit must not lengthen that unit's rows: its own needs do not count
-            const int own = (t.typed && P.unit_full[u] && !P.piece_full[p]) ? 0 : terms_of(p);
-            return P.unit_cells_n[u] == 0 || tt <= std::max(tl, std::max(own, reads_of(upre[u], udir[u], upost[u])));
+            return P.unit_cells_n[u] == 0 || tt <= std::max(opt.tlimit, std::max(terms_of(p), reads_of(upre[u], udir[u], upost[u])));
         };
         {
             size_t first_open = 0;
@@ -402,23 +316,19 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
                 }
                 int u = -1;
                 for (size_t b = first_open; b < P.unit_cells_n.size(); ++b) {
-                    // pair units of a typed partition: one block-transfer round of imports and of outlets (8 each)
-                    const int gmax = (t.typed && P.unit_full[b]) ? opt.pair_streams : G_MAX;
-                    if (P.unit_cells_n[b] + P.piece_size[p] <= LANES && P.unit_imp_n[b] + P.piece_imp[p] <= gmax &&
-                        unit_out_n[b] + (has_out(p) ? 1 : 0) <= gmax && class_ok(p, (int)b)) {
+                    if (P.unit_cells_n[b] + P.piece_size[p] <= LANES && P.unit_imp_n[b] + P.piece_imp[p] <= G_MAX &&
+                        unit_out_n[b] + (has_out(p) ? 1 : 0) <= G_MAX && class_ok(p, (int)b)) {
                         u = (int)b;
                         break;
                     }
                 }
-                if (u < 0) u = new_unit(cur_depth, P.piece_full[p] != 0);
+                if (u < 0) u = new_unit(cur_depth);
                 put_piece(p, u);
                 while (first_open < P.unit_cells_n.size() && P.unit_cells_n[first_open] >= LANES) ++first_open;
             }
         }
-        // the cheap units: free plain pieces by (row terms, size), filled one unit after the other
-        std::vector<int> by_terms;
-        for (int p : fre)
-            if (!P.piece_full[p]) by_terms.push_back(p);
+        // the cheap units: free pieces by (row terms, size), filled one unit after the other
+        std::vector<int> by_terms(fre);
         std::stable_sort(by_terms.begin(), by_terms.end(), [&](int x, int y) {
             return terms_of(x) != terms_of(y) ? terms_of(x) < terms_of(y) : P.piece_size[x] < P.piece_size[y];
         });
@@ -429,7 +339,7 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
                 if (terms_of(p) > 3) break;
                 if (u < 0 || P.unit_cells_n[u] + P.piece_size[p] > LANES) {
                     if (made == cheap_units) break;
-                    u = new_unit(0, false);
+                    u = new_unit(0);
                     ++made;
                 }
                 put_piece(p, u);
@@ -447,21 +357,18 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
             for (int u = 0; u < (int)P.unit_cells_n.size(); ++u) bucket[LANES - P.unit_cells_n[u]].push_back(u);
             for (int p : by_size) {
                 const int sz = P.piece_size[p];
-                const bool pfull = t.typed && P.piece_full[p];
                 int u = -1;
-                for (int pass = 0; pass < 2 && u < 0; ++pass)          // second pass: any unit of a fitting kind with room
+                for (int pass = 0; pass < 2 && u < 0; ++pass)          // second pass: any unit with room
                     for (int f = sz; f <= LANES && u < 0; ++f)
                         for (size_t i = bucket[f].size(); i-- > 0;) {
                             const int b = bucket[f][i];
-                            if (pfull && !P.unit_full[b]) continue;
-                            if (!sel_ok(p, b)) continue;
-                            if ((pass == 1 && !(t.typed && P.unit_full[b] && !pfull)) || class_ok(p, b)) {
+                            if (pass == 1 || class_ok(p, b)) {
                                 u = b;
                                 bucket[f].erase(bucket[f].begin() + (long)i);
                                 break;
                             }
                         }
-                if (u < 0) u = new_unit(0, pfull);
+                if (u < 0) u = new_unit(0);
                 put_piece(p, u);
                 bucket[LANES - P.unit_cells_n[u]].push_back(u);
             }
@@ -476,10 +383,9 @@ void make_partition(const Tree &t, const FlowPlanOptions &opt, int cap, Partitio
 }  // namespace
 
 // ---- lanes against LDS bank conflicts ---------------------------------------------------------------------------------
-// A unit's gather is one ds_read_b128 (pair form) or ds_read_b64 (plain form) per row term, each lane addressing the LDS
-// entry of one upstream neighbour.  The LDS serves a wave's read in fixed lane groups -- four of 16 lanes for b128
-// ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32), two of 32 for b64 -- one cycle per group when the lanes of a
-// group address distinct 16-byte (8-byte) columns of the 256-byte bank row; every further distinct address on a busy
+// A unit's gather is one ds_read_b128 per row term, each lane addressing the LDS entry of one upstream neighbour.  The LDS
+// serves a wave's read in fixed lane groups -- four of 16 lanes for b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the
+// same + 32) -- one cycle per group when the lanes of a group address distinct 16-byte columns of the 256-byte bank row; every further distinct address on a busy
 // column costs the whole CU one more LDS cycle (identical addresses are one broadcast).  Cells were laid on the lanes in
 // the order of their ids: neighbours sit near each other and most reads are clean, but a sixth of the LDS cycles of a run
 // were conflicts (SQ_LDS_BANK_CONFLICT).  Which lane holds which cell is free -- every table goes through the
@@ -489,7 +395,7 @@ struct LaneOpt {
     const FlowTables &t;
     int u;
     int64_t ts;
-    bool plain, chained;
+    bool chained;
     int pre, post, ng;
     int pe[NPAIR];                       // entry (old) -> entry (new); lanes 0..63, imported entries 64..127, zero 128
     std::vector<int> offenders;          // old entries that sit on a busy column as the second, third .. address
@@ -497,7 +403,6 @@ struct LaneOpt {
     static int group128(int lane) { return ((lane >> 5) << 1) | (int)((0x0f0ff0f0u >> (lane & 31)) & 1u); }
 
     LaneOpt(const FlowTables &tt, int unit, int nghost) : t(tt), u(unit), ts((int64_t)tt.n_units * LANES), ng(nghost) {
-        plain = t.unit_plain[u] != 0;
         chained = (t.unit_p[u] & 0x100) != 0;
         pre = t.unit_p[u] & 15;
         post = (t.unit_p[u] >> 4) & 15;
@@ -506,15 +411,15 @@ struct LaneOpt {
     // extra LDS cycles per sub-step of the unit's gather under `pe`
     int cost(bool want_offenders) {
         if (want_offenders) offenders.clear();
-        const int ngroup = plain ? 2 : 4, ncol = plain ? 32 : 16;
+        constexpr int ngroup = 4, ncol = 16;
         int total = 0;
-        int seen[4][32][8], who[4][32][8], nseen[4][32];      // distinct addresses per (group, column) and a lane reading each; 8 hold any realistic pile-up
+        int seen[4][16][8], who[4][16][8], nseen[4][16];      // distinct addresses per (group, column) and a lane reading each; 8 hold any realistic pile-up
         auto column = [&](const unsigned *tab) {
             for (int g = 0; g < ngroup; ++g)
                 for (int c = 0; c < ncol; ++c) nseen[g][c] = 0;
             for (int l = 0; l < LANES; ++l) {
                 const int e_old = (int)(tab[(int64_t)u * LANES + l] >> 4), e = pe[e_old];
-                const int lane = pe[l], g = plain ? lane >> 5 : group128(lane), c = e & (ncol - 1);
+                const int lane = pe[l], g = group128(lane), c = e & (ncol - 1);
                 int k = 0, &m = nseen[g][c];
                 while (k < m && k < 8 && seen[g][c][k] != e) ++k;
                 if (k < m || k >= 8) continue;                   // the same address again: a broadcast
@@ -638,21 +543,6 @@ void lane_optimise(FlowTables &t, int trials, bool debug) {
                 (long long)sb, nunit, (long long)sa, trials, (long long)reads);
 }
 
-bool flow_plain_class(int pre, int post, bool chained, int &cpre, int &cpost) {
-    static const int plain_nc[][2] = {{1, 1}, {1, 2}, {1, 3}, {2, 2}, {2, 3}, {2, 4}, {3, 3}, {4, 2}, {3, 4}, {4, 3}, {4, 4}};
-    static const int plain_ch[][2] = {{1, 2}, {1, 3}, {1, 4}, {2, 3}, {2, 4}};
-    const int(*tab)[2] = chained ? plain_ch : plain_nc;
-    const int cnt = chained ? 5 : 11;
-    int best = -1;
-    for (int i = 0; i < cnt; ++i)
-        if (tab[i][0] >= pre && tab[i][1] >= post && (best < 0 || tab[i][0] + tab[i][1] < tab[best][0] + tab[best][1]))
-            best = i;
-    if (best < 0) return false;
-    cpre = tab[best][0];
-    cpost = tab[best][1];
-    return true;
-}
-
 int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign, const int *comp,
                       int ncomp, const FlowPlanOptions &opt, std::vector<char> &handled, FlowTables &out,
                       std::string &err) {
@@ -660,14 +550,8 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
     handled.assign(n, 0);
     if (n == 0) return 0;
     Tree t;
-    tree_analyse(n, indptr, indices, sign, comp, ncomp, opt.capable, t);
+    tree_analyse(n, indptr, indices, sign, comp, ncomp, t);
     const std::vector<int> &ds = t.ds;
-    const bool have_cap = t.typed;                                  // which cells can fire is known
-    const bool selective = have_cap && opt.plain_min_reads > 0;     // all-pairs partition, heavy units without such cells plain
-    if (selective) {
-        t.typed = false;
-        t.sel_reads = opt.plain_min_reads;
-    }
 
     // ---- the piece capacity.  A smaller capacity than LANES costs streams (every cut is one) and buys units: pieces of
     //      33..64 cells cannot share a unit, so the largest capacity leaves every other unit ~10 lanes short of full
@@ -897,34 +781,6 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
         int &up = out.unit_p[u];
         up = std::max(up & 15, npre) | (std::max((up >> 4) & 15, npost) << 4) | (unit_chain[u] ? 0x100 : 0);
     }
-    // plain units: the kernel is compiled for fewer row shapes; round up (the extra terms read the constant zero)
-    out.unit_plain.assign(nunit, 0);
-    out.typed = have_cap;
-    const std::vector<int> shape_as_cut = out.unit_p;               // before plain units are rounded up to a compiled shape
-    std::vector<char> unit_pair(nunit, 1);
-    if (have_cap && !selective)
-        for (int u = 0; u < nunit; ++u) unit_pair[u] = P.unit_full[u];
-    if (selective) {
-        for (int u = 0; u < nunit; ++u) {
-            const int reads = (out.unit_p[u] & 15) + ((out.unit_p[u] >> 4) & 15);
-            unit_pair[u] = reads < opt.plain_min_reads;
-        }
-        for (int c = 0; c < n; ++c)
-            if (piece[c] >= 0 && t.must_full[c]) unit_pair[unit_of_piece[piece[c]]] = 1;
-    }
-    if (have_cap)
-        for (int u = 0; u < nunit; ++u) {
-            if (unit_pair[u]) continue;
-            int cp = 0, cq = 0;
-            if (!flow_plain_class(out.unit_p[u] & 15, (out.unit_p[u] >> 4) & 15, unit_chain[u] != 0, cp, cq)) continue;
-            // selective: the plain shapes are fewer and round up ((4,1) runs as (4,4)); measured per sub-step, one more
-            // 8-byte read costs ~10 cycles, one more pair ~25, and the plain form starts ~55 cycles behind -- switch only
-            // where that comes out ahead
-            if (selective && 193 + 10 * (cp + cq) >= 138 + 25 * ((out.unit_p[u] & 15) + ((out.unit_p[u] >> 4) & 15))) continue;
-            out.unit_p[u] = cp | (cq << 4) | (unit_chain[u] ? 0x100 : 0) | 0x200;
-            out.unit_plain[u] = 1;
-            out.n_plain_units++;
-        }
     for (int ed = 0; ed < nedge; ++ed) {
         const int u = edge_cons_unit[ed];
         const int gl = out.unit_lmax[u] - 2 * (hgt[edge_reader[ed]] + 1);
@@ -932,11 +788,8 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
         out.unit_glmax[u] = std::max(out.unit_glmax[u], gl);
     }
 
-    out.lane_flags.assign(ts, 0);
+    out.lane_flags.assign(ts, 0);      // (the reassociated planner's: xh_flow_rsum.cpp)
     out.ghost_prod.assign(ts, 0);
-    if (have_cap)
-        for (int c = 0; c < n; ++c)
-            if (piece[c] >= 0 && t.capable[c]) out.lane_flags[(int64_t)unit_of_piece[piece[c]] * LANES + slot_of_cell[c]] = 1;
     for (int ed = 0; ed < nedge; ++ed) out.ghost_prod[(int64_t)edge_cons_unit[ed] * LANES + edge_ghost[ed]] = edge_prod_cell[ed];
 
     std::vector<int> unit_exp(nunit, 0);
@@ -951,8 +804,8 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
         std::vector<int> cost(nunit);
         for (int u = 0; u < nunit; ++u) {
             const int reads = (out.unit_p[u] & 15) + ((out.unit_p[u] >> 4) & 15) + ((out.unit_p[u] & 0x100) ? 1 : 0);
-            // measured per sub-step (profiles/round3): pair form 138 + 25 per value read, plain form 193 + 10
-            cost[u] = (out.unit_plain[u] ? 193 + 10 * reads : 138 + 25 * reads) + (unit_imp_n[u] > 0 ? 15 : 0) + (unit_exp[u] > 0 ? 15 : 0);
+            // measured per sub-step (profiles/round3): 138 + 25 per value read
+            cost[u] = 138 + 25 * reads + (unit_imp_n[u] > 0 ? 15 : 0) + (unit_exp[u] > 0 ? 15 : 0);
         }
         auto coupled = [&](int u) { return unit_imp_n[u] > 0 || unit_exp[u] > 0; };
         out.unit_order.resize(nunit);
@@ -970,7 +823,7 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
             const int two = std::min(nunit, 2 * std::max(nunit - opt.simds, 0));
             auto lds_load = [&](int u) {
                 const int reads = (out.unit_p[u] & 15) + ((out.unit_p[u] >> 4) & 15) + ((out.unit_p[u] & 0x100) ? 1 : 0);
-                return reads * (out.unit_plain[u] ? 8 : 16);
+                return reads * 16;
             };
             std::stable_sort(out.unit_order.begin() + two, out.unit_order.end(),
                              [&](int x, int y) { return lds_load(x) < lds_load(y); });
@@ -1004,57 +857,26 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
     if (opt.lane_trials > 0) lane_optimise(out, opt.lane_trials, opt.debug);
 
     if (opt.debug) {      // partition statistics on stderr
-        std::vector<int> hp(8, 0), hi(9, 0), hx(9, 0), hl(10, 0), hpp(25, 0), hpl(25, 0);
+        std::vector<int> hp(8, 0), hi(9, 0), hx(9, 0), hl(10, 0), hpp(25, 0);
         int n_chain = 0;
         auto bucket = [](int v) { return v == 0 ? 0 : v <= 1 ? 1 : v <= 2 ? 2 : v <= 4 ? 3 : v <= 8 ? 4 : v <= 16 ? 5 : v <= 32 ? 6 : 7; };
         for (int u = 0; u < nunit; ++u) {
             hp[std::max(out.unit_p[u] & 15, (out.unit_p[u] >> 4) & 15)]++;
-            (out.unit_plain[u] ? hpl : hpp)[(out.unit_p[u] & 15) * 5 + ((out.unit_p[u] >> 4) & 15)]++;
+            hpp[(out.unit_p[u] & 15) * 5 + ((out.unit_p[u] >> 4) & 15)]++;
             if (out.unit_p[u] & 0x100) ++n_chain;
             hi[bucket(unit_imp_n[u])]++;
             hx[bucket(unit_exp[u])]++;
             hl[std::min(out.unit_lmax[u] / 16, 9)]++;
         }
-        fprintf(stderr, "flow plan: %d units (%d plain), %d pieces, %d edges, depth %d, skew_ok %d\n", nunit,
-                out.n_plain_units, npiece, nedge, maxdepth + 1, (int)skew_ok);
-        if (have_cap) {
-            int nfull_cells = 0, nmust = 0, nfull_pieces = 0;
-            for (int c = 0; c < n; ++c) {
-                if (piece[c] < 0) continue;
-                nmust += t.must_full[c];
-                if (!out.unit_plain[unit_of_piece[piece[c]]]) ++nfull_cells;
-            }
-            for (int p = 0; p < npiece; ++p) nfull_pieces += P.piece_full[p];
-            fprintf(stderr, "  typed: %d cells need pairs, %d pieces hold one, %d cells sit in pair units\n", nmust,
-                    nfull_pieces, nfull_cells);
-            std::vector<int> hrow(25, 0);
-            for (int c = 0; c < n; ++c)
-                if (piece[c] >= 0 && t.must_full[c]) hrow[std::min(t.cell_pre[c], 4) * 5 + std::min(t.cell_post[c], 4)]++;
-            fprintf(stderr, "  rows of the cells that need pairs, by (terms before, after the diagonal):");
-            for (int a = 0; a <= 4; ++a)
-                for (int b = 0; b <= 4; ++b)
-                    if (hrow[a * 5 + b]) fprintf(stderr, " (%d,%d) %d", a, b, hrow[a * 5 + b]);
-            fprintf(stderr, "\n");
-        }
+        fprintf(stderr, "flow plan: %d units, %d pieces, %d edges, depth %d, skew_ok %d\n", nunit, npiece, nedge, maxdepth + 1,
+                (int)skew_ok);
         fprintf(stderr, "  chained units: %d\n", n_chain);
         fprintf(stderr, "  units by P (1..4):");
         for (int k = 1; k <= 4; ++k) fprintf(stderr, " %d", hp[k]);
-        fprintf(stderr, "\n  pair units by (pre, post) terms:");
+        fprintf(stderr, "\n  units by (pre, post) terms:");
         for (int a = 1; a <= 4; ++a)
             for (int b = 1; b <= 4; ++b)
                 if (hpp[a * 5 + b]) fprintf(stderr, " (%d,%d) %d", a, b, hpp[a * 5 + b]);
-        {
-            std::vector<int> up(256, 0);
-            for (int u = 0; u < nunit; ++u)
-                if (out.unit_plain[u] && ((shape_as_cut[u] ^ out.unit_p[u]) & 0xff)) up[shape_as_cut[u] & 0xff]++;
-            fprintf(stderr, "\n  plain units rounded up to a compiled shape, by their own (pre, post):");
-            for (int k = 0; k < 256; ++k)
-                if (up[k]) fprintf(stderr, " (%d,%d) %d", k & 15, k >> 4, up[k]);
-        }
-        fprintf(stderr, "\n  plain units by (pre, post) terms:");
-        for (int a = 1; a <= 4; ++a)
-            for (int b = 1; b <= 4; ++b)
-                if (hpl[a * 5 + b]) fprintf(stderr, " (%d,%d) %d", a, b, hpl[a * 5 + b]);
         fprintf(stderr, "\n  units by imports (0,1,2,<=4,<=8,<=16,<=32,more):");
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", hi[k]);
         fprintf(stderr, "\n  units by exports (0,1,2,<=4,<=8,<=16,<=32,more):");
@@ -1067,7 +889,7 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
 }
 
 std::string flow_tables_check(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
-                              const std::vector<char> &handled, const FlowTables &t, const unsigned char *capable) {
+                              const std::vector<char> &handled, const FlowTables &t) {
     (void)sign;
     auto fail = [](const std::string &s) { return s; };
     if (t.n_units == 0) {
@@ -1178,27 +1000,12 @@ std::string flow_tables_check(int n, const int64_t *indptr, const int32_t *indic
             found = t.ghost_edge[(int64_t)cu * LANES + k] == ed && t.ghost_prod[(int64_t)cu * LANES + k] == t.edge_prod_cell[ed];
         if (!found) return fail("ghost_prod of stream " + std::to_string(ed));
     }
-    // typed: no cell of a plain unit gathers a cell that can fire; one that can fire itself only as an outlet
-    if (t.typed && capable) {
-        for (int c = 0; c < n; ++c) {
-            if (!handled[c]) continue;
-            const int u = slot_of[c] / LANES;
-            if ((t.lane_flags[slot_of[c]] != 0) != (capable[c] != 0)) return fail("lane flag of cell " + std::to_string(c));
-            if (!t.unit_plain[u]) continue;
-            if (capable[c] && t.ds[c] >= 0 && slot_of[t.ds[c]] / LANES == u)
-                return fail("cell " + std::to_string(c) + " can fire and feeds a cell of its own plain unit");
-            for (int64_t j = indptr[c]; j < indptr[c + 1]; ++j)
-                if (indices[j] != c && capable[indices[j]]) return fail("plain cell " + std::to_string(c) + " gathers a capable cell");
-        }
-    }
-    for (int u = 0; u < t.n_units; ++u)
-        if ((t.unit_p[u] & 0x200) != (t.unit_plain[u] ? 0x200 : 0)) return fail("plain flag of unit " + std::to_string(u));
     return "";
 }
 
 // ---------------------------------------------------------------------------------------------- tables <-> file
 namespace {
-constexpr unsigned long long TABLES_MAGIC = 0x3472546c66485805ull;      // format of flow_tables_save; bump on any change
+constexpr unsigned long long TABLES_MAGIC = 0x3472546c66485806ull;      // format of flow_tables_save; bump on any change
 
 template <class T>
 bool put_vec(FILE *f, const std::vector<T> &v) {
@@ -1220,19 +1027,19 @@ bool get_vec(FILE *f, std::vector<T> &v) {
 }
 template <class F>
 bool tables_io(FILE *f, FlowTables &t, bool write, F &&vec) {
-    int head[15] = {t.n_units, t.n_edges, t.depth, t.n_cells, t.max_imports, t.max_exports, t.n_plain_units, t.skew_ok ? 1 : 0,
-                    t.skew_lmax, t.skew_span, t.typed ? 1 : 0, t.rsum ? 1 : 0, t.n_folded, t.n_special, t.n_pair_units};
+    int head[13] = {t.n_units, t.n_edges, t.depth, t.n_cells, t.max_imports, t.max_exports, t.skew_ok ? 1 : 0,
+                    t.skew_lmax, t.skew_span, t.rsum ? 1 : 0, t.n_folded, t.n_special, t.n_pair_units};
     if (write ? fwrite(head, sizeof(head), 1, f) != 1 : fread(head, sizeof(head), 1, f) != 1) return false;
     if (!write) {
         t.n_units = head[0], t.n_edges = head[1], t.depth = head[2], t.n_cells = head[3], t.max_imports = head[4];
-        t.max_exports = head[5], t.n_plain_units = head[6], t.skew_ok = head[7] != 0, t.skew_lmax = head[8];
-        t.skew_span = head[9], t.typed = head[10] != 0, t.rsum = head[11] != 0, t.n_folded = head[12], t.n_special = head[13], t.n_pair_units = head[14];
+        t.max_exports = head[5], t.skew_ok = head[6] != 0, t.skew_lmax = head[7];
+        t.skew_span = head[8], t.rsum = head[9] != 0, t.n_folded = head[10], t.n_special = head[11], t.n_pair_units = head[12];
     }
     return vec(t.cell_of_slot) && vec(t.export_edge) && vec(t.ghost_edge) && vec(t.edge_cons_unit) && vec(t.unit_terms) &&
            vec(t.ent) && vec(t.lag) && vec(t.ghost_lag) && vec(t.unit_p) && vec(t.unit_lmax) && vec(t.unit_glmax) &&
            vec(t.unit_order) && vec(t.ent2) && vec(t.eprev) && vec(t.edge_prod_cell) && vec(t.edge_cons_cell) &&
            vec(t.unit_depth) && vec(t.piece_of_cell) && vec(t.unit_of_cell) && vec(t.height_of_cell) && vec(t.ds) &&
-           vec(t.unit_plain) && vec(t.lane_flags) && vec(t.ghost_prod) && vec(t.fold_of_slot);
+           vec(t.lane_flags) && vec(t.ghost_prod) && vec(t.fold_of_slot);
 }
 }  // namespace
 

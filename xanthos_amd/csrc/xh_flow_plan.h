@@ -16,20 +16,6 @@ struct FlowPlanOptions {
     bool chain = true;           // sum long front sides on the way along chains of lanes
     bool cut_rule = true;        // chain-aware choice of the children that become streams
     int tlimit = 5;              // pair reads per sub-step a unit may reach by taking in another piece
-    int tlimit_typed = 4;        // the same for the pair units of a typed partition (they pace the run: plain units are cheaper)
-    int tlimit_plain = 6;        // the same for the 8-byte reads of a plain unit
-    // Typed partition: capable[c] != 0 for cells that can fire (velocity * dt / length close to or above 1, or seen
-    // firing in an earlier run).  Cells with such an upstream neighbour need both flows of it (mrtm.py:56-69) and go into
-    // pair units; everything else -- the cells that can fire included, as outlets -- may go into plain units.
-    // nullptr: every unit in pair form.
-    const unsigned char *capable = nullptr;
-    int full_join = 6;           // largest plain sub-piece a pair piece swallows instead of importing its outlet
-    int pair_streams = 8;        // imports, and outlets, a pair unit of a typed partition takes on (<= 16)
-    // Selective form (> 0, with `capable` given): the partition is the one of the all-pairs plan, untouched; afterwards the
-    // units that read at least this many values per sub-step and hold no cell that needs pairs switch to the plain form.
-    // The heavy units pace the run (every stream-linked unit follows the slowest one), and they are where one 8-byte
-    // read per term instead of a 16-byte pair pays most.
-    int plain_min_reads = 0;
     bool balance_lds = false;    // order the claim list's tail by LDS load (XH_WAVE_BALANCE=1: every CU one unit of each quarter)
     int lane_trials = 0;         // > 0: move the cells of a unit to lanes on which its gather meets fewer LDS bank conflicts (swaps tried per unit)
     bool debug = false;          // partition statistics on stderr
@@ -37,20 +23,23 @@ struct FlowPlanOptions {
     // (velocity * dt / length below 1) -- such a cell's outflow is a one-fma recurrence that the lane of its downstream cell can
     // carry in registers, so it needs no lane, no LDS slot and no level of lag of its own.  nullptr: nothing is folded.
     const unsigned char *foldable = nullptr;
-    // Reassociated planner: with `capable` given it makes the SINGLE-SUM partition (xh_flow_rsum.cpp): lanes pass one running
-    // sum instead of a pair; the cells that may fire AND have an upstream neighbour that may -- capable cells and `halo` cells
-    // downstream of every capable cell with a capable neighbour -- sit in pair units of their own.
+    // Reassociated planner: capable[c] != 0 for the cells that can fire (velocity * dt / length close to or above 1).  Given,
+    // it makes the SINGLE-SUM partition (xh_flow_rsum.cpp): lanes pass one running sum instead of a pair; the cells that may
+    // fire AND have an upstream neighbour that may -- capable cells and `halo` cells downstream of every capable cell with a
+    // capable neighbour -- sit in pair units of their own.  nullptr: the plan of pairs.  (The bit-exact planner ignores it:
+    // all of its units gather pairs.  Its "typed" partitions -- 8-byte units for the cells without such a neighbour, rounds 3
+    // to 5 -- went when the single-sum form replaced them: docs/HISTORY.md.)
+    const unsigned char *capable = nullptr;
     int halo = 8;
     int pair_imports = 8;        // ... and take on at most this many imported streams per unit (one import round of the kernel: 12.4-12.6
                                  // against 12.7 ms with 16 -- round 6, same box)
 };
 
 struct FlowTables {
-    int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0, max_exports = 0, n_plain_units = 0;
+    int n_units = 0, n_edges = 0, depth = 0, n_cells = 0, max_imports = 0, max_exports = 0;
     bool skew_ok = false;        // every row has <= 4 terms either side of its diagonal
     int skew_lmax = 0;           // largest lane lag of any unit (sub-steps)
     int skew_span = 1;           // most pipeline levels a stream jumps over
-    bool typed = false;
     bool rsum = false;           // reassociated form (xh_flow_rsum.cpp): ent2[0] = the cell's inflow entry, eprev = its chain entry, unit_p = 0x400 | reads
     std::vector<int> cell_of_slot, export_edge, ghost_edge, edge_cons_unit, unit_terms;
     std::vector<unsigned> ent;                                   // lock-step kernel: [9][units*64]
@@ -58,8 +47,7 @@ struct FlowTables {
     std::vector<unsigned> ent2, eprev;                           // time-skewed kernels: [8][units*64], [units*64]
     // kept for checks and diagnostics
     std::vector<int> edge_prod_cell, edge_cons_cell, unit_depth, piece_of_cell, unit_of_cell, height_of_cell, ds;
-    std::vector<char> unit_plain;
-    std::vector<unsigned char> lane_flags;                       // [units*64] bit 0: the cell can fire by construction
+    std::vector<unsigned char> lane_flags;                       // single-sum plans: [units*64] bit 0 the cell may fire, bit 1 an exit lane (all 0 otherwise)
     std::vector<int> ghost_prod;                                 // [units*64] producer cell of imported stream k of the unit
     std::vector<int> fold_of_slot;                               // reassociated form: [units*64] the leaf cell folded into the lane's cell, or -1 (empty: none)
     int n_folded = 0;
@@ -76,15 +64,11 @@ struct Tree {
     const int8_t *sign = nullptr;
     std::vector<int> ds, nchild, child_ptr, child, cell_pre, cell_post;
     std::vector<char> ok;                 // per cell: its network is a plain tree
-    int sel_reads = 0;                    // selective plain form: pieces / units that hold a cell needing pairs stay below this many reads
-    std::vector<char> must_full;          // typed: the cell has an upstream neighbour that can fire (it gathers both of its flows)
-    const unsigned char *capable = nullptr;
-    bool typed = false;
 };
 // which networks are plain trees (rows {-1 on the diagonal, +1 elsewhere}, every cell feeds <= 1 row, <= 9 terms per row,
 // no cycle); downstream pointers, children lists, row shapes
 void tree_analyse(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign, const int *comp, int ncomp,
-                  const unsigned char *capable, Tree &t);
+                  Tree &t);
 }  // namespace xh_flow
 
 // Partition every tree-shaped network (each cell drains to at most one cell, no cycle, rows = {-1 on the diagonal, +1
@@ -95,9 +79,9 @@ int flow_tables_build(int n, const int64_t *indptr, const int32_t *indices, cons
 
 // Invariants of a built plan (every cell in exactly one slot; streams run strictly down the pipeline; <= 16 imports
 // and outlets per unit; lane lags even and consistent with the "two iterations earlier" rule; every row, expanded
-// through its chains, equals the CSR row in stored order; plain units hold no cell that needs pairs).  Empty = fine.
+// through its chains, equals the CSR row in stored order).  Empty = fine.
 std::string flow_tables_check(int n, const int64_t *indptr, const int32_t *indices, const int8_t *sign,
-                              const std::vector<char> &handled, const FlowTables &t, const unsigned char *capable);
+                              const std::vector<char> &handled, const FlowTables &t);
 
 // The reassociated ("tolerance") form: every upstream neighbour of a cell passes a running sum along a chain, a cell reads
 // the chain's total and its own predecessor -- two values per sub-step for every unit, sums equal to the CSR row's to
@@ -115,6 +99,3 @@ int flow_rsum_planner_version();
 // flow_tables_check before using it.
 bool flow_tables_save(const FlowTables &t, const char *path);
 bool flow_tables_load(const char *path, FlowTables &t);
-
-// The (terms before, terms after) shapes compiled for plain units; rounds up.  Returns false if none fits.
-bool flow_plain_class(int pre, int post, bool chained, int &cpre, int &cpost);

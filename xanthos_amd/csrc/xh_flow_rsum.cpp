@@ -423,7 +423,7 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
     handled.assign(n, 0);
     if (n == 0) return 0;
     Tree t;
-    tree_analyse(n, indptr, indices, sign, comp, ncomp, nullptr, t);
+    tree_analyse(n, indptr, indices, sign, comp, ncomp, t);
     const std::vector<int> &ds = t.ds;
 
     RPart P;
@@ -611,7 +611,6 @@ int flow_tables_build_rsum(int n, const int64_t *indptr, const int32_t *indices,
             if (c < 0) continue;
             out.lane_flags[sl] = (unsigned char)((P.mayfire[c] ? 1 : 0) | ((P.special[c] && ds[c] >= 0 && !P.special[ds[c]]) ? 2 : 0));
         }
-    out.unit_plain.assign(nunit, 0);
 
     std::vector<int> unit_exp(nunit, 0);
     for (int ed = 0; ed < nedge; ++ed) unit_exp[unit_of_piece[piece[P.e_prod[ed]]]]++;

@@ -336,7 +336,7 @@ int flow_tables_host(FlowPlanOptions opt, int n, const int64_t *indptr, const in
     if (flow_tables_build(n, indptr, indices, sign, comp.data(), ncomp, opt, handled, t, err) != 0) return -1;
     if (t.n_units == 0) return 0;
     if (xh_flow_check()) {      // the invariants the host fuzzer holds the planner to, on this very plan
-        const std::string bad = flow_tables_check(n, indptr, indices, sign, handled, t, nullptr);
+        const std::string bad = flow_tables_check(n, indptr, indices, sign, handled, t);
         if (!bad.empty()) {
             err = "flow plan check: " + bad;
             return -1;
@@ -381,7 +381,7 @@ int flow_plan_build(xh_ctx *ctx, int n, const int64_t *indptr, const int32_t *in
                     if (c >= n) ok = false;
                     else if (c >= 0) handled[c] = 1;
                 }
-                if (ok && flow_tables_check(n, indptr, indices, sign, handled, t, nullptr).empty()) return flow_plan_upload(ctx, t, out);
+                if (ok && flow_tables_check(n, indptr, indices, sign, handled, t).empty()) return flow_plan_upload(ctx, t, out);
             }
         }
     }

@@ -19,6 +19,9 @@ __global__ void k_mrtm_wave_args(WaveArgs a, WaveArgs *dst, uint4 *cnt, unsigned
 
 }  // namespace
 
+static unsigned *g_last_place = nullptr;      // placement words of the last launch (XH_FLOW_DEBUG: dumped when a launch faults)
+unsigned *xh_wave_last_place() { return g_last_place; }
+
 int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st) {
     if (!fp || fp->n_units == 0) return XH_OK;
     // a lane must have left month it - 1 before the unit's clock reaches month it + 1 (one pending snapshot per lane)
@@ -130,7 +133,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
         fp->rec_key = rec_key;
     }
 
-    // every unit resident at once (see flow_launch for the LDS-share sizing): one workgroup more per CU than the even split
+    // every unit resident at once (see flow_launch for the LDS-share sizing)
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     // the reassociated plan (xh_flow_rsum.cpp) has a kernel of its own: same argument block, same protocol (xh_mrtm_rsum.hip)
     const void *kernel = fp->rsum ? wave_rsum_kernel() : wave_exact_kernel();
@@ -151,7 +154,14 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
             const char *env = getenv("XH_FLOW_SPARE");            // experiments only
             if (env) n_wg = fp->n_units + std::max(atoi(env), 0);
         }
-        const int per_cu = (n_wg + cus - 1) / cus + 1;
+        // LDS share per workgroup: what spreads the launch over the CUs.  Three more per CU than the even split (one more until
+        // round 6): the workgroups of an XCD must ALL find a CU of that XCD with a contiguous share free before any of them
+        // moves on, and beside another context's kernels that hold LDS of their own the last ones did not -- 999 units + 256
+        // spares = 157 workgroups per XCD against 32 CUs x 6 shares, and the launch sat out its 5 s placement bound (then
+        // routed by the workgroup-per-network kernel: tests/test_gpu_fullsize.py::test_config3_twenty_repetitions_and_
+        // background_load failed in 4 of 5 runs; tools/bg_load_probe.py).  With three, two waves per SIMD are the limit again;
+        // the kernel is no slower on an idle device (12.3-12.5 ms, every unit alone on its SIMD).
+        const int per_cu = (n_wg + cus - 1) / cus + 3;
         const size_t share = ((size_t)(160 * 1024) / (size_t)per_cu) & ~size_t(1023);
         lds = share > lds_static + 1024 ? share - lds_static : 0;
         XH_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -208,6 +218,7 @@ int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io,
     a.ready = cnt;
     a.done = cnt + fp->n_edges;
     a.place = cnt + fp->n_edges + fp->n_units;
+    g_last_place = a.place;
     unsigned *fault = nullptr;
     int rc = xh_fault_word(ctx, &fault);
     if (rc) return rc;
