@@ -25,7 +25,7 @@ constexpr int RING = 8;
 // MODE 8: a unit none of whose cells may fire (not built: what dropping the clamp would buy): S = S1, F2 = F -- 5 operations.
 template <int MODE>
 __global__ void __launch_bounds__(256) k(double *out, unsigned long long *cyc, double tauinv, double dt, double dtinv, double erl,
-                                         const int *perm, int iters, int nact) {
+                                         const int *perm, int iters) {
     __shared__ __attribute__((aligned(16))) char lds_all[4][RING * SLOT_PAIRS * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     lds_c *lds = (lds_c *)lds_all[wave];
@@ -38,7 +38,6 @@ __global__ void __launch_bounds__(256) k(double *out, unsigned long long *cyc, d
     v2d v[5], vn[5], vnn[2];
     for (int w = 0; w < 5; ++w) v[w] = vn[w] = v2d{0.001, 0.001};
     vnn[0] = vnn[1] = v2d{0.001, 0.001};
-    if (lane >= nact) return;      // (round 6: what a unit with few cells would gain if only their lanes were active)
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -137,7 +136,7 @@ int main() {
 #define RUN(M, name)                                                                                                     \
     for (int full = 0; full < 2; ++full) {                                                                               \
         hipLaunchKernelGGL((k<M>), dim3(full ? 256 : 1), dim3(full ? 256 : 64), 0, 0, out, cyc, 1e-4, 10800.0, 1.0 / 10800.0, \
-                           1e-3, perm, iters, 64);                                                                       \
+                           1e-3, perm, iters);                                                                           \
         (void)hipDeviceSynchronize();                                                                                    \
         (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);                                                              \
         printf("%-66s %s %.1f cycles per sub-step\n", name, full ? "4 waves on each of 256 CUs" : "one wave alone           ",  \
@@ -152,16 +151,5 @@ int main() {
     RUN(6, "single sums: 2 ds_read_b64, 8 fp64 operations, ds_write_b64")
     RUN(7, "single sums: the arithmetic alone (no LDS)")
     RUN(8, "single sums without the clamp (a unit that cannot fire; not built)")
-    // a lone wave with only its first lanes active (EXEC): does a unit of <= 16 cells pay for 64 lanes?
-    for (int nact : {32, 16, 8}) {
-        hipLaunchKernelGGL((k<0>), dim3(1), dim3(64), 0, 0, out, cyc, 1e-4, 10800.0, 1.0 / 10800.0, 1e-3, perm, iters, nact);
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
-        printf("reassociated (pairs), one wave alone, lanes 0..%d active: %.1f cycles per sub-step\n", nact - 1, (double)h / (iters * 8.0));
-        hipLaunchKernelGGL((k<6>), dim3(1), dim3(64), 0, 0, out, cyc, 1e-4, 10800.0, 1.0 / 10800.0, 1e-3, perm, iters, nact);
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
-        printf("single sums,          one wave alone, lanes 0..%d active: %.1f cycles per sub-step\n", nact - 1, (double)h / (iters * 8.0));
-    }
     return 0;
 }
