@@ -87,6 +87,10 @@ __device__ __forceinline__ AbcdPre abcd_pre(const AbcdPar &P, const XhExpConsts 
 }
 
 // State recurrence of abcd_dist (:171-228). `first` = month 0 of a march: no snow-melt term in W (:200-201).
+// FASTQ (the calibration marches only, whose objective is held to 1e-9 of the oracle's, not to its bits): the groundwater
+// quotient as a bare product with 1 / (d + 1) -- one rounding more than the quotient, 2 of the march's 89 VALU instructions per
+// member, cell and month.  (The quotient by 2a stays exact in either form: y = rpt - sqrt(...) cancels.)
+template <bool FASTQ = false>
 __device__ __forceinline__ void abcd_step(const AbcdPar &P, AbcdState &s, bool snow_on, bool first, const AbcdPre &r,
                                           double &aet, double &q) {
     double snm = 0.0;
@@ -105,7 +109,7 @@ __device__ __forceinline__ void abcd_step(const AbcdPar &P, AbcdState &s, bool s
     const double sm1 = y * r.decay;                                   // :211
     const double awet = w - y;
     const double c_awet = P.c * awet;
-    s.gw = quot(s.gw + c_awet, P.d1, P.inv_d1);                       // :219-221
+    s.gw = FASTQ ? (s.gw + c_awet) * P.inv_d1 : quot(s.gw + c_awet, P.d1, P.inv_d1);      // :219-221
     double e = y - sm1;                                               // :224-226
     e = (0.0 >= e) ? 0.0 : e;                                         // np.maximum(0, e): NaN e stays NaN
     e = (r.pet <= e || r.pet != r.pet) ? r.pet : e;                   // np.minimum(pet, e): NaN propagates
