@@ -19,7 +19,9 @@ __global__ void k_mrtm_wave_args(WaveArgs a, WaveArgs *dst, uint4 *cnt, unsigned
 
 }  // namespace
 
-static unsigned *g_last_place = nullptr;      // placement words of the last launch (XH_FLOW_DEBUG: dumped when a launch faults)
+// placement words of the process's last dataflow launch: printed by xh_fault_check when a launch faults (diagnosis only -- the
+// copy fails harmlessly if the plan has been destroyed since; with several contexts it may be another context's launch)
+static unsigned *g_last_place = nullptr;
 unsigned *xh_wave_last_place() { return g_last_place; }
 
 int wave_launch(xh_ctx *ctx, FlowPlan *fp, const FlowSched &s, const FlowIO &io, hipStream_t st) {
